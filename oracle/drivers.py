@@ -240,3 +240,6 @@ class RefAcado(_SolverBase):
         fp = C.POINTER(C.c_float)
         ue = np.asarray(uEnd, np.float32) if uEnd is not None else None
         self.L.acado_shiftControls(ue.ctypes.data_as(fp) if ue is not None else None)
+
+
+INTERMEDIATES_DEFAULT = ("d", "evGx", "evGu", "g", "lb", "ub", "sbar", "QDy")
