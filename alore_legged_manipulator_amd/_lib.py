@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI (include/alore_nmpc.h) of libalore_nmpc.so.
+
+There is deliberately no fallback: if the HIP library is missing or cannot be
+loaded the import of the solver fails loudly (``NmpcLibraryError``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libalore_nmpc.so")
+
+FP = C.POINTER(C.c_float)
+IP = C.POINTER(C.c_int)
+
+
+class NmpcLibraryError(RuntimeError):
+    pass
+
+
+class NmpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"alore_nmpc error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("N", C.c_int), ("dt", C.c_float), ("device", C.c_int), ("max_as_iter", C.c_int),
+                ("lanes_per_problem", C.c_int)]
+
+
+BATCH_FLOAT_MEMBERS = ("x", "u", "od", "y", "yN", "W", "WN", "x0", "lbValues", "ubValues", "dual")
+BATCH_MEMBERS = BATCH_FLOAT_MEMBERS + ("status", "n_iter", "kkt", "obj")
+
+
+class Batch(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in BATCH_MEMBERS]
+
+
+class LinOut(C.Structure):
+    _fields_ = [("d", C.c_void_p), ("evGx", C.c_void_p), ("evGu", C.c_void_p)]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("lanes_per_problem", C.c_int), ("problems_per_block", C.c_int), ("threads_per_block", C.c_int),
+                ("grid", C.c_int), ("lds_bytes_per_block", C.c_int), ("last_kernel_ms", C.c_float)]
+
+
+# every symbol include/alore_nmpc.h declares: (name, restype, argtypes)
+SYMBOLS = (
+    ("alore_nmpc_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    ("alore_nmpc_destroy", C.c_int, [C.c_void_p]),
+    ("alore_nmpc_last_error", C.c_char_p, [C.c_void_p]),
+    ("alore_nmpc_version", C.c_char_p, []),
+    ("alore_nmpc_batch_alloc", C.c_int, [C.c_void_p, C.c_int, C.POINTER(Batch)]),
+    ("alore_nmpc_batch_free", C.c_int, [C.c_void_p, C.POINTER(Batch)]),
+    ("alore_nmpc_batch_upload", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(Batch), C.c_int, C.c_void_p]),
+    ("alore_nmpc_batch_download", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(Batch), C.c_int, C.c_void_p]),
+    ("alore_nmpc_batch_default_bounds", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p]),
+    ("alore_nmpc_rti", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.c_void_p]),
+    ("alore_nmpc_linearize", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.POINTER(LinOut), C.c_void_p]),
+    ("alore_nmpc_forward_simulate", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p]),
+    ("alore_nmpc_shift", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_get_launch_info", C.c_int, [C.c_void_p, C.POINTER(LaunchInfo)]),
+    ("alore_nmpc_set_timing", C.c_int, [C.c_void_p, C.c_int]),
+)
+
+_lib = None
+
+
+def load():
+    """Load libalore_nmpc.so and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NmpcLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise NmpcLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, res, args in SYMBOLS:
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NmpcLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

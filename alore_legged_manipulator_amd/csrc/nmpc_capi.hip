@@ -1,0 +1,297 @@
+// nmpc_capi.hip -- implementation of the C ABI declared in include/alore_nmpc.h.
+// Thin host layer: argument checks, launch geometry, HIP stream/event plumbing.
+// There is no CPU path behind this ABI: without a GPU alore_nmpc_create fails.
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "nmpc_kernels.h"
+#include "nmpc_core.h"
+
+struct alore_nmpc_solver {
+    alore_nmpc_config cfg;
+    int n_cu = 256;
+    int lds_limit = 160 * 1024;
+    std::string err;
+    nmpc::LaunchGeom last_geom{};
+    bool have_geom = false;
+    bool timing = false;
+    bool timed_pending = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = -1.0f;
+};
+
+namespace {
+
+int fail(alore_nmpc_handle h, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (h) {
+        h->err = what;
+        if (e != hipSuccess) {
+            h->err += ": ";
+            h->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                   \
+    do {                                                                   \
+        hipError_t e_ = (call);                                            \
+        if (e_ != hipSuccess) return fail(h, ALORE_NMPC_E_HIP, #call, e_); \
+    } while (0)
+
+struct Member {
+    size_t offset; // byte offset of the pointer inside alore_nmpc_batch
+    int per_problem(int N) const { return mult * (per_node ? (N + extra) : 1); }
+    int mult;      // floats per node (or per problem when !per_node)
+    bool per_node;
+    int extra;     // nodes = N + extra
+    bool is_int;
+};
+
+// every member of alore_nmpc_batch with its per-problem element count
+const Member kMembers[] = {
+    {offsetof(alore_nmpc_batch, x), 3, true, 1, false},
+    {offsetof(alore_nmpc_batch, u), 2, true, 0, false},
+    {offsetof(alore_nmpc_batch, od), 3, true, 1, false},
+    {offsetof(alore_nmpc_batch, y), 5, true, 0, false},
+    {offsetof(alore_nmpc_batch, yN), 3, false, 0, false},
+    {offsetof(alore_nmpc_batch, W), 25, true, 0, false},
+    {offsetof(alore_nmpc_batch, WN), 9, false, 0, false},
+    {offsetof(alore_nmpc_batch, x0), 3, false, 0, false},
+    {offsetof(alore_nmpc_batch, lbValues), 2, true, 0, false},
+    {offsetof(alore_nmpc_batch, ubValues), 2, true, 0, false},
+    {offsetof(alore_nmpc_batch, dual), 2, true, 0, false},
+    {offsetof(alore_nmpc_batch, status), 1, false, 0, true},
+    {offsetof(alore_nmpc_batch, n_iter), 1, false, 0, true},
+    {offsetof(alore_nmpc_batch, kkt), 1, false, 0, false},
+    {offsetof(alore_nmpc_batch, obj), 1, false, 0, false},
+};
+constexpr int kNumMembers = sizeof(kMembers) / sizeof(kMembers[0]);
+
+void*& member_ptr(alore_nmpc_batch* b, const Member& m)
+{
+    return *reinterpret_cast<void**>(reinterpret_cast<char*>(b) + m.offset);
+}
+void* member_ptr(const alore_nmpc_batch* b, const Member& m)
+{
+    return *reinterpret_cast<void* const*>(reinterpret_cast<const char*>(b) + m.offset);
+}
+
+bool batch_complete(const alore_nmpc_batch* b)
+{
+    for (int i = 0; i < kNumMembers; ++i)
+        if (!member_ptr(b, kMembers[i])) return false;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* alore_nmpc_version(void) { return "alore_nmpc 0.1 (gfx950)"; }
+
+int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
+{
+    if (!cfg || !out) return ALORE_NMPC_E_INVALID;
+    *out = nullptr;
+    if (cfg->N < 1 || !(cfg->dt > 0.0f)) return ALORE_NMPC_E_INVALID;
+    if (cfg->lanes_per_problem != 0 && cfg->lanes_per_problem != 4 && cfg->lanes_per_problem != 8 &&
+        cfg->lanes_per_problem != 16 && cfg->lanes_per_problem != 32)
+        return ALORE_NMPC_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ALORE_NMPC_E_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return ALORE_NMPC_E_INVALID;
+    if (hipSetDevice(cfg->device) != hipSuccess) return ALORE_NMPC_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return ALORE_NMPC_E_NO_DEVICE;
+    alore_nmpc_solver* h = new (std::nothrow) alore_nmpc_solver;
+    if (!h) return ALORE_NMPC_E_NOMEM;
+    h->cfg = *cfg;
+    if (h->cfg.max_as_iter <= 0) h->cfg.max_as_iter = 64;
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)prop.sharedMemPerBlock : 64 * 1024;
+    if (prop.maxSharedMemoryPerMultiProcessor > (size_t)h->lds_limit)
+        h->lds_limit = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (h->lds_limit > 160 * 1024) h->lds_limit = 160 * 1024;
+    // the horizon must fit the on-chip layout with at least one geometry
+    nmpc::LaunchGeom g;
+    if (!nmpc::rti_geometry(1, cfg->N, cfg->lanes_per_problem, h->lds_limit, h->n_cu, &g)) {
+        delete h;
+        return ALORE_NMPC_E_UNSUPPORTED;
+    }
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        delete h;
+        return ALORE_NMPC_E_HIP;
+    }
+    *out = h;
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_destroy(alore_nmpc_handle h)
+{
+    if (!h) return ALORE_NMPC_E_INVALID;
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return ALORE_NMPC_OK;
+}
+
+const char* alore_nmpc_last_error(alore_nmpc_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int alore_nmpc_batch_alloc(alore_nmpc_handle h, int B, alore_nmpc_batch* out)
+{
+    if (!h || !out || B <= 0) return fail(h, ALORE_NMPC_E_INVALID, "batch_alloc: bad argument");
+    std::memset(out, 0, sizeof(*out));
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (int i = 0; i < kNumMembers; ++i) {
+        const Member& m = kMembers[i];
+        const size_t bytes = (size_t)B * m.per_problem(h->cfg.N) * 4;
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            alore_nmpc_batch_free(h, out);
+            return fail(h, ALORE_NMPC_E_NOMEM, "hipMalloc", e);
+        }
+        (void)hipMemset(p, 0, bytes);
+        member_ptr(out, m) = p;
+    }
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_batch_free(alore_nmpc_handle h, alore_nmpc_batch* b)
+{
+    if (!h || !b) return ALORE_NMPC_E_INVALID;
+    for (int i = 0; i < kNumMembers; ++i) {
+        void*& p = member_ptr(b, kMembers[i]);
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    return ALORE_NMPC_OK;
+}
+
+static int batch_copy(alore_nmpc_handle h, const alore_nmpc_batch* dev, const alore_nmpc_batch* host, int B,
+                      void* stream, bool to_device)
+{
+    if (!h || !dev || !host || B <= 0) return fail(h, ALORE_NMPC_E_INVALID, "batch copy: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < kNumMembers; ++i) {
+        const Member& m = kMembers[i];
+        void* d = member_ptr(dev, m);
+        void* hp = member_ptr(host, m);
+        if (!d || !hp) continue;
+        const size_t bytes = (size_t)B * m.per_problem(h->cfg.N) * 4;
+        if (to_device)
+            HIP_TRY(h, hipMemcpyAsync(d, hp, bytes, hipMemcpyHostToDevice, s));
+        else
+            HIP_TRY(h, hipMemcpyAsync(hp, d, bytes, hipMemcpyDeviceToHost, s));
+    }
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_batch_upload(alore_nmpc_handle h, const alore_nmpc_batch* dev, const alore_nmpc_batch* host, int B,
+                            void* stream)
+{
+    return batch_copy(h, dev, host, B, stream, true);
+}
+
+int alore_nmpc_batch_download(alore_nmpc_handle h, const alore_nmpc_batch* dev, const alore_nmpc_batch* host, int B,
+                              void* stream)
+{
+    return batch_copy(h, dev, host, B, stream, false);
+}
+
+int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, void* stream)
+{
+    if (!h || !dev || B <= 0 || !dev->lbValues || !dev->ubValues)
+        return fail(h, ALORE_NMPC_E_INVALID, "default_bounds: bad argument");
+    const size_t n = (size_t)B * h->cfg.N * 2;
+    HIP_TRY(h, nmpc::launch_fill(const_cast<float*>(dev->lbValues), -3.0f, n, (hipStream_t)stream));
+    HIP_TRY(h, nmpc::launch_fill(const_cast<float*>(dev->ubValues), 3.0f, n, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream)
+{
+    if (!h || !dev || B <= 0 || n_sqp < 1) return fail(h, ALORE_NMPC_E_INVALID, "rti: bad argument");
+    if (!batch_complete(dev)) return fail(h, ALORE_NMPC_E_INVALID, "rti: batch has NULL members");
+    nmpc::LaunchGeom g;
+    if (!nmpc::rti_geometry(B, h->cfg.N, h->cfg.lanes_per_problem, h->lds_limit, h->n_cu, &g))
+        return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: horizon does not fit the LDS layout");
+    nmpc::RtiParams p;
+    p.b = *dev;
+    p.B = B;
+    p.N = h->cfg.N;
+    p.n_sqp = n_sqp;
+    p.max_as_iter = h->cfg.max_as_iter;
+    p.RS = g.RS;
+    const nmpc::IrkConst K = nmpc::make_irk(h->cfg.dt);
+    p.h = K.h; p.hh = K.hh; p.c1h = K.c1h; p.c2h = K.c2h;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
+    HIP_TRY(h, nmpc::launch_rti(p, g, s));
+    if (h->timing) {
+        HIP_TRY(h, hipEventRecord(h->ev1, s));
+        h->timed_pending = true;
+    }
+    h->last_geom = g;
+    h->have_geom = true;
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_linearize(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, const alore_nmpc_lin_out* out,
+                         void* stream)
+{
+    if (!h || !dev || !out || B <= 0 || !dev->x || !dev->u || !dev->od)
+        return fail(h, ALORE_NMPC_E_INVALID, "linearize: bad argument");
+    HIP_TRY(h, nmpc::launch_linearize(*dev, B, h->cfg.N, h->cfg.dt, *out, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_forward_simulate(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, void* stream)
+{
+    if (!h || !dev || B <= 0 || !dev->x || !dev->u || !dev->od)
+        return fail(h, ALORE_NMPC_E_INVALID, "forward_simulate: bad argument");
+    HIP_TRY(h, nmpc::launch_forward_simulate(*dev, B, h->cfg.N, h->cfg.dt, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_shift(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int strategy, const float* xEnd,
+                     const float* uEnd, void* stream)
+{
+    if (!h || !dev || B <= 0 || !dev->x || !dev->u || !dev->od)
+        return fail(h, ALORE_NMPC_E_INVALID, "shift: bad argument");
+    HIP_TRY(h, nmpc::launch_shift(*dev, B, h->cfg.N, h->cfg.dt, strategy, xEnd, uEnd, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_set_timing(alore_nmpc_handle h, int enable)
+{
+    if (!h) return ALORE_NMPC_E_INVALID;
+    h->timing = enable != 0;
+    h->timed_pending = false;
+    h->last_ms = -1.0f;
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_get_launch_info(alore_nmpc_handle h, alore_nmpc_launch_info* out)
+{
+    if (!h || !out) return ALORE_NMPC_E_INVALID;
+    if (!h->have_geom) return fail(h, ALORE_NMPC_E_INVALID, "launch_info: no launch yet");
+    if (h->timing && h->timed_pending) {
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        HIP_TRY(h, hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+        h->timed_pending = false;
+    }
+    out->lanes_per_problem = h->last_geom.L;
+    out->problems_per_block = h->last_geom.G;
+    out->threads_per_block = h->last_geom.threads;
+    out->grid = h->last_geom.grid;
+    out->lds_bytes_per_block = (int)h->last_geom.lds_bytes;
+    out->last_kernel_ms = h->timing ? h->last_ms : -1.0f;
+    return ALORE_NMPC_OK;
+}
+
+} // extern "C"

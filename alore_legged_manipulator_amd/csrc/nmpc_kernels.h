@@ -1,0 +1,45 @@
+// nmpc_kernels.h -- host-side launch interface of the HIP kernels (internal).
+#ifndef ALORE_NMPC_KERNELS_H
+#define ALORE_NMPC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/alore_nmpc.h"
+
+namespace nmpc {
+
+// kernel parameters, passed by value
+struct RtiParams {
+    alore_nmpc_batch b;
+    int B;
+    int N;
+    int n_sqp;
+    int max_as_iter;
+    int RS; // LDS floats per problem (row stride)
+    float h, hh, c1h, c2h;
+};
+
+struct LaunchGeom {
+    int L;       // lanes per problem
+    int G;       // problems per block
+    int threads; // = L * G, multiple of 64
+    int grid;
+    int RS;
+    size_t lds_bytes;
+};
+
+// number of LDS floats one problem needs (before padding) for horizon N
+int rti_row_floats(int N);
+// choose lanes/problem + block shape for (B, N); returns false if N does not fit
+bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g);
+hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
+
+hipError_t launch_linearize(const alore_nmpc_batch& b, int B, int N, float dt, const alore_nmpc_lin_out& o,
+                            hipStream_t s);
+hipError_t launch_forward_simulate(const alore_nmpc_batch& b, int B, int N, float dt, hipStream_t s);
+hipError_t launch_shift(const alore_nmpc_batch& b, int B, int N, float dt, int strategy, const float* xEnd,
+                        const float* uEnd, hipStream_t s);
+hipError_t launch_fill(float* p, float v, size_t n, hipStream_t s);
+
+} // namespace nmpc
+#endif

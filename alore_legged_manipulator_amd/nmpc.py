@@ -1,0 +1,255 @@
+"""Host side of the batched NMPC engine (Python over the C ABI).
+
+Two layers:
+
+* ``BatchedNmpc`` -- thin owner of a solver handle plus a set of torch tensors
+  laid out like the reference's ``ACADOvariables`` members with a leading batch
+  dimension (include/alore_nmpc.h).  torch is used for device memory and
+  streams only; the numerics are the HIP kernels behind ``alore_nmpc_rti``.
+* ``BatchedMpcWrapper`` -- the batched mirror of the reference's
+  ``Tracked_nmpc::MpcWrapper`` (planning_ddr_opt/nmpc_controller/
+  include/nmpc_controller/mpc_wrapper.h:43-141, src/mpc_wrapper.cpp:33-410):
+  same method names and argument meaning, every argument carrying one extra
+  leading batch dimension.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import BATCH_FLOAT_MEMBERS, BATCH_MEMBERS, Batch, Config, LaunchInfo, LinOut, NmpcError
+
+NX, NU, NOD, NY, NYN = 3, 2, 3, 5, 3
+
+
+def member_shapes(B: int, N: int) -> dict:
+    return {
+        "x": (B, N + 1, NX), "u": (B, N, NU), "od": (B, N + 1, NOD), "y": (B, N, NY), "yN": (B, NYN),
+        "W": (B, N, NY, NY), "WN": (B, NYN, NYN), "x0": (B, NX), "lbValues": (B, N, NU),
+        "ubValues": (B, N, NU), "dual": (B, N, NU), "status": (B,), "n_iter": (B,), "kkt": (B,), "obj": (B,),
+    }
+
+
+class BatchedNmpc:
+    """B independent NMPC instances on one GPU.
+
+    ``self.t[name]`` are the device tensors (float32; status/n_iter int32)."""
+
+    def __init__(self, B: int, N: int = 20, dt: float = 0.01, device: int = 0, max_as_iter: int = 64,
+                 lanes_per_problem: int = 0):
+        import torch  # device memory + streams
+        self.torch = torch
+        self.lib = _lib.load()  # raises if the HIP library is missing: no fallback
+        if not torch.cuda.is_available():
+            raise _lib.NmpcLibraryError("no GPU visible to torch: the NMPC engine has no CPU path")
+        self.B, self.N, self.dt = int(B), int(N), float(dt)
+        self.device = torch.device("cuda", device)
+        cfg = Config(self.N, self.dt, device, max_as_iter, lanes_per_problem)
+        h = C.c_void_p()
+        rc = self.lib.alore_nmpc_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise NmpcError(rc, "alore_nmpc_create failed")
+        self.h = h
+        self.t = {}
+        for k, shp in member_shapes(self.B, self.N).items():
+            dt_ = torch.int32 if k in ("status", "n_iter") else torch.float32
+            self.t[k] = torch.zeros(shp, dtype=dt_, device=self.device)
+        self._batch = Batch(**{k: self.t[k].data_ptr() for k in BATCH_MEMBERS})
+        self._check(self.lib.alore_nmpc_batch_default_bounds(self.h, C.byref(self._batch), self.B, self._stream()))
+
+    # -- plumbing
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NmpcError(rc, self.lib.alore_nmpc_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.alore_nmpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data
+    def load(self, batch: dict) -> None:
+        """Copy host arrays (any subset of the float members) to the device."""
+        torch = self.torch
+        shapes = member_shapes(self.B, self.N)
+        for k, v in batch.items():
+            if k not in BATCH_FLOAT_MEMBERS:
+                continue
+            a = np.ascontiguousarray(v, dtype=np.float32).reshape(shapes[k])
+            self.t[k].copy_(torch.from_numpy(a), non_blocking=False)
+
+    def fetch(self, names=("x", "u", "dual", "status", "n_iter", "kkt", "obj")) -> dict:
+        self.torch.cuda.synchronize(self.device)
+        return {k: self.t[k].detach().cpu().numpy().copy() for k in names}
+
+    # -- the hot path
+    def rti(self, n_sqp: int = 1) -> None:
+        """n_sqp x (acado_preparationStep + acado_feedbackStep) for the whole batch, one launch."""
+        self._check(self.lib.alore_nmpc_rti(self.h, C.byref(self._batch), self.B, int(n_sqp), self._stream()))
+
+    def linearize(self) -> dict:
+        torch = self.torch
+        d = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.device)
+        gx = torch.empty((self.B, self.N, 9), dtype=torch.float32, device=self.device)
+        gu = torch.empty((self.B, self.N, 6), dtype=torch.float32, device=self.device)
+        out = LinOut(d.data_ptr(), gx.data_ptr(), gu.data_ptr())
+        self._check(self.lib.alore_nmpc_linearize(self.h, C.byref(self._batch), self.B, C.byref(out), self._stream()))
+        torch.cuda.synchronize(self.device)
+        return {"d": d.cpu().numpy(), "evGx": gx.cpu().numpy(), "evGu": gu.cpu().numpy()}
+
+    def forward_simulate(self) -> None:
+        self._check(self.lib.alore_nmpc_forward_simulate(self.h, C.byref(self._batch), self.B, self._stream()))
+
+    def shift(self, strategy: int = 0, xEnd=None, uEnd=None) -> None:
+        torch = self.torch
+        xe = torch.as_tensor(np.asarray(xEnd, np.float32), device=self.device).reshape(self.B, 3).contiguous() \
+            if xEnd is not None else None
+        ue = torch.as_tensor(np.asarray(uEnd, np.float32), device=self.device).reshape(self.B, 2).contiguous() \
+            if uEnd is not None else None
+        self._check(self.lib.alore_nmpc_shift(self.h, C.byref(self._batch), self.B, int(strategy),
+                                              C.c_void_p(xe.data_ptr()) if xe is not None else None,
+                                              C.c_void_p(ue.data_ptr()) if ue is not None else None, self._stream()))
+
+    def set_timing(self, enable: bool) -> None:
+        self._check(self.lib.alore_nmpc_set_timing(self.h, 1 if enable else 0))
+
+    def launch_info(self) -> dict:
+        li = LaunchInfo()
+        self._check(self.lib.alore_nmpc_get_launch_info(self.h, C.byref(li)))
+        return {k: getattr(li, k) for k, _ in LaunchInfo._fields_}
+
+
+class BatchedMpcWrapper:
+    """Batched mirror of ``Tracked_nmpc::MpcWrapper`` (reference:
+    nmpc_controller/src/mpc_wrapper.cpp).  Array arguments take the reference's
+    Eigen shapes with one leading batch dimension; a shape without the batch
+    dimension is broadcast to every problem.
+
+    Differences, all forced by batching/fusion and documented in DESIGN.md:
+    the preparation step is fused into the next feedback launch, so ``prepare``
+    only flips the readiness flag the reference keeps (``acado_is_prepared_``).
+    """
+
+    kSamples = None  # set per instance (reference: ACADO_N, compile-time 50)
+    kStateSize, kRefSize, kEndRefSize, kInputSize, kCostSize, kOdSize = NX, NY, NYN, NU, NY - NU, NOD
+
+    def __init__(self, B: int, N: int = 20, Q=None, R=None, dt: float = 0.01, device: int = 0, **kw):
+        self.kSamples = N
+        self.B = B
+        self.eng = BatchedNmpc(B, N, dt=dt, device=device, **kw)
+        self.dt_ = dt
+        self.W_ = np.zeros((NY, NY))
+        self.WN_ = np.zeros((NYN, NYN))
+        # mpc_wrapper.cpp:33-93: zero everything, default ICR (0,-0.2,0.2), forward-simulate, prepare
+        if Q is not None and R is not None:
+            self.setCosts(Q, R)
+        self.setICRParameters(np.array([0.0, -0.2, 0.2]))
+        self.eng.forward_simulate()
+        self.acado_is_prepared_ = True
+
+    def _b(self, a, tail):
+        a = np.asarray(a, dtype=np.float64)
+        if a.shape == tuple(tail):
+            a = np.broadcast_to(a, (self.B,) + tuple(tail))
+        assert a.shape == (self.B,) + tuple(tail), (a.shape, tail)
+        return a
+
+    # mpc_wrapper.cpp:106-138
+    def setCosts(self, Q, R, state_cost_scaling: float = 0.0, input_cost_scaling: float = 0.0) -> bool:
+        if state_cost_scaling < 0.0 or input_cost_scaling < 0.0:
+            return False
+        N = self.kSamples
+        self.W_[:3, :3] = np.asarray(Q, np.float64)
+        self.W_[3:, 3:] = np.asarray(R, np.float64)
+        self.WN_ = self.W_[:3, :3].copy()
+        W = np.zeros((N, NY, NY), np.float32)
+        state_scale = np.float32(1.0)
+        for i in range(N):
+            state_scale = np.float32(math.exp(-np.float32(i) / np.float32(N) * np.float32(state_cost_scaling)))
+            input_scale = np.float32(math.exp(-np.float32(i) / np.float32(N) * np.float32(input_cost_scaling)))
+            W[i, :3, :3] = self.W_[:3, :3].astype(np.float32) * state_scale
+            W[i, 3:, 3:] = self.W_[3:, 3:].astype(np.float32) * input_scale
+        WN = self.WN_.astype(np.float32) * state_scale
+        self.eng.load({"W": np.broadcast_to(W, (self.B,) + W.shape), "WN": np.broadcast_to(WN, (self.B, 3, 3))})
+        return True
+
+    # mpc_wrapper.cpp:200-207 -- (xv, yr, yl) broadcast to all N+1 nodes
+    def setICRParameters(self, p_B_I) -> bool:
+        p = self._b(p_B_I, (3,))
+        self.eng.load({"od": np.broadcast_to(p[:, None, :], (self.B, self.kSamples + 1, 3))})
+        return True
+
+    # mpc_wrapper.cpp:219-239
+    def setReferencePose(self, state) -> bool:
+        s = self._b(state, (3,))
+        N = self.kSamples
+        y = np.zeros((self.B, N, NY))
+        y[:, :, :3] = s[:, None, :]
+        self.eng.load({"y": y, "yN": s})
+        self.eng.forward_simulate()
+        return True
+
+    # mpc_wrapper.cpp:242-264 -- states [B,3,N+1], inputs [B,2,N+1] (Eigen shapes)
+    def setTrajectory(self, states, inputs) -> bool:
+        N = self.kSamples
+        st = self._b(states, (3, N + 1))
+        inp = self._b(inputs, (2, N + 1))
+        y = np.concatenate([st[:, :, :N].transpose(0, 2, 1), inp[:, :, :N].transpose(0, 2, 1)], axis=2)
+        self.eng.load({"y": y, "yN": st[:, :, N]})
+        return True
+
+    # mpc_wrapper.cpp:267-275
+    def solve(self, state) -> bool:
+        s = self._b(state, (3,))
+        N = self.kSamples
+        self.eng.load({"x": np.broadcast_to(s[:, None, :], (self.B, N + 1, 3)), "u": np.zeros((self.B, N, 2))})
+        return self.update(s)
+
+    # mpc_wrapper.cpp:279-373
+    def update(self, state, do_preparation: bool = True) -> bool:
+        if not self.acado_is_prepared_:
+            return False
+        self.eng.load({"x0": self._b(state, (3,))})
+        self.eng.rti(1)
+        self.acado_is_prepared_ = False
+        if do_preparation:
+            self.acado_is_prepared_ = True
+        return True
+
+    # mpc_wrapper.cpp:377-383
+    def prepare(self) -> bool:
+        self.acado_is_prepared_ = True
+        return True
+
+    # mpc_wrapper.cpp:386-410 (double out, Eigen shapes)
+    def getState(self, node_index: int):
+        return self.eng.t["x"][:, node_index, :].double().cpu().numpy()
+
+    def getStates(self):
+        return self.eng.t["x"].double().cpu().numpy().transpose(0, 2, 1)
+
+    def getInput(self, node_index: int):
+        return self.eng.t["u"][:, node_index, :].double().cpu().numpy()
+
+    def getInputs(self):
+        return self.eng.t["u"].double().cpu().numpy().transpose(0, 2, 1)
+
+    def getTimestep(self) -> float:
+        return self.dt_
+
+    def getStatus(self):
+        """Per-problem QP status (the reference computes and drops it, mpc_wrapper.cpp:298)."""
+        return self.eng.t["status"].cpu().numpy()

@@ -1,0 +1,156 @@
+/*
+ * alore_nmpc.h -- C ABI of the MI355X-native batched NMPC engine.
+ *
+ * Drop-in boundary for the hot path of ALORE's planning_ddr_opt/nmpc_controller:
+ * the ACADO-generated real-time-iteration solver for the planar ICR skid-steer
+ * model (NX=3, NU=2, NOD=3, NY=5, NYN=3, float32).  The reference exposes that
+ * solver as an `extern "C"` single-instance API over two process-global structs
+ *   (reference: planning_ddr_opt/nmpc_controller/UAV_CAR_model/build/
+ *    quadrotor_mpc_codegen/acado_common.h:104-162 ACADOvariables,
+ *    :170-257 ACADOworkspace, :271-341 function declarations;
+ *    acado_qpoases_interface.hpp:57-63 acado_solve/acado_getNWSR).
+ * This header is the batched form of that interface: the same member arrays,
+ * with one leading batch dimension, resident in GPU memory, solved by one kernel
+ * launch for B independent problems.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative ALORE_NMPC_E_* code;
+ *    nothing throws across this boundary;
+ *  - `alore_nmpc_batch` pointers are DEVICE pointers owned by the caller (or
+ *    obtained from alore_nmpc_batch_alloc); arrays are row-major with the
+ *    problem index outermost and, inside one problem, exactly the reference
+ *    layout (node-major);
+ *  - a handle is bound to one GPU, is not thread-safe, and distinct handles are
+ *    independent;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); all
+ *    work is enqueued on it and the calls do not synchronise unless documented.
+ */
+#ifndef ALORE_NMPC_H
+#define ALORE_NMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALORE_NMPC_NX 3   /* acado_common.h:73  ACADO_NX  */
+#define ALORE_NMPC_NU 2   /* acado_common.h:71  ACADO_NU  */
+#define ALORE_NMPC_NOD 3  /* acado_common.h:67  ACADO_NOD */
+#define ALORE_NMPC_NY 5   /* acado_common.h:79  ACADO_NY  */
+#define ALORE_NMPC_NYN 3  /* acado_common.h:81  ACADO_NYN */
+
+/* error codes (API level).  Per-problem solver status values are reported in
+ * alore_nmpc_batch.status and use qpOASES' returnValue numbers where one applies
+ * (0 ok, 31 Hessian not positive definite, 33 infeasible bounds,
+ * 58 iteration cap reached), as acado_feedbackStep() returns them
+ * (acado_solver.c:1067-1077). */
+#define ALORE_NMPC_OK 0
+#define ALORE_NMPC_E_INVALID (-1)   /* bad argument */
+#define ALORE_NMPC_E_NO_DEVICE (-2) /* no usable GPU / HIP runtime error at create */
+#define ALORE_NMPC_E_HIP (-3)       /* HIP runtime call failed; see alore_nmpc_last_error */
+#define ALORE_NMPC_E_NOMEM (-4)
+#define ALORE_NMPC_E_UNSUPPORTED (-5) /* horizon too long for the on-chip layout */
+
+typedef struct alore_nmpc_solver *alore_nmpc_handle;
+
+typedef struct {
+    int N;           /* horizon (shooting intervals); reference: ACADO_N = 50, acado_common.h:65 */
+    float dt;        /* interval length [s]; reference bakes 0.01 into the tableau, acado_integrator.c:255-257 */
+    int device;      /* HIP device ordinal */
+    int max_as_iter; /* cap on working-set iterations per QP (<=0: default 64); the
+                        reference caps working-set changes at 300, acado_qpoases_interface.hpp:44 */
+    int lanes_per_problem; /* 0 = choose from the batch size; else 4, 8, 16 or 32 */
+} alore_nmpc_config;
+
+/* Batched ACADOvariables + the QP dual carried between ticks + per-problem
+ * results.  B problems, horizon N.  In/out arrays are updated in place, as the
+ * reference updates acadoVariables.x/u and acadoWorkspace.y. */
+typedef struct {
+    float *x;              /* [B][(N+1)*3] in/out  acadoVariables.x  (x, y, psi per node)          */
+    float *u;              /* [B][N*2]     in/out  acadoVariables.u  (vr, vl per node)             */
+    const float *od;       /* [B][(N+1)*3] in      acadoVariables.od (xv, yr, yl per node)         */
+    const float *y;        /* [B][N*5]     in      acadoVariables.y  (x, y, psi, vr, vl reference) */
+    const float *yN;       /* [B][3]       in      acadoVariables.yN                              */
+    const float *W;        /* [B][N*25]    in      acadoVariables.W  (5x5 row-major per node; must be symmetric) */
+    const float *WN;       /* [B][9]       in      acadoVariables.WN (3x3; symmetric)              */
+    const float *x0;       /* [B][3]       in      acadoVariables.x0 (measured state)              */
+    const float *lbValues; /* [B][N*2]     in      acadoVariables.lbValues                         */
+    const float *ubValues; /* [B][N*2]     in      acadoVariables.ubValues                         */
+    float *dual;           /* [B][N*2]     in/out  acadoWorkspace.y: bound multipliers of the last
+                                                   QP (>0 lower active, <0 upper active); their signs
+                                                   seed the next working set (QProblemB.cpp:1010-1036) */
+    int *status;           /* [B] out  0 = solved; see above                                       */
+    int *n_iter;           /* [B] out  working-set iterations of the last QP (role of acado_getNWSR) */
+    float *kkt;            /* [B] out  acado_getKKT() of the last QP (acado_solver.c:1373-1391)     */
+    float *obj;            /* [B] out  acado_getObjective() at the returned iterate (:1393-1450)    */
+} alore_nmpc_batch;
+
+/* optional outputs of alore_nmpc_linearize: the reference's preparation-step
+ * workspace members, any pointer may be NULL */
+typedef struct {
+    float *d;    /* [B][N*3]  acadoWorkspace.d    shooting defects      */
+    float *evGx; /* [B][N*9]  acadoWorkspace.evGx d(phi)/dx, 3x3 per node */
+    float *evGu; /* [B][N*6]  acadoWorkspace.evGu d(phi)/du, 3x2 per node */
+} alore_nmpc_lin_out;
+
+/* ---- lifetime ---------------------------------------------------------- */
+/* replaces acado_initializeSolver() (acado_solver.c:1079-1290) for a batch */
+int alore_nmpc_create(const alore_nmpc_config *cfg, alore_nmpc_handle *out);
+int alore_nmpc_destroy(alore_nmpc_handle h);
+const char *alore_nmpc_last_error(alore_nmpc_handle h); /* text of the last failure (never NULL) */
+const char *alore_nmpc_version(void);
+
+/* ---- device batch storage (convenience; callers may bring their own) ---- */
+int alore_nmpc_batch_alloc(alore_nmpc_handle h, int B, alore_nmpc_batch *out); /* hipMalloc every member */
+int alore_nmpc_batch_free(alore_nmpc_handle h, alore_nmpc_batch *b);
+/* host <-> device copies of whole members, `host` holds HOST pointers laid out
+ * like the device batch; NULL members are skipped.  Asynchronous on `stream`. */
+int alore_nmpc_batch_upload(alore_nmpc_handle h, const alore_nmpc_batch *dev, const alore_nmpc_batch *host,
+                            int B, void *stream);
+int alore_nmpc_batch_download(alore_nmpc_handle h, const alore_nmpc_batch *dev, const alore_nmpc_batch *host,
+                              int B, void *stream);
+/* fill lbValues/ubValues with the model's baked bounds -3/+3
+ * (acado_solver.c:1088-1288, from UAV_CAR_model.cpp:97-101) */
+int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, void *stream);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* n_sqp real-time iterations for B problems in one launch.  One iteration is
+ * acado_preparationStep() on (x,u) followed by acado_feedbackStep()
+ * (acado_solver.c:1057-1077): integrate + sensitivities, objective, QP, expand.
+ * n_sqp = 1 is one reference control tick (MpcWrapper::update,
+ * mpc_wrapper.cpp:279-373).  x, u, dual are updated in place; status, n_iter,
+ * kkt, obj are written. */
+int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int n_sqp, void *stream);
+
+/* preparation-side quantities only (acado_modelSimulation, acado_solver.c:35-78):
+ * writes d / evGx / evGu in the reference layout.  Does not touch the batch. */
+int alore_nmpc_linearize(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, const alore_nmpc_lin_out *out,
+                         void *stream);
+
+/* replaces acado_initializeNodesByForwardSimulation() (acado_solver.c:1292-1312):
+ * x[k+1] <- phi(x[k], u[k]) for k = 0..N-1 */
+int alore_nmpc_forward_simulate(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, void *stream);
+
+/* replaces acado_shiftStates(strategy, xEnd, uEnd) + acado_shiftControls(uEnd)
+ * (acado_solver.c:1314-1371).  xEnd [B][3] / uEnd [B][2] are device pointers or NULL. */
+int alore_nmpc_shift(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int strategy, const float *xEnd,
+                     const float *uEnd, void *stream);
+
+/* ---- introspection ------------------------------------------------------- */
+typedef struct {
+    int lanes_per_problem;  /* of the last alore_nmpc_rti launch */
+    int problems_per_block;
+    int threads_per_block;
+    int grid;
+    int lds_bytes_per_block;
+    float last_kernel_ms;   /* HIP-event duration of the last alore_nmpc_rti launch when timing
+                               is enabled (alore_nmpc_set_timing), else -1 */
+} alore_nmpc_launch_info;
+int alore_nmpc_get_launch_info(alore_nmpc_handle h, alore_nmpc_launch_info *out);
+/* enable = 1: bracket every alore_nmpc_rti launch with HIP events on its stream;
+ * alore_nmpc_get_launch_info then synchronises on the stop event. */
+int alore_nmpc_set_timing(alore_nmpc_handle h, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALORE_NMPC_H */

@@ -1,0 +1,235 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+fixtures generated from the compiled reference.  Needs a real MI355X.
+
+Tolerances (float32 path, BASELINE.json: trajectories within 1e-4 relative of
+the CPU reference): per RTI tick from identical inputs, max-abs error relative
+to max(1, largest entry) < 1e-4 for x and u, < 1e-3 for the multipliers; the
+linearisation (d, Gx, Gu) < 2e-6 absolute.  The reference's own QP solutions
+carry errors of a few 1e-5 (float32 homotopy), which is the floor."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from alore_legged_manipulator_amd.scenarios import make_batch, problem  # noqa: E402
+from oracle.drivers import Oracle  # noqa: E402
+
+IN_KEYS = ("x", "u", "od", "y", "yN", "W", "WN", "x0", "lbValues", "ubValues", "dual")
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
+
+
+def oracle_tick(orc, p):
+    orc.reset()
+    orc.initialize_solver()
+    orc.load(p)
+    orc.preparation_step()
+    st = orc.feedback_step()
+    return st, {k: orc.v[k].copy() for k in ("x", "u", "dual", "dx", "d", "evGx", "evGu")}, orc.get_kkt()
+
+
+@pytest.fixture(scope="module")
+def nmpc_mod():
+    from alore_legged_manipulator_amd import nmpc
+    return nmpc
+
+
+@pytest.mark.parametrize("N,L", [(20, 0), (20, 4), (20, 8), (20, 16), (20, 32), (50, 0), (50, 32), (7, 0), (1, 0)])
+def test_one_tick_matches_oracle(nmpc_mod, N, L):
+    B = 96 if N <= 20 else 40
+    batch = make_batch(B, N, seed=1234 + N, fast_tail=0.3)
+    eng = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=L)
+    eng.load(batch)
+    lin = eng.linearize()
+    eng.rti(1)
+    out = eng.fetch()
+    orc = Oracle(N)
+    for b in range(B):
+        st, ref, kkt = oracle_tick(orc, problem(batch, b))
+        assert st == 0 and out["status"][b] == 0
+        assert np.max(np.abs(lin["d"][b].reshape(-1) - ref["d"])) < 2e-6
+        assert np.max(np.abs(lin["evGx"][b].reshape(-1) - ref["evGx"])) < 2e-6
+        assert np.max(np.abs(lin["evGu"][b].reshape(-1) - ref["evGu"])) < 2e-6
+        assert relerr(out["x"][b].reshape(-1), ref["x"]) < 1e-4, (b, "x")
+        assert relerr(out["u"][b].reshape(-1), ref["u"]) < 1e-4, (b, "u")
+        assert relerr(out["dual"][b].reshape(-1), ref["dual"]) < 1e-3, (b, "dual")
+        assert abs(out["kkt"][b] - kkt) <= 2e-3 * max(1.0, kkt), (b, out["kkt"][b], kkt)
+        assert 1 <= out["n_iter"][b] <= 16
+
+
+@pytest.mark.parametrize("N", [20, 50])
+def test_sqp_iterations_in_kernel(nmpc_mod, N):
+    """K real-time iterations inside one launch == K ticks of the oracle (feasible
+    references; the full-step Gauss-Newton iteration is contractive there)."""
+    B, K = 32, 15
+    batch = make_batch(B, N, seed=99, fast_tail=0.0)
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    eng.load(batch)
+    eng.rti(K)
+    out = eng.fetch()
+    orc = Oracle(N)
+    for b in range(B):
+        orc.reset()
+        orc.initialize_solver()
+        orc.load(problem(batch, b))
+        for _ in range(K):
+            orc.preparation_step()
+            assert orc.feedback_step() == 0
+        assert out["status"][b] == 0
+        assert relerr(out["x"][b].reshape(-1), orc.v["x"]) < 1e-4
+        assert relerr(out["u"][b].reshape(-1), orc.v["u"]) < 1e-4
+        obj = orc.get_objective()
+        assert abs(out["obj"][b] - obj) <= 1e-4 * max(1.0, abs(obj))
+
+
+def test_golden_n50_ticks(nmpc_mod, golden_dir):
+    """All 10 scenarios x 15 ticks of the compiled reference (tests/golden/nmpc_n50.npz),
+    one batch per tick, each tick started from the reference's own iterate."""
+    G = np.load(os.path.join(golden_dir, "nmpc_n50.npz"))
+    S, K = int(G["n_scen"]), int(G["K"])
+    eng = nmpc_mod.BatchedNmpc(S, 50)
+    cur = {k: np.stack([G[f"s{s}_in_{k}"] for s in range(S)]) for k in IN_KEYS}
+    for it in range(K):
+        eng.load(cur)
+        eng.rti(1)
+        out = eng.fetch()
+        for s in range(S):
+            assert out["status"][s] == 0
+            assert relerr(out["x"][s].reshape(-1), G[f"s{s}_x"][it]) < 1e-4, (s, it)
+            assert relerr(out["u"][s].reshape(-1), G[f"s{s}_u"][it]) < 1e-4, (s, it)
+            assert relerr(out["dual"][s].reshape(-1), G[f"s{s}_dual"][it]) < 1e-3, (s, it)
+            assert abs(out["kkt"][s] - G[f"s{s}_kkt"][it]) <= 2e-3 * max(1.0, G[f"s{s}_kkt"][it])
+        cur = dict(cur, x=np.stack([G[f"s{s}_x"][it] for s in range(S)]),
+                   u=np.stack([G[f"s{s}_u"][it] for s in range(S)]),
+                   dual=np.stack([G[f"s{s}_dual"][it] for s in range(S)]))
+
+
+def test_golden_n20_embedded(nmpc_mod, golden_dir):
+    G = np.load(os.path.join(golden_dir, "nmpc_n20_embedded.npz"))
+    S, K, N = int(G["n_scen"]), int(G["K"]), int(G["N"])
+    eng = nmpc_mod.BatchedNmpc(S, N)
+    cur = {k: np.stack([G[f"s{s}_in_{k}"] for s in range(S)]) for k in IN_KEYS}
+    for it in range(K):
+        eng.load(cur)
+        eng.rti(1)
+        out = eng.fetch()
+        for s in range(S):
+            assert out["status"][s] == G[f"s{s}_status"][it] == 0
+            assert relerr(out["x"][s].reshape(-1), G[f"s{s}_x"][it]) < 1e-4
+            assert relerr(out["u"][s].reshape(-1), G[f"s{s}_u"][it]) < 1e-4
+        cur = dict(cur, x=np.stack([G[f"s{s}_x"][it] for s in range(S)]),
+                   u=np.stack([G[f"s{s}_u"][it] for s in range(S)]),
+                   dual=np.stack([G[f"s{s}_dual"][it] for s in range(S)]))
+
+
+def test_ragged_batch_and_full_size_properties(nmpc_mod):
+    """B = 4096 (BASELINE config 2) and a batch size that is not a multiple of the
+    problems per workgroup.  Size-independent properties: every problem of the
+    big batch equals the same problem solved in a small batch (bitwise, the
+    kernel is deterministic and problems are independent); the returned
+    controls respect the bounds; KKT values are finite."""
+    N = 20
+    big = make_batch(4096, N, fast_tail=0.05)
+    eng = nmpc_mod.BatchedNmpc(4096, N)
+    eng.load(big)
+    eng.rti(1)
+    out = eng.fetch()
+    assert (out["status"] == 0).all()
+    assert np.isfinite(out["kkt"]).all() and np.isfinite(out["obj"]).all()
+    assert (out["u"] <= big["ubValues"] + 1e-6).all() and (out["u"] >= big["lbValues"] - 1e-6).all()
+    idx = np.array([0, 1, 63, 64, 777, 2048, 4094, 4095, 3001, 17, 18])  # 11 problems: ragged last block
+    small = {k: v[idx] for k, v in big.items()}
+    eng2 = nmpc_mod.BatchedNmpc(len(idx), N, lanes_per_problem=eng.launch_info()["lanes_per_problem"])
+    eng2.load(small)
+    eng2.rti(1)
+    out2 = eng2.fetch()
+    for k in ("x", "u", "dual"):
+        np.testing.assert_array_equal(out[k][idx], out2[k])
+    # and against the oracle on a sample
+    orc = Oracle(N)
+    for b in idx:
+        st, ref, _ = oracle_tick(orc, problem(big, int(b)))
+        assert st == 0
+        assert relerr(out["u"][b].reshape(-1), ref["u"]) < 1e-4
+
+
+def test_idempotent_at_fixed_point(nmpc_mod):
+    """At a converged iterate with x0 = x[0] a further tick must not move (property)."""
+    N, B = 20, 64
+    batch = make_batch(B, N, seed=5, fast_tail=0.0)
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    eng.load(batch)
+    eng.rti(30)
+    a = eng.fetch()
+    eng.load({"x0": a["x"][:, 0, :]})
+    eng.rti(1)
+    b = eng.fetch()
+    assert np.max(np.abs(a["u"] - b["u"])) < 5e-5
+    assert np.max(np.abs(a["x"] - b["x"])) < 5e-5
+
+
+def test_edge_bounds(nmpc_mod):
+    """Equality bounds (lb == ub) pin a control; lb > ub is reported as infeasible (33)."""
+    N, B = 20, 8
+    batch = make_batch(B, N, seed=8)
+    batch["lbValues"][0, 3, 0] = 0.5
+    batch["ubValues"][0, 3, 0] = 0.5
+    batch["lbValues"][1, 2, 1] = 1.0
+    batch["ubValues"][1, 2, 1] = -1.0
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    eng.load(batch)
+    eng.rti(1)
+    out = eng.fetch()
+    assert out["status"][0] == 0 and abs(out["u"][0, 3, 0] - 0.5) < 1e-6
+    assert out["status"][1] == 33
+    assert (out["status"][2:] == 0).all()
+    orc = Oracle(N)
+    st, ref, _ = oracle_tick(orc, problem(batch, 0))
+    assert st == 0 and relerr(out["u"][0].reshape(-1), ref["u"]) < 1e-4
+
+
+def test_shift_and_forward_sim_match_oracle(nmpc_mod):
+    N, B = 20, 16
+    batch = make_batch(B, N, seed=21)
+    rng = np.random.default_rng(2)
+    batch["u"] = rng.uniform(-2, 2, batch["u"].shape).astype(np.float32)
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    eng.load(batch)
+    eng.forward_simulate()
+    uend = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+    eng.shift(2, None, uend)
+    out = eng.fetch(("x", "u"))
+    orc = Oracle(N)
+    for b in range(B):
+        orc.reset(); orc.initialize_solver(); orc.load(problem(batch, b))
+        orc.initialize_nodes_by_forward_simulation()
+        orc.shift_states(2, None, uend[b])
+        orc.shift_controls(uend[b])
+        assert np.max(np.abs(out["x"][b].reshape(-1) - orc.v["x"])) < 5e-6
+        np.testing.assert_array_equal(out["u"][b].reshape(-1), orc.v["u"])
+
+
+def test_mpc_wrapper_mirror(nmpc_mod):
+    """BatchedMpcWrapper (mirror of Tracked_nmpc::MpcWrapper): setCosts /
+    setICRParameters / setTrajectory / solve, against the oracle driven the way
+    the reference wrapper drives ACADO."""
+    N, B = 20, 12
+    batch = make_batch(B, N, seed=314)
+    w = nmpc_mod.BatchedMpcWrapper(B, N, Q=np.diag([10, 10, 0.5]), R=np.diag([0.1, 0.1]))
+    w.setICRParameters(batch["od"][:, 0, :])
+    states = np.concatenate([batch["y"][:, :, :3], batch["yN"][:, None, :]], 1).transpose(0, 2, 1)
+    inputs = np.concatenate([batch["y"][:, :, 3:], batch["y"][:, -1:, 3:]], 1).transpose(0, 2, 1)
+    w.setTrajectory(states, inputs)
+    assert w.solve(batch["x0"])
+    U = w.getInputs()
+    X = w.getStates()
+    assert U.shape == (B, 2, N) and X.shape == (B, 3, N + 1) and U.dtype == np.float64
+    orc = Oracle(N)
+    for b in range(B):
+        st, ref, _ = oracle_tick(orc, problem(batch, b))
+        assert relerr(U[b].T.reshape(-1).astype(np.float32), ref["u"]) < 1e-4
+        assert relerr(X[b].T.reshape(-1).astype(np.float32), ref["x"]) < 1e-4
