@@ -73,6 +73,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (same soname as /opt/rocm's): import it
+    # first so that the whole process runs on ONE runtime
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NmpcLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -180,6 +180,12 @@ __global__ __launch_bounds__(256) void rti_kernel(const RtiParams p)
                 ROW(F_Q11, k) = w[4]; ROW(F_Q12, k) = w[5]; ROW(F_Q22, k) = w[8];
             }
         }
+        { // a lane only saw its own stages: OR the flag over the group
+            int inf = infeasible ? 1 : 0;
+#pragma unroll
+            for (int off = L / 2; off > 0; off >>= 1) inf |= __shfl_xor(inf, off, L);
+            infeasible = inf != 0;
+        }
         __syncthreads();
 
         const float Dx0 = x00 - ROW(F_X0, 0), Dx1 = x01 - ROW(F_X1, 0), Dx2 = x02 - ROW(F_X2, 0);
@@ -355,12 +361,17 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
     hipError_t e = hipSuccess;
     switch (g.L) {
 #define CASE(LL)                                                                                             \
-    case LL:                                                                                                 \
-        e = hipFuncSetAttribute((const void*)rti_kernel<LL>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                (int)g.lds_bytes);                                                           \
-        if (e != hipSuccess) return e;                                                                       \
+    case LL: {                                                                                               \
+        static size_t configured = 0; /* raise the dynamic-LDS cap once per size, not per launch */          \
+        if (g.lds_bytes > configured) {                                                                      \
+            e = hipFuncSetAttribute((const void*)rti_kernel<LL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)g.lds_bytes);                                                       \
+            if (e != hipSuccess) return e;                                                                   \
+            configured = g.lds_bytes;                                                                        \
+        }                                                                                                    \
         hipLaunchKernelGGL(rti_kernel<LL>, grid, block, g.lds_bytes, s, p);                                  \
-        break;
+        break;                                                                                               \
+    }
         CASE(4)
         CASE(8)
         CASE(16)

@@ -37,29 +37,37 @@ def member_shapes(B: int, N: int) -> dict:
 class BatchedNmpc:
     """B independent NMPC instances on one GPU.
 
-    ``self.t[name]`` are the device tensors (float32; status/n_iter int32)."""
+    ``self.t[name]`` are the device tensors (float32; status/n_iter int32) of
+    slot 0.  ``slots`` > 1 allocates that many independent copies of the whole
+    batch (``self.ts[name]`` has a leading slot dimension); the benchmark uses
+    one slot per timed step so that every step reads its inputs from HBM and
+    starts from the same iterate."""
 
     def __init__(self, B: int, N: int = 20, dt: float = 0.01, device: int = 0, max_as_iter: int = 64,
-                 lanes_per_problem: int = 0):
+                 lanes_per_problem: int = 0, slots: int = 1):
         import torch  # device memory + streams
         self.torch = torch
         self.lib = _lib.load()  # raises if the HIP library is missing: no fallback
         if not torch.cuda.is_available():
             raise _lib.NmpcLibraryError("no GPU visible to torch: the NMPC engine has no CPU path")
-        self.B, self.N, self.dt = int(B), int(N), float(dt)
+        self.B, self.N, self.dt, self.slots = int(B), int(N), float(dt), int(slots)
         self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
         cfg = Config(self.N, self.dt, device, max_as_iter, lanes_per_problem)
         h = C.c_void_p()
         rc = self.lib.alore_nmpc_create(C.byref(cfg), C.byref(h))
         if rc != 0:
             raise NmpcError(rc, "alore_nmpc_create failed")
         self.h = h
-        self.t = {}
+        self.ts = {}
         for k, shp in member_shapes(self.B, self.N).items():
             dt_ = torch.int32 if k in ("status", "n_iter") else torch.float32
-            self.t[k] = torch.zeros(shp, dtype=dt_, device=self.device)
-        self._batch = Batch(**{k: self.t[k].data_ptr() for k in BATCH_MEMBERS})
-        self._check(self.lib.alore_nmpc_batch_default_bounds(self.h, C.byref(self._batch), self.B, self._stream()))
+            self.ts[k] = torch.zeros((self.slots,) + shp, dtype=dt_, device=self.device)
+        self.t = {k: v[0] for k, v in self.ts.items()}
+        self._batches = [Batch(**{k: self.ts[k][s].data_ptr() for k in BATCH_MEMBERS}) for s in range(self.slots)]
+        self._batch = self._batches[0]
+        for b in self._batches:
+            self._check(self.lib.alore_nmpc_batch_default_bounds(self.h, C.byref(b), self.B, self._stream()))
 
     # -- plumbing
     def _stream(self):
@@ -81,24 +89,29 @@ class BatchedNmpc:
             pass
 
     # -- data
-    def load(self, batch: dict) -> None:
-        """Copy host arrays (any subset of the float members) to the device."""
+    def load(self, batch: dict, slot: Optional[int] = 0) -> None:
+        """Copy host arrays (any subset of the float members) to the device;
+        ``slot=None`` fills every slot."""
         torch = self.torch
         shapes = member_shapes(self.B, self.N)
         for k, v in batch.items():
             if k not in BATCH_FLOAT_MEMBERS:
                 continue
-            a = np.ascontiguousarray(v, dtype=np.float32).reshape(shapes[k])
-            self.t[k].copy_(torch.from_numpy(a), non_blocking=False)
+            a = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32).reshape(shapes[k]))
+            if slot is None:
+                d = a.to(self.device)
+                self.ts[k].copy_(d.unsqueeze(0).expand_as(self.ts[k]))
+            else:
+                self.ts[k][slot].copy_(a, non_blocking=False)
 
-    def fetch(self, names=("x", "u", "dual", "status", "n_iter", "kkt", "obj")) -> dict:
+    def fetch(self, names=("x", "u", "dual", "status", "n_iter", "kkt", "obj"), slot: int = 0) -> dict:
         self.torch.cuda.synchronize(self.device)
-        return {k: self.t[k].detach().cpu().numpy().copy() for k in names}
+        return {k: self.ts[k][slot].detach().cpu().numpy().copy() for k in names}
 
     # -- the hot path
-    def rti(self, n_sqp: int = 1) -> None:
+    def rti(self, n_sqp: int = 1, slot: int = 0) -> None:
         """n_sqp x (acado_preparationStep + acado_feedbackStep) for the whole batch, one launch."""
-        self._check(self.lib.alore_nmpc_rti(self.h, C.byref(self._batch), self.B, int(n_sqp), self._stream()))
+        self._check(self.lib.alore_nmpc_rti(self.h, C.byref(self._batches[slot]), self.B, int(n_sqp), self._stream()))
 
     def linearize(self) -> dict:
         torch = self.torch

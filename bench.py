@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""bench.py -- NMPC solves/s of the batched real-time-iteration kernel on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one pass of the hot path over one batch: `alore_nmpc_rti(n_sqp=1)` on
+B = 4096 planar ICR-DDR NMPC problems per GPU (BASELINE.json configs[1]: 3
+states, 2 controls, horizon N = 20), i.e. for every problem exactly what one
+control tick of the reference does (acado_preparationStep + acado_feedbackStep),
+started from the cold start of MpcWrapper::solve (x <- x0 replicated, u <- 0).
+Inputs are synthetic (alore_legged_manipulator_amd/scenarios.py),
+resident in HBM before the timed region; every timed step works on its own
+fresh copy of the batch ("slot") so that all steps do identical work and read
+their inputs from HBM rather than from cache.
+
+Multi-GPU (weak scaling): every rank owns its own B problems (block partition
+of the global index, no data-path communication); the result trajectories
+(x, u, status, kkt) are collected with RCCL all-gathers issued asynchronously in
+buckets of several steps, all completed inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3  # vector FP32 spec peak
+
+
+def algorithmic_bytes_per_solve(N: int) -> int:
+    """Full reference I/O contract per RTI-solve, float32:
+    read 44N+21, write 7N+7 floats."""
+    return 4 * (51 * N + 28)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = auto)")
+    ap.add_argument("--gather", choices=("full", "none"), default="full",
+                    help="multi-GPU: all-gather the result trajectories (default) or keep them sharded")
+    ap.add_argument("--gather-every", type=int, default=16, help="steps per all-gather bucket")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
+    return ap.parse_args()
+
+
+def cpu_baseline(N: int, batch: dict, seconds: float) -> dict:
+    """The oracle (our C restatement of the reference, validated bit-exact against the
+    compiled reference at N=50) timed on the host cores: one solver instance per
+    thread, distinct problems of the bench batch, repeated RTI ticks from the
+    same cold start.  Baseline only -- not the target."""
+    import threading
+
+    from alore_legged_manipulator_amd.scenarios import problem
+    from oracle.drivers import Oracle, RefAcado, ref_available
+
+    cores = os.cpu_count() or 1
+    probs = [problem(batch, b) for b in range(min(64, batch["x"].shape[0]))]
+    # calibrate on one core
+    o = Oracle(N)
+    o.reset(); o.initialize_solver(); o.load(probs[0])
+    t = o.time_rti(200)
+    per_tick = t / 200
+    iters = max(50, int(seconds / cores / max(per_tick, 1e-7) / max(1, len(probs) // cores)))
+    counts = [0] * cores
+    def work(tid):
+        orc = Oracle(N)
+        mine = probs[tid::cores] or probs[:1]
+        for p in mine:
+            orc.reset(); orc.initialize_solver(); orc.load(p)
+            orc.time_rti(iters)
+            counts[tid] += iters
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    wall = time.perf_counter() - t0
+    out = {"value": sum(counts) / wall, "unit": "solves/s", "cores": cores, "kind": "port",
+           "sample": f"{len(probs)} problems of the bench batch x {iters} RTI ticks each (N={N}), "
+                     f"oracle/nmpc_oracle.c -O3, {cores} threads, {wall:.1f} s wall",
+           "single_core_us_per_solve": per_tick * 1e6}
+    if ref_available():  # the reference's own code, N = 50 only: reported next to it, for scale
+        try:
+            from alore_legged_manipulator_amd.scenarios import make_batch
+            r = RefAcado()
+            r.reset(); r.initialize_solver(); r.load(problem(make_batch(1, r.N), 0))
+            tr = r.time_rti(300) / 300
+            out["reference_n50_single_core_us_per_solve"] = tr * 1e6
+        except Exception as e:  # pragma: no cover
+            out["reference_n50_error"] = str(e)
+    return out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    from alore_legged_manipulator_amd.nmpc import BatchedNmpc
+    from alore_legged_manipulator_amd.scenarios import make_batch
+    from alore_legged_manipulator_amd.shard import ResultGatherer
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    B, N = a.batch, a.horizon
+    slots = a.steps + a.warmup
+    # rank r owns global problems [r*B, (r+1)*B): generated locally from the seeded stream
+    batch = make_batch(B, N, offset=rank * B)
+    eng = BatchedNmpc(B, N, device=local_rank, lanes_per_problem=a.lanes, slots=slots)
+    eng.load(batch, slot=None)
+    torch.cuda.synchronize(dev)
+
+    do_gather = world > 1 and a.gather == "full"
+    gatherer = ResultGatherer(dist, world) if do_gather else None
+    ge = max(1, a.gather_every)
+
+    def run_steps(first, count):
+        for i in range(first, first + count):
+            eng.rti(1, slot=i)
+            if do_gather and ((i - first + 1) % ge == 0 or i == first + count - 1):
+                lo = first + ((i - first) // ge) * ge
+                gatherer.submit({"x": eng.ts["x"][lo:i + 1], "u": eng.ts["u"][lo:i + 1],
+                                 "status": eng.ts["status"][lo:i + 1], "kkt": eng.ts["kkt"][lo:i + 1]})
+        if do_gather:
+            gatherer.wait()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # warm-up (untimed)
+    run_steps(0, a.warmup)
+    barrier()
+
+    # the K timed steps, captured once into a hipGraph where possible (single GPU):
+    # K kernel nodes, no host launch overhead inside the timed region
+    graph = None
+    used_graph = False
+    if not a.no_graph and world == 1 and a.steps > 0:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    run_steps(a.warmup, a.steps)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = g
+            used_graph = True
+        except Exception as e:  # fall back to eager launches
+            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize(dev)
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    if graph is not None:
+        graph.replay()
+    else:
+        run_steps(a.warmup, a.steps)
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    # every timed step must have solved every problem
+    st = eng.ts["status"][a.warmup:a.warmup + a.steps]
+    n_bad = int((st != 0).sum().item())
+    n_iter_mean = float(eng.ts["n_iter"][a.warmup:a.warmup + a.steps].float().mean().item())
+
+    if world > 1:
+        tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(tt[0].item()), float(tt[1].item())
+        nb = torch.tensor([n_bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(nb)
+        n_bad = int(nb.item())
+
+    info = eng.launch_info()
+    result = None
+    if rank == 0:
+        total_solves = float(B) * world * a.steps
+        value = total_solves / elapsed
+        ms_per_step = elapsed / a.steps * 1e3
+        kern_ms = dev_ms / a.steps  # average launch duration of the dominant kernel (HIP events, launch stream)
+        bytes_per_launch = algorithmic_bytes_per_solve(N) * B
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(f"B{B}_N{N}", {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        flops_per_solve = 350.0 * N + n_iter_mean * 160.0 * N  # stage-wise algorithm, see DESIGN.md
+        result = {
+            "metric": "nmpc_rti_solves_per_s", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"B={B} per GPU planar ICR-DDR NMPC (3 states, 2 controls), horizon N={N}, "
+                                   "one real-time iteration (prepare+feedback) per problem from the "
+                                   "MpcWrapper::solve cold start, full reference I/O contract",
+                       "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "dt": 0.01,
+                       "parallelism": f"independent shards x{world}" + (", result all-gather" if do_gather else ""),
+                       "lanes_per_problem": info["lanes_per_problem"], "threads_per_block": info["threads_per_block"],
+                       "lds_bytes_per_block": info["lds_bytes_per_block"], "hip_graph": used_graph},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "nmpc::rti_kernel", "kernel_ms_avg": kern_ms,
+                         "algorithmic_bytes_per_solve": algorithmic_bytes_per_solve(N),
+                         "fp32_frac": value / world * flops_per_solve / (FP32_PEAK_TFLOPS * 1e12)},
+            "unsolved_problems": n_bad, "working_set_iters_mean": n_iter_mean,
+        }
+
+    # ---- extras on rank 0 of a single-GPU run: latency, converged solves, large batch, CPU baseline
+    if rank == 0 and world == 1 and not a.no_extras:
+        extras = {}
+        # p50/p99 of one synchronous launch (what a caller of the C ABI sees), B = 4096 and small batches
+        lat = {}
+        for b_lat in (B, 64, 1):
+            hb = batch if b_lat == B else make_batch(b_lat, N)
+            e2 = eng if b_lat == B else BatchedNmpc(b_lat, N, device=local_rank)
+            if b_lat != B:
+                e2.load(hb, slot=None)
+            xs0, us0, ds0 = (torch.from_numpy(hb[k]).to(dev) for k in ("x", "u", "dual"))
+            ts = []
+            for i in range(350):
+                e2.ts["x"][0].copy_(xs0); e2.ts["u"][0].copy_(us0); e2.ts["dual"][0].copy_(ds0)
+                torch.cuda.synchronize(dev)
+                t_a = time.perf_counter()
+                e2.rti(1, slot=0)
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t_a)
+            ts = np.array(ts[50:]) * 1e3
+            lat[f"B{b_lat}"] = {"p50_ms": float(np.percentile(ts, 50)), "p99_ms": float(np.percentile(ts, 99))}
+        extras["launch_latency"] = lat
+        # converged solve: K = 15 real-time iterations inside one launch
+        e3 = BatchedNmpc(B, N, device=local_rank, slots=12)
+        e3.load(batch, slot=None)
+        e3.rti(15, slot=0); e3.rti(15, slot=1)
+        torch.cuda.synchronize(dev)
+        c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for i in range(2, 12):
+            e3.rti(15, slot=i)
+        c1.record(); torch.cuda.synchronize(dev)
+        ms15 = c0.elapsed_time(c1) / 10
+        extras["converged_solve_k15"] = {"ms_per_launch": ms15, "solves_per_s": B / (ms15 * 1e-3)}
+        del e3
+        # large batch (BASELINE configs[3] per-GPU share: 262144 / 8)
+        Bl = 32768
+        try:
+            e4 = BatchedNmpc(Bl, N, device=local_rank, slots=24)
+            e4.load(make_batch(Bl, N), slot=None)
+            e4.rti(1, slot=0); e4.rti(1, slot=1)
+            torch.cuda.synchronize(dev)
+            c0.record()
+            for i in range(2, 24):
+                e4.rti(1, slot=i)
+            c1.record(); torch.cuda.synchronize(dev)
+            msl = c0.elapsed_time(c1) / 22
+            gbs = algorithmic_bytes_per_solve(N) * Bl / (msl * 1e-3) / 1e9
+            extras["large_batch"] = {"batch": Bl, "ms_per_launch": msl, "solves_per_s": Bl / (msl * 1e-3),
+                                     "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                                     "lanes_per_problem": e4.launch_info()["lanes_per_problem"]}
+            del e4
+        except Exception as e:  # pragma: no cover
+            extras["large_batch"] = {"error": str(e)}
+        result["extras"] = extras
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(N, batch, a.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
