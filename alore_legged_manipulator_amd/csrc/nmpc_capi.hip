@@ -2,7 +2,9 @@
 // Thin host layer: argument checks, launch geometry, HIP stream/event plumbing.
 // There is no CPU path behind this ABI: without a GPU alore_nmpc_create fails.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <new>
 #include <string>
 
@@ -20,6 +22,13 @@ struct alore_nmpc_solver {
     bool timed_pending = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = -1.0f;
+    // diagnostic phase stamps (env ALORE_NMPC_STAMPS=1): per-phase cycle shares, printed at destroy
+    bool stamps = false;
+    long long* d_stamps = nullptr;
+    size_t stamps_cap = 0;
+    double stamp_sum[6] = {0, 0, 0, 0, 0, 0};
+    double stamp_max_total = 0;
+    long stamp_n = 0;
 };
 
 namespace {
@@ -99,7 +108,7 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     *out = nullptr;
     if (cfg->N < 1 || !(cfg->dt > 0.0f)) return ALORE_NMPC_E_INVALID;
     if (cfg->lanes_per_problem != 0 && cfg->lanes_per_problem != 4 && cfg->lanes_per_problem != 8 &&
-        cfg->lanes_per_problem != 16 && cfg->lanes_per_problem != 32)
+        cfg->lanes_per_problem != 16 && cfg->lanes_per_problem != 32 && cfg->lanes_per_problem != 64)
         return ALORE_NMPC_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ALORE_NMPC_E_NO_DEVICE;
@@ -126,6 +135,8 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
         delete h;
         return ALORE_NMPC_E_HIP;
     }
+    const char* st = std::getenv("ALORE_NMPC_STAMPS");
+    h->stamps = st && st[0] == '1';
     *out = h;
     return ALORE_NMPC_OK;
 }
@@ -133,6 +144,16 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
 int alore_nmpc_destroy(alore_nmpc_handle h)
 {
     if (!h) return ALORE_NMPC_E_INVALID;
+    if (h->stamps && h->stamp_n > 0) {
+        static const char* names[6] = {"load+linearise", "backward sweeps", "forward sweeps", "kkt+expand",
+                                       "objective+store", "total"};
+        std::fprintf(stderr, "[alore_nmpc stamps] mean cycles per workgroup over %ld workgroup-launches:\n", h->stamp_n);
+        for (int i = 0; i < 6; ++i)
+            std::fprintf(stderr, "  %-16s %10.0f  (%5.1f %%)\n", names[i], h->stamp_sum[i] / h->stamp_n,
+                         100.0 * h->stamp_sum[i] / h->stamp_sum[5]);
+        std::fprintf(stderr, "  slowest workgroup total: %.0f cycles\n", h->stamp_max_total);
+    }
+    if (h->d_stamps) (void)hipFree(h->d_stamps);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -229,7 +250,17 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     p.RS = g.RS;
     const nmpc::IrkConst K = nmpc::make_irk(h->cfg.dt);
     p.h = K.h; p.hh = K.hh; p.c1h = K.c1h; p.c2h = K.c2h;
+    p.stamps = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    if (h->stamps) {
+        const size_t need = (size_t)g.grid * 8;
+        if (need > h->stamps_cap) {
+            if (h->d_stamps) (void)hipFree(h->d_stamps);
+            HIP_TRY(h, hipMalloc((void**)&h->d_stamps, need * sizeof(long long)));
+            h->stamps_cap = need;
+        }
+        p.stamps = h->d_stamps;
+    }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
     HIP_TRY(h, nmpc::launch_rti(p, g, s));
     if (h->timing) {
@@ -238,6 +269,16 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     }
     h->last_geom = g;
     h->have_geom = true;
+    if (h->stamps) { // diagnostic mode: synchronous, never used for timing
+        std::vector<long long> host((size_t)g.grid * 8);
+        HIP_TRY(h, hipStreamSynchronize(s));
+        HIP_TRY(h, hipMemcpy(host.data(), h->d_stamps, host.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int b = 0; b < g.grid; ++b) {
+            for (int i = 0; i < 6; ++i) h->stamp_sum[i] += (double)host[(size_t)b * 8 + i];
+            if ((double)host[(size_t)b * 8 + 5] > h->stamp_max_total) h->stamp_max_total = (double)host[(size_t)b * 8 + 5];
+        }
+        h->stamp_n += g.grid;
+    }
     return ALORE_NMPC_OK;
 }
 

@@ -2,7 +2,7 @@
 //
 // Device functions used by the HIP kernels in nmpc_kernels.hip.  They are plain
 // scalar float32 code (one value per lane), so the same header also compiles
-// with a host compiler: tests/cpu_core_harness.cpp strings the functions
+// with a host compiler: tests/harness/cpu_core_harness.cpp strings the functions
 // together for ONE problem on the CPU to check the algebra against the oracle
 // when no GPU is around.  That harness is test-only; the product library only
 // contains the GPU path.
@@ -17,7 +17,7 @@
 //    implicit stage equations are explicit here: psi_s = psi + c_s*h*w and the
 //    step is a 2-point Gauss quadrature of f(psi_s).  Same map, same
 //    derivatives, no Newton loop, no LU.
-//  * stage_cost      -- Gauss-Newton stage data from the weighting matrix
+//  * stage cost      -- Gauss-Newton stage data from the weighting matrix
 //    (reference: CG/acado_solver.c:103-211 slicing of W, :365-440 gradient).
 //  * riccati_step / forward_step -- the reference condenses the QP to a dense
 //    2N x 2N problem (CG/acado_solver.c:327-363) and runs qpOASES' active-set
@@ -75,13 +75,16 @@ NMPC_HD IrkConst make_irk(float h)
     return c;
 }
 
-// linearisation of one shooting interval.  Gx = I + [0 0 a; 0 0 b; 0 0 0],
-// Gu = [B00 B01; B10 B11; B20 B21] (columns: vr, vl).
-struct StageLin {
-    float a, b;
-    float B00, B01, B10, B11, B20, B21;
-    float phi0, phi1, phi2; // state at the end of the interval
-};
+// 1/x to float32 accuracy: hardware reciprocal + one Newton step on the device
+NMPC_HD float rcp_f(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.0f - x * r);
+#else
+    return 1.0f / x;
+#endif
+}
 
 NMPC_HD void sincos_f(float x, float* s, float* c)
 {
@@ -93,11 +96,19 @@ NMPC_HD void sincos_f(float x, float* s, float* c)
 #endif
 }
 
+// linearisation of one shooting interval.  Gx = I + [0 0 a; 0 0 b; 0 0 0],
+// Gu = [B00 B01; B10 B11; B20 -B20] (columns: vr, vl).
+struct StageLin {
+    float a, b;
+    float B00, B01, B10, B11, B20;
+    float phi0, phi1, phi2; // state at the end of the interval
+};
+
 // x = (px, py, psi), u = (vr, vl), od = (xv, yr, yl)
 NMPC_HD void ddr_linearize(const IrkConst& K, float px, float py, float psi, float vr, float vl, float xv,
                            float yr, float yl, StageLin& o)
 {
-    const float inv = 1.0f / (yl - yr);
+    const float inv = rcp_f(yl - yr);
     const float dv = vr - vl;
     const float w = dv * inv;                     // heading rate
     const float lon = (vr * yl - vl * yr) * inv;  // body-x speed
@@ -124,8 +135,7 @@ NMPC_HD void ddr_linearize(const IrkConst& K, float px, float py, float psi, flo
     o.B01 = K.hh * (lon_l * C + lat_l * S - inv * gxw);
     o.B10 = K.hh * (lon_r * S - lat_r * C + inv * gyw);
     o.B11 = K.hh * (lon_l * S - lat_l * C - inv * gyw);
-    o.B20 = K.h * inv;
-    o.B21 = -o.B20;
+    o.B20 = K.h * inv; // d phi_psi / d vr ; d/d vl = -B20
 }
 
 // symmetric 3x3 as 6 floats
@@ -141,7 +151,7 @@ struct Value {
 
 // everything the backward step needs about stage k
 struct StageQP {
-    float a, b, B00, B01, B10, B11, B20, B21; // dynamics dx+ = A dx + B du + d
+    float a, b, B00, B01, B10, B11, B20; // dynamics dx+ = A dx + B du + d
     float d0, d1, d2;
     Sym3 Q;            // state Hessian of stage k (unused for k = 0)
     float q0, q1, q2;  // state gradient
@@ -162,11 +172,13 @@ struct Policy {
 
 // One backward Riccati step with the controls eliminated one at a time
 // (control 1 first, then control 0); a fixed control is substituted by its
-// bound value instead of being minimised over.  Returns false if a pivot
-// needed for a free control is not positive.
+// bound value instead of being minimised over.  Straight-line code: the two
+// cases of each control differ only in selected operands.  Returns false if a
+// pivot needed for a free control is not positive.
 NMPC_HD bool riccati_step(const StageQP& s, Value& V, Policy& pol, bool need_value)
 {
     const Sym3 P = V.P;
+    const float B21 = -s.B20;
     // s = P d + p
     const float s0 = P.m00 * s.d0 + P.m01 * s.d1 + P.m02 * s.d2 + V.p0;
     const float s1 = P.m01 * s.d0 + P.m11 * s.d1 + P.m12 * s.d2 + V.p1;
@@ -175,47 +187,48 @@ NMPC_HD bool riccati_step(const StageQP& s, Value& V, Policy& pol, bool need_val
     const float PB00 = P.m00 * s.B00 + P.m01 * s.B10 + P.m02 * s.B20;
     const float PB10 = P.m01 * s.B00 + P.m11 * s.B10 + P.m12 * s.B20;
     const float PB20 = P.m02 * s.B00 + P.m12 * s.B10 + P.m22 * s.B20;
-    const float PB01 = P.m00 * s.B01 + P.m01 * s.B11 + P.m02 * s.B21;
-    const float PB11 = P.m01 * s.B01 + P.m11 * s.B11 + P.m12 * s.B21;
-    const float PB21 = P.m02 * s.B01 + P.m12 * s.B11 + P.m22 * s.B21;
+    const float PB01 = P.m00 * s.B01 + P.m01 * s.B11 + P.m02 * B21;
+    const float PB11 = P.m01 * s.B01 + P.m11 * s.B11 + P.m12 * B21;
+    const float PB21 = P.m02 * s.B01 + P.m12 * s.B11 + P.m22 * B21;
     // Huu = R + B' P B
     const float H00 = s.R00 + s.B00 * PB00 + s.B10 * PB10 + s.B20 * PB20;
     const float H01 = s.R01 + s.B00 * PB01 + s.B10 * PB11 + s.B20 * PB21;
-    const float H11 = s.R11 + s.B01 * PB01 + s.B11 * PB11 + s.B21 * PB21;
+    const float H11 = s.R11 + s.B01 * PB01 + s.B11 * PB11 + B21 * PB21;
     // Hux = B' P A, A = I + e(a,b): row j = (PB0j, PB1j, a PB0j + b PB1j + PB2j)
     float G00 = PB00, G01 = PB10, G02 = s.a * PB00 + s.b * PB10 + PB20;
     const float G10 = PB01, G11 = PB11, G12 = s.a * PB01 + s.b * PB11 + PB21;
     // hu = r + B' s
     float hu0 = s.r0 + s.B00 * s0 + s.B10 * s1 + s.B20 * s2;
-    const float hu1 = s.r1 + s.B01 * s0 + s.B11 * s1 + s.B21 * s2;
+    const float hu1 = s.r1 + s.B01 * s0 + s.B11 * s1 + B21 * s2;
 
-    bool ok = true;
     // ---- eliminate control 1
     const bool free1 = (s.st1 == ST_FREE);
-    ok = ok && !(free1 && !(H11 > 0.0f));
-    const float inv11 = 1.0f / H11;
-    const float w1 = free1 ? inv11 : 0.0f;       // 1/H11 if minimised over
+    const bool bad1 = free1 && !(H11 > 0.0f);
+    const float inv11 = rcp_f(H11);
+    const float w1 = free1 ? inv11 : 0.0f;        // 1/H11 if minimised over
     const float z1 = free1 ? -hu1 * inv11 : s.v1; // value of du1 at dx = 0, du0 = 0
     const float t1 = w1 * H01;
-    if (free1) {
-        pol.c10 = -w1 * G10; pol.c11 = -w1 * G11; pol.c12 = -w1 * G12; pol.e1 = -t1; pol.f1 = z1;
-    } else {
-        pol.c10 = G10; pol.c11 = G11; pol.c12 = G12; pol.e1 = H01; pol.f1 = hu1 + H11 * s.v1;
-    }
+    const float g1s = free1 ? -w1 : 1.0f; // record = g1s * (G1, H01) for both cases
+    pol.c10 = g1s * G10;
+    pol.c11 = g1s * G11;
+    pol.c12 = g1s * G12;
+    pol.e1 = g1s * H01;
+    pol.f1 = free1 ? z1 : hu1 + H11 * s.v1;
     const float H00r = H00 - t1 * H01;
     G00 -= t1 * G10; G01 -= t1 * G11; G02 -= t1 * G12;
     hu0 += H01 * z1;
     // ---- eliminate control 0
     const bool free0 = (s.st0 == ST_FREE);
-    ok = ok && !(free0 && !(H00r > 0.0f));
-    const float inv00 = 1.0f / H00r;
+    const bool bad0 = free0 && !(H00r > 0.0f);
+    const float inv00 = rcp_f(H00r);
     const float w0 = free0 ? inv00 : 0.0f;
     const float z0 = free0 ? -hu0 * inv00 : s.v0;
-    if (free0) {
-        pol.c00 = -w0 * G00; pol.c01 = -w0 * G01; pol.c02 = -w0 * G02; pol.f0 = z0;
-    } else {
-        pol.c00 = G00; pol.c01 = G01; pol.c02 = G02; pol.f0 = hu0 + H00r * s.v0;
-    }
+    const float g0s = free0 ? -w0 : 1.0f;
+    pol.c00 = g0s * G00;
+    pol.c01 = g0s * G01;
+    pol.c02 = g0s * G02;
+    pol.f0 = free0 ? z0 : hu0 + H00r * s.v0;
+    const bool ok = !(bad0 || bad1);
     if (!need_value) return ok;
 
     // Hxx = Q + A' P A  and hx = q + A' s
@@ -233,12 +246,14 @@ NMPC_HD bool riccati_step(const StageQP& s, Value& V, Policy& pol, bool need_val
     float hx1 = s.q1 + s1;
     float hx2 = s.q2 + (s.a * s0 + s.b * s1 + s2);
     // control 1 out:  Hxx -= w1 G1'G1 ; hx += G1' z1   (G1 = original row 1)
-    X.m00 -= w1 * G10 * G10; X.m01 -= w1 * G10 * G11; X.m02 -= w1 * G10 * G12;
-    X.m11 -= w1 * G11 * G11; X.m12 -= w1 * G11 * G12; X.m22 -= w1 * G12 * G12;
+    const float wg10 = w1 * G10, wg11 = w1 * G11, wg12 = w1 * G12;
+    X.m00 -= wg10 * G10; X.m01 -= wg10 * G11; X.m02 -= wg10 * G12;
+    X.m11 -= wg11 * G11; X.m12 -= wg11 * G12; X.m22 -= wg12 * G12;
     hx0 += G10 * z1; hx1 += G11 * z1; hx2 += G12 * z1;
     // control 0 out (G0 is the reduced row)
-    X.m00 -= w0 * G00 * G00; X.m01 -= w0 * G00 * G01; X.m02 -= w0 * G00 * G02;
-    X.m11 -= w0 * G01 * G01; X.m12 -= w0 * G01 * G02; X.m22 -= w0 * G02 * G02;
+    const float wg00 = w0 * G00, wg01 = w0 * G01, wg02 = w0 * G02;
+    X.m00 -= wg00 * G00; X.m01 -= wg00 * G01; X.m02 -= wg00 * G02;
+    X.m11 -= wg01 * G01; X.m12 -= wg01 * G02; X.m22 -= wg02 * G02;
     hx0 += G00 * z0; hx1 += G01 * z0; hx2 += G02 * z0;
     V.P = X;
     V.p0 = hx0; V.p1 = hx1; V.p2 = hx2;
@@ -252,16 +267,14 @@ struct StageStep {
     int nst0, nst1; // updated working-set status
 };
 
-NMPC_HD int next_status(int st, float val, float lb, float ub, bool is_eq)
+// primal-dual working-set update of one control, branch-free
+NMPC_HD int next_status(int st, float val, float lb, float ub)
 {
-    if (is_eq) return ST_LOWER;
-    if (st == ST_FREE) {
-        if (val < lb - TOL_PRIMAL) return ST_LOWER;
-        if (val > ub + TOL_PRIMAL) return ST_UPPER;
-        return ST_FREE;
-    }
-    if (st == ST_LOWER) return (val < -TOL_DUAL) ? ST_FREE : ST_LOWER;
-    return (val > TOL_DUAL) ? ST_FREE : ST_UPPER;
+    const int from_free = (val < lb - TOL_PRIMAL) ? ST_LOWER : ((val > ub + TOL_PRIMAL) ? ST_UPPER : ST_FREE);
+    const int from_lower = (val < -TOL_DUAL) ? ST_FREE : ST_LOWER;
+    const int from_upper = (val > TOL_DUAL) ? ST_FREE : ST_UPPER;
+    const int ns = (st == ST_FREE) ? from_free : ((st == ST_LOWER) ? from_lower : from_upper);
+    return (ub - lb > BOUNDTOL) ? ns : ST_LOWER; // equality-bounded controls stay fixed
 }
 
 NMPC_HD float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -276,8 +289,8 @@ NMPC_HD void forward_step(const Policy& pol, int st0, int st1, float dx0, float 
     const float val1 = pol.c10 * dx0 + pol.c11 * dx1 + pol.c12 * dx2 + pol.e1 * raw0 + pol.f1;
     const float b1 = (st1 == ST_UPPER) ? ub1 : lb1;
     const float raw1 = (st1 == ST_FREE) ? val1 : b1;
-    o.nst0 = next_status(st0, val0, lb0, ub0, !(ub0 - lb0 > BOUNDTOL));
-    o.nst1 = next_status(st1, val1, lb1, ub1, !(ub1 - lb1 > BOUNDTOL));
+    o.nst0 = next_status(st0, val0, lb0, ub0);
+    o.nst1 = next_status(st1, val1, lb1, ub1);
     // raw values propagate (they solve the working-set QP exactly); once the
     // working set has settled they are inside the box up to TOL_PRIMAL
     o.du0 = raw0;
@@ -290,8 +303,8 @@ NMPC_HD void forward_step(const Policy& pol, int st0, int st1, float dx0, float 
 // (QProblemB.cpp:1010-1036 with ZERO == 0 in float)
 NMPC_HD int status_from_dual(float y, float lb, float ub)
 {
-    if (!(ub - lb > BOUNDTOL)) return ST_LOWER;
-    return (y > 0.0f) ? ST_LOWER : ((y < 0.0f) ? ST_UPPER : ST_FREE);
+    const int s = (y > 0.0f) ? ST_LOWER : ((y < 0.0f) ? ST_UPPER : ST_FREE);
+    return (ub - lb > BOUNDTOL) ? s : ST_LOWER;
 }
 
 } // namespace nmpc

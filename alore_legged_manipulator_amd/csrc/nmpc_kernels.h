@@ -17,6 +17,7 @@ struct RtiParams {
     int max_as_iter;
     int RS; // LDS floats per problem (row stride)
     float h, hh, c1h, c2h;
+    long long* stamps; // diagnostic builds only: per-block phase cycle counts (8 per block), else null
 };
 
 struct LaunchGeom {

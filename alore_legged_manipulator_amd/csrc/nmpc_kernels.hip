@@ -22,57 +22,57 @@
 
 namespace nmpc {
 
-// LDS fields of one problem row; every field has NS = N + 1 slots
-enum Field : int {
-    F_X0, F_X1, F_X2,   // iterate x      (N+1 nodes)
-    F_U0, F_U1,         // iterate u      (N)
-    F_Y0, F_Y1,         // QP dual        (N)
-    F_A, F_B,           // Gx = I + e(a,b)
-    F_B00, F_B01, F_B10, F_B11, F_B20, F_B21, // Gu
-    F_D0, F_D1, F_D2,   // shooting defect
-    F_Q00, F_Q01, F_Q02, F_Q11, F_Q12, F_Q22, // state Hessian (slot N = terminal)
-    F_QV0, F_QV1, F_QV2, // state gradient  (slot N = terminal)
-    F_R00, F_R01, F_R11, // control Hessian
-    F_RV0, F_RV1,        // control gradient
-    F_LB0, F_LB1, F_UB0, F_UB1, // QP bounds on du
-    F_ST0, F_ST1,        // working-set status (int bits)
-    F_C00, F_C01, F_C02, F_F0, F_C10, F_C11, F_C12, F_E1, F_F1, // policy records
-    F_DU0, F_DU1, F_MU0, F_MU1, // step and multipliers
-    F_DX0, F_DX1, F_DX2, // state step (N+1 nodes)
-    NFIELDS
+// LDS layout.  One problem = N+1 stage records of SR floats (19 float4 slots;
+// the odd slot count spreads the records of consecutive stages over all banks
+// for 16-byte accesses), record N being the terminal node.
+//   slot 0  a b B00 B01        slot 7  st0 st1 du0 du1      slot 13 dx0 dx1 dx2 p2
+//   slot 1  B10 B11 B20 d0     slot 8  c00 c01 c02 f0       slot 14 x0 x1 x2 -
+//   slot 2  d1 d2 q0 q1        slot 9  c10 c11 c12 e1       slot 15 u0 u1 y0 y1
+//   slot 3  q2 r0 r1 R00       slot 10 mu0 mu1 f1 -         slot 16 sb0 sb1 sb2 -
+//   slot 4  R01 R11 Q00 Q01    slot 11 P00 P01 P02 P11      slot 17-18 spare
+//   slot 5  Q02 Q11 Q12 Q22    slot 12 P12 P22 p0 p1
+//   slot 6  lb0 ub0 lb1 ub1
+// (P, p) of record k is the cost-to-go at node k under the working set of the
+// last backward sweep; it lets a later sweep restart below the highest stage
+// whose working set changed instead of at the horizon end.
+constexpr int SLOTS = 19;
+constexpr int SR = SLOTS * 4;
+enum Slot : int {
+    S_LIN0 = 0, S_LIN1 = 1, S_DQ = 2, S_QR = 3, S_RQ = 4, S_QQ = 5, S_BND = 6, S_STDU = 7,
+    S_POL0 = 8, S_POL1 = 9, S_MU = 10, S_V0 = 11, S_V1 = 12, S_DX = 13, S_X = 14, S_UY = 15, S_SB = 16
 };
 
-int rti_row_floats(int N) { return NFIELDS * (N + 1); }
+int rti_row_floats(int N) { return SR * (N + 1); }
 
 bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g)
 {
     if (B <= 0 || N <= 0) return false;
     int L = forced_L;
     if (L == 0) {
-        // aim at >= one 256-thread workgroup of lanes per CU, i.e. B * L >= 256 * n_cu
+        // aim at >= one wavefront per SIMD over the whole chip: B * L >= 256 * n_cu lanes
         long want = (256L * n_cu + B - 1) / B;
         L = 4;
-        while (L < 32 && L < want) L *= 2;
+        while (L < 64 && L < want) L *= 2;
+        // the forward scan works on chunks of L stages: with lanes to spare, cover the horizon in one chunk
+        while (L < 64 && L < N && (long)B * L * 2 <= 512L * n_cu) L *= 2;
     }
-    if (L != 4 && L != 8 && L != 16 && L != 32) return false;
-    for (; L <= 32; L *= 2) {
-        const int row = rti_row_floats(N);
-        const int RS = ((row + 31) / 32) * 32 + (L < 32 ? L : 0);
+    if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return false;
+    for (; L <= 64; L *= 2) {
+        // pad the row so that RS = 4 (mod 64): the G rows of one wavefront start one 16-byte slot apart
+        const int base = rti_row_floats(N);
+        const int RS = base + ((4 - base % 64) + 64) % 64;
         const long row_bytes = 4L * RS;
-        int Gmax = (int)(lds_limit_bytes / row_bytes);
-        // threads = G * L must be a multiple of 64 and <= 256
-        int threads = 256;
-        while (threads >= 64 && threads / L > Gmax) threads -= 64;
-        if (threads < 64) {
+        const int G = 64 / L; // one wavefront per workgroup
+        if ((long)G * row_bytes > lds_limit_bytes) {
             if (forced_L) return false;
-            continue; // try more lanes per problem (fewer problems per block)
+            continue; // more lanes per problem = fewer problems per wavefront
         }
         g->L = L;
-        g->G = threads / L;
-        g->threads = threads;
-        g->grid = (B + g->G - 1) / g->G;
+        g->G = G;
+        g->threads = 64;
+        g->grid = (B + G - 1) / G;
         g->RS = RS;
-        g->lds_bytes = (size_t)row_bytes * g->G;
+        g->lds_bytes = (size_t)row_bytes * G;
         return true;
     }
     return false;
@@ -80,14 +80,54 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
 
 // ---------------------------------------------------------------------------
 
-#define ROW(f, k) row[(f) * NS + (k)]
+struct StageRegs { // slots 0..6 of a stage record
+    float4 l0, l1, dq, qr, rq, qq, bnd;
+};
+
+__device__ __forceinline__ float4 lds4(const float* rec, int slot)
+{
+    return *reinterpret_cast<const float4*>(rec + slot * 4);
+}
+__device__ __forceinline__ void st4(float* rec, int slot, float a, float b, float c, float d)
+{
+    *reinterpret_cast<float4*>(rec + slot * 4) = make_float4(a, b, c, d);
+}
+
+__device__ __forceinline__ void load_stage(const float* rec, StageRegs& r)
+{
+    r.l0 = lds4(rec, S_LIN0); r.l1 = lds4(rec, S_LIN1); r.dq = lds4(rec, S_DQ); r.qr = lds4(rec, S_QR);
+    r.rq = lds4(rec, S_RQ); r.qq = lds4(rec, S_QQ); r.bnd = lds4(rec, S_BND);
+}
 
 template <int L>
-__global__ __launch_bounds__(256) void rti_kernel(const RtiParams p)
+__device__ __forceinline__ float group_sum(float v)
 {
-    extern __shared__ float lds[];
-    const int N = p.N, NS = N + 1;
-    const int G = blockDim.x / L;
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, L);
+    return v;
+}
+template <int L>
+__device__ __forceinline__ int group_or(int v)
+{
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) v |= __shfl_xor(v, off, L);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// one wavefront per workgroup, G = 64 / L problems per wavefront
+template <int L, bool STAMP>
+__global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
+{
+    extern __shared__ float4 lds_raw[];
+    float* lds = reinterpret_cast<float*>(lds_raw);
+    const int N = p.N;
+    constexpr int G = 64 / L;
     const int grp = threadIdx.x / L;
     const int j = threadIdx.x % L;
     const bool writer = (j == 0);
@@ -96,13 +136,16 @@ __global__ __launch_bounds__(256) void rti_kernel(const RtiParams p)
     if (!valid) prob = p.B - 1; // padding groups shadow the last problem, never store
     float* row = lds + (size_t)grp * p.RS;
 
+    long long t_stamp[6];
+    if (STAMP) t_stamp[0] = __builtin_amdgcn_s_memtime();
+
     IrkConst K;
     K.h = p.h; K.hh = p.hh; K.c1h = p.c1h; K.c2h = p.c2h;
 
-    const float* gx = p.b.x + (size_t)prob * NS * 3;
+    const float* gx = p.b.x + (size_t)prob * (N + 1) * 3;
     const float* gu = p.b.u + (size_t)prob * N * 2;
     const float* gdual = p.b.dual + (size_t)prob * N * 2;
-    const float* god = p.b.od + (size_t)prob * NS * 3;
+    const float* god = p.b.od + (size_t)prob * (N + 1) * 3;
     const float* gy = p.b.y + (size_t)prob * N * 5;
     const float* gyN = p.b.yN + (size_t)prob * 3;
     const float* gW = p.b.W + (size_t)prob * N * 25;
@@ -112,215 +155,319 @@ __global__ __launch_bounds__(256) void rti_kernel(const RtiParams p)
 
     // ---- phase 0: iterate -> LDS
     for (int k = j; k <= N; k += L) {
-        ROW(F_X0, k) = gx[k * 3];
-        ROW(F_X1, k) = gx[k * 3 + 1];
-        ROW(F_X2, k) = gx[k * 3 + 2];
-        if (k < N) {
-            ROW(F_U0, k) = gu[k * 2];
-            ROW(F_U1, k) = gu[k * 2 + 1];
-            ROW(F_Y0, k) = gdual[k * 2];
-            ROW(F_Y1, k) = gdual[k * 2 + 1];
-        }
+        float* rec = row + k * SR;
+        st4(rec, S_X, gx[k * 3], gx[k * 3 + 1], gx[k * 3 + 2], 0.0f);
+        if (k < N) st4(rec, S_UY, gu[k * 2], gu[k * 2 + 1], gdual[k * 2], gdual[k * 2 + 1]);
     }
     const float x00 = p.b.x0[(size_t)prob * 3], x01 = p.b.x0[(size_t)prob * 3 + 1],
                 x02 = p.b.x0[(size_t)prob * 3 + 2];
     __syncthreads();
 
     int status = RET_OK, n_iter = 0;
-    float kkt = 0.0f, obj = 0.0f;
+    float kkt = 0.0f;
 
     for (int sqp = 0; sqp < p.n_sqp; ++sqp) {
         // ---- phase A (stage-parallel): linearise, Gauss-Newton cost, bounds, working-set guess
-        bool infeasible = false;
+        int infeasible = 0;
         for (int k = j; k <= N; k += L) {
-            const float px = ROW(F_X0, k), py = ROW(F_X1, k), ps = ROW(F_X2, k);
+            float* rec = row + k * SR;
+            const float4 xk = lds4(rec, S_X);
             if (k < N) {
-                const float vr = ROW(F_U0, k), vl = ROW(F_U1, k);
+                const float4 uy = lds4(rec, S_UY);
+                const float4 xn = lds4(rec + SR, S_X);
+                const float vr = uy.x, vl = uy.y;
                 StageLin lin;
-                ddr_linearize(K, px, py, ps, vr, vl, god[k * 3], god[k * 3 + 1], god[k * 3 + 2], lin);
-                ROW(F_A, k) = lin.a;
-                ROW(F_B, k) = lin.b;
-                ROW(F_B00, k) = lin.B00; ROW(F_B01, k) = lin.B01;
-                ROW(F_B10, k) = lin.B10; ROW(F_B11, k) = lin.B11;
-                ROW(F_B20, k) = lin.B20; ROW(F_B21, k) = lin.B21;
-                ROW(F_D0, k) = lin.phi0 - ROW(F_X0, k + 1);
-                ROW(F_D1, k) = lin.phi1 - ROW(F_X1, k + 1);
-                ROW(F_D2, k) = lin.phi2 - ROW(F_X2, k + 1);
+                ddr_linearize(K, xk.x, xk.y, xk.z, vr, vl, god[k * 3], god[k * 3 + 1], god[k * 3 + 2], lin);
+                const float d0 = lin.phi0 - xn.x, d1 = lin.phi1 - xn.y, d2 = lin.phi2 - xn.z;
                 // Dy = h(x,u) - y ; gradient = W[rows] * Dy ; Hessian blocks of W
                 const float* yk = gy + k * 5;
-                const float e0 = px - yk[0], e1 = py - yk[1], e2 = ps - yk[2], e3 = vr - yk[3], e4 = vl - yk[4];
+                const float e0 = xk.x - yk[0], e1 = xk.y - yk[1], e2 = xk.z - yk[2], e3 = vr - yk[3], e4 = vl - yk[4];
                 const float* Wk = gW + k * 25;
                 float w[25];
 #pragma unroll
                 for (int i = 0; i < 25; ++i) w[i] = Wk[i];
-                ROW(F_QV0, k) = w[0] * e0 + w[1] * e1 + w[2] * e2 + w[3] * e3 + w[4] * e4;
-                ROW(F_QV1, k) = w[5] * e0 + w[6] * e1 + w[7] * e2 + w[8] * e3 + w[9] * e4;
-                ROW(F_QV2, k) = w[10] * e0 + w[11] * e1 + w[12] * e2 + w[13] * e3 + w[14] * e4;
-                ROW(F_RV0, k) = w[15] * e0 + w[16] * e1 + w[17] * e2 + w[18] * e3 + w[19] * e4;
-                ROW(F_RV1, k) = w[20] * e0 + w[21] * e1 + w[22] * e2 + w[23] * e3 + w[24] * e4;
-                ROW(F_Q00, k) = w[0]; ROW(F_Q01, k) = w[1]; ROW(F_Q02, k) = w[2];
-                ROW(F_Q11, k) = w[6]; ROW(F_Q12, k) = w[7]; ROW(F_Q22, k) = w[12];
-                ROW(F_R00, k) = w[18]; ROW(F_R01, k) = w[19]; ROW(F_R11, k) = w[24];
+                const float q0 = w[0] * e0 + w[1] * e1 + w[2] * e2 + w[3] * e3 + w[4] * e4;
+                const float q1 = w[5] * e0 + w[6] * e1 + w[7] * e2 + w[8] * e3 + w[9] * e4;
+                const float q2 = w[10] * e0 + w[11] * e1 + w[12] * e2 + w[13] * e3 + w[14] * e4;
+                const float r0 = w[15] * e0 + w[16] * e1 + w[17] * e2 + w[18] * e3 + w[19] * e4;
+                const float r1 = w[20] * e0 + w[21] * e1 + w[22] * e2 + w[23] * e3 + w[24] * e4;
                 const float lb0 = glb[k * 2] - vr, lb1 = glb[k * 2 + 1] - vl;
                 const float ub0 = gub[k * 2] - vr, ub1 = gub[k * 2 + 1] - vl;
-                ROW(F_LB0, k) = lb0; ROW(F_LB1, k) = lb1;
-                ROW(F_UB0, k) = ub0; ROW(F_UB1, k) = ub1;
-                infeasible = infeasible || (lb0 > ub0 + 1e-6f) || (lb1 > ub1 + 1e-6f);
-                ROW(F_ST0, k) = __int_as_float(status_from_dual(ROW(F_Y0, k), lb0, ub0));
-                ROW(F_ST1, k) = __int_as_float(status_from_dual(ROW(F_Y1, k), lb1, ub1));
+                infeasible |= (lb0 > ub0 + 1e-6f) || (lb1 > ub1 + 1e-6f);
+                st4(rec, S_LIN0, lin.a, lin.b, lin.B00, lin.B01);
+                st4(rec, S_LIN1, lin.B10, lin.B11, lin.B20, d0);
+                st4(rec, S_DQ, d1, d2, q0, q1);
+                st4(rec, S_QR, q2, r0, r1, w[18]);
+                st4(rec, S_RQ, w[19], w[24], w[0], w[1]);
+                st4(rec, S_QQ, w[2], w[6], w[7], w[12]);
+                st4(rec, S_BND, lb0, ub0, lb1, ub1);
+                st4(rec, S_STDU, __int_as_float(status_from_dual(uy.z, lb0, ub0)),
+                    __int_as_float(status_from_dual(uy.w, lb1, ub1)), 0.0f, 0.0f);
             } else {
-                const float e0 = px - gyN[0], e1 = py - gyN[1], e2 = ps - gyN[2];
+                const float e0 = xk.x - gyN[0], e1 = xk.y - gyN[1], e2 = xk.z - gyN[2];
                 float w[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) w[i] = gWN[i];
-                ROW(F_QV0, k) = w[0] * e0 + w[1] * e1 + w[2] * e2;
-                ROW(F_QV1, k) = w[3] * e0 + w[4] * e1 + w[5] * e2;
-                ROW(F_QV2, k) = w[6] * e0 + w[7] * e1 + w[8] * e2;
-                ROW(F_Q00, k) = w[0]; ROW(F_Q01, k) = w[1]; ROW(F_Q02, k) = w[2];
-                ROW(F_Q11, k) = w[4]; ROW(F_Q12, k) = w[5]; ROW(F_Q22, k) = w[8];
+                const float q0 = w[0] * e0 + w[1] * e1 + w[2] * e2;
+                const float q1 = w[3] * e0 + w[4] * e1 + w[5] * e2;
+                const float q2 = w[6] * e0 + w[7] * e1 + w[8] * e2;
+                st4(rec, S_DQ, 0.0f, 0.0f, q0, q1);
+                st4(rec, S_QR, q2, 0.0f, 0.0f, 0.0f);
+                st4(rec, S_RQ, 0.0f, 0.0f, w[0], w[1]);
+                st4(rec, S_QQ, w[2], w[4], w[5], w[8]);
+                // cost-to-go at the terminal node
+                st4(rec, S_V0, w[0], w[1], w[2], w[4]);
+                st4(rec, S_V1, w[5], w[8], q0, q1);
+                rec[S_DX * 4 + 3] = q2;
             }
         }
-        { // a lane only saw its own stages: OR the flag over the group
-            int inf = infeasible ? 1 : 0;
-#pragma unroll
-            for (int off = L / 2; off > 0; off >>= 1) inf |= __shfl_xor(inf, off, L);
-            infeasible = inf != 0;
-        }
+        infeasible = group_or<L>(infeasible);
         __syncthreads();
+        if (STAMP && sqp == 0) t_stamp[1] = __builtin_amdgcn_s_memtime();
 
-        const float Dx0 = x00 - ROW(F_X0, 0), Dx1 = x01 - ROW(F_X1, 0), Dx2 = x02 - ROW(F_X2, 0);
+        const float4 xfirst = lds4(row, S_X);
+        const float Dx0 = x00 - xfirst.x, Dx1 = x01 - xfirst.y, Dx2 = x02 - xfirst.z;
 
-        // ---- phase B: working-set iterations, every lane of the group runs both sweeps
-        bool pd_fail = false, changed = false;
+        // ---- phase B: working-set iterations.  Backward: sequential Riccati sweep, every lane of the
+        //      group runs it on the same LDS addresses (broadcast reads), lane 0 of the group stores.
+        //      Forward: the closed-loop stage maps dx+ = M_k dx + c_k are affine, so the rollout is a
+        //      prefix scan over the lanes (lane j <-> stage j), log2(L) steps instead of N.
+        int pd_fail = 0;
+        bool changed = true; // "this problem still needs a sweep"
+        int khi = N - 1;     // highest stage whose cost-to-go is stale
         int it = 0;
         n_iter = 0;
+        long long t_b = 0, t_f = 0;
         for (;;) {
-            // backward Riccati sweep
-            Value V;
-            V.P.m00 = ROW(F_Q00, N); V.P.m01 = ROW(F_Q01, N); V.P.m02 = ROW(F_Q02, N);
-            V.P.m11 = ROW(F_Q11, N); V.P.m12 = ROW(F_Q12, N); V.P.m22 = ROW(F_Q22, N);
-            V.p0 = ROW(F_QV0, N); V.p1 = ROW(F_QV1, N); V.p2 = ROW(F_QV2, N);
-            bool ok = true;
-            for (int k = N - 1; k >= 0; --k) {
-                StageQP s;
-                s.a = ROW(F_A, k); s.b = ROW(F_B, k);
-                s.B00 = ROW(F_B00, k); s.B01 = ROW(F_B01, k); s.B10 = ROW(F_B10, k);
-                s.B11 = ROW(F_B11, k); s.B20 = ROW(F_B20, k); s.B21 = ROW(F_B21, k);
-                s.d0 = ROW(F_D0, k); s.d1 = ROW(F_D1, k); s.d2 = ROW(F_D2, k);
-                s.Q.m00 = ROW(F_Q00, k); s.Q.m01 = ROW(F_Q01, k); s.Q.m02 = ROW(F_Q02, k);
-                s.Q.m11 = ROW(F_Q11, k); s.Q.m12 = ROW(F_Q12, k); s.Q.m22 = ROW(F_Q22, k);
-                s.q0 = ROW(F_QV0, k); s.q1 = ROW(F_QV1, k); s.q2 = ROW(F_QV2, k);
-                s.R00 = ROW(F_R00, k); s.R01 = ROW(F_R01, k); s.R11 = ROW(F_R11, k);
-                s.r0 = ROW(F_RV0, k); s.r1 = ROW(F_RV1, k);
-                s.st0 = __float_as_int(ROW(F_ST0, k));
-                s.st1 = __float_as_int(ROW(F_ST1, k));
-                s.v0 = (s.st0 == ST_UPPER) ? ROW(F_UB0, k) : ROW(F_LB0, k);
-                s.v1 = (s.st1 == ST_UPPER) ? ROW(F_UB1, k) : ROW(F_LB1, k);
-                Policy pol;
-                ok = riccati_step(s, V, pol, k > 0) && ok;
-                if (writer) {
-                    ROW(F_C00, k) = pol.c00; ROW(F_C01, k) = pol.c01; ROW(F_C02, k) = pol.c02;
-                    ROW(F_F0, k) = pol.f0;
-                    ROW(F_C10, k) = pol.c10; ROW(F_C11, k) = pol.c11; ROW(F_C12, k) = pol.c12;
-                    ROW(F_E1, k) = pol.e1; ROW(F_F1, k) = pol.f1;
+            long long tb0 = 0;
+            if (STAMP) tb0 = __builtin_amdgcn_s_memtime();
+            // ---- backward Riccati sweep from the highest stale stage of this wavefront
+            const int kk = changed ? khi : -1;
+            const int kmax = __builtin_amdgcn_readfirstlane(wave_max(kk)); // wavefront-uniform loop bound
+            {
+                Value V;
+                V.P.m00 = V.P.m01 = V.P.m02 = V.P.m11 = V.P.m12 = V.P.m22 = 0.0f;
+                V.p0 = V.p1 = V.p2 = 0.0f;
+                int ok = 1;
+                auto step = [&](int k, const StageRegs& cur, const float4& cst) {
+                    if (k == kk) { // this group joins the sweep here: cost-to-go of node k+1
+                        const float* rn = row + (k + 1) * SR;
+                        const float4 v0 = lds4(rn, S_V0), v1 = lds4(rn, S_V1);
+                        V.P.m00 = v0.x; V.P.m01 = v0.y; V.P.m02 = v0.z; V.P.m11 = v0.w;
+                        V.P.m12 = v1.x; V.P.m22 = v1.y; V.p0 = v1.z; V.p1 = v1.w;
+                        V.p2 = rn[S_DX * 4 + 3];
+                    }
+                    if (k <= kk) {
+                        StageQP s;
+                        s.a = cur.l0.x; s.b = cur.l0.y; s.B00 = cur.l0.z; s.B01 = cur.l0.w;
+                        s.B10 = cur.l1.x; s.B11 = cur.l1.y; s.B20 = cur.l1.z; s.d0 = cur.l1.w;
+                        s.d1 = cur.dq.x; s.d2 = cur.dq.y; s.q0 = cur.dq.z; s.q1 = cur.dq.w;
+                        s.q2 = cur.qr.x; s.r0 = cur.qr.y; s.r1 = cur.qr.z; s.R00 = cur.qr.w;
+                        s.R01 = cur.rq.x; s.R11 = cur.rq.y; s.Q.m00 = cur.rq.z; s.Q.m01 = cur.rq.w;
+                        s.Q.m02 = cur.qq.x; s.Q.m11 = cur.qq.y; s.Q.m12 = cur.qq.z; s.Q.m22 = cur.qq.w;
+                        s.st0 = __float_as_int(cst.x);
+                        s.st1 = __float_as_int(cst.y);
+                        s.v0 = (s.st0 == ST_UPPER) ? cur.bnd.y : cur.bnd.x;
+                        s.v1 = (s.st1 == ST_UPPER) ? cur.bnd.w : cur.bnd.z;
+                        Policy pol;
+                        ok &= riccati_step(s, V, pol, k > 0) ? 1 : 0;
+                        if (writer) {
+                            float* rec = row + k * SR;
+                            st4(rec, S_POL0, pol.c00, pol.c01, pol.c02, pol.f0);
+                            st4(rec, S_POL1, pol.c10, pol.c11, pol.c12, pol.e1);
+                            rec[S_MU * 4 + 2] = pol.f1;
+                            if (k > 0) {
+                                st4(rec, S_V0, V.P.m00, V.P.m01, V.P.m02, V.P.m11);
+                                st4(rec, S_V1, V.P.m12, V.P.m22, V.p0, V.p1);
+                                rec[S_DX * 4 + 3] = V.p2;
+                            }
+                        }
+                    }
+                };
+                // two register sets, loads of the next record in flight while the current one is used
+                StageRegs ra, rb;
+                float4 sa = make_float4(0, 0, 0, 0), sb4 = sa;
+                int k = kmax;
+                if (k >= 0) { load_stage(row + k * SR, ra); sa = lds4(row + k * SR, S_STDU); }
+                while (k >= 1) {
+                    load_stage(row + (k - 1) * SR, rb); sb4 = lds4(row + (k - 1) * SR, S_STDU);
+                    step(k, ra, sa);
+                    if (k >= 2) { load_stage(row + (k - 2) * SR, ra); sa = lds4(row + (k - 2) * SR, S_STDU); }
+                    step(k - 1, rb, sb4);
+                    k -= 2;
                 }
+                if (k == 0) step(0, ra, sa);
+                pd_fail |= (ok == 0);
             }
-            pd_fail = pd_fail || !ok;
             __syncthreads();
+            long long tf0 = 0;
+            if (STAMP) { tf0 = __builtin_amdgcn_s_memtime(); t_b += tf0 - tb0; }
 
-            // forward sweep: step, multipliers, new working set, KKT terms
-            float dx0 = Dx0, dx1 = Dx1, dx2 = Dx2; // full step  dx_k
-            float sb0 = Dx0, sb1 = Dx1, sb2 = Dx2; // free response sbar_k (du = 0)
-            float gd = 0.0f, comp = 0.0f;
-            changed = false;
-            if (writer) { ROW(F_DX0, 0) = dx0; ROW(F_DX1, 0) = dx1; ROW(F_DX2, 0) = dx2; }
-            for (int k = 0; k < N; ++k) {
-                Policy pol;
-                pol.c00 = ROW(F_C00, k); pol.c01 = ROW(F_C01, k); pol.c02 = ROW(F_C02, k);
-                pol.f0 = ROW(F_F0, k);
-                pol.c10 = ROW(F_C10, k); pol.c11 = ROW(F_C11, k); pol.c12 = ROW(F_C12, k);
-                pol.e1 = ROW(F_E1, k); pol.f1 = ROW(F_F1, k);
-                const int st0 = __float_as_int(ROW(F_ST0, k)), st1 = __float_as_int(ROW(F_ST1, k));
-                const float lb0 = ROW(F_LB0, k), lb1 = ROW(F_LB1, k), ub0 = ROW(F_UB0, k), ub1 = ROW(F_UB1, k);
-                StageStep o;
-                forward_step(pol, st0, st1, dx0, dx1, dx2, lb0, ub0, lb1, ub1, o);
-                changed = changed || (o.nst0 != st0) || (o.nst1 != st1);
-                if (k > 0) {
-                    // (Q_k sbar_k + q_k)' (dx_k - sbar_k)
-                    const float t0 = dx0 - sb0, t1 = dx1 - sb1, t2 = dx2 - sb2;
-                    const float Q00 = ROW(F_Q00, k), Q01 = ROW(F_Q01, k), Q02 = ROW(F_Q02, k),
-                                Q11 = ROW(F_Q11, k), Q12 = ROW(F_Q12, k), Q22 = ROW(F_Q22, k);
-                    gd += (Q00 * sb0 + Q01 * sb1 + Q02 * sb2 + ROW(F_QV0, k)) * t0 +
-                          (Q01 * sb0 + Q11 * sb1 + Q12 * sb2 + ROW(F_QV1, k)) * t1 +
-                          (Q02 * sb0 + Q12 * sb1 + Q22 * sb2 + ROW(F_QV2, k)) * t2;
+            // ---- forward sweep as a prefix scan, stages in chunks of L (lane j <-> stage base + j)
+            const bool first = (it == 0);
+            const bool active = changed;
+            int new_khi = -1;
+            if (__any(active)) {
+                float cx0 = Dx0, cx1 = Dx1, cx2 = Dx2; // state step entering the chunk
+                float cs0 = Dx0, cs1 = Dx1, cs2 = Dx2; // free response entering the chunk (first sweep)
+                for (int base = 0; base < N; base += L) {
+                    const int k = base + j;
+                    const bool in = k < N;
+                    float* rec = row + (in ? k : 0) * SR;
+                    const float4 l0 = lds4(rec, S_LIN0), l1 = lds4(rec, S_LIN1), dq = lds4(rec, S_DQ),
+                                 bnd = lds4(rec, S_BND), sd = lds4(rec, S_STDU), p0 = lds4(rec, S_POL0),
+                                 p1 = lds4(rec, S_POL1), mu = lds4(rec, S_MU);
+                    const int st0 = __float_as_int(sd.x), st1 = __float_as_int(sd.y);
+                    const bool f0 = (st0 == ST_FREE), f1 = (st1 == ST_FREE);
+                    const float b0 = (st0 == ST_UPPER) ? bnd.y : bnd.x, b1 = (st1 == ST_UPPER) ? bnd.w : bnd.z;
+                    // du0 = g0.dx + h0 ; du1 = g1.dx + h1  under the current working set
+                    const float g00 = f0 ? p0.x : 0.0f, g01 = f0 ? p0.y : 0.0f, g02 = f0 ? p0.z : 0.0f;
+                    const float h0 = f0 ? p0.w : b0;
+                    const float g10 = f1 ? p1.x + p1.w * g00 : 0.0f, g11 = f1 ? p1.y + p1.w * g01 : 0.0f,
+                                g12 = f1 ? p1.z + p1.w * g02 : 0.0f;
+                    const float h1 = f1 ? p1.w * h0 + mu.z : b1;
+                    const float a = l0.x, b = l0.y, B00 = l0.z, B01 = l0.w, B10 = l1.x, B11 = l1.y, B20 = l1.z;
+                    const float d0 = l1.w, d1 = dq.x, d2 = dq.y;
+                    // closed-loop stage map  dx+ = M dx + c  (identity for padding lanes)
+                    float m00 = 1.0f, m01 = 0.0f, m02 = 0.0f, m10 = 0.0f, m11 = 1.0f, m12 = 0.0f, m20 = 0.0f,
+                          m21 = 0.0f, m22 = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+                    // free-response map: sbar+ = A sbar + d
+                    float sa_ = 0.0f, sb_ = 0.0f, sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;
+                    if (in) {
+                        const float gd0 = g00 - g10, gd1 = g01 - g11, gd2 = g02 - g12; // B2 = B20 * (1, -1)
+                        m00 = 1.0f + B00 * g00 + B01 * g10; m01 = B00 * g01 + B01 * g11; m02 = a + B00 * g02 + B01 * g12;
+                        m10 = B10 * g00 + B11 * g10; m11 = 1.0f + B10 * g01 + B11 * g11; m12 = b + B10 * g02 + B11 * g12;
+                        m20 = B20 * gd0; m21 = B20 * gd1; m22 = 1.0f + B20 * gd2;
+                        c0 = B00 * h0 + B01 * h1 + d0;
+                        c1 = B10 * h0 + B11 * h1 + d1;
+                        c2 = B20 * (h0 - h1) + d2;
+                        sa_ = a; sb_ = b; sc0 = d0; sc1 = d1; sc2 = d2;
+                    }
+                    // inclusive scan of map composition: after it, lane j holds f_k o ... o f_base
+#pragma unroll
+                    for (int off = 1; off < L; off <<= 1) {
+                        const float pm00 = __shfl_up(m00, off, L), pm01 = __shfl_up(m01, off, L), pm02 = __shfl_up(m02, off, L),
+                                    pm10 = __shfl_up(m10, off, L), pm11 = __shfl_up(m11, off, L), pm12 = __shfl_up(m12, off, L),
+                                    pm20 = __shfl_up(m20, off, L), pm21 = __shfl_up(m21, off, L), pm22 = __shfl_up(m22, off, L),
+                                    pc0 = __shfl_up(c0, off, L), pc1 = __shfl_up(c1, off, L), pc2 = __shfl_up(c2, off, L);
+                        if (j >= off) {
+                            const float n00 = m00 * pm00 + m01 * pm10 + m02 * pm20, n01 = m00 * pm01 + m01 * pm11 + m02 * pm21,
+                                        n02 = m00 * pm02 + m01 * pm12 + m02 * pm22;
+                            const float n10 = m10 * pm00 + m11 * pm10 + m12 * pm20, n11 = m10 * pm01 + m11 * pm11 + m12 * pm21,
+                                        n12 = m10 * pm02 + m11 * pm12 + m12 * pm22;
+                            const float n20 = m20 * pm00 + m21 * pm10 + m22 * pm20, n21 = m20 * pm01 + m21 * pm11 + m22 * pm21,
+                                        n22 = m20 * pm02 + m21 * pm12 + m22 * pm22;
+                            c0 += m00 * pc0 + m01 * pc1 + m02 * pc2;
+                            c1 += m10 * pc0 + m11 * pc1 + m12 * pc2;
+                            c2 += m20 * pc0 + m21 * pc1 + m22 * pc2;
+                            m00 = n00; m01 = n01; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m21 = n21; m22 = n22;
+                        }
+                    }
+                    // state step leaving stage k (= entering k+1), and the one entering stage k
+                    const float o0 = m00 * cx0 + m01 * cx1 + m02 * cx2 + c0;
+                    const float o1 = m10 * cx0 + m11 * cx1 + m12 * cx2 + c1;
+                    const float o2 = m20 * cx0 + m21 * cx1 + m22 * cx2 + c2;
+                    float dx0 = __shfl_up(o0, 1, L), dx1 = __shfl_up(o1, 1, L), dx2 = __shfl_up(o2, 1, L);
+                    if (j == 0) { dx0 = cx0; dx1 = cx1; dx2 = cx2; }
+                    Policy pol;
+                    pol.c00 = p0.x; pol.c01 = p0.y; pol.c02 = p0.z; pol.f0 = p0.w;
+                    pol.c10 = p1.x; pol.c11 = p1.y; pol.c12 = p1.z; pol.e1 = p1.w; pol.f1 = mu.z;
+                    StageStep o;
+                    forward_step(pol, st0, st1, dx0, dx1, dx2, bnd.x, bnd.y, bnd.z, bnd.w, o);
+                    if (in && ((o.nst0 != st0) || (o.nst1 != st1))) new_khi = max(new_khi, k);
+                    if (in && active) {
+                        *reinterpret_cast<float2*>(rec + S_MU * 4) = make_float2(o.mu0, o.mu1);
+                        rec[S_DX * 4] = dx0; rec[S_DX * 4 + 1] = dx1; rec[S_DX * 4 + 2] = dx2;
+                        st4(rec, S_STDU, __int_as_float(o.nst0), __int_as_float(o.nst1), o.du0, o.du1);
+                    }
+                    if (first) { // free response (du = 0): A is a shear, so two chained prefix sums do it
+                        // sbar2 entering stage k = cs2 + sum_{i<k} d2_i
+                        float e2 = sc2;
+#pragma unroll
+                        for (int off = 1; off < L; off <<= 1) { const float t = __shfl_up(e2, off, L); if (j >= off) e2 += t; }
+                        float in2 = __shfl_up(e2, 1, L);
+                        in2 = (j == 0) ? cs2 : cs2 + in2;
+                        float e0 = sa_ * in2 + sc0, e1 = sb_ * in2 + sc1;
+#pragma unroll
+                        for (int off = 1; off < L; off <<= 1) {
+                            const float t0 = __shfl_up(e0, off, L), t1 = __shfl_up(e1, off, L);
+                            if (j >= off) { e0 += t0; e1 += t1; }
+                        }
+                        float in0 = __shfl_up(e0, 1, L), in1 = __shfl_up(e1, 1, L);
+                        in0 = (j == 0) ? cs0 : cs0 + in0;
+                        in1 = (j == 0) ? cs1 : cs1 + in1;
+                        if (in && active) { rec[S_SB * 4] = in0; rec[S_SB * 4 + 1] = in1; rec[S_SB * 4 + 2] = in2; }
+                        // carry to the next chunk: values leaving the last lane
+                        const float l0_ = __shfl(e0, L - 1, L), l1_ = __shfl(e1, L - 1, L), l2_ = __shfl(e2, L - 1, L);
+                        cs0 += l0_; cs1 += l1_; cs2 += l2_;
+                    }
+                    cx0 = __shfl(o0, L - 1, L); cx1 = __shfl(o1, L - 1, L); cx2 = __shfl(o2, L - 1, L);
                 }
-                gd += ROW(F_RV0, k) * o.du0 + ROW(F_RV1, k) * o.du1;
-                comp += (o.mu0 > 1e-12f) ? fabsf(lb0 * o.mu0) : ((o.mu0 < -1e-12f) ? fabsf(ub0 * o.mu0) : 0.0f);
-                comp += (o.mu1 > 1e-12f) ? fabsf(lb1 * o.mu1) : ((o.mu1 < -1e-12f) ? fabsf(ub1 * o.mu1) : 0.0f);
-                const float a = ROW(F_A, k), b = ROW(F_B, k);
-                const float B00 = ROW(F_B00, k), B01 = ROW(F_B01, k), B10 = ROW(F_B10, k),
-                            B11 = ROW(F_B11, k), B20 = ROW(F_B20, k), B21 = ROW(F_B21, k);
-                const float d0 = ROW(F_D0, k), d1 = ROW(F_D1, k), d2 = ROW(F_D2, k);
-                const float n0 = dx0 + a * dx2 + B00 * o.du0 + B01 * o.du1 + d0;
-                const float n1 = dx1 + b * dx2 + B10 * o.du0 + B11 * o.du1 + d1;
-                const float n2 = dx2 + B20 * o.du0 + B21 * o.du1 + d2;
-                const float m0 = sb0 + a * sb2 + d0, m1 = sb1 + b * sb2 + d1, m2 = sb2 + d2;
-                dx0 = n0; dx1 = n1; dx2 = n2;
-                sb0 = m0; sb1 = m1; sb2 = m2;
-                if (writer) {
-                    ROW(F_DU0, k) = o.du0; ROW(F_DU1, k) = o.du1;
-                    ROW(F_MU0, k) = o.mu0; ROW(F_MU1, k) = o.mu1;
-                    ROW(F_DX0, k + 1) = dx0; ROW(F_DX1, k + 1) = dx1; ROW(F_DX2, k + 1) = dx2;
-                    ROW(F_ST0, k) = __int_as_float(o.nst0);
-                    ROW(F_ST1, k) = __int_as_float(o.nst1);
+                if (writer && active) { // node N
+                    float* rec = row + N * SR;
+                    rec[S_DX * 4] = cx0; rec[S_DX * 4 + 1] = cx1; rec[S_DX * 4 + 2] = cx2;
+                    if (first) { rec[S_SB * 4] = cs0; rec[S_SB * 4 + 1] = cs1; rec[S_SB * 4 + 2] = cs2; }
                 }
+                // highest changed stage of the group
+#pragma unroll
+                for (int off = L / 2; off > 0; off >>= 1) new_khi = max(new_khi, __shfl_xor(new_khi, off, L));
             }
-            { // terminal term of g' du
-                const float t0 = dx0 - sb0, t1 = dx1 - sb1, t2 = dx2 - sb2;
-                const float Q00 = ROW(F_Q00, N), Q01 = ROW(F_Q01, N), Q02 = ROW(F_Q02, N), Q11 = ROW(F_Q11, N),
-                            Q12 = ROW(F_Q12, N), Q22 = ROW(F_Q22, N);
-                gd += (Q00 * sb0 + Q01 * sb1 + Q02 * sb2 + ROW(F_QV0, N)) * t0 +
-                      (Q01 * sb0 + Q11 * sb1 + Q12 * sb2 + ROW(F_QV1, N)) * t1 +
-                      (Q02 * sb0 + Q12 * sb1 + Q22 * sb2 + ROW(F_QV2, N)) * t2;
-            }
-            kkt = fabsf(gd) + comp;
             ++it;
-            if (changed) n_iter = it;
-            // block-uniform continuation: any problem of the block still changing?
+            if (active) {
+                changed = (new_khi >= 0);
+                khi = new_khi;
+                if (changed) n_iter = it;
+            }
+            if (STAMP) t_f += __builtin_amdgcn_s_memtime() - tf0;
+            // wavefront-uniform continuation: any problem of this wavefront still changing?
             const int more = __syncthreads_or((changed && it < p.max_as_iter) ? 1 : 0);
             if (!more) break;
         }
-        if (n_iter == 0) n_iter = 1;
-        else if (!changed) n_iter += 1; // the confirming sweep
+        n_iter = (n_iter == 0) ? 1 : (changed ? n_iter : n_iter + 1); // + the confirming sweep
         status = infeasible ? RET_INIT_FAILED_INFEASIBILITY
                             : (pd_fail ? RET_INIT_FAILED_CHOLESKY : (changed ? RET_MAX_NWSR_REACHED : RET_OK));
+        if (STAMP && sqp == 0) { t_stamp[2] = t_b; t_stamp[3] = t_f; t_stamp[4] = __builtin_amdgcn_s_memtime(); }
 
-        // ---- phase C (stage-parallel): expand (acado_expand) and carry the dual
+        // ---- phase C (stage-parallel): KKT value (acado_getKKT), expand (acado_expand), carry the dual
+        float gd = 0.0f, comp = 0.0f;
         for (int k = j; k <= N; k += L) {
-            ROW(F_X0, k) += ROW(F_DX0, k);
-            ROW(F_X1, k) += ROW(F_DX1, k);
-            ROW(F_X2, k) += ROW(F_DX2, k);
+            float* rec = row + k * SR;
+            const float4 dxp = lds4(rec, S_DX), sb = lds4(rec, S_SB), xk = lds4(rec, S_X);
+            if (k > 0) { // (Q_k sbar_k + q_k)' (dx_k - sbar_k)
+                const float4 dq = lds4(rec, S_DQ), qr = lds4(rec, S_QR), rq = lds4(rec, S_RQ), qq = lds4(rec, S_QQ);
+                const float t0 = dxp.x - sb.x, t1 = dxp.y - sb.y, t2 = dxp.z - sb.z;
+                gd += (rq.z * sb.x + rq.w * sb.y + qq.x * sb.z + dq.z) * t0 +
+                      (rq.w * sb.x + qq.y * sb.y + qq.z * sb.z + dq.w) * t1 +
+                      (qq.x * sb.x + qq.z * sb.y + qq.w * sb.z + qr.x) * t2;
+            }
+            st4(rec, S_X, xk.x + dxp.x, xk.y + dxp.y, xk.z + dxp.z, 0.0f);
             if (k < N) {
-                const float lb0 = ROW(F_LB0, k), lb1 = ROW(F_LB1, k), ub0 = ROW(F_UB0, k), ub1 = ROW(F_UB1, k);
+                const float4 qr = lds4(rec, S_QR), bnd = lds4(rec, S_BND), sd = lds4(rec, S_STDU), mu = lds4(rec, S_MU),
+                             uy = lds4(rec, S_UY);
+                gd += qr.y * sd.z + qr.z * sd.w;
+                comp += (mu.x > 1e-12f) ? fabsf(bnd.x * mu.x) : ((mu.x < -1e-12f) ? fabsf(bnd.y * mu.x) : 0.0f);
+                comp += (mu.y > 1e-12f) ? fabsf(bnd.z * mu.y) : ((mu.y < -1e-12f) ? fabsf(bnd.w * mu.y) : 0.0f);
                 // a free control may sit up to TOL_PRIMAL outside its box: keep the iterate feasible
-                ROW(F_U0, k) += (lb0 <= ub0) ? clampf(ROW(F_DU0, k), lb0, ub0) : ROW(F_DU0, k);
-                ROW(F_U1, k) += (lb1 <= ub1) ? clampf(ROW(F_DU1, k), lb1, ub1) : ROW(F_DU1, k);
-                ROW(F_Y0, k) = ROW(F_MU0, k);
-                ROW(F_Y1, k) = ROW(F_MU1, k);
+                const float du0 = (bnd.x <= bnd.y) ? clampf(sd.z, bnd.x, bnd.y) : sd.z;
+                const float du1 = (bnd.z <= bnd.w) ? clampf(sd.w, bnd.z, bnd.w) : sd.w;
+                st4(rec, S_UY, uy.x + du0, uy.y + du1, mu.x, mu.y);
             }
         }
+        kkt = fabsf(group_sum<L>(gd)) + group_sum<L>(comp);
         __syncthreads();
     }
+    if (STAMP) t_stamp[5] = __builtin_amdgcn_s_memtime();
 
     // ---- objective at the returned iterate (acado_getObjective) + write-back
     float part = 0.0f;
     for (int k = j; k <= N; k += L) {
-        const float px = ROW(F_X0, k), py = ROW(F_X1, k), ps = ROW(F_X2, k);
+        const float* rec = row + k * SR;
+        const float4 xk = lds4(rec, S_X);
         if (k < N) {
-            const float vr = ROW(F_U0, k), vl = ROW(F_U1, k);
+            const float4 uy = lds4(rec, S_UY);
             const float* yk = gy + k * 5;
             const float* Wk = gW + k * 25;
-            float e[5] = {px - yk[0], py - yk[1], ps - yk[2], vr - yk[3], vl - yk[4]};
+            float e[5] = {xk.x - yk[0], xk.y - yk[1], xk.z - yk[2], uy.x - yk[3], uy.y - yk[4]};
             float acc = 0.0f;
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
@@ -329,29 +476,37 @@ __global__ __launch_bounds__(256) void rti_kernel(const RtiParams p)
                 acc += e[c] * t;
             }
             part += acc;
+            if (valid) {
+                float* ou = p.b.u + (size_t)prob * N * 2;
+                float* od = p.b.dual + (size_t)prob * N * 2;
+                ou[k * 2] = uy.x; ou[k * 2 + 1] = uy.y;
+                od[k * 2] = uy.z; od[k * 2 + 1] = uy.w;
+            }
         } else { // the reference uses only the diagonal of WN here (acado_solver.c:1442-1444)
-            const float e0 = px - gyN[0], e1 = py - gyN[1], e2 = ps - gyN[2];
+            const float e0 = xk.x - gyN[0], e1 = xk.y - gyN[1], e2 = xk.z - gyN[2];
             part += e0 * e0 * gWN[0] + e1 * e1 * gWN[4] + e2 * e2 * gWN[8];
         }
         if (valid) {
-            float* ox = p.b.x + (size_t)prob * NS * 3;
-            ox[k * 3] = px; ox[k * 3 + 1] = py; ox[k * 3 + 2] = ps;
-            if (k < N) {
-                float* ou = p.b.u + (size_t)prob * N * 2;
-                float* od = p.b.dual + (size_t)prob * N * 2;
-                ou[k * 2] = ROW(F_U0, k); ou[k * 2 + 1] = ROW(F_U1, k);
-                od[k * 2] = ROW(F_Y0, k); od[k * 2 + 1] = ROW(F_Y1, k);
-            }
+            float* ox = p.b.x + (size_t)prob * (N + 1) * 3;
+            ox[k * 3] = xk.x; ox[k * 3 + 1] = xk.y; ox[k * 3 + 2] = xk.z;
         }
     }
-#pragma unroll
-    for (int off = L / 2; off > 0; off >>= 1) part += __shfl_xor(part, off, L);
-    obj = 0.5f * part;
+    const float obj = 0.5f * group_sum<L>(part);
     if (valid && writer) {
         p.b.status[prob] = status;
         p.b.n_iter[prob] = n_iter;
         p.b.kkt[prob] = kkt;
         p.b.obj[prob] = obj;
+    }
+    if (STAMP && threadIdx.x == 0 && p.stamps) {
+        long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        const long long t_end = __builtin_amdgcn_s_memtime();
+        o[0] = t_stamp[1] - t_stamp[0]; // load + phase A
+        o[1] = t_stamp[2];              // backward sweeps
+        o[2] = t_stamp[3];              // forward sweeps
+        o[3] = t_stamp[5] - t_stamp[4]; // phase C
+        o[4] = t_end - t_stamp[5];      // objective + write-back
+        o[5] = t_end - t_stamp[0];      // total
     }
 }
 
@@ -359,23 +514,28 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
 {
     dim3 grid(g.grid), block(g.threads);
     hipError_t e = hipSuccess;
+    const bool stamp = p.stamps != nullptr;
     switch (g.L) {
-#define CASE(LL)                                                                                             \
-    case LL: {                                                                                               \
-        static size_t configured = 0; /* raise the dynamic-LDS cap once per size, not per launch */          \
-        if (g.lds_bytes > configured) {                                                                      \
-            e = hipFuncSetAttribute((const void*)rti_kernel<LL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)g.lds_bytes);                                                       \
-            if (e != hipSuccess) return e;                                                                   \
-            configured = g.lds_bytes;                                                                        \
-        }                                                                                                    \
-        hipLaunchKernelGGL(rti_kernel<LL>, grid, block, g.lds_bytes, s, p);                                  \
-        break;                                                                                               \
+#define CASE(LL)                                                                                              \
+    case LL: {                                                                                                \
+        static size_t configured[2] = {0, 0}; /* raise the dynamic-LDS cap once per size, not per launch */   \
+        const void* fn = stamp ? (const void*)rti_kernel<LL, true> : (const void*)rti_kernel<LL, false>;      \
+        if (g.lds_bytes > configured[stamp]) {                                                                \
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);        \
+            if (e != hipSuccess) return e;                                                                    \
+            configured[stamp] = g.lds_bytes;                                                                  \
+        }                                                                                                     \
+        if (stamp)                                                                                            \
+            hipLaunchKernelGGL((rti_kernel<LL, true>), grid, block, g.lds_bytes, s, p);                       \
+        else                                                                                                  \
+            hipLaunchKernelGGL((rti_kernel<LL, false>), grid, block, g.lds_bytes, s, p);                      \
+        break;                                                                                                \
     }
         CASE(4)
         CASE(8)
         CASE(16)
         CASE(32)
+        CASE(64)
 #undef CASE
     default:
         return hipErrorInvalidValue;
@@ -408,7 +568,7 @@ __global__ void linearize_kernel(alore_nmpc_batch b, int B, int N, IrkConst K, a
     }
     if (o.evGu) {
         float* g = o.evGu + (size_t)t * 6;
-        g[0] = lin.B00; g[1] = lin.B01; g[2] = lin.B10; g[3] = lin.B11; g[4] = lin.B20; g[5] = lin.B21;
+        g[0] = lin.B00; g[1] = lin.B01; g[2] = lin.B10; g[3] = lin.B11; g[4] = lin.B20; g[5] = -lin.B20;
     }
 }
 

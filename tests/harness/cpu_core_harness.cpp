@@ -31,7 +31,7 @@ int core_linearize(int N, float dt, const float* x, const float* u, const float*
         float* g = Gx + k * 9;
         g[0] = 1; g[1] = 0; g[2] = l.a; g[3] = 0; g[4] = 1; g[5] = l.b; g[6] = 0; g[7] = 0; g[8] = 1;
         float* b = Gu + k * 6;
-        b[0] = l.B00; b[1] = l.B01; b[2] = l.B10; b[3] = l.B11; b[4] = l.B20; b[5] = l.B21;
+        b[0] = l.B00; b[1] = l.B01; b[2] = l.B10; b[3] = l.B11; b[4] = l.B20; b[5] = -l.B20;
     }
     return 0;
 }
@@ -43,16 +43,19 @@ int core_rti(int N, float dt, float* x, float* u, const float* od, const float* 
     const IrkConst K = make_irk(dt);
     std::vector<StageQP> st(N);
     std::vector<Policy> pol(N);
-    std::vector<float> lb0(N), lb1(N), ub0(N), ub1(N), du0(N), du1(N), mu0(N), mu1(N), dxs(3 * (N + 1));
+    std::vector<Value> Vs(N + 1); // cost-to-go per node, kept for partial restarts of the backward sweep
+    std::vector<float> lb0(N), lb1(N), ub0(N), ub1(N), du0(N), du1(N), mu0(N), mu1(N), dxs(3 * (N + 1)),
+        sbs(3 * (N + 1));
     Sym3 QN;
     float qN[3];
     bool infeasible = false;
+    // ---- phase A
     for (int k = 0; k < N; ++k) {
         StageLin l;
         const float px = x[k * 3], py = x[k * 3 + 1], ps = x[k * 3 + 2], vr = u[k * 2], vl = u[k * 2 + 1];
         ddr_linearize(K, px, py, ps, vr, vl, od[k * 3], od[k * 3 + 1], od[k * 3 + 2], l);
         StageQP& s = st[k];
-        s.a = l.a; s.b = l.b; s.B00 = l.B00; s.B01 = l.B01; s.B10 = l.B10; s.B11 = l.B11; s.B20 = l.B20; s.B21 = l.B21;
+        s.a = l.a; s.b = l.b; s.B00 = l.B00; s.B01 = l.B01; s.B10 = l.B10; s.B11 = l.B11; s.B20 = l.B20;
         s.d0 = l.phi0 - x[k * 3 + 3]; s.d1 = l.phi1 - x[k * 3 + 4]; s.d2 = l.phi2 - x[k * 3 + 5];
         const float* yk = y + k * 5;
         const float* w = W + k * 25;
@@ -76,64 +79,71 @@ int core_rti(int N, float dt, float* x, float* u, const float* od, const float* 
         qN[1] = WN[3] * e0 + WN[4] * e1 + WN[5] * e2;
         qN[2] = WN[6] * e0 + WN[7] * e1 + WN[8] * e2;
         QN.m00 = WN[0]; QN.m01 = WN[1]; QN.m02 = WN[2]; QN.m11 = WN[4]; QN.m12 = WN[5]; QN.m22 = WN[8];
+        Vs[N].P = QN; Vs[N].p0 = qN[0]; Vs[N].p1 = qN[1]; Vs[N].p2 = qN[2];
     }
     const float Dx0 = x0[0] - x[0], Dx1 = x0[1] - x[1], Dx2 = x0[2] - x[2];
-    bool pd_fail = false, changed = false;
-    int it = 0, n_iter = 0;
-    float kkt = 0;
+    // ---- phase B
+    bool pd_fail = false, changed = true;
+    int it = 0, n_iter = 0, khi = N - 1;
     for (;;) {
-        Value V;
-        V.P = QN; V.p0 = qN[0]; V.p1 = qN[1]; V.p2 = qN[2];
+        Value V = Vs[khi + 1];
         bool ok = true;
-        for (int k = N - 1; k >= 0; --k) {
+        for (int k = khi; k >= 0; --k) {
             StageQP& s = st[k];
             s.v0 = (s.st0 == ST_UPPER) ? ub0[k] : lb0[k];
             s.v1 = (s.st1 == ST_UPPER) ? ub1[k] : lb1[k];
             ok = riccati_step(s, V, pol[k], k > 0) && ok;
+            if (k > 0) Vs[k] = V;
         }
         pd_fail = pd_fail || !ok;
-        float dx0 = Dx0, dx1 = Dx1, dx2 = Dx2, sb0 = Dx0, sb1 = Dx1, sb2 = Dx2, gd = 0, comp = 0;
-        changed = false;
-        dxs[0] = dx0; dxs[1] = dx1; dxs[2] = dx2;
+        float dx0 = Dx0, dx1 = Dx1, dx2 = Dx2, sb0 = Dx0, sb1 = Dx1, sb2 = Dx2;
+        const bool first = (it == 0);
+        int new_khi = -1;
         for (int k = 0; k < N; ++k) {
             StageQP& s = st[k];
             StageStep o;
             forward_step(pol[k], s.st0, s.st1, dx0, dx1, dx2, lb0[k], ub0[k], lb1[k], ub1[k], o);
-            changed = changed || o.nst0 != s.st0 || o.nst1 != s.st1;
-            if (k > 0) {
-                const float t0 = dx0 - sb0, t1 = dx1 - sb1, t2 = dx2 - sb2;
-                gd += (s.Q.m00 * sb0 + s.Q.m01 * sb1 + s.Q.m02 * sb2 + s.q0) * t0 +
-                      (s.Q.m01 * sb0 + s.Q.m11 * sb1 + s.Q.m12 * sb2 + s.q1) * t1 +
-                      (s.Q.m02 * sb0 + s.Q.m12 * sb1 + s.Q.m22 * sb2 + s.q2) * t2;
-            }
-            gd += s.r0 * o.du0 + s.r1 * o.du1;
-            comp += (o.mu0 > 1e-12f) ? std::fabs(lb0[k] * o.mu0) : ((o.mu0 < -1e-12f) ? std::fabs(ub0[k] * o.mu0) : 0.0f);
-            comp += (o.mu1 > 1e-12f) ? std::fabs(lb1[k] * o.mu1) : ((o.mu1 < -1e-12f) ? std::fabs(ub1[k] * o.mu1) : 0.0f);
+            if (o.nst0 != s.st0 || o.nst1 != s.st1) new_khi = k;
+            dxs[k * 3] = dx0; dxs[k * 3 + 1] = dx1; dxs[k * 3 + 2] = dx2;
+            if (first) { sbs[k * 3] = sb0; sbs[k * 3 + 1] = sb1; sbs[k * 3 + 2] = sb2; }
             const float n0 = dx0 + s.a * dx2 + s.B00 * o.du0 + s.B01 * o.du1 + s.d0;
             const float n1 = dx1 + s.b * dx2 + s.B10 * o.du0 + s.B11 * o.du1 + s.d1;
-            const float n2 = dx2 + s.B20 * o.du0 + s.B21 * o.du1 + s.d2;
-            const float m0 = sb0 + s.a * sb2 + s.d0, m1 = sb1 + s.b * sb2 + s.d1, m2 = sb2 + s.d2;
-            dx0 = n0; dx1 = n1; dx2 = n2; sb0 = m0; sb1 = m1; sb2 = m2;
+            const float n2 = dx2 + s.B20 * (o.du0 - o.du1) + s.d2;
+            dx0 = n0; dx1 = n1; dx2 = n2;
+            if (first) {
+                const float m0 = sb0 + s.a * sb2 + s.d0, m1 = sb1 + s.b * sb2 + s.d1, m2 = sb2 + s.d2;
+                sb0 = m0; sb1 = m1; sb2 = m2;
+            }
             du0[k] = o.du0; du1[k] = o.du1; mu0[k] = o.mu0; mu1[k] = o.mu1;
-            dxs[(k + 1) * 3] = dx0; dxs[(k + 1) * 3 + 1] = dx1; dxs[(k + 1) * 3 + 2] = dx2;
             s.st0 = o.nst0; s.st1 = o.nst1;
         }
-        {
-            const float t0 = dx0 - sb0, t1 = dx1 - sb1, t2 = dx2 - sb2;
-            gd += (QN.m00 * sb0 + QN.m01 * sb1 + QN.m02 * sb2 + qN[0]) * t0 +
-                  (QN.m01 * sb0 + QN.m11 * sb1 + QN.m12 * sb2 + qN[1]) * t1 +
-                  (QN.m02 * sb0 + QN.m12 * sb1 + QN.m22 * sb2 + qN[2]) * t2;
-        }
-        kkt = std::fabs(gd) + comp;
+        dxs[N * 3] = dx0; dxs[N * 3 + 1] = dx1; dxs[N * 3 + 2] = dx2;
+        if (first) { sbs[N * 3] = sb0; sbs[N * 3 + 1] = sb1; sbs[N * 3 + 2] = sb2; }
         ++it;
+        changed = new_khi >= 0;
+        khi = new_khi;
         if (changed) n_iter = it;
         if (!(changed && it < max_as_iter)) break;
     }
-    if (n_iter == 0) n_iter = 1;
-    else if (!changed) n_iter += 1;
+    n_iter = (n_iter == 0) ? 1 : (changed ? n_iter : n_iter + 1);
+    // ---- phase C
+    float gd = 0, comp = 0;
     for (int k = 0; k <= N; ++k) {
-        x[k * 3] += dxs[k * 3]; x[k * 3 + 1] += dxs[k * 3 + 1]; x[k * 3 + 2] += dxs[k * 3 + 2];
+        const float* dxp = &dxs[k * 3];
+        const float* sb = &sbs[k * 3];
+        if (k > 0) {
+            const Sym3& Q = (k < N) ? st[k].Q : QN;
+            const float q0 = (k < N) ? st[k].q0 : qN[0], q1 = (k < N) ? st[k].q1 : qN[1], q2 = (k < N) ? st[k].q2 : qN[2];
+            const float t0 = dxp[0] - sb[0], t1 = dxp[1] - sb[1], t2 = dxp[2] - sb[2];
+            gd += (Q.m00 * sb[0] + Q.m01 * sb[1] + Q.m02 * sb[2] + q0) * t0 +
+                  (Q.m01 * sb[0] + Q.m11 * sb[1] + Q.m12 * sb[2] + q1) * t1 +
+                  (Q.m02 * sb[0] + Q.m12 * sb[1] + Q.m22 * sb[2] + q2) * t2;
+        }
+        x[k * 3] += dxp[0]; x[k * 3 + 1] += dxp[1]; x[k * 3 + 2] += dxp[2];
         if (k < N) {
+            gd += st[k].r0 * du0[k] + st[k].r1 * du1[k];
+            comp += (mu0[k] > 1e-12f) ? std::fabs(lb0[k] * mu0[k]) : ((mu0[k] < -1e-12f) ? std::fabs(ub0[k] * mu0[k]) : 0.0f);
+            comp += (mu1[k] > 1e-12f) ? std::fabs(lb1[k] * mu1[k]) : ((mu1[k] < -1e-12f) ? std::fabs(ub1[k] * mu1[k]) : 0.0f);
             if (dx_out) { dx_out[k * 2] = du0[k]; dx_out[k * 2 + 1] = du1[k]; }
             u[k * 2] += (lb0[k] <= ub0[k]) ? clampf(du0[k], lb0[k], ub0[k]) : du0[k];
             u[k * 2 + 1] += (lb1[k] <= ub1[k]) ? clampf(du1[k], lb1[k], ub1[k]) : du1[k];
@@ -143,7 +153,7 @@ int core_rti(int N, float dt, float* x, float* u, const float* od, const float* 
     *status_out = infeasible ? RET_INIT_FAILED_INFEASIBILITY
                              : (pd_fail ? RET_INIT_FAILED_CHOLESKY : (changed ? RET_MAX_NWSR_REACHED : RET_OK));
     *n_iter_out = n_iter;
-    *kkt_out = kkt;
+    *kkt_out = std::fabs(gd) + comp;
     return 0;
 }
 }
