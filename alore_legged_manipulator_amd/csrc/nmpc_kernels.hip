@@ -1,48 +1,64 @@
 // nmpc_kernels.hip -- gfx950 kernels of the batched NMPC real-time iteration.
 //
-// Mapping.  A workgroup holds G problems; each problem is worked on by a group
-// of L consecutive lanes (L = 4..32, a power of two, so a group never straddles
-// a 64-lane wavefront).  All per-stage data of a problem live in one LDS row
-// laid out field-major ([field][stage]) so that
-//   * the stage-parallel phases (linearise, cost, expand) run with lane j of a
-//     group on stages j, j+L, ... and touch consecutive LDS banks, and
-//   * the two sequential sweeps of the QP (Riccati backward, rollout forward)
-//     are executed by every lane of the group on the same addresses (LDS
-//     broadcast reads, no conflicts; lane 0 of the group stores).
-// Row strides are padded to L mod 32 so that the groups of one 32-lane half
-// hit disjoint banks.  Global traffic per tick is the algorithmic minimum:
-// every input member is read once, x/u/dual are written once.
+// Mapping.  One wavefront per workgroup; a wavefront holds G = 64 / L problems, each worked on by a
+// group of L consecutive lanes (L = 4..64, a power of two).  All per-stage data of a problem live in
+// LDS as N+1 "stage records" of 19 sixteen-byte slots (the odd slot count spreads consecutive
+// records over all banks), followed by a staging copy of the read-only inputs.
+//   * load: the reference layout is contiguous per problem, so a group streams its problem in with
+//     16-byte-per-lane coalesced loads, all issued before the first LDS store (one memory round trip);
+//   * stage-parallel phases (linearise + Gauss-Newton cost, KKT/expand, objective): lane j of the
+//     group takes stages j, j+L, ...;
+//   * backward Riccati sweep: sequential in the stages; the 3x3 algebra of a stage is split by rows
+//     over the lanes of each quad (lane r holds row r of the cost-to-go) with DPP quad exchanges,
+//     stage data are LDS broadcast reads, and the sweep restarts below the highest stage whose
+//     working set changed (the cost-to-go of every node is kept in its record);
+//   * forward sweep: the closed-loop stage maps are affine, so the rollout is a prefix scan over
+//     lanes (lane j <-> stage j): log2(L) steps instead of N.
+// Global traffic per tick is the algorithmic minimum: every input member is read once, x/u/dual
+// and four scalars are written once.
 //
-// Reference for what is computed: see nmpc_core.h.  One launch runs n_sqp
-// real-time iterations (acado_preparationStep + acado_feedbackStep,
-// CG/acado_solver.c:1057-1077) for every problem of the batch.
+// Reference for what is computed: see nmpc_core.h.  One launch runs n_sqp real-time iterations
+// (acado_preparationStep + acado_feedbackStep, CG/acado_solver.c:1057-1077) for the whole batch.
 #include "nmpc_kernels.h"
 
 #include "nmpc_core.h"
 
 namespace nmpc {
 
-// LDS layout.  One problem = N+1 stage records of SR floats (19 float4 slots;
-// the odd slot count spreads the records of consecutive stages over all banks
-// for 16-byte accesses), record N being the terminal node.
-//   slot 0  a b B00 B01        slot 7  st0 st1 du0 du1      slot 13 dx0 dx1 dx2 p2
-//   slot 1  B10 B11 B20 d0     slot 8  c00 c01 c02 f0       slot 14 x0 x1 x2 -
-//   slot 2  d1 d2 q0 q1        slot 9  c10 c11 c12 e1       slot 15 u0 u1 y0 y1
-//   slot 3  q2 r0 r1 R00       slot 10 mu0 mu1 f1 -         slot 16 sb0 sb1 sb2 -
-//   slot 4  R01 R11 Q00 Q01    slot 11 P00 P01 P02 P11      slot 17-18 spare
-//   slot 5  Q02 Q11 Q12 Q22    slot 12 P12 P22 p0 p1
-//   slot 6  lb0 ub0 lb1 ub1
-// (P, p) of record k is the cost-to-go at node k under the working set of the
-// last backward sweep; it lets a later sweep restart below the highest stage
-// whose working set changed instead of at the horizon end.
+// Stage record (floats; slot = 4 floats).  Record N is the terminal node.
+//   slot 0  B00 B01 B10 B11      slot 7  lb0 ub0 lb1 ub1       slot 12 P00 P01 P02 p0   (cost-to-go
+//   slot 1  B20 B21 a   b        slot 8  st0 st1 du0 du1       slot 13 P10 P11 P12 p1    at this node,
+//   slot 2  d0  d1  d2  r0       slot 9  c00 c01 c02 f0        slot 14 P20 P21 P22 p2    row-wise)
+//   slot 3  R00 R01 R11 r1       slot 10 c10 c11 c12 e1        slot 15 dx0 dx1 dx2 -
+//   slot 4  Q00 Q01 Q02 q0       slot 11 mu0 mu1 f1  -         slot 16 x0  x1  x2  -
+//   slot 5  Q10 Q11 Q12 q1                                     slot 17 u0  u1  y0  y1
+//   slot 6  Q20 Q21 Q22 q2                                     slot 18 sb0 sb1 sb2 -
 constexpr int SLOTS = 19;
 constexpr int SR = SLOTS * 4;
 enum Slot : int {
-    S_LIN0 = 0, S_LIN1 = 1, S_DQ = 2, S_QR = 3, S_RQ = 4, S_QQ = 5, S_BND = 6, S_STDU = 7,
-    S_POL0 = 8, S_POL1 = 9, S_MU = 10, S_V0 = 11, S_V1 = 12, S_DX = 13, S_X = 14, S_UY = 15, S_SB = 16
+    S_B0 = 0, S_B1 = 1, S_D = 2, S_R = 3, S_Q = 4, S_BND = 7, S_STDU = 8, S_POL0 = 9, S_POL1 = 10, S_MU = 11,
+    S_V = 12, S_DX = 15, S_X = 16, S_UY = 17, S_SB = 18
 };
 
-int rti_row_floats(int N) { return SR * (N + 1); }
+// After the records: a staging copy of the read-only inputs of the problem, filled by coalesced
+// loads, each sub-array padded to 16 bytes.
+__host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+struct Staging {
+    int W, y, od, lb, ub, end; // float offsets from the start of the staging area
+};
+__host__ __device__ inline Staging staging_layout(int N)
+{
+    Staging s;
+    s.W = 0;
+    s.y = s.W + pad4(25 * N);
+    s.od = s.y + pad4(5 * N);
+    s.lb = s.od + pad4(3 * (N + 1));
+    s.ub = s.lb + pad4(2 * N);
+    s.end = s.ub + pad4(2 * N);
+    return s;
+}
+
+int rti_row_floats(int N) { return SR * (N + 1) + staging_layout(N).end; }
 
 bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g)
 {
@@ -58,9 +74,9 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
     }
     if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return false;
     for (; L <= 64; L *= 2) {
-        // pad the row so that RS = 4 (mod 64): the G rows of one wavefront start one 16-byte slot apart
-        const int base = rti_row_floats(N);
-        const int RS = base + ((4 - base % 64) + 64) % 64;
+        // rows of one wavefront must start on different 16-byte bank slots: RS/4 not a multiple of 16
+        int RS = rti_row_floats(N);
+        if ((RS & 63) == 0) RS += 4;
         const long row_bytes = 4L * RS;
         const int G = 64 / L; // one wavefront per workgroup
         if ((long)G * row_bytes > lds_limit_bytes) {
@@ -80,10 +96,6 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
 
 // ---------------------------------------------------------------------------
 
-struct StageRegs { // slots 0..6 of a stage record
-    float4 l0, l1, dq, qr, rq, qq, bnd;
-};
-
 __device__ __forceinline__ float4 lds4(const float* rec, int slot)
 {
     return *reinterpret_cast<const float4*>(rec + slot * 4);
@@ -93,10 +105,18 @@ __device__ __forceinline__ void st4(float* rec, int slot, float a, float b, floa
     *reinterpret_cast<float4*>(rec + slot * 4) = make_float4(a, b, c, d);
 }
 
-__device__ __forceinline__ void load_stage(const float* rec, StageRegs& r)
+// DPP quad permutes: data of another lane of the same quad, no LDS traffic
+template <int CTRL>
+__device__ __forceinline__ float dpp(float x)
 {
-    r.l0 = lds4(rec, S_LIN0); r.l1 = lds4(rec, S_LIN1); r.dq = lds4(rec, S_DQ); r.qr = lds4(rec, S_QR);
-    r.rq = lds4(rec, S_RQ); r.qq = lds4(rec, S_QQ); r.bnd = lds4(rec, S_BND);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+constexpr int QP_BC0 = 0x00, QP_BC1 = 0x55, QP_BC2 = 0xAA, QP_SWAP1 = 0xB1, QP_SWAP2 = 0x4E;
+__device__ __forceinline__ float quad_sum(float x)
+{
+    x += dpp<QP_SWAP1>(x);
+    x += dpp<QP_SWAP2>(x);
+    return x;
 }
 
 template <int L>
@@ -118,6 +138,241 @@ __device__ __forceinline__ int wave_max(int v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
     return v;
+}
+
+// ---- scans over the lanes of a group with DPP row shifts / row broadcasts (no LDS traffic) --------
+// scan_prev<L, STEP>(x, ident): the partner value of step STEP of an inclusive scan over groups of
+// L lanes: steps 0..3 fetch lane-1,-2,-4,-8 inside a row of 16, step 4 the total of the previous
+// row (lane 15), step 5 the total of the first half wavefront (lane 31); `ident` where there is no
+// partner.  Combining cur (op) prev in this order gives an inclusive scan also for
+// non-commutative associative operators.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_id(float x, float ident)
+{
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(x), CTRL, ROWMASK, 0xF, false));
+}
+template <int L>
+constexpr int scan_steps()
+{
+    return L == 4 ? 2 : L == 8 ? 3 : L == 16 ? 4 : L == 32 ? 5 : 6;
+}
+template <int L, int STEP>
+__device__ __forceinline__ float scan_prev(float x, float ident, int j)
+{
+    if constexpr (STEP == 0) {
+        const float v = dpp_id<0x111, 0xF>(x, ident);
+        return (L >= 16) ? v : ((j >= 1) ? v : ident);
+    } else if constexpr (STEP == 1) {
+        const float v = dpp_id<0x112, 0xF>(x, ident);
+        return (L >= 16) ? v : ((j >= 2) ? v : ident);
+    } else if constexpr (STEP == 2) {
+        const float v = dpp_id<0x114, 0xF>(x, ident);
+        return (L >= 16) ? v : ((j >= 4) ? v : ident);
+    } else if constexpr (STEP == 3) {
+        return dpp_id<0x118, 0xF>(x, ident);
+    } else if constexpr (STEP == 4) {
+        return dpp_id<0x142, 0xA>(x, ident); // row_bcast:15 into rows 1 and 3
+    } else {
+        return dpp_id<0x143, 0xC>(x, ident); // row_bcast:31 into rows 2 and 3
+    }
+}
+template <int L, int STEP = 0>
+__device__ __forceinline__ float prefix_sum(float x, int j)
+{
+    if constexpr (STEP < scan_steps<L>()) {
+        x += scan_prev<L, STEP>(x, 0.0f, j);
+        return prefix_sum<L, STEP + 1>(x, j);
+    } else {
+        return x;
+    }
+}
+// value of the previous / next lane of the group, `fill` at the group edge
+template <int L>
+__device__ __forceinline__ float shift_up1(float x, float fill, int j)
+{
+    const float v = dpp_id<0x138, 0xF>(x, fill); // wave_shr:1
+    return (j == 0) ? fill : v;
+}
+template <int L>
+__device__ __forceinline__ float shift_down1(float x, float fill, int j)
+{
+    const float v = dpp_id<0x130, 0xF>(x, fill); // wave_shl:1
+    return (j == L - 1) ? fill : v;
+}
+// value held by the last lane of the group
+template <int L>
+__device__ __forceinline__ float group_last(float v)
+{
+    return __shfl(v, L - 1, L);
+}
+template <int L>
+__device__ __forceinline__ float suffix_sum(float x, int j)
+{
+    const float pre = prefix_sum<L>(x, j);
+    return group_last<L>(pre) - pre + x;
+}
+
+// closed-loop stage map dx+ = M dx + c, composed over the lanes of a group
+struct AffineMap {
+    float m00, m01, m02, m10, m11, m12, m20, m21, m22, c0, c1, c2;
+};
+template <int L, int STEP = 0>
+__device__ __forceinline__ void scan_maps(AffineMap& f, int j)
+{
+    if constexpr (STEP < scan_steps<L>()) {
+        AffineMap g; // the partner map (identity where there is none)
+        g.m00 = scan_prev<L, STEP>(f.m00, 1.0f, j); g.m01 = scan_prev<L, STEP>(f.m01, 0.0f, j);
+        g.m02 = scan_prev<L, STEP>(f.m02, 0.0f, j); g.m10 = scan_prev<L, STEP>(f.m10, 0.0f, j);
+        g.m11 = scan_prev<L, STEP>(f.m11, 1.0f, j); g.m12 = scan_prev<L, STEP>(f.m12, 0.0f, j);
+        g.m20 = scan_prev<L, STEP>(f.m20, 0.0f, j); g.m21 = scan_prev<L, STEP>(f.m21, 0.0f, j);
+        g.m22 = scan_prev<L, STEP>(f.m22, 1.0f, j);
+        g.c0 = scan_prev<L, STEP>(f.c0, 0.0f, j); g.c1 = scan_prev<L, STEP>(f.c1, 0.0f, j);
+        g.c2 = scan_prev<L, STEP>(f.c2, 0.0f, j);
+        AffineMap n; // f o g
+        n.m00 = f.m00 * g.m00 + f.m01 * g.m10 + f.m02 * g.m20;
+        n.m01 = f.m00 * g.m01 + f.m01 * g.m11 + f.m02 * g.m21;
+        n.m02 = f.m00 * g.m02 + f.m01 * g.m12 + f.m02 * g.m22;
+        n.m10 = f.m10 * g.m00 + f.m11 * g.m10 + f.m12 * g.m20;
+        n.m11 = f.m10 * g.m01 + f.m11 * g.m11 + f.m12 * g.m21;
+        n.m12 = f.m10 * g.m02 + f.m11 * g.m12 + f.m12 * g.m22;
+        n.m20 = f.m20 * g.m00 + f.m21 * g.m10 + f.m22 * g.m20;
+        n.m21 = f.m20 * g.m01 + f.m21 * g.m11 + f.m22 * g.m21;
+        n.m22 = f.m20 * g.m02 + f.m21 * g.m12 + f.m22 * g.m22;
+        n.c0 = f.m00 * g.c0 + f.m01 * g.c1 + f.m02 * g.c2 + f.c0;
+        n.c1 = f.m10 * g.c0 + f.m11 * g.c1 + f.m12 * g.c2 + f.c1;
+        n.c2 = f.m20 * g.c0 + f.m21 * g.c1 + f.m22 * g.c2 + f.c2;
+        f = n;
+        scan_maps<L, STEP + 1>(f, j);
+    }
+}
+
+// Group-cooperative copies global -> LDS.  The loads of a batch are all issued before the first
+// store, so a batch costs one memory round trip; 16 bytes per lane where the element count (hence
+// every per-problem base address) allows it.
+template <int L, int U>
+__device__ __forceinline__ void ldg_vec(const float* g, int n4, int j, float4 (&q)[U])
+{
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = u * L + j;
+        q[u] = (i < n4) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int L, int U>
+__device__ __forceinline__ void sts_vec(float* l, int n4, int j, const float4 (&q)[U])
+{
+    float4* l4 = reinterpret_cast<float4*>(l);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = u * L + j;
+        if (i < n4) l4[i] = q[u];
+    }
+}
+template <int L, int U>
+__device__ __forceinline__ void ldg_scl(const float* g, int n, int j, float (&f)[U])
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = u * L + j;
+        f[u] = (i < n) ? g[i] : 0.0f;
+    }
+}
+// plain loop for whatever the first batch did not cover (long horizons) or for unaligned arrays
+template <int L>
+__device__ __forceinline__ void copy_tail(const float* g, float* l, int from, int n, int j)
+{
+    for (int i = from + j; i < n; i += L) l[i] = g[i];
+}
+__device__ __forceinline__ bool vec_ok(const float* g, int n)
+{
+    return ((n & 3) == 0) && ((reinterpret_cast<size_t>(g) & 15) == 0);
+}
+
+// ---- backward Riccati step, rows of the 3x3 algebra spread over the lanes of a quad ------------
+// Lane r (0..2) of every quad holds row r of the cost-to-go: P[r][0..2] and p[r]; lane 3 shadows
+// lane 2 and contributes zero to the quad sums.  Same algebra as nmpc_core.h::riccati_step.
+struct RowValue {
+    float P0, P1, P2, p;
+};
+struct StageBcast { // wavefront-uniform-per-group stage data (LDS broadcast reads)
+    float4 b0, b1, d, R, bnd;
+    float2 st;
+};
+struct RowPolicy {
+    float c0c, c1c;     // component r of the two gain / multiplier rows
+    float f0, e1, f1;   // group-uniform
+};
+
+__device__ __forceinline__ void load_bcast(const float* rec, StageBcast& s)
+{
+    s.b0 = lds4(rec, S_B0); s.b1 = lds4(rec, S_B1); s.d = lds4(rec, S_D); s.R = lds4(rec, S_R);
+    s.bnd = lds4(rec, S_BND);
+    s.st = *reinterpret_cast<const float2*>(rec + S_STDU * 4);
+}
+
+__device__ __forceinline__ int riccati_rows(const StageBcast& s, float4 qrow, float Br0, float Br1, bool is2,
+                                            RowValue& V, RowPolicy& pol, bool need_value)
+{
+    const float B00 = s.b0.x, B01 = s.b0.y, B10 = s.b0.z, B11 = s.b0.w, B20 = s.b1.x, B21 = s.b1.y;
+    const float a = s.b1.z, b = s.b1.w;
+    const float al = is2 ? a : 0.0f, be = is2 ? b : 0.0f;
+    const int st0 = __float_as_int(s.st.x), st1 = __float_as_int(s.st.y);
+    const float v0 = (st0 == ST_UPPER) ? s.bnd.y : s.bnd.x;
+    const float v1 = (st1 == ST_UPPER) ? s.bnd.w : s.bnd.z;
+
+    const float sr = V.P0 * s.d.x + V.P1 * s.d.y + V.P2 * s.d.z + V.p;     // (P d + p)[r]
+    const float PB0 = V.P0 * B00 + V.P1 * B10 + V.P2 * B20;                 // (P B)[r][0]
+    const float PB1 = V.P0 * B01 + V.P1 * B11 + V.P2 * B21;                 // (P B)[r][1]
+    const float H00 = s.R.x + quad_sum(Br0 * PB0);                          // R + B' P B
+    const float H01 = s.R.y + quad_sum(Br0 * PB1);
+    const float H11 = s.R.z + quad_sum(Br1 * PB1);
+    float hu0 = s.d.w + quad_sum(Br0 * sr);                                 // r + B' s
+    const float hu1 = s.R.w + quad_sum(Br1 * sr);
+    // component r of the rows of Hux = B' P A
+    float G0c = PB0 + al * dpp<QP_BC0>(PB0) + be * dpp<QP_BC1>(PB0);
+    const float G1c = PB1 + al * dpp<QP_BC0>(PB1) + be * dpp<QP_BC1>(PB1);
+
+    // eliminate control 1, then control 0 (group-uniform scalars)
+    const bool free1 = (st1 == ST_FREE);
+    const bool bad1 = free1 && !(H11 > 0.0f);
+    const float inv11 = rcp_f(H11);
+    const float w1 = free1 ? inv11 : 0.0f;
+    const float z1 = free1 ? -hu1 * inv11 : v1;
+    const float t1 = w1 * H01;
+    const float g1s = free1 ? -w1 : 1.0f;
+    pol.c1c = g1s * G1c;
+    pol.e1 = g1s * H01;
+    pol.f1 = free1 ? z1 : hu1 + H11 * v1;
+    const float H00r = H00 - t1 * H01;
+    G0c -= t1 * G1c;
+    hu0 += H01 * z1;
+    const bool free0 = (st0 == ST_FREE);
+    const bool bad0 = free0 && !(H00r > 0.0f);
+    const float inv00 = rcp_f(H00r);
+    const float w0 = free0 ? inv00 : 0.0f;
+    const float z0 = free0 ? -hu0 * inv00 : v0;
+    const float g0s = free0 ? -w0 : 1.0f;
+    pol.c0c = g0s * G0c;
+    pol.f0 = free0 ? z0 : hu0 + H00r * v0;
+    if (need_value) {
+        // row r of Q + A' P A and of q + A' s
+        const float m = a * V.P0 + b * V.P1 + V.P2; // (P A)[r][2]
+        const float m0 = dpp<QP_BC0>(m), m1 = dpp<QP_BC1>(m);
+        float X0 = qrow.x + (is2 ? m0 : V.P0);
+        float X1 = qrow.y + (is2 ? m1 : V.P1);
+        float X2 = qrow.z + m + al * m0 + be * m1;
+        float hx = qrow.w + sr + al * dpp<QP_BC0>(sr) + be * dpp<QP_BC1>(sr);
+        // minus the rank-one terms of the two eliminated controls
+        const float wg1 = w1 * G1c, wg0 = w0 * G0c;
+        X0 -= wg1 * dpp<QP_BC0>(G1c) + wg0 * dpp<QP_BC0>(G0c);
+        X1 -= wg1 * dpp<QP_BC1>(G1c) + wg0 * dpp<QP_BC1>(G0c);
+        X2 -= wg1 * dpp<QP_BC2>(G1c) + wg0 * dpp<QP_BC2>(G0c);
+        hx += G1c * z1 + G0c * z0;
+        V.P0 = X0; V.P1 = X1; V.P2 = X2; V.p = hx;
+    }
+    return (bad0 || bad1) ? 0 : 1;
 }
 
 // one wavefront per workgroup, G = 64 / L problems per wavefront
@@ -153,15 +408,61 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
     const float* glb = p.b.lbValues + (size_t)prob * N * 2;
     const float* gub = p.b.ubValues + (size_t)prob * N * 2;
 
-    // ---- phase 0: iterate -> LDS
-    for (int k = j; k <= N; k += L) {
-        float* rec = row + k * SR;
-        st4(rec, S_X, gx[k * 3], gx[k * 3 + 1], gx[k * 3 + 2], 0.0f);
-        if (k < N) st4(rec, S_UY, gu[k * 2], gu[k * 2 + 1], gdual[k * 2], gdual[k * 2 + 1]);
+    // ---- phase 0: coalesced loads.  Read-only inputs -> staging, iterate (x, u, dual) -> records.
+    const Staging SG = staging_layout(N);
+    float* stg = row + (N + 1) * SR;
+    {
+        constexpr int UW = (128 + L - 1) / L; // first batch: up to 128 float4 of W (a 20-node horizon)
+        constexpr int UV = (32 + L - 1) / L;  // ... 32 float4 of y / lb / ub
+        constexpr int UX = (64 + L - 1) / L;  // ... 64 floats of od / x / u / dual
+        const bool vW = vec_ok(gW, 25 * N), vy = vec_ok(gy, 5 * N), vb = vec_ok(glb, 2 * N) && vec_ok(gub, 2 * N);
+        float4 qW[UW], qy[UV], qlb[UV], qub[UV];
+        float fod[UX], fx[UX], fu[UX], fd[UX];
+        if (vW) ldg_vec<L, UW>(gW, (25 * N) >> 2, j, qW);
+        if (vy) ldg_vec<L, UV>(gy, (5 * N) >> 2, j, qy);
+        if (vb) { ldg_vec<L, UV>(glb, (2 * N) >> 2, j, qlb); ldg_vec<L, UV>(gub, (2 * N) >> 2, j, qub); }
+        ldg_scl<L, UX>(god, 3 * (N + 1), j, fod);
+        ldg_scl<L, UX>(gx, 3 * (N + 1), j, fx);
+        ldg_scl<L, UX>(gu, 2 * N, j, fu);
+        ldg_scl<L, UX>(gdual, 2 * N, j, fd);
+        if (vW) sts_vec<L, UW>(stg + SG.W, (25 * N) >> 2, j, qW);
+        if (vy) sts_vec<L, UV>(stg + SG.y, (5 * N) >> 2, j, qy);
+        if (vb) { sts_vec<L, UV>(stg + SG.lb, (2 * N) >> 2, j, qlb); sts_vec<L, UV>(stg + SG.ub, (2 * N) >> 2, j, qub); }
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+            const int i = u * L + j;
+            if (i < 3 * (N + 1)) {
+                stg[SG.od + i] = fod[u];
+                row[(i / 3) * SR + S_X * 4 + (i % 3)] = fx[u];
+            }
+            if (i < 2 * N) {
+                float* rec = row + (i >> 1) * SR + S_UY * 4 + (i & 1);
+                rec[0] = fu[u];
+                rec[2] = fd[u];
+            }
+        }
+        // whatever the first batch did not cover
+        copy_tail<L>(gW, stg + SG.W, vW ? min(25 * N, 4 * UW * L) : 0, 25 * N, j);
+        copy_tail<L>(gy, stg + SG.y, vy ? min(5 * N, 4 * UV * L) : 0, 5 * N, j);
+        copy_tail<L>(glb, stg + SG.lb, vb ? min(2 * N, 4 * UV * L) : 0, 2 * N, j);
+        copy_tail<L>(gub, stg + SG.ub, vb ? min(2 * N, 4 * UV * L) : 0, 2 * N, j);
+        copy_tail<L>(god, stg + SG.od, UX * L, 3 * (N + 1), j);
+        for (int i = UX * L + j; i < 3 * (N + 1); i += L) row[(i / 3) * SR + S_X * 4 + (i % 3)] = gx[i];
+        for (int i = UX * L + j; i < 2 * N; i += L) {
+            float* rec = row + (i >> 1) * SR + S_UY * 4 + (i & 1);
+            rec[0] = gu[i];
+            rec[2] = gdual[i];
+        }
     }
     const float x00 = p.b.x0[(size_t)prob * 3], x01 = p.b.x0[(size_t)prob * 3 + 1],
                 x02 = p.b.x0[(size_t)prob * 3 + 2];
     __syncthreads();
+
+    // row role of this lane inside its quad (backward sweep)
+    const int rq = j & 3;
+    const int rr = (rq < 3) ? rq : 2; // lane 3 shadows lane 2 ...
+    const bool is2 = (rr == 2);
+    const float rowmask = (rq < 3) ? 1.0f : 0.0f; // ... and contributes nothing to the quad sums
 
     int status = RET_OK, n_iter = 0;
     float kkt = 0.0f;
@@ -177,12 +478,13 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                 const float4 xn = lds4(rec + SR, S_X);
                 const float vr = uy.x, vl = uy.y;
                 StageLin lin;
-                ddr_linearize(K, xk.x, xk.y, xk.z, vr, vl, god[k * 3], god[k * 3 + 1], god[k * 3 + 2], lin);
+                const float* odk = stg + SG.od + k * 3;
+                ddr_linearize(K, xk.x, xk.y, xk.z, vr, vl, odk[0], odk[1], odk[2], lin);
                 const float d0 = lin.phi0 - xn.x, d1 = lin.phi1 - xn.y, d2 = lin.phi2 - xn.z;
                 // Dy = h(x,u) - y ; gradient = W[rows] * Dy ; Hessian blocks of W
-                const float* yk = gy + k * 5;
+                const float* yk = stg + SG.y + k * 5;
                 const float e0 = xk.x - yk[0], e1 = xk.y - yk[1], e2 = xk.z - yk[2], e3 = vr - yk[3], e4 = vl - yk[4];
-                const float* Wk = gW + k * 25;
+                const float* Wk = stg + SG.W + k * 25;
                 float w[25];
 #pragma unroll
                 for (int i = 0; i < 25; ++i) w[i] = Wk[i];
@@ -191,15 +493,18 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                 const float q2 = w[10] * e0 + w[11] * e1 + w[12] * e2 + w[13] * e3 + w[14] * e4;
                 const float r0 = w[15] * e0 + w[16] * e1 + w[17] * e2 + w[18] * e3 + w[19] * e4;
                 const float r1 = w[20] * e0 + w[21] * e1 + w[22] * e2 + w[23] * e3 + w[24] * e4;
-                const float lb0 = glb[k * 2] - vr, lb1 = glb[k * 2 + 1] - vl;
-                const float ub0 = gub[k * 2] - vr, ub1 = gub[k * 2 + 1] - vl;
+                const float* lbk = stg + SG.lb + k * 2;
+                const float* ubk = stg + SG.ub + k * 2;
+                const float lb0 = lbk[0] - vr, lb1 = lbk[1] - vl;
+                const float ub0 = ubk[0] - vr, ub1 = ubk[1] - vl;
                 infeasible |= (lb0 > ub0 + 1e-6f) || (lb1 > ub1 + 1e-6f);
-                st4(rec, S_LIN0, lin.a, lin.b, lin.B00, lin.B01);
-                st4(rec, S_LIN1, lin.B10, lin.B11, lin.B20, d0);
-                st4(rec, S_DQ, d1, d2, q0, q1);
-                st4(rec, S_QR, q2, r0, r1, w[18]);
-                st4(rec, S_RQ, w[19], w[24], w[0], w[1]);
-                st4(rec, S_QQ, w[2], w[6], w[7], w[12]);
+                st4(rec, S_B0, lin.B00, lin.B01, lin.B10, lin.B11);
+                st4(rec, S_B1, lin.B20, -lin.B20, lin.a, lin.b);
+                st4(rec, S_D, d0, d1, d2, r0);
+                st4(rec, S_R, w[18], w[19], w[24], r1);
+                st4(rec, S_Q, w[0], w[1], w[2], q0);
+                st4(rec, S_Q + 1, w[5], w[6], w[7], q1);
+                st4(rec, S_Q + 2, w[10], w[11], w[12], q2);
                 st4(rec, S_BND, lb0, ub0, lb1, ub1);
                 st4(rec, S_STDU, __int_as_float(status_from_dual(uy.z, lb0, ub0)),
                     __int_as_float(status_from_dual(uy.w, lb1, ub1)), 0.0f, 0.0f);
@@ -211,14 +516,13 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                 const float q0 = w[0] * e0 + w[1] * e1 + w[2] * e2;
                 const float q1 = w[3] * e0 + w[4] * e1 + w[5] * e2;
                 const float q2 = w[6] * e0 + w[7] * e1 + w[8] * e2;
-                st4(rec, S_DQ, 0.0f, 0.0f, q0, q1);
-                st4(rec, S_QR, q2, 0.0f, 0.0f, 0.0f);
-                st4(rec, S_RQ, 0.0f, 0.0f, w[0], w[1]);
-                st4(rec, S_QQ, w[2], w[4], w[5], w[8]);
+                st4(rec, S_Q, w[0], w[1], w[2], q0);
+                st4(rec, S_Q + 1, w[3], w[4], w[5], q1);
+                st4(rec, S_Q + 2, w[6], w[7], w[8], q2);
                 // cost-to-go at the terminal node
-                st4(rec, S_V0, w[0], w[1], w[2], w[4]);
-                st4(rec, S_V1, w[5], w[8], q0, q1);
-                rec[S_DX * 4 + 3] = q2;
+                st4(rec, S_V, w[0], w[1], w[2], q0);
+                st4(rec, S_V + 1, w[3], w[4], w[5], q1);
+                st4(rec, S_V + 2, w[6], w[7], w[8], q2);
             }
         }
         infeasible = group_or<L>(infeasible);
@@ -228,10 +532,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
         const float4 xfirst = lds4(row, S_X);
         const float Dx0 = x00 - xfirst.x, Dx1 = x01 - xfirst.y, Dx2 = x02 - xfirst.z;
 
-        // ---- phase B: working-set iterations.  Backward: sequential Riccati sweep, every lane of the
-        //      group runs it on the same LDS addresses (broadcast reads), lane 0 of the group stores.
-        //      Forward: the closed-loop stage maps dx+ = M_k dx + c_k are affine, so the rollout is a
-        //      prefix scan over the lanes (lane j <-> stage j), log2(L) steps instead of N.
+        // ---- phase B: working-set iterations
         int pd_fail = 0;
         bool changed = true; // "this problem still needs a sweep"
         int khi = N - 1;     // highest stage whose cost-to-go is stale
@@ -245,58 +546,51 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             const int kk = changed ? khi : -1;
             const int kmax = __builtin_amdgcn_readfirstlane(wave_max(kk)); // wavefront-uniform loop bound
             {
-                Value V;
-                V.P.m00 = V.P.m01 = V.P.m02 = V.P.m11 = V.P.m12 = V.P.m22 = 0.0f;
-                V.p0 = V.p1 = V.p2 = 0.0f;
+                RowValue V;
+                V.P0 = V.P1 = V.P2 = V.p = 0.0f;
                 int ok = 1;
-                auto step = [&](int k, const StageRegs& cur, const float4& cst) {
-                    if (k == kk) { // this group joins the sweep here: cost-to-go of node k+1
-                        const float* rn = row + (k + 1) * SR;
-                        const float4 v0 = lds4(rn, S_V0), v1 = lds4(rn, S_V1);
-                        V.P.m00 = v0.x; V.P.m01 = v0.y; V.P.m02 = v0.z; V.P.m11 = v0.w;
-                        V.P.m12 = v1.x; V.P.m22 = v1.y; V.p0 = v1.z; V.p1 = v1.w;
-                        V.p2 = rn[S_DX * 4 + 3];
-                    }
-                    if (k <= kk) {
-                        StageQP s;
-                        s.a = cur.l0.x; s.b = cur.l0.y; s.B00 = cur.l0.z; s.B01 = cur.l0.w;
-                        s.B10 = cur.l1.x; s.B11 = cur.l1.y; s.B20 = cur.l1.z; s.d0 = cur.l1.w;
-                        s.d1 = cur.dq.x; s.d2 = cur.dq.y; s.q0 = cur.dq.z; s.q1 = cur.dq.w;
-                        s.q2 = cur.qr.x; s.r0 = cur.qr.y; s.r1 = cur.qr.z; s.R00 = cur.qr.w;
-                        s.R01 = cur.rq.x; s.R11 = cur.rq.y; s.Q.m00 = cur.rq.z; s.Q.m01 = cur.rq.w;
-                        s.Q.m02 = cur.qq.x; s.Q.m11 = cur.qq.y; s.Q.m12 = cur.qq.z; s.Q.m22 = cur.qq.w;
-                        s.st0 = __float_as_int(cst.x);
-                        s.st1 = __float_as_int(cst.y);
-                        s.v0 = (s.st0 == ST_UPPER) ? cur.bnd.y : cur.bnd.x;
-                        s.v1 = (s.st1 == ST_UPPER) ? cur.bnd.w : cur.bnd.z;
-                        Policy pol;
-                        ok &= riccati_step(s, V, pol, k > 0) ? 1 : 0;
-                        if (writer) {
-                            float* rec = row + k * SR;
-                            st4(rec, S_POL0, pol.c00, pol.c01, pol.c02, pol.f0);
-                            st4(rec, S_POL1, pol.c10, pol.c11, pol.c12, pol.e1);
-                            rec[S_MU * 4 + 2] = pol.f1;
-                            if (k > 0) {
-                                st4(rec, S_V0, V.P.m00, V.P.m01, V.P.m02, V.P.m11);
-                                st4(rec, S_V1, V.P.m12, V.P.m22, V.p0, V.p1);
-                                rec[S_DX * 4 + 3] = V.p2;
-                            }
-                        }
+                // Every lane computes every step (a group that has not joined yet works on garbage that
+                // is never stored); only the stores are predicated.  Lanes 0..2 of the first quad store
+                // their row / components, lane 3 the three group-uniform scalars, in the same instructions.
+                auto step = [&](int k, const StageBcast& cur, const float4& qrow, const float2& brow, const float4& vnext) {
+                    const bool join = (k == kk); // this group joins the sweep here: cost-to-go of node k+1
+                    V.P0 = join ? vnext.x : V.P0; V.P1 = join ? vnext.y : V.P1;
+                    V.P2 = join ? vnext.z : V.P2; V.p = join ? vnext.w : V.p;
+                    RowPolicy pol;
+                    const int good = riccati_rows(cur, qrow, brow.x * rowmask, brow.y * rowmask, is2, V, pol, k > 0);
+                    ok &= (k <= kk) ? good : 1;
+                    if (j < 4 && k <= kk) {
+                        float* rec = row + k * SR;
+                        rec[S_POL0 * 4 + j] = (j < 3) ? pol.c0c : pol.f0;
+                        rec[S_POL1 * 4 + j] = (j < 3) ? pol.c1c : pol.e1;
+                        // lane 3 parks f1 in the multiplier slot (mu is rewritten by the forward sweep)
+                        const int slot = (j < 3) ? S_V + j : S_MU;
+                        const float w0_ = (j < 3) ? V.P0 : 0.0f, w1_ = (j < 3) ? V.P1 : 0.0f,
+                                    w2_ = (j < 3) ? V.P2 : pol.f1, w3_ = (j < 3) ? V.p : 0.0f;
+                        st4(rec, slot, w0_, w1_, w2_, w3_);
                     }
                 };
+                auto fetch = [&](int k, StageBcast& sb, float4& qrow, float2& brow, float4& vnext) {
+                    const float* rec = row + k * SR;
+                    load_bcast(rec, sb);
+                    qrow = lds4(rec, S_Q + rr);
+                    brow = *reinterpret_cast<const float2*>(rec + 2 * rr);
+                    vnext = lds4(rec + SR, S_V + rr);
+                };
                 // two register sets, loads of the next record in flight while the current one is used
-                StageRegs ra, rb;
-                float4 sa = make_float4(0, 0, 0, 0), sb4 = sa;
+                StageBcast sa, sb;
+                float4 qa = make_float4(0, 0, 0, 0), qb = qa, va = qa, vb = qa;
+                float2 ba = make_float2(0, 0), bb = ba;
                 int k = kmax;
-                if (k >= 0) { load_stage(row + k * SR, ra); sa = lds4(row + k * SR, S_STDU); }
+                if (k >= 0) fetch(k, sa, qa, ba, va);
                 while (k >= 1) {
-                    load_stage(row + (k - 1) * SR, rb); sb4 = lds4(row + (k - 1) * SR, S_STDU);
-                    step(k, ra, sa);
-                    if (k >= 2) { load_stage(row + (k - 2) * SR, ra); sa = lds4(row + (k - 2) * SR, S_STDU); }
-                    step(k - 1, rb, sb4);
+                    fetch(k - 1, sb, qb, bb, vb);
+                    step(k, sa, qa, ba, va);
+                    if (k >= 2) fetch(k - 2, sa, qa, ba, va);
+                    step(k - 1, sb, qb, bb, vb);
                     k -= 2;
                 }
-                if (k == 0) step(0, ra, sa);
+                if (k == 0) step(0, sa, qa, ba, va);
                 pd_fail |= (ok == 0);
             }
             __syncthreads();
@@ -314,7 +608,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                     const int k = base + j;
                     const bool in = k < N;
                     float* rec = row + (in ? k : 0) * SR;
-                    const float4 l0 = lds4(rec, S_LIN0), l1 = lds4(rec, S_LIN1), dq = lds4(rec, S_DQ),
+                    const float4 l0 = lds4(rec, S_B0), l1 = lds4(rec, S_B1), dd = lds4(rec, S_D),
                                  bnd = lds4(rec, S_BND), sd = lds4(rec, S_STDU), p0 = lds4(rec, S_POL0),
                                  p1 = lds4(rec, S_POL1), mu = lds4(rec, S_MU);
                     const int st0 = __float_as_int(sd.x), st1 = __float_as_int(sd.y);
@@ -326,49 +620,32 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                     const float g10 = f1 ? p1.x + p1.w * g00 : 0.0f, g11 = f1 ? p1.y + p1.w * g01 : 0.0f,
                                 g12 = f1 ? p1.z + p1.w * g02 : 0.0f;
                     const float h1 = f1 ? p1.w * h0 + mu.z : b1;
-                    const float a = l0.x, b = l0.y, B00 = l0.z, B01 = l0.w, B10 = l1.x, B11 = l1.y, B20 = l1.z;
-                    const float d0 = l1.w, d1 = dq.x, d2 = dq.y;
+                    const float B00 = l0.x, B01 = l0.y, B10 = l0.z, B11 = l0.w, B20 = l1.x, a = l1.z, b = l1.w;
+                    const float d0 = dd.x, d1 = dd.y, d2 = dd.z;
                     // closed-loop stage map  dx+ = M dx + c  (identity for padding lanes)
-                    float m00 = 1.0f, m01 = 0.0f, m02 = 0.0f, m10 = 0.0f, m11 = 1.0f, m12 = 0.0f, m20 = 0.0f,
-                          m21 = 0.0f, m22 = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+                    AffineMap f;
+                    f.m00 = 1.0f; f.m01 = 0.0f; f.m02 = 0.0f; f.m10 = 0.0f; f.m11 = 1.0f; f.m12 = 0.0f;
+                    f.m20 = 0.0f; f.m21 = 0.0f; f.m22 = 1.0f; f.c0 = 0.0f; f.c1 = 0.0f; f.c2 = 0.0f;
                     // free-response map: sbar+ = A sbar + d
                     float sa_ = 0.0f, sb_ = 0.0f, sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;
                     if (in) {
                         const float gd0 = g00 - g10, gd1 = g01 - g11, gd2 = g02 - g12; // B2 = B20 * (1, -1)
-                        m00 = 1.0f + B00 * g00 + B01 * g10; m01 = B00 * g01 + B01 * g11; m02 = a + B00 * g02 + B01 * g12;
-                        m10 = B10 * g00 + B11 * g10; m11 = 1.0f + B10 * g01 + B11 * g11; m12 = b + B10 * g02 + B11 * g12;
-                        m20 = B20 * gd0; m21 = B20 * gd1; m22 = 1.0f + B20 * gd2;
-                        c0 = B00 * h0 + B01 * h1 + d0;
-                        c1 = B10 * h0 + B11 * h1 + d1;
-                        c2 = B20 * (h0 - h1) + d2;
+                        f.m00 = 1.0f + B00 * g00 + B01 * g10; f.m01 = B00 * g01 + B01 * g11; f.m02 = a + B00 * g02 + B01 * g12;
+                        f.m10 = B10 * g00 + B11 * g10; f.m11 = 1.0f + B10 * g01 + B11 * g11; f.m12 = b + B10 * g02 + B11 * g12;
+                        f.m20 = B20 * gd0; f.m21 = B20 * gd1; f.m22 = 1.0f + B20 * gd2;
+                        f.c0 = B00 * h0 + B01 * h1 + d0;
+                        f.c1 = B10 * h0 + B11 * h1 + d1;
+                        f.c2 = B20 * (h0 - h1) + d2;
                         sa_ = a; sb_ = b; sc0 = d0; sc1 = d1; sc2 = d2;
                     }
                     // inclusive scan of map composition: after it, lane j holds f_k o ... o f_base
-#pragma unroll
-                    for (int off = 1; off < L; off <<= 1) {
-                        const float pm00 = __shfl_up(m00, off, L), pm01 = __shfl_up(m01, off, L), pm02 = __shfl_up(m02, off, L),
-                                    pm10 = __shfl_up(m10, off, L), pm11 = __shfl_up(m11, off, L), pm12 = __shfl_up(m12, off, L),
-                                    pm20 = __shfl_up(m20, off, L), pm21 = __shfl_up(m21, off, L), pm22 = __shfl_up(m22, off, L),
-                                    pc0 = __shfl_up(c0, off, L), pc1 = __shfl_up(c1, off, L), pc2 = __shfl_up(c2, off, L);
-                        if (j >= off) {
-                            const float n00 = m00 * pm00 + m01 * pm10 + m02 * pm20, n01 = m00 * pm01 + m01 * pm11 + m02 * pm21,
-                                        n02 = m00 * pm02 + m01 * pm12 + m02 * pm22;
-                            const float n10 = m10 * pm00 + m11 * pm10 + m12 * pm20, n11 = m10 * pm01 + m11 * pm11 + m12 * pm21,
-                                        n12 = m10 * pm02 + m11 * pm12 + m12 * pm22;
-                            const float n20 = m20 * pm00 + m21 * pm10 + m22 * pm20, n21 = m20 * pm01 + m21 * pm11 + m22 * pm21,
-                                        n22 = m20 * pm02 + m21 * pm12 + m22 * pm22;
-                            c0 += m00 * pc0 + m01 * pc1 + m02 * pc2;
-                            c1 += m10 * pc0 + m11 * pc1 + m12 * pc2;
-                            c2 += m20 * pc0 + m21 * pc1 + m22 * pc2;
-                            m00 = n00; m01 = n01; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m21 = n21; m22 = n22;
-                        }
-                    }
+                    scan_maps<L>(f, j);
                     // state step leaving stage k (= entering k+1), and the one entering stage k
-                    const float o0 = m00 * cx0 + m01 * cx1 + m02 * cx2 + c0;
-                    const float o1 = m10 * cx0 + m11 * cx1 + m12 * cx2 + c1;
-                    const float o2 = m20 * cx0 + m21 * cx1 + m22 * cx2 + c2;
-                    float dx0 = __shfl_up(o0, 1, L), dx1 = __shfl_up(o1, 1, L), dx2 = __shfl_up(o2, 1, L);
-                    if (j == 0) { dx0 = cx0; dx1 = cx1; dx2 = cx2; }
+                    const float o0 = f.m00 * cx0 + f.m01 * cx1 + f.m02 * cx2 + f.c0;
+                    const float o1 = f.m10 * cx0 + f.m11 * cx1 + f.m12 * cx2 + f.c1;
+                    const float o2 = f.m20 * cx0 + f.m21 * cx1 + f.m22 * cx2 + f.c2;
+                    const float dx0 = shift_up1<L>(o0, cx0, j), dx1 = shift_up1<L>(o1, cx1, j),
+                                dx2 = shift_up1<L>(o2, cx2, j);
                     Policy pol;
                     pol.c00 = p0.x; pol.c01 = p0.y; pol.c02 = p0.z; pol.f0 = p0.w;
                     pol.c10 = p1.x; pol.c11 = p1.y; pol.c12 = p1.z; pol.e1 = p1.w; pol.f1 = mu.z;
@@ -381,27 +658,15 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                         st4(rec, S_STDU, __int_as_float(o.nst0), __int_as_float(o.nst1), o.du0, o.du1);
                     }
                     if (first) { // free response (du = 0): A is a shear, so two chained prefix sums do it
-                        // sbar2 entering stage k = cs2 + sum_{i<k} d2_i
-                        float e2 = sc2;
-#pragma unroll
-                        for (int off = 1; off < L; off <<= 1) { const float t = __shfl_up(e2, off, L); if (j >= off) e2 += t; }
-                        float in2 = __shfl_up(e2, 1, L);
-                        in2 = (j == 0) ? cs2 : cs2 + in2;
-                        float e0 = sa_ * in2 + sc0, e1 = sb_ * in2 + sc1;
-#pragma unroll
-                        for (int off = 1; off < L; off <<= 1) {
-                            const float t0 = __shfl_up(e0, off, L), t1 = __shfl_up(e1, off, L);
-                            if (j >= off) { e0 += t0; e1 += t1; }
-                        }
-                        float in0 = __shfl_up(e0, 1, L), in1 = __shfl_up(e1, 1, L);
-                        in0 = (j == 0) ? cs0 : cs0 + in0;
-                        in1 = (j == 0) ? cs1 : cs1 + in1;
+                        const float e2 = prefix_sum<L>(sc2, j);            // sum_{i<=k} d2_i
+                        const float in2 = cs2 + shift_up1<L>(e2, 0.0f, j); // sbar2 entering stage k
+                        const float e0 = prefix_sum<L>(sa_ * in2 + sc0, j), e1 = prefix_sum<L>(sb_ * in2 + sc1, j);
+                        const float in0 = cs0 + shift_up1<L>(e0, 0.0f, j), in1 = cs1 + shift_up1<L>(e1, 0.0f, j);
                         if (in && active) { rec[S_SB * 4] = in0; rec[S_SB * 4 + 1] = in1; rec[S_SB * 4 + 2] = in2; }
                         // carry to the next chunk: values leaving the last lane
-                        const float l0_ = __shfl(e0, L - 1, L), l1_ = __shfl(e1, L - 1, L), l2_ = __shfl(e2, L - 1, L);
-                        cs0 += l0_; cs1 += l1_; cs2 += l2_;
+                        cs0 += group_last<L>(e0); cs1 += group_last<L>(e1); cs2 += group_last<L>(e2);
                     }
-                    cx0 = __shfl(o0, L - 1, L); cx1 = __shfl(o1, L - 1, L); cx2 = __shfl(o2, L - 1, L);
+                    cx0 = group_last<L>(o0); cx1 = group_last<L>(o1); cx2 = group_last<L>(o2);
                 }
                 if (writer && active) { // node N
                     float* rec = row + N * SR;
@@ -434,17 +699,17 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             float* rec = row + k * SR;
             const float4 dxp = lds4(rec, S_DX), sb = lds4(rec, S_SB), xk = lds4(rec, S_X);
             if (k > 0) { // (Q_k sbar_k + q_k)' (dx_k - sbar_k)
-                const float4 dq = lds4(rec, S_DQ), qr = lds4(rec, S_QR), rq = lds4(rec, S_RQ), qq = lds4(rec, S_QQ);
+                const float4 q0 = lds4(rec, S_Q), q1 = lds4(rec, S_Q + 1), q2 = lds4(rec, S_Q + 2);
                 const float t0 = dxp.x - sb.x, t1 = dxp.y - sb.y, t2 = dxp.z - sb.z;
-                gd += (rq.z * sb.x + rq.w * sb.y + qq.x * sb.z + dq.z) * t0 +
-                      (rq.w * sb.x + qq.y * sb.y + qq.z * sb.z + dq.w) * t1 +
-                      (qq.x * sb.x + qq.z * sb.y + qq.w * sb.z + qr.x) * t2;
+                gd += (q0.x * sb.x + q0.y * sb.y + q0.z * sb.z + q0.w) * t0 +
+                      (q1.x * sb.x + q1.y * sb.y + q1.z * sb.z + q1.w) * t1 +
+                      (q2.x * sb.x + q2.y * sb.y + q2.z * sb.z + q2.w) * t2;
             }
             st4(rec, S_X, xk.x + dxp.x, xk.y + dxp.y, xk.z + dxp.z, 0.0f);
             if (k < N) {
-                const float4 qr = lds4(rec, S_QR), bnd = lds4(rec, S_BND), sd = lds4(rec, S_STDU), mu = lds4(rec, S_MU),
-                             uy = lds4(rec, S_UY);
-                gd += qr.y * sd.z + qr.z * sd.w;
+                const float4 dd = lds4(rec, S_D), R = lds4(rec, S_R), bnd = lds4(rec, S_BND), sd = lds4(rec, S_STDU),
+                             mu = lds4(rec, S_MU), uy = lds4(rec, S_UY);
+                gd += dd.w * sd.z + R.w * sd.w; // r' du
                 comp += (mu.x > 1e-12f) ? fabsf(bnd.x * mu.x) : ((mu.x < -1e-12f) ? fabsf(bnd.y * mu.x) : 0.0f);
                 comp += (mu.y > 1e-12f) ? fabsf(bnd.z * mu.y) : ((mu.y < -1e-12f) ? fabsf(bnd.w * mu.y) : 0.0f);
                 // a free control may sit up to TOL_PRIMAL outside its box: keep the iterate feasible
@@ -465,8 +730,8 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
         const float4 xk = lds4(rec, S_X);
         if (k < N) {
             const float4 uy = lds4(rec, S_UY);
-            const float* yk = gy + k * 5;
-            const float* Wk = gW + k * 25;
+            const float* yk = stg + SG.y + k * 5;
+            const float* Wk = stg + SG.W + k * 25;
             float e[5] = {xk.x - yk[0], xk.y - yk[1], xk.z - yk[2], uy.x - yk[3], uy.y - yk[4]};
             float acc = 0.0f;
 #pragma unroll

@@ -38,7 +38,7 @@ def nmpc_mod():
     return nmpc
 
 
-@pytest.mark.parametrize("N,L", [(20, 0), (20, 4), (20, 8), (20, 16), (20, 32), (20, 64), (50, 0), (50, 32), (50, 8), (7, 0), (1, 0)])
+@pytest.mark.parametrize("N,L", [(20, 0), (20, 4), (20, 8), (20, 16), (20, 32), (20, 64), (50, 0), (50, 32), (50, 16), (7, 0), (1, 0)])
 def test_one_tick_matches_oracle(nmpc_mod, N, L):
     B = 96 if N <= 20 else 40
     batch = make_batch(B, N, seed=1234 + N, fast_tail=0.3)
