@@ -26,7 +26,7 @@ class NmpcError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("N", C.c_int), ("dt", C.c_float), ("device", C.c_int), ("max_as_iter", C.c_int),
-                ("lanes_per_problem", C.c_int)]
+                ("lanes_per_problem", C.c_int), ("warm_start_steps", C.c_int)]
 
 
 BATCH_FLOAT_MEMBERS = ("x", "u", "od", "y", "yN", "W", "WN", "x0", "lbValues", "ubValues", "dual")

@@ -26,8 +26,10 @@ struct alore_nmpc_solver {
     bool stamps = false;
     long long* d_stamps = nullptr;
     size_t stamps_cap = 0;
-    double stamp_sum[6] = {0, 0, 0, 0, 0, 0};
+    double stamp_sum[7] = {0, 0, 0, 0, 0, 0, 0};
     double stamp_max_total = 0;
+    double stamp_max[7] = {0, 0, 0, 0, 0, 0, 0};
+    double stamp_slowest[7] = {0, 0, 0, 0, 0, 0, 0};
     long stamp_n = 0;
 };
 
@@ -120,6 +122,7 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     if (!h) return ALORE_NMPC_E_NOMEM;
     h->cfg = *cfg;
     if (h->cfg.max_as_iter <= 0) h->cfg.max_as_iter = 64;
+    if (h->cfg.warm_start_steps < 0) h->cfg.warm_start_steps = 8;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)prop.sharedMemPerBlock : 64 * 1024;
     if (prop.maxSharedMemoryPerMultiProcessor > (size_t)h->lds_limit)
@@ -145,13 +148,17 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
 {
     if (!h) return ALORE_NMPC_E_INVALID;
     if (h->stamps && h->stamp_n > 0) {
-        static const char* names[6] = {"load+linearise", "backward sweeps", "forward sweeps", "kkt+expand",
-                                       "objective+store", "total"};
+        static const char* names[7] = {"load+linearise", "backward sweeps", "forward sweeps", "kkt+expand",
+                                       "objective+store", "total", "ws prediction"};
         std::fprintf(stderr, "[alore_nmpc stamps] mean cycles per workgroup over %ld workgroup-launches:\n", h->stamp_n);
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 7; ++i)
             std::fprintf(stderr, "  %-16s %10.0f  (%5.1f %%)\n", names[i], h->stamp_sum[i] / h->stamp_n,
                          100.0 * h->stamp_sum[i] / h->stamp_sum[5]);
-        std::fprintf(stderr, "  slowest workgroup total: %.0f cycles\n", h->stamp_max_total);
+        std::fprintf(stderr, "  slowest workgroup total: %.0f cycles; its phases:", h->stamp_max_total);
+        for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %.0f", h->stamp_slowest[i]);
+        std::fprintf(stderr, "\n  per-phase maxima:");
+        for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %.0f", h->stamp_max[i]);
+        std::fprintf(stderr, "\n");
     }
     if (h->d_stamps) (void)hipFree(h->d_stamps);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -247,6 +254,7 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     p.N = h->cfg.N;
     p.n_sqp = n_sqp;
     p.max_as_iter = h->cfg.max_as_iter;
+    p.pg_steps = h->cfg.warm_start_steps;
     p.RS = g.RS;
     const nmpc::IrkConst K = nmpc::make_irk(h->cfg.dt);
     p.h = K.h; p.hh = K.hh; p.c1h = K.c1h; p.c2h = K.c2h;
@@ -274,8 +282,13 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
         HIP_TRY(h, hipStreamSynchronize(s));
         HIP_TRY(h, hipMemcpy(host.data(), h->d_stamps, host.size() * sizeof(long long), hipMemcpyDeviceToHost));
         for (int b = 0; b < g.grid; ++b) {
-            for (int i = 0; i < 6; ++i) h->stamp_sum[i] += (double)host[(size_t)b * 8 + i];
-            if ((double)host[(size_t)b * 8 + 5] > h->stamp_max_total) h->stamp_max_total = (double)host[(size_t)b * 8 + 5];
+            for (int i = 0; i < 7; ++i) h->stamp_sum[i] += (double)host[(size_t)b * 8 + i];
+            for (int i = 0; i < 7; ++i)
+                if ((double)host[(size_t)b * 8 + i] > h->stamp_max[i]) h->stamp_max[i] = (double)host[(size_t)b * 8 + i];
+            if ((double)host[(size_t)b * 8 + 5] > h->stamp_max_total) {
+                h->stamp_max_total = (double)host[(size_t)b * 8 + 5];
+                for (int i = 0; i < 7; ++i) h->stamp_slowest[i] = (double)host[(size_t)b * 8 + i];
+            }
         }
         h->stamp_n += g.grid;
     }

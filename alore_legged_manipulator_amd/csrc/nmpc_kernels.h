@@ -15,6 +15,7 @@ struct RtiParams {
     int N;
     int n_sqp;
     int max_as_iter;
+    int pg_steps; // projected-gradient steps of the working-set prediction (0 = off)
     int RS; // LDS floats per problem (row stride)
     float h, hh, c1h, c2h;
     long long* stamps; // diagnostic builds only: per-block phase cycle counts (8 per block), else null

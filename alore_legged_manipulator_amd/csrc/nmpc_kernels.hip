@@ -21,6 +21,8 @@
 // (acado_preparationStep + acado_feedbackStep, CG/acado_solver.c:1057-1077) for the whole batch.
 #include "nmpc_kernels.h"
 
+#include <type_traits>
+
 #include "nmpc_core.h"
 
 namespace nmpc {
@@ -200,11 +202,49 @@ __device__ __forceinline__ float shift_down1(float x, float fill, int j)
     const float v = dpp_id<0x130, 0xF>(x, fill); // wave_shl:1
     return (j == L - 1) ? fill : v;
 }
-// value held by the last lane of the group
+// value held by the last lane of the group.  v_readlane through inline asm with explicit wait
+// states: the builtin form returned stale data right behind the DPP / VALU producers here.
+__device__ __forceinline__ float readlane_f(float v, int lane31_or_63)
+{
+    float r;
+    if (lane31_or_63 == 31)
+        asm volatile("s_nop 4\n\tv_readlane_b32 %0, %1, 31\n\ts_nop 1" : "=s"(r) : "v"(v));
+    else
+        asm volatile("s_nop 4\n\tv_readlane_b32 %0, %1, 63\n\ts_nop 1" : "=s"(r) : "v"(v));
+    return r;
+}
 template <int L>
 __device__ __forceinline__ float group_last(float v)
 {
-    return __shfl(v, L - 1, L);
+    if constexpr (L == 64) {
+        return readlane_f(v, 63);
+    } else if constexpr (L == 32) {
+        const float a = readlane_f(v, 31), b = readlane_f(v, 63);
+        return (threadIdx.x < 32) ? a : b;
+    } else {
+        return __shfl(v, L - 1, L);
+    }
+}
+// group-wide sum / max through the DPP scans
+template <int L>
+__device__ __forceinline__ float group_total(float v, int j)
+{
+    return group_last<L>(prefix_sum<L>(v, j));
+}
+template <int L, int STEP = 0>
+__device__ __forceinline__ int prefix_max_i(int x, int j)
+{
+    if constexpr (STEP < scan_steps<L>()) {
+        const int o = __float_as_int(scan_prev<L, STEP>(__int_as_float(x), __int_as_float(-2147483647 - 1), j));
+        return prefix_max_i<L, STEP + 1>(max(x, o), j);
+    } else {
+        return x;
+    }
+}
+template <int L>
+__device__ __forceinline__ int group_max_i(int v, int j)
+{
+    return __float_as_int(group_last<L>(__int_as_float(prefix_max_i<L>(v, j))));
 }
 template <int L>
 __device__ __forceinline__ float suffix_sum(float x, int j)
@@ -532,6 +572,91 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
         const float4 xfirst = lds4(row, S_X);
         const float Dx0 = x00 - xfirst.x, Dx1 = x01 - xfirst.y, Dx2 = x02 - xfirst.z;
 
+        // ---- working-set prediction for cold starts (no dual information, every control free): if the
+        //      clipped Jacobi step of the condensed QP hits a bound, a few projected-gradient steps
+        //      (Hessian applied stage-wise by prefix / suffix sums over the lanes, step length from a
+        //      short power iteration) predict which bounds are active, and that set is what the first
+        //      Riccati sweep starts from.  Only a guess: the sweeps below still iterate until the
+        //      working set reproduces itself, so the solution is the same with or without it.
+        long long t_pg = 0;
+        if (p.pg_steps > 0 && N <= L) {
+            long long tp0 = 0;
+            if (STAMP) tp0 = __builtin_amdgcn_s_memtime();
+            const bool in = j < N;
+            float* rec = row + (in ? j : 0) * SR;
+            const float* recn = rec + SR; // node j+1
+            const float msk = in ? 1.0f : 0.0f;
+            const float4 l0 = lds4(rec, S_B0), l1 = lds4(rec, S_B1), dd = lds4(rec, S_D), RR = lds4(rec, S_R),
+                         bnd = lds4(rec, S_BND), sd = lds4(rec, S_STDU);
+            const float4 q0 = lds4(recn, S_Q), q1 = lds4(recn, S_Q + 1), q2 = lds4(recn, S_Q + 2), ln = lds4(recn, S_B1);
+            const int nonfree = in ? (__float_as_int(sd.x) | __float_as_int(sd.y)) : 0;
+            const bool cold = group_or<L>(nonfree) == 0;
+            const float B00 = l0.x * msk, B01 = l0.y * msk, B10 = l0.z * msk, B11 = l0.w * msk, B20 = l1.x * msk;
+            const float a = l1.z * msk, b = l1.w * msk, d0 = dd.x * msk, d1 = dd.y * msk, d2 = dd.z * msk;
+            const float r0 = dd.w * msk, r1 = RR.w * msk, R00 = RR.x * msk, R01 = RR.y * msk, R11 = RR.z * msk;
+            const float Q00 = q0.x * msk, Q01 = q0.y * msk, Q02 = q0.z * msk, qv0 = q0.w * msk;
+            const float Q10 = q1.x * msk, Q11 = q1.y * msk, Q12 = q1.z * msk, qv1 = q1.w * msk;
+            const float Q20 = q2.x * msk, Q21 = q2.y * msk, Q22 = q2.z * msk, qv2 = q2.w * msk;
+            const bool has_next = (j + 1 < N);
+            const float an = has_next ? ln.z : 0.0f, bn = has_next ? ln.w : 0.0f; // shear of stage j+1
+            const float lb0 = bnd.x * msk, ub0 = bnd.y * msk, lb1 = bnd.z * msk, ub1 = bnd.w * msk;
+            // H du (AFF = false) or the gradient H du + g (AFF = true) of the condensed QP
+            auto apply = [&](float u0, float u1, auto aff_tag, float& g0, float& g1) {
+                constexpr bool AFF = decltype(aff_tag)::value;
+                const float X2 = prefix_sum<L>(B20 * (u0 - u1) + (AFF ? d2 : 0.0f), j) + (AFF ? Dx2 : 0.0f); // psi at node j+1
+                const float in2 = shift_up1<L>(X2, AFF ? Dx2 : 0.0f, j);
+                const float X0 = prefix_sum<L>(a * in2 + B00 * u0 + B01 * u1 + (AFF ? d0 : 0.0f), j) + (AFF ? Dx0 : 0.0f);
+                const float X1 = prefix_sum<L>(b * in2 + B10 * u0 + B11 * u1 + (AFF ? d1 : 0.0f), j) + (AFF ? Dx1 : 0.0f);
+                const float y0 = Q00 * X0 + Q01 * X1 + Q02 * X2 + (AFF ? qv0 : 0.0f);
+                const float y1 = Q10 * X0 + Q11 * X1 + Q12 * X2 + (AFF ? qv1 : 0.0f);
+                const float y2 = Q20 * X0 + Q21 * X1 + Q22 * X2 + (AFF ? qv2 : 0.0f);
+                const float Lx = suffix_sum<L>(y0, j), Ly = suffix_sum<L>(y1, j); // adjoint at node j+1
+                const float nx = shift_down1<L>(Lx, 0.0f, j), ny = shift_down1<L>(Ly, 0.0f, j);
+                const float Lp = suffix_sum<L>(y2 + an * nx + bn * ny, j);
+                g0 = R00 * u0 + R01 * u1 + (AFF ? r0 : 0.0f) + B00 * Lx + B10 * Ly + B20 * Lp;
+                g1 = R01 * u0 + R11 * u1 + (AFF ? r1 : 0.0f) + B01 * Lx + B11 * Ly - B20 * Lp;
+            };
+            // gradient at du = 0 and the clipped R-scaled (Jacobi) step
+            const float is0 = in ? rcp_f(fmaxf(R00, 1e-20f)) : 0.0f, is1 = in ? rcp_f(fmaxf(R11, 1e-20f)) : 0.0f;
+            float g0, g1;
+            apply(0.0f, 0.0f, std::true_type{}, g0, g1);
+            const float j0 = -is0 * g0, j1 = -is1 * g1;
+            const int hits = (j0 < lb0) | (j0 > ub0) | (j1 < lb1) | (j1 > ub1);
+            const bool run = cold && (group_or<L>(hits) != 0);
+            if (__any(run)) {
+                // largest eigenvalue of R^-1/2 H R^-1/2 by a short power iteration
+                const float s0 = in ? __builtin_amdgcn_rsqf(fmaxf(R00, 1e-20f)) : 0.0f,
+                            s1 = in ? __builtin_amdgcn_rsqf(fmaxf(R11, 1e-20f)) : 0.0f;
+                float v0 = msk, v1 = msk, lam = 1.0f;
+#pragma unroll 1
+                for (int t = 0; t < 2; ++t) {
+                    float h0, h1;
+                    apply(s0 * v0, s1 * v1, std::false_type{}, h0, h1);
+                    const float w0 = s0 * h0, w1 = s1 * h1;
+                    const float nn = group_total<L>(w0 * w0 + w1 * w1, j), nv = group_total<L>(v0 * v0 + v1 * v1, j);
+                    const float rn = __builtin_amdgcn_rsqf(fmaxf(nn, 1e-30f));
+                    lam = nn * rn * __builtin_amdgcn_rsqf(fmaxf(nv, 1e-30f));
+                    v0 = w0 * rn; v1 = w1 * rn;
+                }
+                const float alpha = __builtin_amdgcn_rcpf(1.15f * fmaxf(lam, 1.0f));
+                const float a0 = alpha * is0, a1 = alpha * is1;
+                float u0 = clampf(-a0 * g0, lb0, ub0), u1 = clampf(-a1 * g1, lb1, ub1); // first step from 0
+#pragma unroll 1
+                for (int t = 1; t < p.pg_steps; ++t) {
+                    apply(u0, u1, std::true_type{}, g0, g1);
+                    u0 = clampf(u0 - a0 * g0, lb0, ub0);
+                    u1 = clampf(u1 - a1 * g1, lb1, ub1);
+                }
+                if (in && run) {
+                    const int n0 = (ub0 - lb0 > BOUNDTOL) ? ((u0 <= lb0) ? ST_LOWER : ((u0 >= ub0) ? ST_UPPER : ST_FREE)) : ST_LOWER;
+                    const int n1 = (ub1 - lb1 > BOUNDTOL) ? ((u1 <= lb1) ? ST_LOWER : ((u1 >= ub1) ? ST_UPPER : ST_FREE)) : ST_LOWER;
+                    *reinterpret_cast<float2*>(rec + S_STDU * 4) = make_float2(__int_as_float(n0), __int_as_float(n1));
+                }
+            }
+            __syncthreads();
+            if (STAMP) t_pg = __builtin_amdgcn_s_memtime() - tp0;
+        }
+
         // ---- phase B: working-set iterations
         int pd_fail = 0;
         bool changed = true; // "this problem still needs a sweep"
@@ -544,7 +669,11 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             if (STAMP) tb0 = __builtin_amdgcn_s_memtime();
             // ---- backward Riccati sweep from the highest stale stage of this wavefront
             const int kk = changed ? khi : -1;
-            const int kmax = __builtin_amdgcn_readfirstlane(wave_max(kk)); // wavefront-uniform loop bound
+            int kmax_v; // wavefront-uniform loop bound
+            if constexpr (L == 64) kmax_v = kk;
+            else if constexpr (L == 32) kmax_v = max(__float_as_int(readlane_f(__int_as_float(kk), 31)), __float_as_int(readlane_f(__int_as_float(kk), 63)));
+            else kmax_v = wave_max(kk);
+            const int kmax = __builtin_amdgcn_readfirstlane(kmax_v);
             {
                 RowValue V;
                 V.P0 = V.P1 = V.P2 = V.p = 0.0f;
@@ -674,8 +803,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                     if (first) { rec[S_SB * 4] = cs0; rec[S_SB * 4 + 1] = cs1; rec[S_SB * 4 + 2] = cs2; }
                 }
                 // highest changed stage of the group
-#pragma unroll
-                for (int off = L / 2; off > 0; off >>= 1) new_khi = max(new_khi, __shfl_xor(new_khi, off, L));
+                new_khi = group_max_i<L>(new_khi, j);
             }
             ++it;
             if (active) {
@@ -692,6 +820,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
         status = infeasible ? RET_INIT_FAILED_INFEASIBILITY
                             : (pd_fail ? RET_INIT_FAILED_CHOLESKY : (changed ? RET_MAX_NWSR_REACHED : RET_OK));
         if (STAMP && sqp == 0) { t_stamp[2] = t_b; t_stamp[3] = t_f; t_stamp[4] = __builtin_amdgcn_s_memtime(); }
+        if (STAMP && sqp == 0 && threadIdx.x == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 8 + 6] = t_pg;
 
         // ---- phase C (stage-parallel): KKT value (acado_getKKT), expand (acado_expand), carry the dual
         float gd = 0.0f, comp = 0.0f;

@@ -44,7 +44,7 @@ class BatchedNmpc:
     starts from the same iterate."""
 
     def __init__(self, B: int, N: int = 20, dt: float = 0.01, device: int = 0, max_as_iter: int = 64,
-                 lanes_per_problem: int = 0, slots: int = 1):
+                 lanes_per_problem: int = 0, slots: int = 1, warm_start_steps: int = -1):
         import torch  # device memory + streams
         self.torch = torch
         self.lib = _lib.load()  # raises if the HIP library is missing: no fallback
@@ -53,7 +53,7 @@ class BatchedNmpc:
         self.B, self.N, self.dt, self.slots = int(B), int(N), float(dt), int(slots)
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        cfg = Config(self.N, self.dt, device, max_as_iter, lanes_per_problem)
+        cfg = Config(self.N, self.dt, device, max_as_iter, lanes_per_problem, warm_start_steps)
         h = C.c_void_p()
         rc = self.lib.alore_nmpc_create(C.byref(cfg), C.byref(h))
         if rc != 0:

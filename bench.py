@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = auto)")
+    ap.add_argument("--warm-start-steps", type=int, default=-1, help="working-set prediction steps (-1 = library default)")
     ap.add_argument("--gather", choices=("full", "none"), default="full",
                     help="multi-GPU: all-gather the result trajectories (default) or keep them sharded")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per all-gather bucket")
@@ -137,7 +138,8 @@ def main():
     slots = a.steps + a.warmup
     # rank r owns global problems [r*B, (r+1)*B): generated locally from the seeded stream
     batch = make_batch(B, N, offset=rank * B)
-    eng = BatchedNmpc(B, N, device=local_rank, lanes_per_problem=a.lanes, slots=slots)
+    eng = BatchedNmpc(B, N, device=local_rank, lanes_per_problem=a.lanes, slots=slots,
+                      warm_start_steps=a.warm_start_steps)
     eng.load(batch, slot=None)
     torch.cuda.synchronize(dev)
 
