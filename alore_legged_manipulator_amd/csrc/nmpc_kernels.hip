@@ -67,12 +67,14 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
     if (B <= 0 || N <= 0) return false;
     int L = forced_L;
     if (L == 0) {
-        // aim at >= one wavefront per SIMD over the whole chip: B * L >= 256 * n_cu lanes
-        long want = (256L * n_cu + B - 1) / B;
-        L = 4;
-        while (L < 64 && L < want) L *= 2;
-        // the forward scan works on chunks of L stages: with lanes to spare, cover the horizon in one chunk
-        while (L < 64 && L < N && (long)B * L * 2 <= 512L * n_cu) L *= 2;
+        // One chunk of the lane scans should cover the horizon (L >= N): the forward sweep is then a
+        // single scan and the working-set prediction is available.  Measured on MI355X at N = 20:
+        // L = 32 is the fastest choice from B = 1 to B = 32768 (the sequential sweeps cost the same
+        // for any L, a wider group shortens every stage-parallel phase and needs less LDS per
+        // wavefront, which is what bounds residency).
+        L = 16;
+        while (L < 64 && L < N) L *= 2;
+        (void)n_cu;
     }
     if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return false;
     for (; L <= 64; L *= 2) {
