@@ -1,0 +1,154 @@
+"""ctypes binding of the C++ host layer (alore_legged_manipulator_amd/host/*.hpp ->
+libalore_nmpc_host.so): reference sampling (TrajAnal / getRefPoints / smooth_yaw) and the batched
+controller tick, i.e. the ROS-free part of the reference's nmpc node."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libalore_nmpc_host.so")
+DP = C.POINTER(C.c_double)
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (one HIP runtime per process, see _lib.py)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run __graft_entry__.build()")
+    L = C.CDLL(LIB_PATH)
+    L.alore_host_sampler_create.restype = C.c_void_p
+    L.alore_host_sampler_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double]
+    L.alore_host_sampler_destroy.argtypes = [C.c_void_p]
+    L.alore_host_sampler_traj.argtypes = [C.c_void_p, C.c_double, C.c_int] + [DP] * 6
+    L.alore_host_sampler_odom.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+    L.alore_host_sampler_icr.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+    L.alore_host_sampler_refs.argtypes = [C.c_void_p, C.c_double, C.c_int, DP, DP, C.POINTER(C.c_int)]
+    L.alore_host_sampler_duration.restype = C.c_double
+    L.alore_host_sampler_duration.argtypes = [C.c_void_p]
+    L.alore_host_sampler_state.argtypes = [C.c_void_p, C.c_double, DP, DP, DP]
+    L.alore_host_sampler_flat.argtypes = [C.c_void_p, C.c_double, DP, DP, DP]
+    L.alore_host_sampler_sequence.argtypes = [C.c_void_p, DP, C.c_int]
+    L.alore_host_normlize_theta.argtypes = [DP]
+    L.alore_host_controller_create.restype = C.c_void_p
+    L.alore_host_controller_create.argtypes = [C.c_int, C.c_int, C.c_double, DP, DP, C.c_int, C.c_double, C.c_double, C.c_int]
+    L.alore_host_controller_destroy.argtypes = [C.c_void_p]
+    L.alore_host_controller_robot.restype = C.c_void_p
+    L.alore_host_controller_robot.argtypes = [C.c_void_p, C.c_int]
+    L.alore_host_controller_tick.argtypes = [C.c_void_p, C.c_double, DP]
+    L.alore_host_controller_prediction.argtypes = [C.c_void_p, C.c_int, DP, DP, C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(DP)
+
+
+class Polynome:
+    """ROS-free carstatemsgs/Polynome: flat-space (theta, s) minimum-jerk trajectory."""
+
+    def __init__(self, innerpoints, t_pts, init_pva, tail_pva, start_position, ICR, traj_start_time=0.0):
+        self.innerpoints = np.ascontiguousarray(innerpoints, np.float64).reshape(-1, 2)
+        self.t_pts = np.ascontiguousarray(t_pts, np.float64)
+        self.init_pva = np.ascontiguousarray(init_pva, np.float64).reshape(6)   # p0 p1 v0 v1 a0 a1
+        self.tail_pva = np.ascontiguousarray(tail_pva, np.float64).reshape(6)
+        self.start_position = np.ascontiguousarray(start_position, np.float64).reshape(3)
+        self.ICR = np.ascontiguousarray(ICR, np.float64).reshape(3)              # (yr, yl, xv) as sent
+        self.traj_start_time = float(traj_start_time)
+        assert self.innerpoints.shape[0] == self.t_pts.size - 1
+
+
+class RefSampler:
+    """One robot's TrajAnal + getRefPoints + smooth_yaw (host only)."""
+
+    def __init__(self, N, dt=0.01, state_seq_res=0.1, integral_res_int=4, _borrowed=None):
+        self.L = load()
+        self.N = N
+        self._own = _borrowed is None
+        self.h = _borrowed or self.L.alore_host_sampler_create(N, dt, state_seq_res, integral_res_int)
+
+    def __del__(self):
+        try:
+            if self._own and self.h:
+                self.L.alore_host_sampler_destroy(self.h)
+        except Exception:
+            pass
+
+    def traj(self, m: Polynome):
+        inner = m.innerpoints if m.innerpoints.size else np.zeros((1, 2))
+        rc = self.L.alore_host_sampler_traj(self.h, m.traj_start_time, m.t_pts.size, _dp(inner), _dp(m.t_pts),
+                                            _dp(m.init_pva), _dp(m.tail_pva), _dp(m.start_position), _dp(m.ICR))
+        if rc != 0:
+            raise ValueError("bad Polynome")
+
+    def odom(self, x, y, yaw): self.L.alore_host_sampler_odom(self.h, x, y, yaw)
+    def icr(self, yr, yl, xv): self.L.alore_host_sampler_icr(self.h, yr, yl, xv)
+    def duration(self): return self.L.alore_host_sampler_duration(self.h)
+
+    def refs(self, now, smooth=True):
+        rs = np.zeros((self.N + 1, 3)); ri = np.zeros((self.N + 1, 2)); g = C.c_int(0)
+        if self.L.alore_host_sampler_refs(self.h, now, 1 if smooth else 0, _dp(rs), _dp(ri), C.byref(g)) != 0:
+            raise RuntimeError("getRefPoints failed")
+        return rs, ri, bool(g.value)
+
+    def state(self, t):
+        p = np.zeros(3); v = np.zeros(2); a = np.zeros(2)
+        if self.L.alore_host_sampler_state(self.h, t, _dp(p), _dp(v), _dp(a)) != 0:
+            raise IndexError("t outside the state sequence")
+        return p, v, a
+
+    def flat(self, t):
+        p = np.zeros(2); v = np.zeros(2); a = np.zeros(2)
+        self.L.alore_host_sampler_flat(self.h, t, _dp(p), _dp(v), _dp(a))
+        return p, v, a
+
+    def sequence(self):
+        buf = np.zeros((4096, 4))
+        n = self.L.alore_host_sampler_sequence(self.h, _dp(buf), 4096)
+        return buf[:n].copy()
+
+
+def normlize_theta(th: float) -> float:
+    v = C.c_double(th)
+    load().alore_host_normlize_theta(C.byref(v))
+    return v.value
+
+
+class BatchedMpcController:
+    """B copies of the reference's nmpc node tick (mpc.cpp CmdCallback), GPU-backed."""
+
+    def __init__(self, B, N=20, dt=0.01, matrix_q=(10.0, 10.0, 0.5), matrix_r=(0.1, 0.1), delay_num=1,
+                 state_seq_res=0.1, integral_res_int=4, device=0):
+        self.L = load()
+        self.B, self.N = B, N
+        q = np.asarray(matrix_q, np.float64); r = np.asarray(matrix_r, np.float64)
+        self.h = self.L.alore_host_controller_create(B, N, dt, _dp(q), _dp(r), delay_num, state_seq_res,
+                                                     integral_res_int, device)
+        if not self.h:
+            raise RuntimeError("controller creation failed (no GPU?)")
+        self.robots = [RefSampler(N, dt, _borrowed=self.L.alore_host_controller_robot(self.h, b)) for b in range(B)]
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.alore_host_controller_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def tick(self, now):
+        cmd = np.zeros((self.B, 2))
+        if self.L.alore_host_controller_tick(self.h, now, _dp(cmd)) != 0:
+            raise RuntimeError("tick failed")
+        return cmd
+
+    def prediction(self, b):
+        s = np.zeros((self.N + 1, 3)); u = np.zeros((self.N, 2)); st = C.c_int(0)
+        self.L.alore_host_controller_prediction(self.h, b, _dp(s), _dp(u), C.byref(st))
+        return s, u, st.value

@@ -1,0 +1,327 @@
+// mpc_controller.hpp -- C++ host layer above the C ABI: batched mirrors of the reference's
+// Tracked_nmpc::MpcWrapper (A10) and of the ROS-free part of MpcController (A11).
+//
+//   MpcWrapper        P/nmpc_controller/include/nmpc_controller/mpc_wrapper.h:43-141,
+//                     P/nmpc_controller/src/mpc_wrapper.cpp:33-410
+//   MpcController     P/nmpc_controller/include/nmpc_controller/mpc.h:83-200,
+//                     P/nmpc_controller/src/mpc.cpp:6-98 (parameters), :124-171 (callbacks),
+//                     :173-240 (CmdCallback), :243-277 (normlize_theta, smooth_yaw),
+//                     :296-350 (run), :407-461 (getRefPoints), :502-509 (cmdPub)
+// with P = /root/reference/planning_ddr_opt.  Same method names and argument meaning; every robot of
+// the batch is one instance of the reference node.  ROS time is replaced by an explicit `now`
+// argument, messages by plain structs (traj_anal.hpp: Polynome).  The numerics run on the GPU through
+// include/alore_nmpc.h; this layer only does what the reference does in double precision on the host.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/alore_nmpc.h"
+#include "traj_anal.hpp"
+
+namespace alore {
+
+enum STATE { kX = 0, kY = 1, kPsi = 2 };       // mpc.h:57-61
+enum CONTROL { kVr = 0, kVl = 1 };             // mpc.h:64-67
+enum ONLINEDATA { kXv = 0, kYr = 1, kYl = 2 }; // mpc.h:70-74
+
+struct CarICR { // mpc.h:76-81
+    double yr = -0.2, yl = 0.2, xv = 0.0;
+};
+
+// ---- A10: batched MpcWrapper -------------------------------------------------------------------
+class BatchedMpcWrapper {
+public:
+    static constexpr int kStateSize = ALORE_NMPC_NX, kRefSize = ALORE_NMPC_NY, kEndRefSize = ALORE_NMPC_NYN,
+                         kInputSize = ALORE_NMPC_NU, kCostSize = ALORE_NMPC_NY - ALORE_NMPC_NU,
+                         kOdSize = ALORE_NMPC_NOD;
+    const int B, kSamples;
+
+    BatchedMpcWrapper(int batch, int N, double dt = 0.01, int device = 0) : B(batch), kSamples(N), dt_(dt)
+    {
+        alore_nmpc_config cfg{N, (float)dt, device, 0, 0, -1};
+        const int rc = alore_nmpc_create(&cfg, &h_);
+        if (rc != ALORE_NMPC_OK) throw std::runtime_error("alore_nmpc_create failed (" + std::to_string(rc) + "): no CPU path");
+        check(alore_nmpc_batch_alloc(h_, B, &dev_));
+        check(alore_nmpc_batch_default_bounds(h_, &dev_, B, nullptr));
+        x_.assign((size_t)B * 3 * (N + 1), 0.f); u_.assign((size_t)B * 2 * N, 0.f);
+        od_.assign((size_t)B * 3 * (N + 1), 0.f); y_.assign((size_t)B * 5 * N, 0.f); yN_.assign((size_t)B * 3, 0.f);
+        W_.assign((size_t)B * 25 * N, 0.f); WN_.assign((size_t)B * 9, 0.f); x0_.assign((size_t)B * 3, 0.f);
+        status_.assign(B, 0);
+        // mpc_wrapper.cpp:33-93: everything zero, default ICR (0, -0.2, 0.2), forward simulation, prepared
+        const double icr[3] = {0.0, -0.2, 0.2};
+        for (int b = 0; b < B; ++b) setICRParameters(b, icr);
+        upload_all();
+        check(alore_nmpc_forward_simulate(h_, &dev_, B, nullptr));
+        acado_is_prepared_ = true;
+    }
+    ~BatchedMpcWrapper()
+    {
+        if (h_) {
+            alore_nmpc_batch_free(h_, &dev_);
+            alore_nmpc_destroy(h_);
+        }
+    }
+    BatchedMpcWrapper(const BatchedMpcWrapper&) = delete;
+    BatchedMpcWrapper& operator=(const BatchedMpcWrapper&) = delete;
+
+    // mpc_wrapper.cpp:106-138 (Q 3x3, R 2x2 row-major; the same weights for every robot)
+    bool setCosts(const double Q[9], const double R[4], double state_cost_scaling = 0.0, double input_cost_scaling = 0.0)
+    {
+        if (state_cost_scaling < 0.0 || input_cost_scaling < 0.0) return false;
+        const int N = kSamples;
+        float state_scale = 1.0f, input_scale = 1.0f;
+        std::vector<float> W((size_t)25 * N, 0.f);
+        for (int i = 0; i < N; ++i) {
+            state_scale = std::exp(-float(i) / float(N) * float(state_cost_scaling));
+            input_scale = std::exp(-float(i) / float(N) * float(input_cost_scaling));
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) W[(size_t)i * 25 + r * 5 + c] = (float)Q[r * 3 + c] * state_scale;
+            for (int r = 0; r < 2; ++r)
+                for (int c = 0; c < 2; ++c) W[(size_t)i * 25 + (3 + r) * 5 + 3 + c] = (float)R[r * 2 + c] * input_scale;
+        }
+        for (int b = 0; b < B; ++b) {
+            std::memcpy(&W_[(size_t)b * 25 * N], W.data(), W.size() * sizeof(float));
+            for (int k = 0; k < 9; ++k) WN_[(size_t)b * 9 + k] = (float)Q[k] * state_scale;
+        }
+        dirty_costs_ = true;
+        return true;
+    }
+    // mpc_wrapper.cpp:200-207: (xv, yr, yl) to all N+1 nodes of robot b
+    bool setICRParameters(int b, const double p_B_I[3])
+    {
+        for (int k = 0; k <= kSamples; ++k)
+            for (int i = 0; i < 3; ++i) od_[((size_t)b * (kSamples + 1) + k) * 3 + i] = (float)p_B_I[i];
+        return true;
+    }
+    // mpc_wrapper.cpp:242-264: states 3 x (N+1), inputs 2 x (N+1), column-major like the Eigen arguments
+    bool setTrajectory(int b, const double* states, const double* inputs)
+    {
+        const int N = kSamples;
+        for (int k = 0; k < N; ++k) {
+            float* y = &y_[((size_t)b * N + k) * 5];
+            y[0] = (float)states[k * 3]; y[1] = (float)states[k * 3 + 1]; y[2] = (float)states[k * 3 + 2];
+            y[3] = (float)inputs[k * 2]; y[4] = (float)inputs[k * 2 + 1];
+        }
+        for (int i = 0; i < 3; ++i) yN_[(size_t)b * 3 + i] = (float)states[N * 3 + i];
+        return true;
+    }
+    // mpc_wrapper.cpp:267-275: reset the iterate of robot b (x <- state replicated, u <- 0)
+    void resetIterate(int b, const double state[3])
+    {
+        for (int k = 0; k <= kSamples; ++k)
+            for (int i = 0; i < 3; ++i) x_[((size_t)b * (kSamples + 1) + k) * 3 + i] = (float)state[i];
+        std::fill(u_.begin() + (size_t)b * 2 * kSamples, u_.begin() + (size_t)(b + 1) * 2 * kSamples, 0.f);
+        dirty_iterate_ = true;
+    }
+    // mpc_wrapper.cpp:279-373 for all robots at once: states = B x 3
+    bool update(const double* states, bool do_preparation = true)
+    {
+        if (!acado_is_prepared_) return false;
+        for (size_t i = 0; i < (size_t)B * 3; ++i) x0_[i] = (float)states[i];
+        alore_nmpc_batch host{};
+        host.od = od_.data(); host.y = y_.data(); host.yN = yN_.data(); host.x0 = x0_.data();
+        if (dirty_costs_) { host.W = W_.data(); host.WN = WN_.data(); }
+        if (dirty_iterate_) { host.x = x_.data(); host.u = u_.data(); }
+        check(alore_nmpc_batch_upload(h_, &dev_, &host, B, nullptr));
+        dirty_costs_ = dirty_iterate_ = false;
+        check(alore_nmpc_rti(h_, &dev_, B, 1, nullptr));
+        alore_nmpc_batch out{};
+        out.x = x_.data(); out.u = u_.data(); out.status = status_.data();
+        check(alore_nmpc_batch_download(h_, &dev_, &out, B, nullptr));
+        if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("hipStreamSynchronize");
+        acado_is_prepared_ = false;
+        if (do_preparation) acado_is_prepared_ = true; // the preparation is fused into the next launch
+        return true;
+    }
+    bool solve(const double* states) // mpc_wrapper.cpp:267-275 for every robot
+    {
+        for (int b = 0; b < B; ++b) resetIterate(b, states + (size_t)b * 3);
+        return update(states);
+    }
+    bool prepare() { acado_is_prepared_ = true; return true; } // mpc_wrapper.cpp:377-383
+    // mpc_wrapper.cpp:386-410 (double out)
+    void getStates(int b, double* out /* 3 x (N+1) col-major */) const
+    {
+        for (int i = 0; i < 3 * (kSamples + 1); ++i) out[i] = x_[(size_t)b * 3 * (kSamples + 1) + i];
+    }
+    void getInputs(int b, double* out /* 2 x N col-major */) const
+    {
+        for (int i = 0; i < 2 * kSamples; ++i) out[i] = u_[(size_t)b * 2 * kSamples + i];
+    }
+    double getInput(int b, int node, int which) const { return u_[((size_t)b * kSamples + node) * 2 + which]; }
+    int getStatus(int b) const { return status_[b]; }
+    double getTimestep() const { return dt_; }
+
+private:
+    void check(int rc) const
+    {
+        if (rc != ALORE_NMPC_OK) throw std::runtime_error(std::string("alore_nmpc: ") + alore_nmpc_last_error(h_));
+    }
+    void upload_all()
+    {
+        alore_nmpc_batch host{};
+        host.x = x_.data(); host.u = u_.data(); host.od = od_.data(); host.y = y_.data(); host.yN = yN_.data();
+        host.W = W_.data(); host.WN = WN_.data(); host.x0 = x0_.data();
+        check(alore_nmpc_batch_upload(h_, &dev_, &host, B, nullptr));
+        if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("hipStreamSynchronize");
+    }
+    alore_nmpc_handle h_ = nullptr;
+    alore_nmpc_batch dev_{};
+    std::vector<float> x_, u_, od_, y_, yN_, W_, WN_, x0_;
+    std::vector<int> status_;
+    bool acado_is_prepared_ = false, dirty_costs_ = true, dirty_iterate_ = true;
+    const double dt_;
+};
+
+// ---- A11: reference sampling + tick logic, one entry per robot -------------------------------------
+// Pure host code (no GPU): usable and tested on its own.
+class RefSampler {
+public:
+    TrajAnal traj_, new_traj_;
+    double new_traj_start_time_ = 0.0, start_time = -1.0, traj_duration = 0.0;
+    bool receive_traj_ = false, at_goal = false, has_odom = false;
+    CarICR car_icr_;
+    double est_state_[3] = {0, 0, 0};
+    int N_;
+    double dt_;
+    std::vector<double> reference_states_; // 3 x (N+1), column-major (Eigen layout)
+    std::vector<double> reference_inputs_; // 2 x (N+1)
+
+    RefSampler(int N, double dt, double state_seq_res = 0.1, double Integral_appr_resInt = 4) : N_(N), dt_(dt)
+    {
+        traj_.setRes(state_seq_res, Integral_appr_resInt);
+        new_traj_.setRes(state_seq_res, Integral_appr_resInt);
+        reference_states_.assign((size_t)3 * (N + 1), 0.0);
+        reference_inputs_.assign((size_t)2 * (N + 1), 0.0);
+    }
+    // mpc.cpp:112-122
+    void OdomCallback(double x, double y, double yaw) { has_odom = true; est_state_[0] = x; est_state_[1] = y; est_state_[2] = yaw; }
+    // mpc.cpp:124-128: point.x = yr, point.y = yl, point.z = xv
+    void ICRCallback(double yr, double yl, double xv) { car_icr_.yr = yr; car_icr_.yl = yl; car_icr_.xv = xv; }
+    // mpc.cpp:130-171
+    void TrajCallback(const Polynome& msg)
+    {
+        if (new_traj_.if_get_traj_) {
+            traj_ = new_traj_;
+            traj_duration = traj_.get_traj_duration();
+            start_time = new_traj_start_time_;
+            new_traj_.if_get_traj_ = false;
+        }
+        new_traj_.setTraj(msg);
+        new_traj_start_time_ = msg.traj_start_time;
+        new_traj_.if_get_traj_ = true;
+        receive_traj_ = true;
+        at_goal = false;
+    }
+    // mpc.cpp:177-182
+    void swapInNewTraj(double now)
+    {
+        if (new_traj_.if_get_traj_ && now > new_traj_start_time_) {
+            traj_ = new_traj_;
+            traj_duration = traj_.get_traj_duration();
+            start_time = new_traj_start_time_;
+            new_traj_.if_get_traj_ = false;
+        }
+    }
+    static void normlize_theta(double& th) // mpc.cpp:243-246
+    {
+        while (th > M_PI) th -= 2 * M_PI;
+        while (th < -M_PI) th += 2 * M_PI;
+    }
+    // mpc.cpp:407-461
+    void getRefPoints(double now)
+    {
+        const int T = N_;
+        const double dt = dt_;
+        const double t_cur = now - start_time;
+        at_goal = (t_cur > traj_duration + 1.0);
+        int j = 0;
+        for (double temp_t = t_cur + dt; j <= T; ++j, temp_t += dt) {
+            double P[3], V[2];
+            const bool inside = temp_t <= traj_duration;
+            const double tq = inside ? temp_t : traj_duration;
+            traj_.getPstate(tq, P);
+            traj_.getVstate(tq, V);
+            reference_states_[j * 3 + kX] = P[0];
+            reference_states_[j * 3 + kY] = P[1];
+            reference_states_[j * 3 + kPsi] = P[2];
+            reference_inputs_[j * 2 + kVl] = inside ? V[1] - V[0] * car_icr_.yl : 0.0;
+            reference_inputs_[j * 2 + kVr] = inside ? V[1] - V[0] * car_icr_.yr : 0.0;
+            normlize_theta(reference_states_[j * 3 + kPsi]);
+        }
+    }
+    // mpc.cpp:248-277
+    void smooth_yaw()
+    {
+        auto psi = [&](int i) -> double& { return reference_states_[i * 3 + kPsi]; };
+        double dyaw = psi(0) - est_state_[kPsi];
+        while (dyaw >= M_PI / 2) { psi(0) -= M_PI * 2; dyaw = psi(0) - est_state_[kPsi]; }
+        while (dyaw <= -M_PI / 2) { psi(0) += M_PI * 2; dyaw = psi(0) - est_state_[kPsi]; }
+        for (int i = 0; i < N_; ++i) {
+            dyaw = psi(i + 1) - psi(i);
+            while (dyaw >= M_PI / 2) { psi(i + 1) -= M_PI * 2; dyaw = psi(i + 1) - psi(i); }
+            while (dyaw <= -M_PI / 2) { psi(i + 1) += M_PI * 2; dyaw = psi(i + 1) - psi(i); }
+        }
+    }
+};
+
+// The ROS-free control tick of the reference node for B robots (mpc.cpp:173-240 CmdCallback + :296-350
+// run + :502-509 cmdPub).  `tick(now)` returns, per robot, the wheel-speed command
+// (right_wheel_ome, left_wheel_ome) = predicted input column `delay_num`.
+class BatchedMpcController {
+public:
+    BatchedMpcWrapper mpc_wrapper_;
+    std::vector<RefSampler> robots;
+    int delay_num_ = 1;
+    bool solve_from_scratch_ = true;
+
+    BatchedMpcController(int B, int N, double dt, const double matrix_q[3], const double matrix_r[2], int delay_num = 1,
+                         double state_seq_res = 0.1, double Integral_appr_resInt = 4, int device = 0)
+        : mpc_wrapper_(B, N, dt, device), delay_num_(delay_num)
+    {
+        // mpc.cpp:67-85: diagonal weights from ~matrix_q / ~matrix_r
+        const double Q[9] = {matrix_q[0], 0, 0, 0, matrix_q[1], 0, 0, 0, matrix_q[2]};
+        const double R[4] = {matrix_r[0], 0, 0, matrix_r[1]};
+        mpc_wrapper_.setCosts(Q, R);
+        robots.reserve(B);
+        for (int b = 0; b < B; ++b) robots.emplace_back(N, dt, state_seq_res, Integral_appr_resInt);
+    }
+    // cmd: B x 2 (right, left).  Robots without odometry / trajectory keep a zero command.
+    void tick(double now, double* cmd)
+    {
+        const int B = mpc_wrapper_.B, N = mpc_wrapper_.kSamples;
+        std::vector<double> est((size_t)B * 3, 0.0);
+        for (int b = 0; b < B; ++b) {
+            RefSampler& r = robots[b];
+            if (!r.has_odom || !r.receive_traj_) continue;
+            r.swapInNewTraj(now);
+            r.getRefPoints(now);
+            r.smooth_yaw();
+            const double icr[3] = {r.car_icr_.xv, r.car_icr_.yr, r.car_icr_.yl}; // mpc.cpp:305-310
+            mpc_wrapper_.setICRParameters(b, icr);
+            mpc_wrapper_.setTrajectory(b, r.reference_states_.data(), r.reference_inputs_.data());
+            for (int i = 0; i < 3; ++i) est[(size_t)b * 3 + i] = r.est_state_[i];
+        }
+        if (solve_from_scratch_) { // mpc.cpp:317-320
+            mpc_wrapper_.solve(est.data());
+            solve_from_scratch_ = false;
+        } else {
+            mpc_wrapper_.update(est.data(), false);
+        }
+        mpc_wrapper_.prepare(); // the reference's preparation thread (mpc.cpp:336, 394-403)
+        for (int b = 0; b < B; ++b) {
+            const int node = delay_num_ < N ? delay_num_ : N - 1;
+            cmd[b * 2 + 0] = mpc_wrapper_.getInput(b, node, kVr);
+            cmd[b * 2 + 1] = mpc_wrapper_.getInput(b, node, kVl);
+            if (robots[b].at_goal || !robots[b].has_odom || !robots[b].receive_traj_) { cmd[b * 2] = 0.0; cmd[b * 2 + 1] = 0.0; }
+        }
+    }
+};
+
+} // namespace alore

@@ -1,0 +1,307 @@
+// traj_anal.hpp -- host-side reference sampling for the NMPC (float64, no Eigen, no ROS).
+//
+// Restates, for the controller side of the hot path:
+//   * the banded LU of gcopter        P/back_end/include/gcopter/minco.hpp:43-200   (BandedSystem)
+//   * the minimum-jerk spline solve    P/back_end/include/gcopter/minco.hpp:772-913  (MINCO_S3NU::
+//                                       setConditions / setParameters / getTrajectory)
+//   * quintic piece evaluation         P/back_end/include/gcopter/trajectory.hpp:75-135, 472-502
+//   * TrajAnal                         P/nmpc_controller/include/nmpc_controller/traj_anal.hpp:11-139
+// with P = /root/reference/planning_ddr_opt.  The trajectory lives in "flat" space: component 0 is the
+// yaw theta(t), component 1 the arc length s(t); the Cartesian pose is recovered by Simpson
+// integration of  x' = s' cos(theta) + theta' xv sin(theta),  y' = s' sin(theta) - theta' xv cos(theta).
+//
+// None of this can be compiled from the reference here (Eigen/ROS absent), so parity for these rows is
+// UNPINNED; tests/test_host_layer.py pins the restatement with analytic known answers instead.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <stdexcept>
+#include <vector>
+
+namespace alore {
+
+// A x = b for a banded A stored as in "Matrix Computations": entry (i, j) at [(i - j + q) * n + j].
+// LU without pivoting, exactly the elimination order of the reference (minco.hpp:99-131).
+class BandedSystem {
+public:
+    void create(int n, int p, int q)
+    {
+        n_ = n; lower_ = p; upper_ = q;
+        data_.assign((size_t)n * (p + q + 1), 0.0);
+    }
+    void reset() { std::fill(data_.begin(), data_.end(), 0.0); }
+    double& operator()(int i, int j) { return data_[(size_t)(i - j + upper_) * n_ + j]; }
+    double operator()(int i, int j) const { return data_[(size_t)(i - j + upper_) * n_ + j]; }
+
+    void factorizeLU()
+    {
+        for (int k = 0; k <= n_ - 2; ++k) {
+            const int iM = std::min(k + lower_, n_ - 1);
+            double cVl = (*this)(k, k);
+            for (int i = k + 1; i <= iM; ++i)
+                if ((*this)(i, k) != 0.0) (*this)(i, k) /= cVl;
+            const int jM = std::min(k + upper_, n_ - 1);
+            for (int j = k + 1; j <= jM; ++j) {
+                cVl = (*this)(k, j);
+                if (cVl != 0.0)
+                    for (int i = k + 1; i <= iM; ++i)
+                        if ((*this)(i, k) != 0.0) (*this)(i, j) -= (*this)(i, k) * cVl;
+            }
+        }
+    }
+    // b: n rows of `m` columns, row-major; solved in place (minco.hpp:137-167)
+    void solve(std::vector<double>& b, int m) const
+    {
+        for (int j = 0; j <= n_ - 1; ++j) {
+            const int iM = std::min(j + lower_, n_ - 1);
+            for (int i = j + 1; i <= iM; ++i)
+                if ((*this)(i, j) != 0.0)
+                    for (int c = 0; c < m; ++c) b[(size_t)i * m + c] -= (*this)(i, j) * b[(size_t)j * m + c];
+        }
+        for (int j = n_ - 1; j >= 0; --j) {
+            for (int c = 0; c < m; ++c) b[(size_t)j * m + c] /= (*this)(j, j);
+            const int iM = std::max(0, j - upper_);
+            for (int i = iM; i <= j - 1; ++i)
+                if ((*this)(i, j) != 0.0)
+                    for (int c = 0; c < m; ++c) b[(size_t)i * m + c] -= (*this)(i, j) * b[(size_t)j * m + c];
+        }
+    }
+
+private:
+    int n_ = 0, lower_ = 0, upper_ = 0;
+    std::vector<double> data_;
+};
+
+// One quintic piece in 2 flat coordinates.  c[d][i] multiplies t^i (ascending powers); the reference
+// stores the same numbers with descending powers (trajectory.hpp:75-88, minco.hpp:900-913).
+struct Piece5 {
+    double duration = 0.0;
+    double c[2][6] = {{0}};
+    void pos(double t, double out[2]) const
+    {
+        for (int d = 0; d < 2; ++d) {
+            double tn = 1.0, v = 0.0;
+            for (int i = 0; i <= 5; ++i) { v += tn * c[d][i]; tn *= t; }
+            out[d] = v;
+        }
+    }
+    void vel(double t, double out[2]) const
+    {
+        for (int d = 0; d < 2; ++d) {
+            double tn = 1.0, v = 0.0;
+            for (int i = 1; i <= 5; ++i) { v += i * tn * c[d][i]; tn *= t; }
+            out[d] = v;
+        }
+    }
+    void acc(double t, double out[2]) const
+    {
+        for (int d = 0; d < 2; ++d) {
+            double tn = 1.0, v = 0.0;
+            for (int i = 2; i <= 5; ++i) { v += (i - 1) * i * tn * c[d][i]; tn *= t; }
+            out[d] = v;
+        }
+    }
+};
+
+class Trajectory5 {
+public:
+    std::vector<Piece5> pieces;
+    double totalDuration() const
+    {
+        double s = 0.0;
+        for (const auto& p : pieces) s += p.duration;
+        return s;
+    }
+    // trajectory.hpp:472-490: walks the pieces, t becomes the local time; past the end the last piece
+    // is extrapolated
+    int locatePieceIdx(double& t) const
+    {
+        const int N = (int)pieces.size();
+        int idx;
+        double dur;
+        for (idx = 0; idx < N && t > (dur = pieces[idx].duration); ++idx) t -= dur;
+        if (idx == N) {
+            --idx;
+            t += pieces[idx].duration;
+        }
+        return idx;
+    }
+    void getPos(double t, double out[2]) const { const int i = locatePieceIdx(t); pieces[i].pos(t, out); }
+    void getVel(double t, double out[2]) const { const int i = locatePieceIdx(t); pieces[i].vel(t, out); }
+    void getAcc(double t, double out[2]) const { const int i = locatePieceIdx(t); pieces[i].acc(t, out); }
+};
+
+// Minimum-jerk (s = 3) spline through inner points with given boundary P/V/A and piece times:
+// the 6M x 6M banded system of minco.hpp:817-898.
+class MincoS3NU {
+public:
+    // head / tail: [dim][p, v, a]
+    void setConditions(const double head[2][3], const double tail[2][3], int pieceNum)
+    {
+        N_ = pieceNum;
+        for (int d = 0; d < 2; ++d)
+            for (int k = 0; k < 3; ++k) { head_[d][k] = head[d][k]; tail_[d][k] = tail[d][k]; }
+        A_.create(6 * N_, 6, 6);
+        b_.assign((size_t)6 * N_ * 2, 0.0);
+    }
+    // inPs: (N-1) inner points, [i][dim]; ts: N piece durations
+    void setParameters(const std::vector<std::array<double, 2>>& inPs, const std::vector<double>& ts)
+    {
+        if ((int)ts.size() != N_ || (int)inPs.size() != N_ - 1) throw std::invalid_argument("MincoS3NU sizes");
+        T1_ = ts;
+        const int N = N_;
+        std::vector<double> T2(N), T3(N), T4(N), T5(N);
+        for (int i = 0; i < N; ++i) {
+            T2[i] = T1_[i] * T1_[i]; T3[i] = T2[i] * T1_[i]; T4[i] = T2[i] * T2[i]; T5[i] = T4[i] * T1_[i];
+        }
+        A_.reset();
+        std::fill(b_.begin(), b_.end(), 0.0);
+        auto& A = A_;
+        A(0, 0) = 1.0; A(1, 1) = 1.0; A(2, 2) = 2.0;
+        for (int d = 0; d < 2; ++d) { B(0, d) = head_[d][0]; B(1, d) = head_[d][1]; B(2, d) = head_[d][2]; }
+        for (int i = 0; i < N - 1; ++i) {
+            const int r = 6 * i;
+            const double t1 = T1_[i];
+            A(r + 3, r + 3) = 6.0; A(r + 3, r + 4) = 24.0 * t1; A(r + 3, r + 5) = 60.0 * T2[i]; A(r + 3, r + 9) = -6.0;
+            A(r + 4, r + 4) = 24.0; A(r + 4, r + 5) = 120.0 * t1; A(r + 4, r + 10) = -24.0;
+            A(r + 5, r) = 1.0; A(r + 5, r + 1) = t1; A(r + 5, r + 2) = T2[i]; A(r + 5, r + 3) = T3[i];
+            A(r + 5, r + 4) = T4[i]; A(r + 5, r + 5) = T5[i];
+            A(r + 6, r) = 1.0; A(r + 6, r + 1) = t1; A(r + 6, r + 2) = T2[i]; A(r + 6, r + 3) = T3[i];
+            A(r + 6, r + 4) = T4[i]; A(r + 6, r + 5) = T5[i]; A(r + 6, r + 6) = -1.0;
+            A(r + 7, r + 1) = 1.0; A(r + 7, r + 2) = 2 * t1; A(r + 7, r + 3) = 3 * T2[i]; A(r + 7, r + 4) = 4 * T3[i];
+            A(r + 7, r + 5) = 5 * T4[i]; A(r + 7, r + 7) = -1.0;
+            A(r + 8, r + 2) = 2.0; A(r + 8, r + 3) = 6 * t1; A(r + 8, r + 4) = 12 * T2[i]; A(r + 8, r + 5) = 20 * T3[i];
+            A(r + 8, r + 8) = -2.0;
+            for (int d = 0; d < 2; ++d) B(r + 5, d) = inPs[i][d];
+        }
+        const int e = 6 * N;
+        const double t1 = T1_[N - 1];
+        A(e - 3, e - 6) = 1.0; A(e - 3, e - 5) = t1; A(e - 3, e - 4) = T2[N - 1]; A(e - 3, e - 3) = T3[N - 1];
+        A(e - 3, e - 2) = T4[N - 1]; A(e - 3, e - 1) = T5[N - 1];
+        A(e - 2, e - 5) = 1.0; A(e - 2, e - 4) = 2 * t1; A(e - 2, e - 3) = 3 * T2[N - 1]; A(e - 2, e - 2) = 4 * T3[N - 1];
+        A(e - 2, e - 1) = 5 * T4[N - 1];
+        A(e - 1, e - 4) = 2; A(e - 1, e - 3) = 6 * t1; A(e - 1, e - 2) = 12 * T2[N - 1]; A(e - 1, e - 1) = 20 * T3[N - 1];
+        for (int d = 0; d < 2; ++d) { B(e - 3, d) = tail_[d][0]; B(e - 2, d) = tail_[d][1]; B(e - 1, d) = tail_[d][2]; }
+        A_.factorizeLU();
+        A_.solve(b_, 2);
+    }
+    void getTrajectory(Trajectory5& traj) const
+    {
+        traj.pieces.clear();
+        traj.pieces.reserve(N_);
+        for (int i = 0; i < N_; ++i) {
+            Piece5 p;
+            p.duration = T1_[i];
+            for (int d = 0; d < 2; ++d)
+                for (int k = 0; k < 6; ++k) p.c[d][k] = b_[(size_t)(6 * i + k) * 2 + d];
+            traj.pieces.push_back(p);
+        }
+    }
+
+private:
+    double& B(int r, int d) { return b_[(size_t)r * 2 + d]; }
+    int N_ = 0;
+    double head_[2][3] = {{0}}, tail_[2][3] = {{0}};
+    BandedSystem A_;
+    std::vector<double> b_;
+    std::vector<double> T1_;
+};
+
+// the message the planner sends to the controller (P/utils/carstatemsgs/msg/Polynome.msg), ROS-free
+struct Polynome {
+    double traj_start_time = 0.0;
+    std::vector<std::array<double, 2>> innerpoints; // (theta, s)
+    std::vector<double> t_pts;
+    double init_p[2] = {0, 0}, init_v[2] = {0, 0}, init_a[2] = {0, 0};
+    double tail_p[2] = {0, 0}, tail_v[2] = {0, 0}, tail_a[2] = {0, 0};
+    double start_position[3] = {0, 0, 0}; // x, y, theta
+    double ICR[3] = {0, 0, 0};            // as sent: (yr, yl, xv) -> TrajAnal keeps it as a vector, .z = xv
+};
+
+class TrajAnal {
+public:
+    bool if_get_traj_ = false;
+
+    void setRes(double state_seq_res, double Integral_appr_resInt)
+    {
+        state_seq_res_ = state_seq_res;
+        Integral_appr_resInt_ = (int)Integral_appr_resInt;
+    }
+    // traj_anal.hpp:36-53
+    void setTraj(const double start_state[3], const double initstate[2][3], const double finalstate[2][3],
+                 const std::vector<std::array<double, 2>>& innerpoints, const std::vector<double>& pieceTimes,
+                 const double ICR[3])
+    {
+        const int traj_num = (int)pieceTimes.size();
+        if ((int)innerpoints.size() != traj_num - 1) throw std::invalid_argument("Innerpoints.cols() != pieceTimes.size()-1");
+        minco_.setConditions(initstate, finalstate, traj_num);
+        minco_.setParameters(innerpoints, pieceTimes);
+        minco_.getTrajectory(traj_);
+        for (int i = 0; i < 3; ++i) { start_state_[i] = start_state[i]; ICR_[i] = ICR[i]; }
+        getSeq();
+    }
+    void setTraj(const Polynome& m)
+    {
+        const double init[2][3] = {{m.init_p[0], m.init_v[0], m.init_a[0]}, {m.init_p[1], m.init_v[1], m.init_a[1]}};
+        const double fin[2][3] = {{m.tail_p[0], m.tail_v[0], m.tail_a[0]}, {m.tail_p[1], m.tail_v[1], m.tail_a[1]}};
+        setTraj(m.start_position, init, fin, m.innerpoints, m.t_pts, m.ICR);
+    }
+    // traj_anal.hpp:55-95: composite Simpson, one checkpoint every state_seq_res_
+    void getSeq()
+    {
+        state_sequence_.clear();
+        const double res = state_seq_res_ / Integral_appr_resInt_;
+        const double half = res / 2.0, sixth = res / 6.0;
+        double cur[3] = {start_state_[0], start_state_[1], start_state_[2]};
+        state_sequence_.push_back({cur[0], cur[1], cur[2], 0.0});
+        const int sequence_num = (int)std::floor(traj_.totalDuration() / res);
+        double p1[2], p2[2], p3[2], v1[2], v2[2], v3[2];
+        traj_.getPos(0.0, p3);
+        traj_.getVel(0.0, v3);
+        for (int i = 0; i < sequence_num; ++i) {
+            p1[0] = p3[0]; p1[1] = p3[1]; v1[0] = v3[0]; v1[1] = v3[1];
+            traj_.getPos(i * res + half, p2);
+            traj_.getVel(i * res + half, v2);
+            traj_.getPos(i * res + res, p3);
+            traj_.getVel(i * res + res, v3);
+            cur[0] += sixth * (xdot(p1, v1) + 4.0 * xdot(p2, v2) + xdot(p3, v3));
+            cur[1] += sixth * (ydot(p1, v1) + 4.0 * ydot(p2, v2) + ydot(p3, v3));
+            if (i % Integral_appr_resInt_ == Integral_appr_resInt_ - 1)
+                state_sequence_.push_back({cur[0], cur[1], p3[0], (i + 1) * res});
+        }
+    }
+    const std::vector<std::array<double, 4>>& get_state_sequence_() const { return state_sequence_; }
+    double get_traj_duration() const { return traj_.totalDuration(); }
+    // traj_anal.hpp:105-130: nearest checkpoint + one Simpson panel
+    void getPstate(double t, double out[3]) const
+    {
+        const int index = (int)std::floor(t / state_seq_res_);
+        const double floor_t = index * state_seq_res_;
+        const double diff_t = t - floor_t;
+        const auto& st = state_sequence_.at((size_t)index);
+        double p1[2], p2[2], p3[2], v1[2], v2[2], v3[2];
+        traj_.getPos(floor_t, p1); traj_.getVel(floor_t, v1);
+        traj_.getPos(floor_t + diff_t / 2.0, p2); traj_.getVel(floor_t + diff_t / 2.0, v2);
+        traj_.getPos(t, p3); traj_.getVel(t, v3);
+        out[0] = st[0] + diff_t / 6.0 * (xdot(p1, v1) + 4.0 * xdot(p2, v2) + xdot(p3, v3));
+        out[1] = st[1] + diff_t / 6.0 * (ydot(p1, v1) + 4.0 * ydot(p2, v2) + ydot(p3, v3));
+        out[2] = p3[0];
+    }
+    void getVstate(double t, double out[2]) const { traj_.getVel(t, out); } // (theta', s')
+    void getAstate(double t, double out[2]) const { traj_.getAcc(t, out); }
+    const Trajectory5& trajectory() const { return traj_; }
+
+private:
+    double xdot(const double p[2], const double v[2]) const { return v[1] * std::cos(p[0]) + v[0] * ICR_[2] * std::sin(p[0]); }
+    double ydot(const double p[2], const double v[2]) const { return v[1] * std::sin(p[0]) - v[0] * ICR_[2] * std::cos(p[0]); }
+    MincoS3NU minco_;
+    Trajectory5 traj_;
+    double start_state_[3] = {0, 0, 0};
+    double ICR_[3] = {0, 0, 0};
+    std::vector<std::array<double, 4>> state_sequence_;
+    double state_seq_res_ = 0.1;
+    int Integral_appr_resInt_ = 4;
+};
+
+} // namespace alore
