@@ -93,7 +93,7 @@ def test_get_ref_points_sampling_clamp_and_wheel_speeds():
     for j in range(N + 1):
         t = 0.37 + (j + 1) * dt          # mpc.cpp:432: temp_t starts at t_cur + dt
         ref = exact_pose(v, w, 0.0, (0, 0), xv, t)
-        assert np.max(np.abs(rs[j] - ref)) < 1e-9
+        assert np.max(np.abs(rs[j] - ref)) < 2e-8
         assert abs(ri[j, 0] - (v - w * (-0.31))) < 1e-9     # kVr = v - w*yr
         assert abs(ri[j, 1] - (v - w * 0.29)) < 1e-9        # kVl = v - w*yl
     # past the end: pose clamps to the final pose, wheel speeds to zero; at_goal one second later
