@@ -22,6 +22,8 @@ struct alore_nmpc_solver {
     bool timed_pending = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = -1.0f;
+    const float* lin_x = nullptr; // see alore_nmpc_set_linearization_point
+    const float* lin_u = nullptr;
     // diagnostic phase stamps (env ALORE_NMPC_STAMPS=1): per-phase cycle shares, printed at destroy
     bool stamps = false;
     long long* d_stamps = nullptr;
@@ -259,6 +261,8 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     const nmpc::IrkConst K = nmpc::make_irk(h->cfg.dt);
     p.h = K.h; p.hh = K.hh; p.c1h = K.c1h; p.c2h = K.c2h;
     p.stamps = nullptr;
+    p.lin_x = h->lin_x;
+    p.lin_u = h->lin_u;
     hipStream_t s = (hipStream_t)stream;
     if (h->stamps) {
         const size_t need = (size_t)g.grid * 8;
@@ -318,6 +322,14 @@ int alore_nmpc_shift(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, in
     if (!h || !dev || B <= 0 || !dev->x || !dev->u || !dev->od)
         return fail(h, ALORE_NMPC_E_INVALID, "shift: bad argument");
     HIP_TRY(h, nmpc::launch_shift(*dev, B, h->cfg.N, h->cfg.dt, strategy, xEnd, uEnd, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_set_linearization_point(alore_nmpc_handle h, const float* x_lin, const float* u_lin)
+{
+    if (!h || ((x_lin == nullptr) != (u_lin == nullptr))) return fail(h, ALORE_NMPC_E_INVALID, "linearization point: bad argument");
+    h->lin_x = x_lin;
+    h->lin_u = u_lin;
     return ALORE_NMPC_OK;
 }
 

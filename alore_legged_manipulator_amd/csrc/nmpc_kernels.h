@@ -18,6 +18,8 @@ struct RtiParams {
     int pg_steps; // projected-gradient steps of the working-set prediction (0 = off)
     int RS; // LDS floats per problem (row stride)
     float h, hh, c1h, c2h;
+    const float* lin_x; // optional [B][(N+1)*3]: linearisation point of the first iteration (else null)
+    const float* lin_u; // optional [B][N*2]
     long long* stamps; // diagnostic builds only: per-block phase cycle counts (8 per block), else null
 };
 

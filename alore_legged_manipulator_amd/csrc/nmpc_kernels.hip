@@ -514,11 +514,24 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
         int infeasible = 0;
         for (int k = j; k <= N; k += L) {
             float* rec = row + k * SR;
-            const float4 xk = lds4(rec, S_X);
+            float4 xk = lds4(rec, S_X);
+            // ACADO-compatibility mode, first iteration only: linearise (and evaluate the residual) at
+            // the point the caller prepared on, which may differ from the iterate that is expanded
+            const bool relin = (sqp == 0) && (p.lin_x != nullptr);
+            if (relin) {
+                const float* lx = p.lin_x + ((size_t)prob * (N + 1) + k) * 3;
+                xk = make_float4(lx[0], lx[1], lx[2], 0.0f);
+            }
             if (k < N) {
                 const float4 uy = lds4(rec, S_UY);
-                const float4 xn = lds4(rec + SR, S_X);
-                const float vr = uy.x, vl = uy.y;
+                float4 xn = lds4(rec + SR, S_X);
+                float vr = uy.x, vl = uy.y;
+                if (relin) {
+                    const float* lx = p.lin_x + ((size_t)prob * (N + 1) + k + 1) * 3;
+                    const float* lu = p.lin_u + ((size_t)prob * N + k) * 2;
+                    xn = make_float4(lx[0], lx[1], lx[2], 0.0f);
+                    vr = lu[0]; vl = lu[1];
+                }
                 StageLin lin;
                 const float* odk = stg + SG.od + k * 3;
                 ddr_linearize(K, xk.x, xk.y, xk.z, vr, vl, odk[0], odk[1], odk[2], lin);
@@ -537,8 +550,8 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                 const float r1 = w[20] * e0 + w[21] * e1 + w[22] * e2 + w[23] * e3 + w[24] * e4;
                 const float* lbk = stg + SG.lb + k * 2;
                 const float* ubk = stg + SG.ub + k * 2;
-                const float lb0 = lbk[0] - vr, lb1 = lbk[1] - vl;
-                const float ub0 = ubk[0] - vr, ub1 = ubk[1] - vl;
+                const float lb0 = lbk[0] - uy.x, lb1 = lbk[1] - uy.y; // bounds on du from the current u
+                const float ub0 = ubk[0] - uy.x, ub1 = ubk[1] - uy.y;
                 infeasible |= (lb0 > ub0 + 1e-6f) || (lb1 > ub1 + 1e-6f);
                 st4(rec, S_B0, lin.B00, lin.B01, lin.B10, lin.B11);
                 st4(rec, S_B1, lin.B20, -lin.B20, lin.a, lin.b);

@@ -124,6 +124,15 @@ int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch 
  * kkt, obj are written. */
 int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int n_sqp, void *stream);
 
+/* ACADO split semantics.  The reference prepares (linearises, evaluates h(x,u)) in
+ * acado_preparationStep() and solves/expands in acado_feedbackStep(); a caller may change
+ * acadoVariables.x/u in between (MpcWrapper::solve does, mpc_wrapper.cpp:267-275), in which case the
+ * reference expands the CURRENT iterate with the linearisation of the PREPARED one.  To reproduce
+ * that, give the prepared iterate here (device pointers [B][(N+1)*3], [B][N*2], kept by the handle
+ * until reset with NULL, NULL): the first iteration of every following alore_nmpc_rti linearises
+ * at (x_lin, u_lin) and expands batch.x / batch.u.  Default (NULL): linearise at the iterate. */
+int alore_nmpc_set_linearization_point(alore_nmpc_handle h, const float *x_lin, const float *u_lin);
+
 /* preparation-side quantities only (acado_modelSimulation, acado_solver.c:35-78):
  * writes d / evGx / evGu in the reference layout.  Does not touch the batch. */
 int alore_nmpc_linearize(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, const alore_nmpc_lin_out *out,
