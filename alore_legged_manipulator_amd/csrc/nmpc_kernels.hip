@@ -221,8 +221,8 @@ __device__ __forceinline__ float group_last(float v)
     if constexpr (L == 64) {
         return readlane_f(v, 63);
     } else if constexpr (L == 32) {
-        const float a = readlane_f(v, 31), b = readlane_f(v, 63);
-        return (threadIdx.x < 32) ? a : b;
+        // ds_swizzle, bit-mask mode (and = 0, or = 31, xor = 0): every lane reads lane 31 of its half
+        return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x03E0));
     } else {
         return __shfl(v, L - 1, L);
     }
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
 #pragma unroll 1
                 for (int t = 1; t < p.pg_steps; ++t) {
                     apply(u0, u1, std::true_type{}, g0, g1);
-                    u0 = clampf(u0 - a0 * g0, lb0, ub0);
-                    u1 = clampf(u1 - a1 * g1, lb1, ub1);
+                    u0 = __builtin_amdgcn_fmed3f(u0 - a0 * g0, lb0, ub0);
+                    u1 = __builtin_amdgcn_fmed3f(u1 - a1 * g1, lb1, ub1);
                 }
                 if (in && run) {
                     const int n0 = (ub0 - lb0 > BOUNDTOL) ? ((u0 <= lb0) ? ST_LOWER : ((u0 >= ub0) ? ST_UPPER : ST_FREE)) : ST_LOWER;
