@@ -61,6 +61,11 @@ SYMBOLS = (
     ("alore_nmpc_linearize", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.POINTER(LinOut), C.c_void_p]),
     ("alore_nmpc_forward_simulate", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p]),
     ("alore_nmpc_shift", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_refs_init", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    ("alore_nmpc_refs_set_trajectory", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                 C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    ("alore_nmpc_refs_sample", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p]),
     ("alore_nmpc_set_linearization_point", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("alore_nmpc_get_launch_info", C.c_int, [C.c_void_p, C.POINTER(LaunchInfo)]),
     ("alore_nmpc_set_timing", C.c_int, [C.c_void_p, C.c_int]),

@@ -22,6 +22,13 @@ struct alore_nmpc_solver {
     bool timed_pending = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = -1.0f;
+    // device-side reference sampling (alore_nmpc_refs_*)
+    nmpc::RefStore refs{};
+    int refs_B = 0;
+    double* d_est = nullptr;  // [B][3]
+    double* d_icr = nullptr;  // [B][3]
+    double* d_psi = nullptr;  // [B][N+1]
+    int* d_goal = nullptr;    // [B]
     const float* lin_x = nullptr; // see alore_nmpc_set_linearization_point
     const float* lin_u = nullptr;
     // diagnostic phase stamps (env ALORE_NMPC_STAMPS=1): per-phase cycle shares, printed at destroy
@@ -163,6 +170,14 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
         std::fprintf(stderr, "\n");
     }
     if (h->d_stamps) (void)hipFree(h->d_stamps);
+    if (h->refs.dur) (void)hipFree(h->refs.dur);
+    if (h->refs.coef) (void)hipFree(h->refs.coef);
+    if (h->refs.ckpt) (void)hipFree(h->refs.ckpt);
+    if (h->refs.meta) (void)hipFree(h->refs.meta);
+    if (h->d_est) (void)hipFree(h->d_est);
+    if (h->d_icr) (void)hipFree(h->d_icr);
+    if (h->d_psi) (void)hipFree(h->d_psi);
+    if (h->d_goal) (void)hipFree(h->d_goal);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -268,6 +283,14 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
         const size_t need = (size_t)g.grid * 8;
         if (need > h->stamps_cap) {
             if (h->d_stamps) (void)hipFree(h->d_stamps);
+    if (h->refs.dur) (void)hipFree(h->refs.dur);
+    if (h->refs.coef) (void)hipFree(h->refs.coef);
+    if (h->refs.ckpt) (void)hipFree(h->refs.ckpt);
+    if (h->refs.meta) (void)hipFree(h->refs.meta);
+    if (h->d_est) (void)hipFree(h->d_est);
+    if (h->d_icr) (void)hipFree(h->d_icr);
+    if (h->d_psi) (void)hipFree(h->d_psi);
+    if (h->d_goal) (void)hipFree(h->d_goal);
             HIP_TRY(h, hipMalloc((void**)&h->d_stamps, need * sizeof(long long)));
             h->stamps_cap = need;
         }
@@ -322,6 +345,62 @@ int alore_nmpc_shift(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, in
     if (!h || !dev || B <= 0 || !dev->x || !dev->u || !dev->od)
         return fail(h, ALORE_NMPC_E_INVALID, "shift: bad argument");
     HIP_TRY(h, nmpc::launch_shift(*dev, B, h->cfg.N, h->cfg.dt, strategy, xEnd, uEnd, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_refs_init(alore_nmpc_handle h, int B, int max_pieces, int max_checkpoints)
+{
+    if (!h || B <= 0 || max_pieces <= 0 || max_checkpoints <= 0 || h->refs.dur)
+        return fail(h, ALORE_NMPC_E_INVALID, "refs_init: bad argument or already initialised");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    h->refs.P = max_pieces;
+    h->refs.C = max_checkpoints;
+    h->refs_B = B;
+    HIP_TRY(h, hipMalloc((void**)&h->refs.dur, sizeof(double) * B * max_pieces));
+    HIP_TRY(h, hipMalloc((void**)&h->refs.coef, sizeof(double) * B * max_pieces * 12));
+    HIP_TRY(h, hipMalloc((void**)&h->refs.ckpt, sizeof(double) * B * max_checkpoints * 2));
+    HIP_TRY(h, hipMalloc((void**)&h->refs.meta, sizeof(double) * B * 8));
+    HIP_TRY(h, hipMemset(h->refs.meta, 0, sizeof(double) * B * 8));
+    HIP_TRY(h, hipMalloc((void**)&h->d_est, sizeof(double) * B * 3));
+    HIP_TRY(h, hipMalloc((void**)&h->d_icr, sizeof(double) * B * 3));
+    HIP_TRY(h, hipMalloc((void**)&h->d_psi, sizeof(double) * B * (h->cfg.N + 1)));
+    HIP_TRY(h, hipMalloc((void**)&h->d_goal, sizeof(int) * B));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_refs_set_trajectory(alore_nmpc_handle h, int robot, int n_pieces, const double* durations,
+                                   const double* coeffs, int n_ckpt, const double* ckpt_xy, double start_time,
+                                   double state_seq_res, double xv, void* stream)
+{
+    if (!h || !h->refs.dur || robot < 0 || robot >= h->refs_B || n_pieces <= 0 || n_pieces > h->refs.P || n_ckpt <= 0 ||
+        n_ckpt > h->refs.C || !durations || !coeffs || !ckpt_xy || !(state_seq_res > 0.0))
+        return fail(h, ALORE_NMPC_E_INVALID, "refs_set_trajectory: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double total = 0.0;
+    for (int i = 0; i < n_pieces; ++i) total += durations[i];
+    const double meta[8] = {start_time, total, xv, state_seq_res, (double)n_pieces, (double)n_ckpt, 1.0, 0.0};
+    HIP_TRY(h, hipMemcpyAsync(h->refs.dur + (size_t)robot * h->refs.P, durations, sizeof(double) * n_pieces, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->refs.coef + (size_t)robot * h->refs.P * 12, coeffs, sizeof(double) * n_pieces * 12, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->refs.ckpt + (size_t)robot * h->refs.C * 2, ckpt_xy, sizeof(double) * n_ckpt * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->refs.meta + (size_t)robot * 8, meta, sizeof(meta), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipStreamSynchronize(s)); // the host buffers (and `meta`) may go away after return
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, double now, const double* est,
+                           const double* icr, int do_smooth, int* at_goal, void* stream)
+{
+    if (!h || !h->refs.dur || !dev || B <= 0 || B > h->refs_B || !est || !icr || !dev->y || !dev->yN || !dev->od || !dev->x0)
+        return fail(h, ALORE_NMPC_E_INVALID, "refs_sample: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_est, est, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_icr, icr, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, nmpc::launch_ref_sample(h->refs, *dev, B, h->cfg.N, (double)h->cfg.dt, now, h->d_est, h->d_icr, h->d_goal,
+                                       h->d_psi, do_smooth, s));
+    if (at_goal) {
+        HIP_TRY(h, hipMemcpyAsync(at_goal, h->d_goal, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
     return ALORE_NMPC_OK;
 }
 

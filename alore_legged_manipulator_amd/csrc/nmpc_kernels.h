@@ -45,5 +45,17 @@ hipError_t launch_shift(const alore_nmpc_batch& b, int B, int N, float dt, int s
                         const float* uEnd, hipStream_t s);
 hipError_t launch_fill(float* p, float v, size_t n, hipStream_t s);
 
+// device-side reference sampling (ref_sampler.hip)
+struct RefStore {
+    double* dur;   // [B][P]        piece durations
+    double* coef;  // [B][P][2][6]  ascending powers
+    double* ckpt;  // [B][C][2]     x, y at t = k * res
+    double* meta;  // [B][8]        start_time, duration, xv(traj ICR.z), res, n_pieces, n_ckpt, valid, -
+    int P, C;
+};
+hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now,
+                             const double* est, const double* icr, int* at_goal, double* psi_scratch, int do_smooth,
+                             hipStream_t st);
+
 } // namespace nmpc
 #endif

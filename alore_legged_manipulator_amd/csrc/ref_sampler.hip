@@ -1,0 +1,139 @@
+// ref_sampler.hip -- reference sampling on the device.
+//
+// What the reference does on the host every control tick before the solver runs
+//   MpcController::getRefPoints   P/nmpc_controller/src/mpc.cpp:407-461
+//   TrajAnal::getPstate/getVstate P/nmpc_controller/include/nmpc_controller/traj_anal.hpp:105-134
+//   Trajectory<5,2>::getPos/getVel P/back_end/include/gcopter/trajectory.hpp:75-103, 472-502
+//   MpcController::smooth_yaw     P/nmpc_controller/src/mpc.cpp:248-277
+//   MpcWrapper::setTrajectory / setICRParameters  P/nmpc_controller/src/mpc_wrapper.cpp:200-207, 242-264
+// is done here for B robots by two small kernels that write y, yN, od and x0 of the batch directly, so
+// that a tick uploads 24 bytes of odometry per robot instead of 5N+... floats of references.
+// The trajectory itself (quintic coefficients of the minimum-jerk spline and the Simpson checkpoints)
+// is prepared on the host when a new Polynome arrives, as in the reference (TrajCallback), and kept in
+// device memory.  Arithmetic is float64 like the reference's; the cast to float32 happens on the store,
+// as in MpcWrapper::setTrajectory.
+#include "nmpc_kernels.h"
+
+namespace nmpc {
+
+__device__ __forceinline__ int locate(const double* dur, int n, double& t)
+{ // Trajectory::locatePieceIdx
+    int idx;
+    double d = 0.0;
+    for (idx = 0; idx < n && t > (d = dur[idx]); ++idx) t -= d;
+    if (idx == n) {
+        --idx;
+        t += dur[idx];
+    }
+    return idx;
+}
+__device__ __forceinline__ void eval_pv(const double* dur, const double* coef, int n, double t, double p[2], double v[2])
+{
+    double tl = t;
+    const int i = locate(dur, n, tl);
+    const double* c = coef + (size_t)i * 12;
+    for (int d = 0; d < 2; ++d) {
+        double tn = 1.0, pp = 0.0, vv = 0.0;
+        const double* cd = c + d * 6;
+        for (int k = 0; k <= 5; ++k) { pp += tn * cd[k]; tn *= tl; }
+        tn = 1.0;
+        for (int k = 1; k <= 5; ++k) { vv += k * tn * cd[k]; tn *= tl; }
+        p[d] = pp; v[d] = vv;
+    }
+}
+
+// one thread per (robot, node j); j = 0..N
+__global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, double dt, double now,
+                                  const double* est /* [B][3] */, const double* icr /* [B][3] xv yr yl */, int* at_goal,
+                                  double* psi_raw /* [B][N+1] normalised headings for the unwrap pass, or null */)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * (N + 1)) return;
+    const int r = (int)(t / (N + 1)), j = (int)(t % (N + 1));
+    const double* m = s.meta + (size_t)r * 8;
+    if (m[6] == 0.0) return; // no trajectory yet: leave the references alone
+    const double start_time = m[0], duration = m[1], xv = m[2], res = m[3];
+    const int np = (int)m[4], nc = (int)m[5];
+    const double* dur = s.dur + (size_t)r * s.P;
+    const double* coef = s.coef + (size_t)r * s.P * 12;
+    const double t_cur = now - start_time;
+    double temp_t = t_cur + dt;
+    for (int i = 0; i < j; ++i) temp_t += dt; // the reference accumulates (mpc.cpp:432)
+    const bool inside = temp_t <= duration;
+    const double tq = inside ? temp_t : duration;
+    // TrajAnal::getPstate
+    int index = (int)floor(tq / res);
+    if (index > nc - 1) index = nc - 1;
+    const double floor_t = index * res, diff_t = tq - floor_t;
+    double p1[2], p2[2], p3[2], v1[2], v2[2], v3[2];
+    eval_pv(dur, coef, np, floor_t, p1, v1);
+    eval_pv(dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
+    eval_pv(dur, coef, np, tq, p3, v3);
+    auto xd = [&](const double* p, const double* v) { return v[1] * cos(p[0]) + v[0] * xv * sin(p[0]); };
+    auto yd = [&](const double* p, const double* v) { return v[1] * sin(p[0]) - v[0] * xv * cos(p[0]); };
+    const double* ck = s.ckpt + ((size_t)r * s.C + index) * 2;
+    const double X = ck[0] + diff_t / 6.0 * (xd(p1, v1) + 4.0 * xd(p2, v2) + xd(p3, v3));
+    const double Y = ck[1] + diff_t / 6.0 * (yd(p1, v1) + 4.0 * yd(p2, v2) + yd(p3, v3));
+    double psi = p3[0];
+    while (psi > M_PI) psi -= 2 * M_PI; // normlize_theta
+    while (psi < -M_PI) psi += 2 * M_PI;
+    if (psi_raw) psi_raw[t] = psi;
+    const double yr = icr[(size_t)r * 3 + 1], yl = icr[(size_t)r * 3 + 2];
+    const double vr = inside ? v3[1] - v3[0] * yr : 0.0, vl = inside ? v3[1] - v3[0] * yl : 0.0;
+    if (j < N) {
+        float* y = const_cast<float*>(b.y) + ((size_t)r * N + j) * 5;
+        y[0] = (float)X; y[1] = (float)Y; y[2] = (float)psi; y[3] = (float)vr; y[4] = (float)vl;
+    } else {
+        float* yN = const_cast<float*>(b.yN) + (size_t)r * 3;
+        yN[0] = (float)X; yN[1] = (float)Y; yN[2] = (float)psi;
+    }
+    float* od = const_cast<float*>(b.od) + ((size_t)r * (N + 1) + j) * 3; // setICRParameters
+    od[0] = (float)icr[(size_t)r * 3]; od[1] = (float)yr; od[2] = (float)yl;
+    if (j == 0) {
+        float* x0 = const_cast<float*>(b.x0) + (size_t)r * 3;
+        x0[0] = (float)est[(size_t)r * 3]; x0[1] = (float)est[(size_t)r * 3 + 1]; x0[2] = (float)est[(size_t)r * 3 + 2];
+        if (at_goal) at_goal[r] = (t_cur > duration + 1.0) ? 1 : 0;
+    }
+}
+
+// smooth_yaw: sequential in the nodes, one thread per robot; unwraps the float64 headings and casts
+// afterwards, like the reference (smooth_yaw, then the float cast in MpcWrapper::setTrajectory).
+__global__ void ref_unwrap_kernel(RefStore s, alore_nmpc_batch b, int B, int N, const double* est, const double* psi_raw)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    if (s.meta[(size_t)r * 8 + 6] == 0.0) return;
+    const double* pr = psi_raw + (size_t)r * (N + 1);
+    double prev = pr[0];
+    double dyaw = prev - est[(size_t)r * 3 + 2];
+    while (dyaw >= M_PI / 2) { prev -= M_PI * 2; dyaw = prev - est[(size_t)r * 3 + 2]; }
+    while (dyaw <= -M_PI / 2) { prev += M_PI * 2; dyaw = prev - est[(size_t)r * 3 + 2]; }
+    float* y = const_cast<float*>(b.y) + (size_t)r * N * 5;
+    float* yN = const_cast<float*>(b.yN) + (size_t)r * 3;
+    if (N > 0) y[2] = (float)prev; else yN[2] = (float)prev;
+    for (int i = 0; i < N; ++i) {
+        double cur = pr[i + 1];
+        dyaw = cur - prev;
+        while (dyaw >= M_PI / 2) { cur -= M_PI * 2; dyaw = cur - prev; }
+        while (dyaw <= -M_PI / 2) { cur += M_PI * 2; dyaw = cur - prev; }
+        if (i + 1 < N) y[(size_t)(i + 1) * 5 + 2] = (float)cur; else yN[2] = (float)cur;
+        prev = cur;
+    }
+}
+
+hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now,
+                             const double* est, const double* icr, int* at_goal, double* psi_scratch, int do_smooth,
+                             hipStream_t st)
+{
+    const long total = (long)B * (N + 1);
+    const int threads = 128;
+    const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+    hipLaunchKernelGGL(ref_sample_kernel, dim3(blocks), dim3(threads), 0, st, s, b, B, N, dt, now, est, icr, at_goal,
+                       do_smooth ? psi_scratch : nullptr);
+    if (do_smooth) {
+        hipLaunchKernelGGL(ref_unwrap_kernel, dim3((B + 63) / 64), dim3(64), 0, st, s, b, B, N, est, psi_scratch);
+    }
+    return hipGetLastError();
+}
+
+} // namespace nmpc

@@ -41,6 +41,9 @@ def load():
     L.alore_host_controller_robot.restype = C.c_void_p
     L.alore_host_controller_robot.argtypes = [C.c_void_p, C.c_int]
     L.alore_host_controller_tick.argtypes = [C.c_void_p, C.c_double, DP]
+    L.alore_host_sampler_at_goal.argtypes = [C.c_void_p]
+    L.alore_host_controller_device_refs.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.alore_host_controller_references.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.alore_host_controller_prediction.argtypes = [C.c_void_p, C.c_int, DP, DP, C.POINTER(C.c_int)]
     _lib = L
     return L
@@ -90,6 +93,9 @@ class RefSampler:
     def odom(self, x, y, yaw): self.L.alore_host_sampler_odom(self.h, x, y, yaw)
     def icr(self, yr, yl, xv): self.L.alore_host_sampler_icr(self.h, yr, yl, xv)
     def duration(self): return self.L.alore_host_sampler_duration(self.h)
+
+    @property
+    def at_goal(self): return bool(self.L.alore_host_sampler_at_goal(self.h))
 
     def refs(self, now, smooth=True):
         rs = np.zeros((self.N + 1, 3)); ri = np.zeros((self.N + 1, 2)); g = C.c_int(0)
@@ -147,6 +153,19 @@ class BatchedMpcController:
         if self.L.alore_host_controller_tick(self.h, now, _dp(cmd)) != 0:
             raise RuntimeError("tick failed")
         return cmd
+
+    def use_device_references(self, max_pieces=64, max_checkpoints=1024):
+        """Sample the references on the GPU from now on (include/alore_nmpc.h: alore_nmpc_refs_*)."""
+        if self.L.alore_host_controller_device_refs(self.h, max_pieces, max_checkpoints) != 0:
+            raise RuntimeError("device reference store could not be created")
+
+    def references(self):
+        """(y, yN, od, x0) as the solver saw them on the last tick (read back from the device)."""
+        y = np.zeros((self.B, self.N, 5), np.float32); yN = np.zeros((self.B, 3), np.float32)
+        od = np.zeros((self.B, self.N + 1, 3), np.float32); x0 = np.zeros((self.B, 3), np.float32)
+        if self.L.alore_host_controller_references(self.h, y.ctypes.data, yN.ctypes.data, od.ctypes.data, x0.ctypes.data) != 0:
+            raise RuntimeError("reference download failed")
+        return y, yN, od, x0
 
     def prediction(self, b):
         s = np.zeros((self.N + 1, 3)); u = np.zeros((self.N, 2)); st = C.c_int(0)

@@ -58,6 +58,7 @@ int alore_host_sampler_refs(void* s_, double now, int do_smooth, double* ref_sta
     *at_goal = s->at_goal ? 1 : 0;
     return 0;
 }
+int alore_host_sampler_at_goal(void* s) { return static_cast<RefSampler*>(s)->at_goal ? 1 : 0; }
 double alore_host_sampler_duration(void* s) { return static_cast<RefSampler*>(s)->new_traj_.get_traj_duration(); }
 // direct TrajAnal queries on the pending (latest) trajectory
 int alore_host_sampler_state(void* s_, double t, double* p3, double* v2, double* a2)
@@ -97,10 +98,19 @@ void* alore_host_controller_create(int B, int N, double dt, const double* matrix
     } catch (...) { return nullptr; }
 }
 void alore_host_controller_destroy(void* c) { delete static_cast<BatchedMpcController*>(c); }
+int alore_host_controller_device_refs(void* c, int max_pieces, int max_checkpoints)
+{
+    try { static_cast<BatchedMpcController*>(c)->useDeviceReferences(max_pieces, max_checkpoints); return 0; } catch (...) { return -1; }
+}
 void* alore_host_controller_robot(void* c, int b) { return &static_cast<BatchedMpcController*>(c)->robots.at(b); }
 int alore_host_controller_tick(void* c, double now, double* cmd)
 {
     try { static_cast<BatchedMpcController*>(c)->tick(now, cmd); return 0; } catch (...) { return -1; }
+}
+// the references the solver saw on the last tick (device copies): y B x N x 5, yN B x 3, od B x (N+1) x 3, x0 B x 3
+int alore_host_controller_references(void* c_, float* y, float* yN, float* od, float* x0)
+{
+    try { static_cast<BatchedMpcController*>(c_)->mpc_wrapper_.downloadReferences(y, yN, od, x0); return 0; } catch (...) { return -1; }
 }
 void alore_host_controller_prediction(void* c_, int b, double* states /* 3 x (N+1) */, double* inputs /* 2 x N */, int* status)
 {

@@ -119,13 +119,40 @@ public:
         std::fill(u_.begin() + (size_t)b * 2 * kSamples, u_.begin() + (size_t)(b + 1) * 2 * kSamples, 0.f);
         dirty_iterate_ = true;
     }
+    // ---- references sampled on the device (alore_nmpc_refs_*): od, y, yN and x0 never leave the GPU
+    void enableDeviceRefs(int max_pieces, int max_checkpoints)
+    {
+        check(alore_nmpc_refs_init(h_, B, max_pieces, max_checkpoints));
+        device_refs_ = true;
+    }
+    bool deviceRefs() const { return device_refs_; }
+    // the trajectory robot b tracks from `start_time` on (TrajAnal as prepared by TrajCallback)
+    void setDeviceTrajectory(int b, const TrajAnal& traj, double start_time)
+    {
+        const auto& pieces = traj.trajectory().pieces;
+        const auto& seq = traj.get_state_sequence_();
+        std::vector<double> dur(pieces.size()), coef(pieces.size() * 12), ck(seq.size() * 2);
+        for (size_t i = 0; i < pieces.size(); ++i) {
+            dur[i] = pieces[i].duration;
+            std::memcpy(&coef[i * 12], pieces[i].c, sizeof(double) * 12);
+        }
+        for (size_t i = 0; i < seq.size(); ++i) { ck[i * 2] = seq[i][0]; ck[i * 2 + 1] = seq[i][1]; }
+        check(alore_nmpc_refs_set_trajectory(h_, b, (int)pieces.size(), dur.data(), coef.data(), (int)seq.size(), ck.data(),
+                                             start_time, traj.state_seq_res(), traj.icr_xv(), nullptr));
+    }
+    // getRefPoints + smooth_yaw + setTrajectory + setICRParameters + the x0 of update() for all robots
+    void sampleDeviceRefs(double now, const double* est /* B x 3 */, const double* icr /* B x 3: xv yr yl */, int* at_goal)
+    {
+        check(alore_nmpc_refs_sample(h_, &dev_, B, now, est, icr, 1, at_goal, nullptr));
+    }
+
     // mpc_wrapper.cpp:279-373 for all robots at once: states = B x 3
     bool update(const double* states, bool do_preparation = true)
     {
         if (!acado_is_prepared_) return false;
         for (size_t i = 0; i < (size_t)B * 3; ++i) x0_[i] = (float)states[i];
         alore_nmpc_batch host{};
-        host.od = od_.data(); host.y = y_.data(); host.yN = yN_.data(); host.x0 = x0_.data();
+        if (!device_refs_) { host.od = od_.data(); host.y = y_.data(); host.yN = yN_.data(); host.x0 = x0_.data(); }
         if (dirty_costs_) { host.W = W_.data(); host.WN = WN_.data(); }
         if (dirty_iterate_) { host.x = x_.data(); host.u = u_.data(); }
         check(alore_nmpc_batch_upload(h_, &dev_, &host, B, nullptr));
@@ -145,6 +172,14 @@ public:
         return update(states);
     }
     bool prepare() { acado_is_prepared_ = true; return true; } // mpc_wrapper.cpp:377-383
+    // what the solver saw on the last launch (device copies of the reference members)
+    void downloadReferences(float* y, float* yN, float* od, float* x0)
+    {
+        alore_nmpc_batch out{};
+        out.y = y; out.yN = yN; out.od = od; out.x0 = x0;
+        check(alore_nmpc_batch_download(h_, &dev_, &out, B, nullptr));
+        if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("hipStreamSynchronize");
+    }
     // mpc_wrapper.cpp:386-410 (double out)
     void getStates(int b, double* out /* 3 x (N+1) col-major */) const
     {
@@ -175,7 +210,7 @@ private:
     alore_nmpc_batch dev_{};
     std::vector<float> x_, u_, od_, y_, yN_, W_, WN_, x0_;
     std::vector<int> status_;
-    bool acado_is_prepared_ = false, dirty_costs_ = true, dirty_iterate_ = true;
+    bool acado_is_prepared_ = false, dirty_costs_ = true, dirty_iterate_ = true, device_refs_ = false;
     const double dt_;
 };
 
@@ -186,6 +221,7 @@ public:
     TrajAnal traj_, new_traj_;
     double new_traj_start_time_ = 0.0, start_time = -1.0, traj_duration = 0.0;
     bool receive_traj_ = false, at_goal = false, has_odom = false;
+    unsigned traj_version = 0; // bumped whenever traj_ is replaced (device copies follow it)
     CarICR car_icr_;
     double est_state_[3] = {0, 0, 0};
     int N_;
@@ -209,6 +245,7 @@ public:
     {
         if (new_traj_.if_get_traj_) {
             traj_ = new_traj_;
+            ++traj_version;
             traj_duration = traj_.get_traj_duration();
             start_time = new_traj_start_time_;
             new_traj_.if_get_traj_ = false;
@@ -224,6 +261,7 @@ public:
     {
         if (new_traj_.if_get_traj_ && now > new_traj_start_time_) {
             traj_ = new_traj_;
+            ++traj_version;
             traj_duration = traj_.get_traj_duration();
             start_time = new_traj_start_time_;
             new_traj_.if_get_traj_ = false;
@@ -280,6 +318,7 @@ public:
     std::vector<RefSampler> robots;
     int delay_num_ = 1;
     bool solve_from_scratch_ = true;
+    std::vector<unsigned> uploaded_version_; // device-reference mode: traj_version last sent per robot
 
     BatchedMpcController(int B, int N, double dt, const double matrix_q[3], const double matrix_r[2], int delay_num = 1,
                          double state_seq_res = 0.1, double Integral_appr_resInt = 4, int device = 0)
@@ -292,12 +331,37 @@ public:
         robots.reserve(B);
         for (int b = 0; b < B; ++b) robots.emplace_back(N, dt, state_seq_res, Integral_appr_resInt);
     }
+    // Sample the references on the GPU from now on (alore_nmpc_refs_*): a tick then uploads the
+    // odometry and ICR of every robot (48 bytes each) instead of its 5N+3 reference floats.
+    void useDeviceReferences(int max_pieces = 64, int max_checkpoints = 1024)
+    {
+        mpc_wrapper_.enableDeviceRefs(max_pieces, max_checkpoints);
+        uploaded_version_.assign(robots.size(), 0u);
+    }
     // cmd: B x 2 (right, left).  Robots without odometry / trajectory keep a zero command.
     void tick(double now, double* cmd)
     {
         const int B = mpc_wrapper_.B, N = mpc_wrapper_.kSamples;
         std::vector<double> est((size_t)B * 3, 0.0);
-        for (int b = 0; b < B; ++b) {
+        if (mpc_wrapper_.deviceRefs()) {
+            std::vector<double> icr((size_t)B * 3, 0.0);
+            std::vector<int> goal(B, 0);
+            for (int b = 0; b < B; ++b) {
+                RefSampler& r = robots[b];
+                icr[(size_t)b * 3] = r.car_icr_.xv; icr[(size_t)b * 3 + 1] = r.car_icr_.yr; icr[(size_t)b * 3 + 2] = r.car_icr_.yl;
+                if (!r.has_odom || !r.receive_traj_) continue;
+                r.swapInNewTraj(now);
+                if (r.traj_version != uploaded_version_[b]) {
+                    mpc_wrapper_.setDeviceTrajectory(b, r.traj_, r.start_time);
+                    uploaded_version_[b] = r.traj_version;
+                }
+                for (int i = 0; i < 3; ++i) est[(size_t)b * 3 + i] = r.est_state_[i];
+            }
+            mpc_wrapper_.sampleDeviceRefs(now, est.data(), icr.data(), goal.data());
+            for (int b = 0; b < B; ++b)
+                if (uploaded_version_[b]) robots[b].at_goal = goal[b] != 0;
+        }
+        for (int b = 0; b < B && !mpc_wrapper_.deviceRefs(); ++b) {
             RefSampler& r = robots[b];
             if (!r.has_odom || !r.receive_traj_) continue;
             r.swapInNewTraj(now);

@@ -291,6 +291,8 @@ public:
     void getVstate(double t, double out[2]) const { traj_.getVel(t, out); } // (theta', s')
     void getAstate(double t, double out[2]) const { traj_.getAcc(t, out); }
     const Trajectory5& trajectory() const { return traj_; }
+    double state_seq_res() const { return state_seq_res_; }
+    double icr_xv() const { return ICR_[2]; }
 
 private:
     double xdot(const double p[2], const double v[2]) const { return v[1] * std::cos(p[0]) + v[0] * ICR_[2] * std::sin(p[0]); }

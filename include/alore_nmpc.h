@@ -147,6 +147,25 @@ int alore_nmpc_forward_simulate(alore_nmpc_handle h, const alore_nmpc_batch *dev
 int alore_nmpc_shift(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int strategy, const float *xEnd,
                      const float *uEnd, void *stream);
 
+/* ---- reference sampling on the device -------------------------------------- */
+/* What the reference node does on the host every tick before the solver runs --
+ * MpcController::getRefPoints (nmpc_controller/src/mpc.cpp:407-461, sampling TrajAnal::getPstate /
+ * getVstate, traj_anal.hpp:105-134, at t_cur + (j+1) dt, clamped at the end of the trajectory, wheel
+ * speeds vr = s' - theta' yr, vl = s' - theta' yl), MpcController::smooth_yaw (:248-277) and
+ * MpcWrapper::setTrajectory / setICRParameters (mpc_wrapper.cpp:200-207, 242-264) -- done by two
+ * small kernels for B robots, writing y, yN, od and x0 of the batch in place.  The trajectory of a
+ * robot (quintic coefficients [piece][dim theta,s][power 0..5] of the minimum-jerk spline and the
+ * Simpson checkpoints (x, y) every state_seq_res seconds, traj_anal.hpp:55-95) is prepared on the host
+ * when a new Polynome arrives, like the reference's TrajCallback, and kept on the device. */
+int alore_nmpc_refs_init(alore_nmpc_handle h, int B, int max_pieces, int max_checkpoints);
+int alore_nmpc_refs_set_trajectory(alore_nmpc_handle h, int robot, int n_pieces, const double *durations,
+                                   const double *coeffs, int n_ckpt, const double *ckpt_xy, double start_time,
+                                   double state_seq_res, double xv, void *stream);
+/* est [B][3] = odometry (x, y, yaw), icr [B][3] = (xv, yr, yl): HOST pointers (24 bytes per robot per
+ * tick); at_goal [B] (host, may be NULL; forces a stream synchronisation when given) */
+int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, double now, const double *est,
+                           const double *icr, int do_smooth, int *at_goal, void *stream);
+
 /* ---- introspection ------------------------------------------------------- */
 typedef struct {
     int lanes_per_problem;  /* of the last alore_nmpc_rti launch */

@@ -159,3 +159,63 @@ def test_controller_tick_matches_oracle_pipeline():
         assert np.max(np.abs(cmd[b] - u[1])) < 1e-4 * max(1.0, np.max(np.abs(u))), (b, cmd[b], u[1])
         ps, pu, st = ctl.prediction(b)
         assert st == 0 and np.max(np.abs(ps.reshape(-1) - orc.v["x"])) < 1e-4 * max(1.0, np.max(np.abs(orc.v["x"])))
+
+
+@pytest.mark.gpu
+def test_device_reference_sampling_matches_host_sampler():
+    """alore_nmpc_refs_* (ref_sampler.hip) against the float64 host RefSampler: y, yN, od, x0 as float32,
+    across heading wrap-around, the end of the trajectory, a trajectory swap and a robot without trajectory."""
+    from alore_legged_manipulator_amd.host import BatchedMpcController
+    B, N, dt = 9, 20, 0.01
+    rng = np.random.default_rng(31)
+    host = BatchedMpcController(B, N, dt)
+    dev = BatchedMpcController(B, N, dt)
+    dev.use_device_references(max_pieces=8, max_checkpoints=64)
+    lone = [RefSampler(N, dt) for _ in range(B)]
+
+    def feed(b, fn):
+        for r in (host.robots[b], dev.robots[b], lone[b]):
+            fn(r)
+
+    spec = []
+    for b in range(B - 1):                       # robot B-1 never gets a trajectory
+        v, w, xv = rng.uniform(0.5, 1.8), rng.uniform(-1.2, 1.2), rng.uniform(0, 0.3)
+        th0 = math.pi - 0.1 if b == 0 else rng.uniform(-3, 3)   # b = 0: heading crosses +pi at once
+        if b == 0:
+            w = 1.5
+        pieces = [0.4] * int(rng.integers(1, 5))
+        m = arc_polynome(v, w, th0, pieces, xv=xv, t0=0.0)
+        yr, yl = -rng.uniform(0.2, 0.35), rng.uniform(0.2, 0.35)
+        od = (rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), th0 + rng.uniform(-0.3, 0.3))
+        feed(b, lambda r: (r.traj(m), r.odom(*od), r.icr(yr, yl, xv)))
+        spec.append((od, (xv, yr, yl)))
+    feed(B - 1, lambda r: r.odom(0.1, 0.2, 0.3))
+
+    def check(now):
+        ch, cd = host.tick(now), dev.tick(now)
+        yh, yNh, odh, x0h = host.references()
+        yd, yNd, odd, x0d = dev.references()
+        for b in range(B - 1):
+            rs, ri, goal = lone[b].refs(now, smooth=True)
+            want = np.concatenate([rs[:N], ri[:N]], 1).astype(np.float32)
+            tol = 2e-6 * max(1.0, float(np.max(np.abs(want))))
+            assert np.max(np.abs(yd[b] - want)) <= tol, (now, b, np.max(np.abs(yd[b] - want)))
+            assert np.max(np.abs(yNd[b] - rs[N].astype(np.float32))) <= tol
+            assert np.array_equal(odd[b], np.tile(np.float32(spec[b][1]), (N + 1, 1)))
+            assert np.array_equal(x0d[b], np.float32(spec[b][0]))
+            assert np.max(np.abs(yd[b] - yh[b])) <= tol and np.max(np.abs(yNd[b] - yNh[b])) <= tol
+            assert dev.robots[b].at_goal == goal == host.robots[b].at_goal
+        # same references -> same commands (the solver is deterministic; refs may differ in the last ulp)
+        assert np.max(np.abs(ch - cd)) < 1e-4
+        assert np.all(cd[B - 1] == 0.0)
+
+    check(0.123)                                  # first tick (solve from scratch)
+    check(0.133)                                  # warm tick
+    check(0.35)                                   # horizons of the 1-piece robots run past the end (0.4 s)
+    # a new trajectory arrives for robot 2, starting in the future: old one keeps being tracked until then
+    m2 = arc_polynome(1.1, -0.7, 0.4, [0.5, 0.5], xv=0.1, t0=0.5)
+    feed(2, lambda r: r.traj(m2))
+    check(0.45)
+    check(0.55)                                   # swapped in
+    check(5.0)                                    # everybody is at the goal: zero commands
+    assert np.all(dev.tick(5.01) == 0.0)
