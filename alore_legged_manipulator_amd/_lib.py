@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libalore_nmpc.so")
+# ALORE_NMPC_LIB: another build of the same C ABI (A/B timing of kernel variants); never a CPU library
+LIB_PATH = os.environ.get("ALORE_NMPC_LIB") or os.path.join(HERE, "libalore_nmpc.so")
 
 FP = C.POINTER(C.c_float)
 IP = C.POINTER(C.c_int)

@@ -122,6 +122,15 @@ __device__ __forceinline__ float quad_sum(float x)
     x += dpp<QP_SWAP2>(x);
     return x;
 }
+// base + the values of lanes 0, 1, 2 of the quad (lane 3 is not read): three DPP-operand adds, the same
+// summation order in every lane
+__device__ __forceinline__ float rows_sum(float base, float x)
+{
+    float h = base + dpp<QP_BC0>(x);
+    h += dpp<QP_BC1>(x);
+    h += dpp<QP_BC2>(x);
+    return h;
+}
 
 template <int L>
 __device__ __forceinline__ float group_sum(float v)
@@ -367,11 +376,11 @@ __device__ __forceinline__ int riccati_rows(const StageBcast& s, float4 qrow, fl
     const float sr = V.P0 * s.d.x + V.P1 * s.d.y + V.P2 * s.d.z + V.p;     // (P d + p)[r]
     const float PB0 = V.P0 * B00 + V.P1 * B10 + V.P2 * B20;                 // (P B)[r][0]
     const float PB1 = V.P0 * B01 + V.P1 * B11 + V.P2 * B21;                 // (P B)[r][1]
-    const float H00 = s.R.x + quad_sum(Br0 * PB0);                          // R + B' P B
-    const float H01 = s.R.y + quad_sum(Br0 * PB1);
-    const float H11 = s.R.z + quad_sum(Br1 * PB1);
-    float hu0 = s.d.w + quad_sum(Br0 * sr);                                 // r + B' s
-    const float hu1 = s.R.w + quad_sum(Br1 * sr);
+    const float H00 = rows_sum(s.R.x, Br0 * PB0);                           // R + B' P B
+    const float H01 = rows_sum(s.R.y, Br0 * PB1);
+    const float H11 = rows_sum(s.R.z, Br1 * PB1);
+    float hu0 = rows_sum(s.d.w, Br0 * sr);                                  // r + B' s
+    const float hu1 = rows_sum(s.R.w, Br1 * sr);
     // component r of the rows of Hux = B' P A
     float G0c = PB0 + al * dpp<QP_BC0>(PB0) + be * dpp<QP_BC1>(PB0);
     const float G1c = PB1 + al * dpp<QP_BC0>(PB1) + be * dpp<QP_BC1>(PB1);
@@ -379,7 +388,7 @@ __device__ __forceinline__ int riccati_rows(const StageBcast& s, float4 qrow, fl
     // eliminate control 1, then control 0 (group-uniform scalars)
     const bool free1 = (st1 == ST_FREE);
     const bool bad1 = free1 && !(H11 > 0.0f);
-    const float inv11 = rcp_f(H11);
+    const float inv11 = __builtin_amdgcn_rcpf(H11); // 1 ulp, like the division it stands for
     const float w1 = free1 ? inv11 : 0.0f;
     const float z1 = free1 ? -hu1 * inv11 : v1;
     const float t1 = w1 * H01;
@@ -392,7 +401,7 @@ __device__ __forceinline__ int riccati_rows(const StageBcast& s, float4 qrow, fl
     hu0 += H01 * z1;
     const bool free0 = (st0 == ST_FREE);
     const bool bad0 = free0 && !(H00r > 0.0f);
-    const float inv00 = rcp_f(H00r);
+    const float inv00 = __builtin_amdgcn_rcpf(H00r);
     const float w0 = free0 ? inv00 : 0.0f;
     const float z0 = free0 ? -hu0 * inv00 : v0;
     const float g0s = free0 ? -w0 : 1.0f;
@@ -502,9 +511,8 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
 
     // row role of this lane inside its quad (backward sweep)
     const int rq = j & 3;
-    const int rr = (rq < 3) ? rq : 2; // lane 3 shadows lane 2 ...
+    const int rr = (rq < 3) ? rq : 2; // lane 3 shadows lane 2 (rows_sum never reads it)
     const bool is2 = (rr == 2);
-    const float rowmask = (rq < 3) ? 1.0f : 0.0f; // ... and contributes nothing to the quad sums
 
     int status = RET_OK, n_iter = 0;
     float kkt = 0.0f;
@@ -693,17 +701,14 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                 RowValue V;
                 V.P0 = V.P1 = V.P2 = V.p = 0.0f;
                 int ok = 1;
-                // Every lane computes every step (a group that has not joined yet works on garbage that
-                // is never stored); only the stores are predicated.  Lanes 0..2 of the first quad store
-                // their row / components, lane 3 the three group-uniform scalars, in the same instructions.
-                auto step = [&](int k, const StageBcast& cur, const float4& qrow, const float2& brow, const float4& vnext) {
-                    const bool join = (k == kk); // this group joins the sweep here: cost-to-go of node k+1
-                    V.P0 = join ? vnext.x : V.P0; V.P1 = join ? vnext.y : V.P1;
-                    V.P2 = join ? vnext.z : V.P2; V.p = join ? vnext.w : V.p;
+                // Every group that still iterates sweeps from the highest stale stage of the wavefront:
+                // above its own stale stage it recomputes, bit for bit, what its records already hold.  Lanes 0..2 of the
+                // first quad store their row / components, lane 3 the three group-uniform scalars, in the
+                // same instructions.
+                auto step = [&](int k, const StageBcast& cur, const float4& qrow, const float2& brow) {
                     RowPolicy pol;
-                    const int good = riccati_rows(cur, qrow, brow.x * rowmask, brow.y * rowmask, is2, V, pol, k > 0);
-                    ok &= (k <= kk) ? good : 1;
-                    if (j < 4 && k <= kk) {
+                    ok &= riccati_rows(cur, qrow, brow.x, brow.y, is2, V, pol, k > 0);
+                    if (j < 4 && changed) { // a settled group keeps its records (and its multipliers)
                         float* rec = row + k * SR;
                         rec[S_POL0 * 4 + j] = (j < 3) ? pol.c0c : pol.f0;
                         rec[S_POL1 * 4 + j] = (j < 3) ? pol.c1c : pol.e1;
@@ -714,27 +719,30 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                         st4(rec, slot, w0_, w1_, w2_, w3_);
                     }
                 };
-                auto fetch = [&](int k, StageBcast& sb, float4& qrow, float2& brow, float4& vnext) {
+                auto fetch = [&](int k, StageBcast& sb, float4& qrow, float2& brow) {
                     const float* rec = row + k * SR;
                     load_bcast(rec, sb);
                     qrow = lds4(rec, S_Q + rr);
                     brow = *reinterpret_cast<const float2*>(rec + 2 * rr);
-                    vnext = lds4(rec + SR, S_V + rr);
                 };
                 // two register sets, loads of the next record in flight while the current one is used
                 StageBcast sa, sb;
-                float4 qa = make_float4(0, 0, 0, 0), qb = qa, va = qa, vb = qa;
+                float4 qa = make_float4(0, 0, 0, 0), qb = qa;
                 float2 ba = make_float2(0, 0), bb = ba;
                 int k = kmax;
-                if (k >= 0) fetch(k, sa, qa, ba, va);
+                if (k >= 0) {
+                    const float4 v0 = lds4(row + (k + 1) * SR, S_V + rr); // cost-to-go of node kmax + 1
+                    V.P0 = v0.x; V.P1 = v0.y; V.P2 = v0.z; V.p = v0.w;
+                    fetch(k, sa, qa, ba);
+                }
                 while (k >= 1) {
-                    fetch(k - 1, sb, qb, bb, vb);
-                    step(k, sa, qa, ba, va);
-                    if (k >= 2) fetch(k - 2, sa, qa, ba, va);
-                    step(k - 1, sb, qb, bb, vb);
+                    fetch(k - 1, sb, qb, bb);
+                    step(k, sa, qa, ba);
+                    if (k >= 2) fetch(k - 2, sa, qa, ba);
+                    step(k - 1, sb, qb, bb);
                     k -= 2;
                 }
-                if (k == 0) step(0, sa, qa, ba, va);
+                if (k == 0) step(0, sa, qa, ba);
                 pd_fail |= (ok == 0);
             }
             __syncthreads();
