@@ -3,7 +3,35 @@
 summary for profiles/ (our kernels in full, everything else as one line)."""
 import csv, glob, os, sys
 
+def from_rocpd(db, lines):
+    """rocprofv3 >= 7 writes a rocpd SQLite database unless --output-format csv is given."""
+    import sqlite3
+    c = sqlite3.connect(db)
+    lines.append(f"# {os.path.basename(db)} (rocpd): per-kernel statistics, durations in ns")
+    lines.append("name,calls,total_ns,avg_ns,min_ns,max_ns")
+    other = 0
+    for name, n, tot, avg, mn, mx in c.execute(
+            "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name"):
+        if "nmpc::" in name:
+            lines.append(f"{name},{n},{tot},{avg:.1f},{mn},{mx}")
+        else:
+            other += tot
+    lines.append(f"(all non-nmpc kernels: torch fills/copies of the bench setup),,{other},,,")
+    lines.append("# launch geometry / resources per nmpc kernel")
+    for r in c.execute("select distinct name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
+                       "from kernels where name like '%nmpc::%'"):
+        lines.append(f"{r[0]}: grid={r[1]} wg={r[2]} VGPR={r[3]} AGPR={r[4]} SGPR={r[5]} LDS={r[6]} scratch={r[7]}")
+
+
 def main(d, out):
+    dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+    if dbs:
+        lines = []
+        for db in dbs:
+            from_rocpd(db, lines)
+        open(out, "w").write("\n".join(lines) + "\n")
+        print("\n".join(lines))
+        return
     stats = glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True)
     trace = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)
     lines = []
