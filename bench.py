@@ -54,8 +54,9 @@ def parse():
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = auto)")
     ap.add_argument("--warm-start-steps", type=int, default=-1, help="working-set prediction steps (-1 = library default)")
-    ap.add_argument("--gather", choices=("full", "none"), default="full",
-                    help="multi-GPU: all-gather the result trajectories (default) or keep them sharded")
+    ap.add_argument("--gather", choices=("last", "full", "none"), default="last",
+                    help="multi-GPU: all-gather the trajectories of the last timed step inside the timed region (default), "
+                         "of every step in overlapped buckets (full: eager launches), or keep results sharded (none)")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per all-gather bucket")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,8 +171,9 @@ def main():
     eng.load(batch, slot=None)
     torch.cuda.synchronize(dev)
 
-    do_gather = world > 1 and a.gather == "full"
-    gatherer = ResultGatherer(dist, world) if do_gather else None
+    do_gather = world > 1 and a.gather == "full"      # every step, bucketed, overlapped with the next solves
+    gather_last = world > 1 and a.gather == "last"    # one all-gather of the final trajectories
+    gatherer = ResultGatherer(dist, world) if (do_gather or gather_last) else None
     ge = max(1, a.gather_every)
 
     def run_steps(first, count):
@@ -193,17 +195,18 @@ def main():
     run_steps(0, a.warmup)
     barrier()
 
-    # the K timed steps, captured once into a hipGraph where possible (single GPU):
-    # K kernel nodes, no host launch overhead inside the timed region
+    # the K timed steps, captured once into a hipGraph (K kernel nodes, no host launch overhead inside the
+    # timed region); collectives stay outside the graph, so per-step gathering launches eagerly
     graph = None
     used_graph = False
-    if not a.no_graph and world == 1 and a.steps > 0:
+    if not a.no_graph and not do_gather and a.steps > 0:
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                # thread_local: the RCCL watchdog thread of a multi-rank run must not invalidate the capture
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     run_steps(a.warmup, a.steps)
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = g
@@ -223,6 +226,10 @@ def main():
     else:
         run_steps(a.warmup, a.steps)
     ev1.record()
+    if gather_last:  # the converged trajectories of the last batch on every rank (x, u, status, kkt)
+        last = a.warmup + a.steps - 1
+        gatherer.submit({k: eng.ts[k][last] for k in ("x", "u", "status", "kkt")})
+        gatherer.wait()
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -267,7 +274,8 @@ def main():
                                    "one real-time iteration (prepare+feedback) per problem from the "
                                    "MpcWrapper::solve cold start, full reference I/O contract",
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "dt": 0.01,
-                       "parallelism": f"independent shards x{world}" + (", result all-gather" if do_gather else ""),
+                       "parallelism": f"independent shards x{world}" + (", result all-gather every step" if do_gather else
+                                                                         (", result all-gather of the last step" if gather_last else "")),
                        "lanes_per_problem": info["lanes_per_problem"], "threads_per_block": info["threads_per_block"],
                        "lds_bytes_per_block": info["lds_bytes_per_block"], "hip_graph": used_graph},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
