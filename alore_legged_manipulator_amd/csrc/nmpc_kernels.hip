@@ -645,7 +645,10 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             apply(0.0f, 0.0f, std::true_type{}, g0, g1);
             const float j0 = -is0 * g0, j1 = -is1 * g1;
             const int hits = (j0 < lb0) | (j0 > ub0) | (j1 < lb1) | (j1 > ub1);
-            const bool run = cold && (group_or<L>(hits) != 0);
+            // a control weight that is not positive: no prediction, the all-free first sweep then reports the
+            // indefinite Hessian exactly where the reference's initial Cholesky does (status 31)
+            const int badw = in ? ((!(R00 > 0.0f)) | (!(R11 > 0.0f))) : 0;
+            const bool run = cold && (group_or<L>(hits | (badw << 1)) == 1);
             if (__any(run)) {
                 // largest eigenvalue of R^-1/2 H R^-1/2 by a short power iteration
                 const float s0 = in ? __builtin_amdgcn_rsqf(fmaxf(R00, 1e-20f)) : 0.0f,

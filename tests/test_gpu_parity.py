@@ -233,3 +233,38 @@ def test_mpc_wrapper_mirror(nmpc_mod):
         st, ref, _ = oracle_tick(orc, problem(batch, b))
         assert relerr(U[b].T.reshape(-1).astype(np.float32), ref["u"]) < 1e-4
         assert relerr(X[b].T.reshape(-1).astype(np.float32), ref["x"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_status_codes_indefinite_and_iteration_cap(nmpc_mod):
+    """qpOASES return values on the failure paths the reference can take (acado_feedbackStep's return value,
+    ignored at mpc_wrapper.cpp:298 but kept in batch.status here): 31 when the Hessian is not positive
+    definite (QProblemB::setupCholeskyDecomposition), 58 when the working set is still changing at the
+    iteration cap (nWSR exhausted); healthy neighbours in the same wavefront are unaffected."""
+    N, B = 20, 8
+    batch = make_batch(B, N, seed=77, fast_tail=1.0)        # every problem hits its bounds
+    # problem 3: negative control weight and no state weight -> indefinite QP
+    batch["W"][3] = 0.0
+    batch["W"][3, :, 3, 3] = -1.0
+    batch["W"][3, :, 4, 4] = -1.0
+    batch["WN"][3] = 0.0
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    eng.load(batch)
+    eng.rti(1)
+    out = eng.fetch()
+    assert out["status"][3] == 31
+    ok = np.arange(B) != 3
+    assert (out["status"][ok] == 0).all()
+    orc = Oracle(N)
+    st, _, _ = oracle_tick(orc, problem(batch, 3))
+    assert st == 31                                          # the reference's own code says the same
+    for b in (2, 4):                                         # neighbours of the bad problem, same wavefront
+        st, ref, _ = oracle_tick(orc, problem(batch, b))
+        assert st == 0 and relerr(out["u"][b].reshape(-1), ref["u"]) < 1e-4
+    # iteration cap: no prediction, one sweep allowed -> bound-hitting problems cannot finish
+    eng1 = nmpc_mod.BatchedNmpc(B, N, max_as_iter=1, warm_start_steps=0)
+    eng1.load(batch)
+    eng1.rti(1)
+    o1 = eng1.fetch()
+    assert (o1["status"][ok] == 58).sum() >= 1 and set(np.unique(o1["status"][ok])) <= {0, 58}
+    assert np.isfinite(o1["x"]).all() and np.isfinite(o1["u"]).all()
