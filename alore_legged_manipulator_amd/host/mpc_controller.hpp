@@ -13,7 +13,9 @@
 // include/alore_nmpc.h; this layer only does what the reference does in double precision on the host.
 #pragma once
 
+#ifndef ALORE_HOST_SAMPLER_ONLY // (tests/harness/sanitize_driver.cpp builds the GPU-free part alone)
 #include <hip/hip_runtime_api.h>
+#endif
 
 #include <cmath>
 #include <cstring>
@@ -34,6 +36,7 @@ struct CarICR { // mpc.h:76-81
     double yr = -0.2, yl = 0.2, xv = 0.0;
 };
 
+#ifndef ALORE_HOST_SAMPLER_ONLY
 // ---- A10: batched MpcWrapper -------------------------------------------------------------------
 class BatchedMpcWrapper {
 public:
@@ -214,6 +217,8 @@ private:
     const double dt_;
 };
 
+#endif // ALORE_HOST_SAMPLER_ONLY
+
 // ---- A11: reference sampling + tick logic, one entry per robot -------------------------------------
 // Pure host code (no GPU): usable and tested on its own.
 class RefSampler {
@@ -309,6 +314,7 @@ public:
     }
 };
 
+#ifndef ALORE_HOST_SAMPLER_ONLY
 // The ROS-free control tick of the reference node for B robots (mpc.cpp:173-240 CmdCallback + :296-350
 // run + :502-509 cmdPub).  `tick(now)` returns, per robot, the wheel-speed command
 // (right_wheel_ome, left_wheel_ome) = predicted input column `delay_num`.
@@ -387,5 +393,7 @@ public:
         }
     }
 };
+
+#endif // ALORE_HOST_SAMPLER_ONLY
 
 } // namespace alore
