@@ -340,6 +340,46 @@ def main():
             del e4
         except Exception as e:  # pragma: no cover
             extras["large_batch"] = {"error": str(e)}
+        # warm tick (closed-loop regime): converge first (K = 15), disturb the measured state by a millimetre /
+        # milliradian, then time ONE real-time iteration from the carried iterate and duals -- no working-set
+        # prediction, normally a single Riccati sweep
+        try:
+            e5 = BatchedNmpc(B, N, device=local_rank, slots=24)
+            e5.load(batch, slot=None)
+            for i in range(24):
+                e5.rti(15, slot=i)
+            e5.ts["x0"].add_(1e-3)
+            torch.cuda.synchronize(dev)
+            e5.rti(1, slot=0); e5.rti(1, slot=1)
+            torch.cuda.synchronize(dev)
+            c0.record()
+            for i in range(2, 24):
+                e5.rti(1, slot=i)
+            c1.record(); torch.cuda.synchronize(dev)
+            msw = c0.elapsed_time(c1) / 22
+            extras["warm_tick"] = {"ms_per_launch": msw, "solves_per_s": B / (msw * 1e-3),
+                                   "working_set_iters_mean": float(e5.ts["n_iter"][2:24].float().mean().item()),
+                                   "unsolved": int((e5.ts["status"][2:24] != 0).sum().item())}
+            del e5
+        except Exception as e:  # pragma: no cover
+            extras["warm_tick"] = {"error": str(e)}
+        # the reference's own generated horizon (N = 50), same batch size: next to the compiled reference's
+        # single-core time in cpu_baseline.reference_n50_single_core_us_per_solve
+        try:
+            e6 = BatchedNmpc(B, 50, device=local_rank, slots=12)
+            e6.load(make_batch(B, 50), slot=None)
+            e6.rti(1, slot=0); e6.rti(1, slot=1)
+            torch.cuda.synchronize(dev)
+            c0.record()
+            for i in range(2, 12):
+                e6.rti(1, slot=i)
+            c1.record(); torch.cuda.synchronize(dev)
+            ms50 = c0.elapsed_time(c1) / 10
+            extras["reference_horizon_n50"] = {"batch": B, "ms_per_launch": ms50, "solves_per_s": B / (ms50 * 1e-3),
+                                               "lanes_per_problem": e6.launch_info()["lanes_per_problem"]}
+            del e6
+        except Exception as e:  # pragma: no cover
+            extras["reference_horizon_n50"] = {"error": str(e)}
         result["extras"] = extras
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
