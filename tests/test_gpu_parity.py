@@ -268,3 +268,28 @@ def test_status_codes_indefinite_and_iteration_cap(nmpc_mod):
     o1 = eng1.fetch()
     assert (o1["status"][ok] == 58).sum() >= 1 and set(np.unique(o1["status"][ok])) <= {0, 58}
     assert np.isfinite(o1["x"]).all() and np.isfinite(o1["u"]).all()
+
+
+@pytest.mark.gpu
+def test_config3_whole_batch_on_one_gpu(nmpc_mod):
+    """BASELINE configs[3] (262144 problems, the 8-GPU batch) as ONE launch: every problem solved, sampled
+    problems within tolerance of the oracle, and the answer of a problem does not depend on the batch it is in
+    (bit-identical to a 4096-problem run of the same problems)."""
+    N, B = 20, 262144
+    hb = make_batch(B, N)
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    eng.load(hb)
+    eng.rti(1)
+    out = eng.fetch()
+    assert (out["status"] == 0).all() and np.isfinite(out["x"]).all() and np.isfinite(out["u"]).all()
+    orc = Oracle(N)
+    for b in (0, 1, B // 3, B // 2, B - 2, B - 1):
+        st, ref, _ = oracle_tick(orc, problem(hb, b))
+        assert st == 0 and relerr(out["u"][b].reshape(-1), ref["u"]) < 1e-4 and relerr(out["x"][b].reshape(-1), ref["x"]) < 1e-4
+    lo = B - 4096
+    small = nmpc_mod.BatchedNmpc(4096, N)
+    small.load({k: v[lo:] for k, v in hb.items()})
+    small.rti(1)
+    so = small.fetch()
+    for k in ("x", "u", "dual", "kkt", "obj", "n_iter"):
+        assert np.array_equal(so[k], out[k][lo:]), k
