@@ -363,6 +363,27 @@ def main():
             del e5
         except Exception as e:  # pragma: no cover
             extras["warm_tick"] = {"error": str(e)}
+        # independent batches streamed over several HIP streams (launches may overlap: the tail of one batch
+        # runs next to the bulk of the next).  Throughput of a streaming deployment; NOT the headline, whose
+        # launches are serialised so that per-launch durations mean something.
+        try:
+            streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+            nslots = min(slots, 60)
+            for i in range(2 * len(streams)):  # first launches on a new stream are slow
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    eng.rti(1, slot=i % nslots)
+            torch.cuda.synchronize(dev)
+            t_a = time.perf_counter()
+            for i in range(nslots):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    eng.rti(1, slot=i)
+            torch.cuda.synchronize(dev)
+            t_b = time.perf_counter()
+            extras["streamed_batches"] = {"streams": len(streams), "launches": nslots,
+                                          "ms_per_launch": (t_b - t_a) / nslots * 1e3,
+                                          "solves_per_s": B * nslots / (t_b - t_a)}
+        except Exception as e:  # pragma: no cover
+            extras["streamed_batches"] = {"error": str(e)}
         # the reference's own generated horizon (N = 50), same batch size: next to the compiled reference's
         # single-core time in cpu_baseline.reference_n50_single_core_us_per_solve
         try:
