@@ -42,6 +42,14 @@ class LinOut(C.Structure):
     _fields_ = [("d", C.c_void_p), ("evGx", C.c_void_p), ("evGu", C.c_void_p)]
 
 
+class PolynomeMsg(C.Structure):
+    """alore_polynome (include/alore_nmpc.h): one planner message, P/utils/carstatemsgs/msg/Polynome.msg"""
+    _fields_ = [("n_pieces", C.c_int), ("innerpoints", C.c_void_p), ("t_pts", C.c_void_p),
+                ("init_p", C.c_double * 2), ("init_v", C.c_double * 2), ("init_a", C.c_double * 2),
+                ("tail_p", C.c_double * 2), ("tail_v", C.c_double * 2), ("tail_a", C.c_double * 2),
+                ("start_position", C.c_double * 3), ("ICR", C.c_double * 3), ("traj_start_time", C.c_double)]
+
+
 class LaunchInfo(C.Structure):
     _fields_ = [("lanes_per_problem", C.c_int), ("problems_per_block", C.c_int), ("threads_per_block", C.c_int),
                 ("grid", C.c_int), ("lds_bytes_per_block", C.c_int), ("last_kernel_ms", C.c_float)]
@@ -65,6 +73,8 @@ SYMBOLS = (
     ("alore_nmpc_refs_init", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("alore_nmpc_refs_set_trajectory", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                  C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    ("alore_nmpc_refs_set_polynomes", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
+    ("alore_nmpc_refs_download", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("alore_nmpc_refs_sample", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p]),
     ("alore_nmpc_set_linearization_point", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -10,6 +10,7 @@
 
 #include "nmpc_kernels.h"
 #include "nmpc_core.h"
+#include "minco_core.h"
 
 struct alore_nmpc_solver {
     alore_nmpc_config cfg;
@@ -29,6 +30,15 @@ struct alore_nmpc_solver {
     double* d_icr = nullptr;  // [B][3]
     double* d_psi = nullptr;  // [B][N+1]
     int* d_goal = nullptr;    // [B]
+    // Polynome -> store on the device: staging + workspace for chunks of kPolyChunk messages
+    static constexpr int kPolyChunk = 256;
+    char* d_poly = nullptr;       // packed message arrays (layout: poly_layout)
+    double* d_band = nullptr;     // [chunk][band_doubles(P)]
+    double* d_rhs = nullptr;      // [chunk][rhs_doubles(P)]
+    int* d_panels = nullptr;      // [chunk]
+    int* d_overflow = nullptr;    // [1]
+    double* d_inc = nullptr;      // [chunk][C * res_int][2], grown on demand
+    size_t inc_doubles = 0;
     const float* lin_x = nullptr; // see alore_nmpc_set_linearization_point
     const float* lin_u = nullptr;
     // diagnostic phase stamps (env ALORE_NMPC_STAMPS=1): per-phase cycle shares, printed at destroy
@@ -178,6 +188,12 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->d_icr) (void)hipFree(h->d_icr);
     if (h->d_psi) (void)hipFree(h->d_psi);
     if (h->d_goal) (void)hipFree(h->d_goal);
+    if (h->d_poly) (void)hipFree(h->d_poly);
+    if (h->d_band) (void)hipFree(h->d_band);
+    if (h->d_rhs) (void)hipFree(h->d_rhs);
+    if (h->d_panels) (void)hipFree(h->d_panels);
+    if (h->d_overflow) (void)hipFree(h->d_overflow);
+    if (h->d_inc) (void)hipFree(h->d_inc);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -291,6 +307,12 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     if (h->d_icr) (void)hipFree(h->d_icr);
     if (h->d_psi) (void)hipFree(h->d_psi);
     if (h->d_goal) (void)hipFree(h->d_goal);
+    if (h->d_poly) (void)hipFree(h->d_poly);
+    if (h->d_band) (void)hipFree(h->d_band);
+    if (h->d_rhs) (void)hipFree(h->d_rhs);
+    if (h->d_panels) (void)hipFree(h->d_panels);
+    if (h->d_overflow) (void)hipFree(h->d_overflow);
+    if (h->d_inc) (void)hipFree(h->d_inc);
             HIP_TRY(h, hipMalloc((void**)&h->d_stamps, need * sizeof(long long)));
             h->stamps_cap = need;
         }
@@ -384,6 +406,117 @@ int alore_nmpc_refs_set_trajectory(alore_nmpc_handle h, int robot, int n_pieces,
     HIP_TRY(h, hipMemcpyAsync(h->refs.ckpt + (size_t)robot * h->refs.C * 2, ckpt_xy, sizeof(double) * n_ckpt * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->refs.meta + (size_t)robot * 8, meta, sizeof(meta), hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipStreamSynchronize(s)); // the host buffers (and `meta`) may go away after return
+    return ALORE_NMPC_OK;
+}
+
+namespace {
+struct PolyLayout { // byte offsets of the packed message arrays of one chunk
+    size_t robot, n_pieces, inner, t_pts, pva, start, icr, t0, end;
+};
+PolyLayout poly_layout(int chunk, int P)
+{
+    PolyLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 15) & ~size_t(15); return at; };
+    L.robot = take(sizeof(int) * chunk);
+    L.n_pieces = take(sizeof(int) * chunk);
+    L.inner = take(sizeof(double) * chunk * (P > 1 ? P - 1 : 1) * 2);
+    L.t_pts = take(sizeof(double) * chunk * P);
+    L.pva = take(sizeof(double) * chunk * 12);
+    L.start = take(sizeof(double) * chunk * 3);
+    L.icr = take(sizeof(double) * chunk * 3);
+    L.t0 = take(sizeof(double) * chunk);
+    L.end = o;
+    return L;
+}
+} // namespace
+
+int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int* robots, const alore_polynome* msgs,
+                                  double state_seq_res, int integral_res_int, void* stream)
+{
+    if (!h || !h->refs.dur || count < 0 || (count > 0 && (!robots || !msgs)) || !(state_seq_res > 0.0) || integral_res_int < 1)
+        return fail(h, ALORE_NMPC_E_INVALID, "refs_set_polynomes: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const int P = h->refs.P, CH = alore_nmpc_solver::kPolyChunk, Pi = (P > 1 ? P - 1 : 1);
+    const PolyLayout L = poly_layout(CH, P);
+    if (!h->d_poly) {
+        HIP_TRY(h, hipMalloc((void**)&h->d_poly, L.end));
+        HIP_TRY(h, hipMalloc((void**)&h->d_band, sizeof(double) * CH * minco::band_doubles(P)));
+        HIP_TRY(h, hipMalloc((void**)&h->d_rhs, sizeof(double) * CH * minco::rhs_doubles(P)));
+        HIP_TRY(h, hipMalloc((void**)&h->d_panels, sizeof(int) * CH));
+        HIP_TRY(h, hipMalloc((void**)&h->d_overflow, sizeof(int)));
+    }
+    const size_t need = (size_t)CH * h->refs.C * integral_res_int * 2;
+    if (need > h->inc_doubles) {
+        if (h->d_inc) (void)hipFree(h->d_inc);
+        h->d_inc = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&h->d_inc, sizeof(double) * need));
+        h->inc_doubles = need;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(int), s));
+    std::vector<char> pack(L.end);
+    for (int base = 0; base < count; base += CH) {
+        const int n = (count - base < CH) ? count - base : CH;
+        std::fill(pack.begin(), pack.end(), 0);
+        int* p_robot = reinterpret_cast<int*>(pack.data() + L.robot);
+        int* p_np = reinterpret_cast<int*>(pack.data() + L.n_pieces);
+        double* p_inner = reinterpret_cast<double*>(pack.data() + L.inner);
+        double* p_t = reinterpret_cast<double*>(pack.data() + L.t_pts);
+        double* p_pva = reinterpret_cast<double*>(pack.data() + L.pva);
+        double* p_start = reinterpret_cast<double*>(pack.data() + L.start);
+        double* p_icr = reinterpret_cast<double*>(pack.data() + L.icr);
+        double* p_t0 = reinterpret_cast<double*>(pack.data() + L.t0);
+        for (int i = 0; i < n; ++i) {
+            const alore_polynome& m = msgs[base + i];
+            if (robots[base + i] < 0 || robots[base + i] >= h->refs_B)
+                return fail(h, ALORE_NMPC_E_INVALID, "refs_set_polynomes: robot index out of range");
+            p_robot[i] = robots[base + i];
+            p_np[i] = m.n_pieces; // > P is reported by the kernel through the overflow flag
+            const int M = (m.n_pieces >= 1 && m.n_pieces <= P) ? m.n_pieces : 0;
+            if (M > 0 && (!m.t_pts || (M > 1 && !m.innerpoints)))
+                return fail(h, ALORE_NMPC_E_INVALID, "refs_set_polynomes: null array in a message");
+            for (int k = 0; k < M; ++k) p_t[(size_t)i * P + k] = m.t_pts[k];
+            for (int k = 0; k < 2 * (M - 1); ++k) p_inner[(size_t)i * Pi * 2 + k] = m.innerpoints[k];
+            for (int d = 0; d < 2; ++d) {
+                p_pva[i * 12 + d] = m.init_p[d]; p_pva[i * 12 + 2 + d] = m.init_v[d]; p_pva[i * 12 + 4 + d] = m.init_a[d];
+                p_pva[i * 12 + 6 + d] = m.tail_p[d]; p_pva[i * 12 + 8 + d] = m.tail_v[d]; p_pva[i * 12 + 10 + d] = m.tail_a[d];
+            }
+            for (int k = 0; k < 3; ++k) { p_start[i * 3 + k] = m.start_position[k]; p_icr[i * 3 + k] = m.ICR[k]; }
+            p_t0[i] = m.traj_start_time;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_poly, pack.data(), L.end, hipMemcpyHostToDevice, s));
+        nmpc::PolyBatch pb;
+        pb.robot = reinterpret_cast<const int*>(h->d_poly + L.robot);
+        pb.n_pieces = reinterpret_cast<const int*>(h->d_poly + L.n_pieces);
+        pb.inner = reinterpret_cast<const double*>(h->d_poly + L.inner);
+        pb.t_pts = reinterpret_cast<const double*>(h->d_poly + L.t_pts);
+        pb.pva = reinterpret_cast<const double*>(h->d_poly + L.pva);
+        pb.start = reinterpret_cast<const double*>(h->d_poly + L.start);
+        pb.icr = reinterpret_cast<const double*>(h->d_poly + L.icr);
+        pb.t0 = reinterpret_cast<const double*>(h->d_poly + L.t0);
+        pb.P = P;
+        HIP_TRY(h, nmpc::launch_traj_build(h->refs, pb, n, state_seq_res, integral_res_int, h->d_band, h->d_rhs, h->d_panels,
+                                           h->d_inc, h->d_overflow, s));
+        HIP_TRY(h, hipStreamSynchronize(s)); // `pack` is reused by the next chunk
+    }
+    int ov = 0;
+    HIP_TRY(h, hipMemcpyAsync(&ov, h->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (ov & 1) return fail(h, ALORE_NMPC_E_INVALID, "refs_set_polynomes: a message has more pieces than max_pieces (or none)");
+    if (ov & 2) return fail(h, ALORE_NMPC_E_INVALID, "refs_set_polynomes: a trajectory needs more checkpoints than max_checkpoints");
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_refs_download(alore_nmpc_handle h, int robot, double* meta8, double* durations, double* coeffs, double* ckpt_xy)
+{
+    if (!h || !h->refs.dur || robot < 0 || robot >= h->refs_B) return fail(h, ALORE_NMPC_E_INVALID, "refs_download: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (meta8) HIP_TRY(h, hipMemcpy(meta8, h->refs.meta + (size_t)robot * 8, sizeof(double) * 8, hipMemcpyDeviceToHost));
+    if (durations) HIP_TRY(h, hipMemcpy(durations, h->refs.dur + (size_t)robot * h->refs.P, sizeof(double) * h->refs.P, hipMemcpyDeviceToHost));
+    if (coeffs) HIP_TRY(h, hipMemcpy(coeffs, h->refs.coef + (size_t)robot * h->refs.P * 12, sizeof(double) * h->refs.P * 12, hipMemcpyDeviceToHost));
+    if (ckpt_xy) HIP_TRY(h, hipMemcpy(ckpt_xy, h->refs.ckpt + (size_t)robot * h->refs.C * 2, sizeof(double) * h->refs.C * 2, hipMemcpyDeviceToHost));
     return ALORE_NMPC_OK;
 }
 

@@ -53,6 +53,20 @@ struct RefStore {
     double* meta;  // [B][8]        start_time, duration, xv(traj ICR.z), res, n_pieces, n_ckpt, valid, -
     int P, C;
 };
+// a batch of Polynome messages in device memory (P = stride of the per-message arrays = max pieces)
+struct PolyBatch {
+    const int* robot;      // [count] destination slot in the store
+    const int* n_pieces;   // [count]
+    const double* inner;   // [count][max(P-1,1)][2]  (theta, s)
+    const double* t_pts;   // [count][P]
+    const double* pva;     // [count][12]  init p0 p1 v0 v1 a0 a1, tail p0 p1 v0 v1 a0 a1
+    const double* start;   // [count][3]   start_position
+    const double* icr;     // [count][3]   (yr, yl, xv) as sent
+    const double* t0;      // [count]      traj_start_time
+    int P;
+};
+hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, double res, int res_int, double* band_ws,
+                             double* rhs_ws, int* n_panels, double* inc, int* overflow, hipStream_t st);
 hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now,
                              const double* est, const double* icr, int* at_goal, double* psi_scratch, int do_smooth,
                              hipStream_t st);

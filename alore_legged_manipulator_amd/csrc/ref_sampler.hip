@@ -14,33 +14,11 @@
 // as in MpcWrapper::setTrajectory.
 #include "nmpc_kernels.h"
 
+#include "minco_core.h"
+
 namespace nmpc {
 
-__device__ __forceinline__ int locate(const double* dur, int n, double& t)
-{ // Trajectory::locatePieceIdx
-    int idx;
-    double d = 0.0;
-    for (idx = 0; idx < n && t > (d = dur[idx]); ++idx) t -= d;
-    if (idx == n) {
-        --idx;
-        t += dur[idx];
-    }
-    return idx;
-}
-__device__ __forceinline__ void eval_pv(const double* dur, const double* coef, int n, double t, double p[2], double v[2])
-{
-    double tl = t;
-    const int i = locate(dur, n, tl);
-    const double* c = coef + (size_t)i * 12;
-    for (int d = 0; d < 2; ++d) {
-        double tn = 1.0, pp = 0.0, vv = 0.0;
-        const double* cd = c + d * 6;
-        for (int k = 0; k <= 5; ++k) { pp += tn * cd[k]; tn *= tl; }
-        tn = 1.0;
-        for (int k = 1; k <= 5; ++k) { vv += k * tn * cd[k]; tn *= tl; }
-        p[d] = pp; v[d] = vv;
-    }
-}
+using minco::eval_pv;
 
 // one thread per (robot, node j); j = 0..N
 __global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, double dt, double now,
@@ -69,8 +47,8 @@ __global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
     eval_pv(dur, coef, np, floor_t, p1, v1);
     eval_pv(dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
     eval_pv(dur, coef, np, tq, p3, v3);
-    auto xd = [&](const double* p, const double* v) { return v[1] * cos(p[0]) + v[0] * xv * sin(p[0]); };
-    auto yd = [&](const double* p, const double* v) { return v[1] * sin(p[0]) - v[0] * xv * cos(p[0]); };
+    auto xd = [&](const double* p, const double* v) { return minco::xdot(p, v, xv); };
+    auto yd = [&](const double* p, const double* v) { return minco::ydot(p, v, xv); };
     const double* ck = s.ckpt + ((size_t)r * s.C + index) * 2;
     const double X = ck[0] + diff_t / 6.0 * (xd(p1, v1) + 4.0 * xd(p2, v2) + xd(p3, v3));
     const double Y = ck[1] + diff_t / 6.0 * (yd(p1, v1) + 4.0 * yd(p2, v2) + yd(p3, v3));
@@ -119,6 +97,102 @@ __global__ void ref_unwrap_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
         if (i + 1 < N) y[(size_t)(i + 1) * 5 + 2] = (float)cur; else yN[2] = (float)cur;
         prev = cur;
     }
+}
+
+// ---- Polynome messages -> trajectory store, on the device (TrajAnal::setTraj: setConditions /
+//      setParameters / getTrajectory, then getSeq; traj_anal.hpp:36-95).  Three kernels:
+//      spline (one thread per message: 6M x 6M banded LU, sequential by nature), Simpson panels (one thread
+//      per (message, panel): independent), checkpoints (one thread per message: the running sum, in the
+//      reference's order so that the result is the host's to the last bits).
+__global__ void traj_spline_kernel(RefStore s, PolyBatch m, int count, double res, int res_int, double* band_ws,
+                                   double* rhs_ws, int* n_panels, int* overflow)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int r = m.robot[t], M = m.n_pieces[t];
+    double* meta = s.meta + (size_t)r * 8;
+    n_panels[t] = 0;
+    if (M < 1 || M > s.P) { meta[6] = 0.0; atomicOr(overflow, 1); return; }
+    const double* T = m.t_pts + (size_t)t * m.P;
+    const double* pva = m.pva + (size_t)t * 12; // init p0 p1 v0 v1 a0 a1, tail p0 p1 v0 v1 a0 a1
+    double head[2][3], tail[2][3];
+    for (int d = 0; d < 2; ++d) {
+        head[d][0] = pva[d]; head[d][1] = pva[2 + d]; head[d][2] = pva[4 + d];
+        tail[d][0] = pva[6 + d]; tail[d][1] = pva[8 + d]; tail[d][2] = pva[10 + d];
+    }
+    double* band = band_ws + (size_t)t * minco::band_doubles(m.P);
+    double* rhs = rhs_ws + (size_t)t * minco::rhs_doubles(m.P);
+    minco::spline_solve(M, T, m.inner + (size_t)t * (m.P > 1 ? m.P - 1 : 1) * 2, head, tail, band, rhs);
+    double* dur = s.dur + (size_t)r * s.P;
+    double* coef = s.coef + (size_t)r * s.P * 12;
+    double total = 0.0;
+    for (int i = 0; i < M; ++i) {
+        dur[i] = T[i];
+        total += T[i];
+        for (int d = 0; d < 2; ++d)
+            for (int k = 0; k < 6; ++k) coef[(size_t)i * 12 + d * 6 + k] = rhs[(6 * i + k) * 2 + d];
+    }
+    const double fine = res / res_int;
+    const int seq = (int)floor(total / fine);
+    const int nck = 1 + seq / res_int;
+    if (nck > s.C) { meta[6] = 0.0; atomicOr(overflow, 2); return; }
+    n_panels[t] = seq;
+    meta[0] = m.t0[t]; meta[1] = total; meta[2] = m.icr[(size_t)t * 3 + 2]; meta[3] = res;
+    meta[4] = (double)M; meta[5] = (double)nck; meta[6] = 1.0; meta[7] = 0.0;
+    double* ck = s.ckpt + (size_t)r * s.C * 2;
+    ck[0] = m.start[(size_t)t * 3];
+    ck[1] = m.start[(size_t)t * 3 + 1];
+}
+
+__global__ void traj_panel_kernel(RefStore s, PolyBatch m, int count, double res, int res_int, const int* n_panels,
+                                  int max_panels, double* inc)
+{
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)count * max_panels) return;
+    const int t = (int)(g / max_panels), i = (int)(g % max_panels);
+    if (i >= n_panels[t]) return;
+    const int r = m.robot[t];
+    const double* meta = s.meta + (size_t)r * 8;
+    const double fine = res / res_int;
+    double dx, dy;
+    minco::simpson_panel(s.dur + (size_t)r * s.P, s.coef + (size_t)r * s.P * 12, (int)meta[4], meta[2], i * fine, fine, dx, dy);
+    inc[g * 2] = dx;
+    inc[g * 2 + 1] = dy;
+}
+
+__global__ void traj_checkpoint_kernel(RefStore s, PolyBatch m, int count, int res_int, const int* n_panels,
+                                       int max_panels, const double* inc)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int n = n_panels[t];
+    if (n <= 0 && s.meta[(size_t)m.robot[t] * 8 + 6] == 0.0) return;
+    double* ck = s.ckpt + (size_t)m.robot[t] * s.C * 2;
+    double x = ck[0], y = ck[1];
+    const double* in = inc + (size_t)t * max_panels * 2;
+    for (int i = 0; i < n; ++i) {
+        x += in[i * 2];
+        y += in[i * 2 + 1];
+        if (i % res_int == res_int - 1) {
+            const int c = (i + 1) / res_int;
+            ck[c * 2] = x;
+            ck[c * 2 + 1] = y;
+        }
+    }
+}
+
+hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, double res, int res_int, double* band_ws,
+                             double* rhs_ws, int* n_panels, double* inc, int* overflow, hipStream_t st)
+{
+    const int max_panels = s.C * res_int;
+    hipLaunchKernelGGL(traj_spline_kernel, dim3((count + 63) / 64), dim3(64), 0, st, s, m, count, res, res_int, band_ws,
+                       rhs_ws, n_panels, overflow);
+    const long total = (long)count * max_panels;
+    hipLaunchKernelGGL(traj_panel_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st, s, m, count, res, res_int,
+                       n_panels, max_panels, inc);
+    hipLaunchKernelGGL(traj_checkpoint_kernel, dim3((count + 63) / 64), dim3(64), 0, st, s, m, count, res_int, n_panels,
+                       max_panels, inc);
+    return hipGetLastError();
 }
 
 hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now,

@@ -42,7 +42,7 @@ def load():
     L.alore_host_controller_robot.argtypes = [C.c_void_p, C.c_int]
     L.alore_host_controller_tick.argtypes = [C.c_void_p, C.c_double, DP]
     L.alore_host_sampler_at_goal.argtypes = [C.c_void_p]
-    L.alore_host_controller_device_refs.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.alore_host_controller_device_refs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.alore_host_controller_references.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.alore_host_controller_prediction.argtypes = [C.c_void_p, C.c_int, DP, DP, C.POINTER(C.c_int)]
     _lib = L
@@ -154,9 +154,10 @@ class BatchedMpcController:
             raise RuntimeError("tick failed")
         return cmd
 
-    def use_device_references(self, max_pieces=64, max_checkpoints=1024):
-        """Sample the references on the GPU from now on (include/alore_nmpc.h: alore_nmpc_refs_*)."""
-        if self.L.alore_host_controller_device_refs(self.h, max_pieces, max_checkpoints) != 0:
+    def use_device_references(self, max_pieces=64, max_checkpoints=1024, build_on_device=True):
+        """Sample the references on the GPU from now on (include/alore_nmpc.h: alore_nmpc_refs_*); with
+        build_on_device the Polynome messages are turned into splines + checkpoints there too."""
+        if self.L.alore_host_controller_device_refs(self.h, max_pieces, max_checkpoints, 1 if build_on_device else 0) != 0:
             raise RuntimeError("device reference store could not be created")
 
     def references(self):

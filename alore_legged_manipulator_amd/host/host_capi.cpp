@@ -98,9 +98,9 @@ void* alore_host_controller_create(int B, int N, double dt, const double* matrix
     } catch (...) { return nullptr; }
 }
 void alore_host_controller_destroy(void* c) { delete static_cast<BatchedMpcController*>(c); }
-int alore_host_controller_device_refs(void* c, int max_pieces, int max_checkpoints)
+int alore_host_controller_device_refs(void* c, int max_pieces, int max_checkpoints, int build_on_device)
 {
-    try { static_cast<BatchedMpcController*>(c)->useDeviceReferences(max_pieces, max_checkpoints); return 0; } catch (...) { return -1; }
+    try { static_cast<BatchedMpcController*>(c)->useDeviceReferences(max_pieces, max_checkpoints, build_on_device != 0); return 0; } catch (...) { return -1; }
 }
 void* alore_host_controller_robot(void* c, int b) { return &static_cast<BatchedMpcController*>(c)->robots.at(b); }
 int alore_host_controller_tick(void* c, double now, double* cmd)

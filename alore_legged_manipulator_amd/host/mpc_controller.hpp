@@ -143,6 +143,28 @@ public:
         check(alore_nmpc_refs_set_trajectory(h_, b, (int)pieces.size(), dur.data(), coef.data(), (int)seq.size(), ck.data(),
                                              start_time, traj.state_seq_res(), traj.icr_xv(), nullptr));
     }
+    // the same store filled on the device from the planner messages themselves
+    void setDevicePolynomes(const std::vector<int>& robots, const std::vector<const Polynome*>& msgs, double state_seq_res,
+                            int integral_res_int)
+    {
+        std::vector<alore_polynome> pm(msgs.size());
+        std::vector<std::vector<double>> inner(msgs.size());
+        for (size_t i = 0; i < msgs.size(); ++i) {
+            const Polynome& m = *msgs[i];
+            alore_polynome& q = pm[i];
+            q.n_pieces = (int)m.t_pts.size();
+            for (const auto& ip : m.innerpoints) { inner[i].push_back(ip[0]); inner[i].push_back(ip[1]); }
+            q.innerpoints = inner[i].data();
+            q.t_pts = m.t_pts.data();
+            for (int d = 0; d < 2; ++d) {
+                q.init_p[d] = m.init_p[d]; q.init_v[d] = m.init_v[d]; q.init_a[d] = m.init_a[d];
+                q.tail_p[d] = m.tail_p[d]; q.tail_v[d] = m.tail_v[d]; q.tail_a[d] = m.tail_a[d];
+            }
+            for (int k = 0; k < 3; ++k) { q.start_position[k] = m.start_position[k]; q.ICR[k] = m.ICR[k]; }
+            q.traj_start_time = m.traj_start_time;
+        }
+        check(alore_nmpc_refs_set_polynomes(h_, (int)pm.size(), robots.data(), pm.data(), state_seq_res, integral_res_int, nullptr));
+    }
     // getRefPoints + smooth_yaw + setTrajectory + setICRParameters + the x0 of update() for all robots
     void sampleDeviceRefs(double now, const double* est /* B x 3 */, const double* icr /* B x 3: xv yr yl */, int* at_goal)
     {
@@ -227,6 +249,11 @@ public:
     double new_traj_start_time_ = 0.0, start_time = -1.0, traj_duration = 0.0;
     bool receive_traj_ = false, at_goal = false, has_odom = false;
     unsigned traj_version = 0; // bumped whenever traj_ is replaced (device copies follow it)
+    // build_on_device: the spline and the Simpson checkpoints of a new message are computed by the GPU
+    // (alore_nmpc_refs_set_polynomes); the host only keeps the message and its duration
+    bool build_on_device = false;
+    Polynome msg_, new_msg_;
+    double new_duration_ = 0.0;
     CarICR car_icr_;
     double est_state_[3] = {0, 0, 0};
     int N_;
@@ -248,14 +275,14 @@ public:
     // mpc.cpp:130-171
     void TrajCallback(const Polynome& msg)
     {
-        if (new_traj_.if_get_traj_) {
-            traj_ = new_traj_;
-            ++traj_version;
-            traj_duration = traj_.get_traj_duration();
-            start_time = new_traj_start_time_;
-            new_traj_.if_get_traj_ = false;
+        if (new_traj_.if_get_traj_) promote();
+        if (build_on_device) {
+            new_msg_ = msg;
+            new_duration_ = 0.0;
+            for (double t : msg.t_pts) new_duration_ += t;
+        } else {
+            new_traj_.setTraj(msg);
         }
-        new_traj_.setTraj(msg);
         new_traj_start_time_ = msg.traj_start_time;
         new_traj_.if_get_traj_ = true;
         receive_traj_ = true;
@@ -264,13 +291,21 @@ public:
     // mpc.cpp:177-182
     void swapInNewTraj(double now)
     {
-        if (new_traj_.if_get_traj_ && now > new_traj_start_time_) {
+        if (new_traj_.if_get_traj_ && now > new_traj_start_time_) promote();
+    }
+    // the pending trajectory becomes the tracked one (mpc.cpp:139-144, 177-182)
+    void promote()
+    {
+        if (build_on_device) {
+            msg_ = new_msg_;
+            traj_duration = new_duration_;
+        } else {
             traj_ = new_traj_;
-            ++traj_version;
             traj_duration = traj_.get_traj_duration();
-            start_time = new_traj_start_time_;
-            new_traj_.if_get_traj_ = false;
         }
+        ++traj_version;
+        start_time = new_traj_start_time_;
+        new_traj_.if_get_traj_ = false;
     }
     static void normlize_theta(double& th) // mpc.cpp:243-246
     {
@@ -325,10 +360,13 @@ public:
     int delay_num_ = 1;
     bool solve_from_scratch_ = true;
     std::vector<unsigned> uploaded_version_; // device-reference mode: traj_version last sent per robot
+    double state_seq_res_ = 0.1;
+    int integral_res_int_ = 4;
 
     BatchedMpcController(int B, int N, double dt, const double matrix_q[3], const double matrix_r[2], int delay_num = 1,
                          double state_seq_res = 0.1, double Integral_appr_resInt = 4, int device = 0)
-        : mpc_wrapper_(B, N, dt, device), delay_num_(delay_num)
+        : mpc_wrapper_(B, N, dt, device), delay_num_(delay_num), state_seq_res_(state_seq_res),
+          integral_res_int_((int)Integral_appr_resInt)
     {
         // mpc.cpp:67-85: diagonal weights from ~matrix_q / ~matrix_r
         const double Q[9] = {matrix_q[0], 0, 0, 0, matrix_q[1], 0, 0, 0, matrix_q[2]};
@@ -339,10 +377,16 @@ public:
     }
     // Sample the references on the GPU from now on (alore_nmpc_refs_*): a tick then uploads the
     // odometry and ICR of every robot (48 bytes each) instead of its 5N+3 reference floats.
-    void useDeviceReferences(int max_pieces = 64, int max_checkpoints = 1024)
+    // build_on_device: new Polynome messages are also turned into splines + checkpoints by the GPU, all
+    // robots whose trajectory changed in one call (otherwise the host does it, as the reference's TrajCallback)
+    void useDeviceReferences(int max_pieces = 64, int max_checkpoints = 1024, bool build_on_device = true)
     {
         mpc_wrapper_.enableDeviceRefs(max_pieces, max_checkpoints);
         uploaded_version_.assign(robots.size(), 0u);
+        for (auto& r : robots) {
+            if (r.receive_traj_ && build_on_device) throw std::logic_error("useDeviceReferences: call before the first trajectory");
+            r.build_on_device = build_on_device;
+        }
     }
     // cmd: B x 2 (right, left).  Robots without odometry / trajectory keep a zero command.
     void tick(double now, double* cmd)
@@ -352,17 +396,22 @@ public:
         if (mpc_wrapper_.deviceRefs()) {
             std::vector<double> icr((size_t)B * 3, 0.0);
             std::vector<int> goal(B, 0);
+            std::vector<int> fresh_robots;
+            std::vector<const Polynome*> fresh_msgs;
             for (int b = 0; b < B; ++b) {
                 RefSampler& r = robots[b];
                 icr[(size_t)b * 3] = r.car_icr_.xv; icr[(size_t)b * 3 + 1] = r.car_icr_.yr; icr[(size_t)b * 3 + 2] = r.car_icr_.yl;
                 if (!r.has_odom || !r.receive_traj_) continue;
                 r.swapInNewTraj(now);
                 if (r.traj_version != uploaded_version_[b]) {
-                    mpc_wrapper_.setDeviceTrajectory(b, r.traj_, r.start_time);
+                    if (r.build_on_device) { fresh_robots.push_back(b); fresh_msgs.push_back(&r.msg_); }
+                    else mpc_wrapper_.setDeviceTrajectory(b, r.traj_, r.start_time);
                     uploaded_version_[b] = r.traj_version;
                 }
                 for (int i = 0; i < 3; ++i) est[(size_t)b * 3 + i] = r.est_state_[i];
             }
+            if (!fresh_robots.empty())
+                mpc_wrapper_.setDevicePolynomes(fresh_robots, fresh_msgs, state_seq_res_, integral_res_int_);
             mpc_wrapper_.sampleDeviceRefs(now, est.data(), icr.data(), goal.data());
             for (int b = 0; b < B; ++b)
                 if (uploaded_version_[b]) robots[b].at_goal = goal[b] != 0;

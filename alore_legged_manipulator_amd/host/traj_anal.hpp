@@ -19,59 +19,9 @@
 #include <stdexcept>
 #include <vector>
 
+#include "../csrc/minco_core.h"
+
 namespace alore {
-
-// A x = b for a banded A stored as in "Matrix Computations": entry (i, j) at [(i - j + q) * n + j].
-// LU without pivoting, exactly the elimination order of the reference (minco.hpp:99-131).
-class BandedSystem {
-public:
-    void create(int n, int p, int q)
-    {
-        n_ = n; lower_ = p; upper_ = q;
-        data_.assign((size_t)n * (p + q + 1), 0.0);
-    }
-    void reset() { std::fill(data_.begin(), data_.end(), 0.0); }
-    double& operator()(int i, int j) { return data_[(size_t)(i - j + upper_) * n_ + j]; }
-    double operator()(int i, int j) const { return data_[(size_t)(i - j + upper_) * n_ + j]; }
-
-    void factorizeLU()
-    {
-        for (int k = 0; k <= n_ - 2; ++k) {
-            const int iM = std::min(k + lower_, n_ - 1);
-            double cVl = (*this)(k, k);
-            for (int i = k + 1; i <= iM; ++i)
-                if ((*this)(i, k) != 0.0) (*this)(i, k) /= cVl;
-            const int jM = std::min(k + upper_, n_ - 1);
-            for (int j = k + 1; j <= jM; ++j) {
-                cVl = (*this)(k, j);
-                if (cVl != 0.0)
-                    for (int i = k + 1; i <= iM; ++i)
-                        if ((*this)(i, k) != 0.0) (*this)(i, j) -= (*this)(i, k) * cVl;
-            }
-        }
-    }
-    // b: n rows of `m` columns, row-major; solved in place (minco.hpp:137-167)
-    void solve(std::vector<double>& b, int m) const
-    {
-        for (int j = 0; j <= n_ - 1; ++j) {
-            const int iM = std::min(j + lower_, n_ - 1);
-            for (int i = j + 1; i <= iM; ++i)
-                if ((*this)(i, j) != 0.0)
-                    for (int c = 0; c < m; ++c) b[(size_t)i * m + c] -= (*this)(i, j) * b[(size_t)j * m + c];
-        }
-        for (int j = n_ - 1; j >= 0; --j) {
-            for (int c = 0; c < m; ++c) b[(size_t)j * m + c] /= (*this)(j, j);
-            const int iM = std::max(0, j - upper_);
-            for (int i = iM; i <= j - 1; ++i)
-                if ((*this)(i, j) != 0.0)
-                    for (int c = 0; c < m; ++c) b[(size_t)i * m + c] -= (*this)(i, j) * b[(size_t)j * m + c];
-        }
-    }
-
-private:
-    int n_ = 0, lower_ = 0, upper_ = 0;
-    std::vector<double> data_;
-};
 
 // One quintic piece in 2 flat coordinates.  c[d][i] multiplies t^i (ascending powers); the reference
 // stores the same numbers with descending powers (trajectory.hpp:75-88, minco.hpp:900-913).
@@ -142,49 +92,18 @@ public:
         N_ = pieceNum;
         for (int d = 0; d < 2; ++d)
             for (int k = 0; k < 3; ++k) { head_[d][k] = head[d][k]; tail_[d][k] = tail[d][k]; }
-        A_.create(6 * N_, 6, 6);
-        b_.assign((size_t)6 * N_ * 2, 0.0);
     }
-    // inPs: (N-1) inner points, [i][dim]; ts: N piece durations
+    // inPs: (N-1) inner points, [i][dim]; ts: N piece durations.  The system and its banded LU are
+    // csrc/minco_core.h (shared with the device build of the same trajectory).
     void setParameters(const std::vector<std::array<double, 2>>& inPs, const std::vector<double>& ts)
     {
         if ((int)ts.size() != N_ || (int)inPs.size() != N_ - 1) throw std::invalid_argument("MincoS3NU sizes");
         T1_ = ts;
-        const int N = N_;
-        std::vector<double> T2(N), T3(N), T4(N), T5(N);
-        for (int i = 0; i < N; ++i) {
-            T2[i] = T1_[i] * T1_[i]; T3[i] = T2[i] * T1_[i]; T4[i] = T2[i] * T2[i]; T5[i] = T4[i] * T1_[i];
-        }
-        A_.reset();
-        std::fill(b_.begin(), b_.end(), 0.0);
-        auto& A = A_;
-        A(0, 0) = 1.0; A(1, 1) = 1.0; A(2, 2) = 2.0;
-        for (int d = 0; d < 2; ++d) { B(0, d) = head_[d][0]; B(1, d) = head_[d][1]; B(2, d) = head_[d][2]; }
-        for (int i = 0; i < N - 1; ++i) {
-            const int r = 6 * i;
-            const double t1 = T1_[i];
-            A(r + 3, r + 3) = 6.0; A(r + 3, r + 4) = 24.0 * t1; A(r + 3, r + 5) = 60.0 * T2[i]; A(r + 3, r + 9) = -6.0;
-            A(r + 4, r + 4) = 24.0; A(r + 4, r + 5) = 120.0 * t1; A(r + 4, r + 10) = -24.0;
-            A(r + 5, r) = 1.0; A(r + 5, r + 1) = t1; A(r + 5, r + 2) = T2[i]; A(r + 5, r + 3) = T3[i];
-            A(r + 5, r + 4) = T4[i]; A(r + 5, r + 5) = T5[i];
-            A(r + 6, r) = 1.0; A(r + 6, r + 1) = t1; A(r + 6, r + 2) = T2[i]; A(r + 6, r + 3) = T3[i];
-            A(r + 6, r + 4) = T4[i]; A(r + 6, r + 5) = T5[i]; A(r + 6, r + 6) = -1.0;
-            A(r + 7, r + 1) = 1.0; A(r + 7, r + 2) = 2 * t1; A(r + 7, r + 3) = 3 * T2[i]; A(r + 7, r + 4) = 4 * T3[i];
-            A(r + 7, r + 5) = 5 * T4[i]; A(r + 7, r + 7) = -1.0;
-            A(r + 8, r + 2) = 2.0; A(r + 8, r + 3) = 6 * t1; A(r + 8, r + 4) = 12 * T2[i]; A(r + 8, r + 5) = 20 * T3[i];
-            A(r + 8, r + 8) = -2.0;
-            for (int d = 0; d < 2; ++d) B(r + 5, d) = inPs[i][d];
-        }
-        const int e = 6 * N;
-        const double t1 = T1_[N - 1];
-        A(e - 3, e - 6) = 1.0; A(e - 3, e - 5) = t1; A(e - 3, e - 4) = T2[N - 1]; A(e - 3, e - 3) = T3[N - 1];
-        A(e - 3, e - 2) = T4[N - 1]; A(e - 3, e - 1) = T5[N - 1];
-        A(e - 2, e - 5) = 1.0; A(e - 2, e - 4) = 2 * t1; A(e - 2, e - 3) = 3 * T2[N - 1]; A(e - 2, e - 2) = 4 * T3[N - 1];
-        A(e - 2, e - 1) = 5 * T4[N - 1];
-        A(e - 1, e - 4) = 2; A(e - 1, e - 3) = 6 * t1; A(e - 1, e - 2) = 12 * T2[N - 1]; A(e - 1, e - 1) = 20 * T3[N - 1];
-        for (int d = 0; d < 2; ++d) { B(e - 3, d) = tail_[d][0]; B(e - 2, d) = tail_[d][1]; B(e - 1, d) = tail_[d][2]; }
-        A_.factorizeLU();
-        A_.solve(b_, 2);
+        std::vector<double> inner((size_t)2 * (N_ > 1 ? N_ - 1 : 1), 0.0);
+        for (int i = 0; i < N_ - 1; ++i) { inner[2 * i] = inPs[i][0]; inner[2 * i + 1] = inPs[i][1]; }
+        band_.assign((size_t)minco::band_doubles(N_), 0.0);
+        b_.assign((size_t)minco::rhs_doubles(N_), 0.0);
+        minco::spline_solve(N_, T1_.data(), inner.data(), head_, tail_, band_.data(), b_.data());
     }
     void getTrajectory(Trajectory5& traj) const
     {
@@ -200,11 +119,9 @@ public:
     }
 
 private:
-    double& B(int r, int d) { return b_[(size_t)r * 2 + d]; }
     int N_ = 0;
     double head_[2][3] = {{0}}, tail_[2][3] = {{0}};
-    BandedSystem A_;
-    std::vector<double> b_;
+    std::vector<double> band_, b_;
     std::vector<double> T1_;
 };
 

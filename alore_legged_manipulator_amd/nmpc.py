@@ -136,6 +136,52 @@ class BatchedNmpc:
                                               C.c_void_p(xe.data_ptr()) if xe is not None else None,
                                               C.c_void_p(ue.data_ptr()) if ue is not None else None, self._stream()))
 
+    # -- reference sampling on the device (include/alore_nmpc.h: alore_nmpc_refs_*)
+    def refs_init(self, max_pieces: int = 64, max_checkpoints: int = 1024) -> None:
+        self._refs_shape = (int(max_pieces), int(max_checkpoints))
+        self._check(self.lib.alore_nmpc_refs_init(self.h, self.B, max_pieces, max_checkpoints))
+
+    def refs_set_polynomes(self, robots, msgs, state_seq_res: float = 0.1, integral_res_int: int = 4) -> None:
+        """msgs: objects with the fields of Polynome.msg (alore_legged_manipulator_amd.host.Polynome)."""
+        n = len(msgs)
+        arr = (_lib.PolynomeMsg * n)()
+        keep = []
+        for q, m in zip(arr, msgs):
+            inner = np.ascontiguousarray(m.innerpoints, np.float64).reshape(-1)
+            t_pts = np.ascontiguousarray(m.t_pts, np.float64)
+            keep += [inner, t_pts]
+            q.n_pieces = t_pts.size
+            q.innerpoints = inner.ctypes.data if inner.size else None
+            q.t_pts = t_pts.ctypes.data
+            pva0, pva1 = np.asarray(m.init_pva, np.float64), np.asarray(m.tail_pva, np.float64)
+            for d in range(2):
+                q.init_p[d], q.init_v[d], q.init_a[d] = pva0[d], pva0[2 + d], pva0[4 + d]
+                q.tail_p[d], q.tail_v[d], q.tail_a[d] = pva1[d], pva1[2 + d], pva1[4 + d]
+            for k in range(3):
+                q.start_position[k] = float(m.start_position[k]); q.ICR[k] = float(m.ICR[k])
+            q.traj_start_time = float(m.traj_start_time)
+        rb = np.ascontiguousarray(robots, np.int32)
+        self._check(self.lib.alore_nmpc_refs_set_polynomes(self.h, n, rb.ctypes.data, C.addressof(arr) if n else None,
+                                                           float(state_seq_res), int(integral_res_int), self._stream()))
+
+    def refs_download(self, robot: int) -> dict:
+        P, Cn = self._refs_shape
+        meta = np.zeros(8); dur = np.zeros(P); coef = np.zeros((P, 2, 6)); ck = np.zeros((Cn, 2))
+        self._check(self.lib.alore_nmpc_refs_download(self.h, int(robot), meta.ctypes.data, dur.ctypes.data,
+                                                      coef.ctypes.data, ck.ctypes.data))
+        n, c = int(meta[4]), int(meta[5])
+        return {"start_time": meta[0], "duration": meta[1], "xv": meta[2], "res": meta[3], "valid": bool(meta[6]),
+                "durations": dur[:n], "coeffs": coef[:n], "checkpoints": ck[:c]}
+
+    def refs_sample(self, now: float, est, icr, smooth: bool = True, slot: int = 0):
+        """Writes y, yN, od, x0 of `slot` from the stored trajectories; returns the at_goal flags."""
+        est = np.ascontiguousarray(est, np.float64).reshape(self.B, 3)
+        icr = np.ascontiguousarray(icr, np.float64).reshape(self.B, 3)
+        goal = np.zeros(self.B, np.int32)
+        self._check(self.lib.alore_nmpc_refs_sample(self.h, C.byref(self._batches[slot]), self.B, float(now), est.ctypes.data,
+                                                    icr.ctypes.data, 1 if smooth else 0, goal.ctypes.data, self._stream()))
+        return goal.astype(bool)
+
     def set_timing(self, enable: bool) -> None:
         self._check(self.lib.alore_nmpc_set_timing(self.h, 1 if enable else 0))
 

@@ -161,6 +161,28 @@ int alore_nmpc_refs_init(alore_nmpc_handle h, int B, int max_pieces, int max_che
 int alore_nmpc_refs_set_trajectory(alore_nmpc_handle h, int robot, int n_pieces, const double *durations,
                                    const double *coeffs, int n_ckpt, const double *ckpt_xy, double start_time,
                                    double state_seq_res, double xv, void *stream);
+/* The same store filled from the wire format itself: a batch of planner messages
+ * (P/utils/carstatemsgs/msg/Polynome.msg) is turned into spline coefficients and Simpson checkpoints on
+ * the device -- TrajAnal::setTraj (traj_anal.hpp:36-53: MINCO_S3NU::setConditions / setParameters /
+ * getTrajectory, P/back_end/include/gcopter/minco.hpp:751-913, banded LU :99-199) and TrajAnal::getSeq
+ * (traj_anal.hpp:55-95) -- for `count` robots at once; robots[i] is the store slot of msgs[i].  Host
+ * pointers; returns after the store is complete.  Fails (and marks the slot invalid) when a message has
+ * more pieces than max_pieces or needs more checkpoints than max_checkpoints. */
+typedef struct alore_polynome {
+    int n_pieces;              /* = len(t_pts) */
+    const double *innerpoints; /* (n_pieces - 1) x 2: (theta, s) = innerpoints[i].x, .y */
+    const double *t_pts;       /* n_pieces piece durations */
+    double init_p[2], init_v[2], init_a[2], tail_p[2], tail_v[2], tail_a[2]; /* .x, .y of the message fields */
+    double start_position[3];  /* x, y, theta */
+    double ICR[3];             /* (yr, yl, xv) as sent */
+    double traj_start_time;
+} alore_polynome;
+int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int *robots, const alore_polynome *msgs,
+                                  double state_seq_res, int integral_res_int, void *stream);
+/* read one slot back (tests, logging): meta8 = start_time, duration, xv, state_seq_res, n_pieces, n_ckpt,
+ * valid, 0; durations [max_pieces]; coeffs [max_pieces][2][6]; ckpt_xy [max_checkpoints][2]; any may be NULL */
+int alore_nmpc_refs_download(alore_nmpc_handle h, int robot, double *meta8, double *durations, double *coeffs,
+                             double *ckpt_xy);
 /* est [B][3] = odometry (x, y, yaw), icr [B][3] = (xv, yr, yl): HOST pointers (24 bytes per robot per
  * tick); at_goal [B] (host, may be NULL; forces a stream synchronisation when given) */
 int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, double now, const double *est,
