@@ -384,6 +384,37 @@ def main():
                                           "solves_per_s": B * nslots / (t_b - t_a)}
         except Exception as e:  # pragma: no cover
             extras["streamed_batches"] = {"error": str(e)}
+        # the whole control tick of the reference node for B robots (host controller -> C ABI -> kernels ->
+        # wheel-speed commands; mpc.cpp CmdCallback): reference sampling on the host (as the reference does)
+        # against reference sampling on the device
+        try:
+            from alore_legged_manipulator_amd.host import BatchedMpcController, Polynome
+            ticks = {}
+            rng = np.random.default_rng(7)
+            vw = rng.uniform([0.5, -1.0], [1.8, 1.0], (B, 2))
+            for mode in ("host_refs", "device_refs"):
+                ctl = BatchedMpcController(B, N, 0.01, device=local_rank)
+                if mode == "device_refs":
+                    ctl.use_device_references(max_pieces=8, max_checkpoints=64, build_on_device=True)
+                for b in range(B):
+                    v, w = vw[b]
+                    T = np.array([0.5, 0.5, 0.5, 0.5]); Tc = np.cumsum(T)
+                    ctl.robots[b].traj(Polynome(np.stack([w * Tc[:-1], v * Tc[:-1]], 1), T, [0, 0, w, v, 0, 0],
+                                                [w * Tc[-1], v * Tc[-1], w, v, 0, 0], [0, 0, 0], [-0.3, 0.3, 0.1], 0.0))
+                    ctl.robots[b].odom(0.01, -0.01, 0.02)
+                    ctl.robots[b].icr(-0.3, 0.3, 0.1)
+                ctl.tick(0.05); ctl.tick(0.06)
+                t_a = time.perf_counter()
+                nt = 30
+                for i in range(nt):
+                    ctl.tick(0.07 + 0.01 * i)
+                t_b = time.perf_counter()
+                ticks[mode] = {"ms_per_tick": (t_b - t_a) / nt * 1e3, "robot_ticks_per_s": B * nt / (t_b - t_a)}
+                del ctl
+            ticks["robots"] = B
+            extras["controller_tick"] = ticks
+        except Exception as e:  # pragma: no cover
+            extras["controller_tick"] = {"error": f"{type(e).__name__}: {e}"}
         # the reference's own generated horizon (N = 50), same batch size: next to the compiled reference's
         # single-core time in cpu_baseline.reference_n50_single_core_us_per_solve
         try:
