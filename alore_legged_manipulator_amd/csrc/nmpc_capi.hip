@@ -140,7 +140,7 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     alore_nmpc_solver* h = new (std::nothrow) alore_nmpc_solver;
     if (!h) return ALORE_NMPC_E_NOMEM;
     h->cfg = *cfg;
-    if (h->cfg.max_as_iter <= 0) h->cfg.max_as_iter = 64;
+    if (h->cfg.max_as_iter <= 0) h->cfg.max_as_iter = 128;
     if (h->cfg.warm_start_steps < 0) h->cfg.warm_start_steps = 8;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)prop.sharedMemPerBlock : 64 * 1024;

@@ -304,6 +304,40 @@ NMPC_HD void forward_step(const Policy& pol, int st0, int st1, float dx0, float 
     o.mu1 = (st1 == ST_FREE) ? 0.0f : val1;
 }
 
+// ---- safeguard: primal active-set iteration -----------------------------------------------------
+// The primal-dual update above changes every violated control at once; it is exact when it stops but
+// it can cycle (seen on far-off warm starts with stale duals).  After AS_SWITCH sweeps the solver
+// continues as a textbook primal active-set method on the same stage-wise factorisation: a feasible
+// point `cur` moves towards the minimiser `tgt` of the current working-set QP up to the first blocking
+// bound (that control is added), a full step releases the fixed control whose multiplier has the most
+// wrong sign, and a full step without such a control is the solution.  One Riccati sweep per change,
+// finite for a strictly convex QP.
+constexpr int AS_SWITCH = 16;
+constexpr float AS_NONE = 3.0e38f;
+
+// step length at which free control (cur -> tgt) meets a bound it would cross; AS_NONE if it does not
+NMPC_HD float asm_ratio(int st, float cur, float tgt, float lb, float ub, int& hit)
+{
+    hit = ST_FREE;
+    if (st != ST_FREE) return AS_NONE;
+    if (tgt > ub + TOL_PRIMAL) { hit = ST_UPPER; return (ub - cur) / (tgt - cur); }
+    if (tgt < lb - TOL_PRIMAL) { hit = ST_LOWER; return (lb - cur) / (tgt - cur); }
+    return AS_NONE;
+}
+// how wrong the sign of the multiplier of a fixed control is (0: fine)
+NMPC_HD float asm_violation(int st, float mult, float lb, float ub)
+{
+    if (!(ub - lb > BOUNDTOL)) return 0.0f; // equality-bounded controls stay fixed
+    if (st == ST_LOWER) return (mult < -TOL_DUAL) ? -mult : 0.0f;
+    if (st == ST_UPPER) return (mult > TOL_DUAL) ? mult : 0.0f;
+    return 0.0f;
+}
+// working set of a feasible point: a control sitting on a bound is fixed there
+NMPC_HD int asm_status_of(float cur, float lb, float ub)
+{
+    return (cur <= lb) ? ST_LOWER : ((cur >= ub) ? ST_UPPER : ST_FREE);
+}
+
 // initial working set from the previous dual, as qpOASES guesses it
 // (QProblemB.cpp:1010-1036 with ZERO == 0 in float)
 NMPC_HD int status_from_dual(float y, float lb, float ub)

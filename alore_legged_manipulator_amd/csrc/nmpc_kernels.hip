@@ -426,6 +426,136 @@ __device__ __forceinline__ int riccati_rows(const StageBcast& s, float4 qrow, fl
     return (bad0 || bad1) ? 0 : 1;
 }
 
+// ---- primal active-set safeguard (nmpc_core.h: AS_SWITCH) ----------------------------------------------
+// Runs after the main loop for the rare problems whose primal-dual iteration has not settled, out of
+// line and deliberately plain (every lane of the group walks the stages itself: no scans, no prefetch)
+// so that it costs the main loop nothing.  On entry the records hold the last working-set solution
+// (du in S_STDU.zw); on exit they hold the solution (du, multipliers, dx, statuses) like after a
+// settled main loop.  The feasible point of the method lives in the spare floats S_SB.w / S_DX.w.
+// Returns (sweep count) | bit 29: a stage Hessian pivot was not positive | bit 30: iteration cap reached.
+// (Everything by value: a reference argument would give the kernel a scratch frame.)
+template <int L>
+__device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool mine, float Dx0, float Dx1, float Dx2,
+                                              int max_it, int it)
+{
+    int pd_fail = 0;
+    const int rq = j & 3, rr = (rq < 3) ? rq : 2;
+    const bool is2 = (rr == 2);
+    __syncthreads();
+    if (mine && j == 0) { // start: clip the last solution into the box, fix what sits on a bound
+        for (int k = 0; k < N; ++k) {
+            float* rec = row + k * SR;
+            const float4 sd = lds4(rec, S_STDU), bnd = lds4(rec, S_BND);
+            const float c0 = (bnd.x <= bnd.y) ? clampf(sd.z, bnd.x, bnd.y) : sd.z;
+            const float c1 = (bnd.z <= bnd.w) ? clampf(sd.w, bnd.z, bnd.w) : sd.w;
+            const int s0 = (bnd.y - bnd.x > BOUNDTOL) ? asm_status_of(c0, bnd.x, bnd.y) : ST_LOWER;
+            const int s1 = (bnd.w - bnd.z > BOUNDTOL) ? asm_status_of(c1, bnd.z, bnd.w) : ST_LOWER;
+            rec[S_SB * 4 + 3] = c0; rec[S_DX * 4 + 3] = c1;
+            *reinterpret_cast<float2*>(rec + S_STDU * 4) = make_float2(__int_as_float(s0), __int_as_float(s1));
+        }
+    }
+    __syncthreads();
+    int todo = mine ? 1 : 0;
+    for (;;) {
+        // backward sweep over the whole horizon (rows over the quad lanes, as in the main loop)
+        {
+            const float4 vN = lds4(row + N * SR, S_V + rr);
+            RowValue V;
+            V.P0 = vN.x; V.P1 = vN.y; V.P2 = vN.z; V.p = vN.w;
+            int ok = 1;
+            for (int k = N - 1; k >= 0; --k) {
+                float* rec = row + k * SR;
+                StageBcast sb;
+                load_bcast(rec, sb);
+                const float4 qrow = lds4(rec, S_Q + rr);
+                const float2 brow = *reinterpret_cast<const float2*>(rec + 2 * rr);
+                RowPolicy pol;
+                ok &= riccati_rows(sb, qrow, brow.x, brow.y, is2, V, pol, k > 0);
+                if (j < 4 && todo) {
+                    rec[S_POL0 * 4 + j] = (j < 3) ? pol.c0c : pol.f0;
+                    rec[S_POL1 * 4 + j] = (j < 3) ? pol.c1c : pol.e1;
+                    const int slot = (j < 3) ? S_V + j : S_MU;
+                    st4(rec, slot, (j < 3) ? V.P0 : 0.0f, (j < 3) ? V.P1 : 0.0f, (j < 3) ? V.P2 : pol.f1, (j < 3) ? V.p : 0.0f);
+                }
+            }
+            if (todo) pd_fail |= (ok == 0);
+        }
+        __syncthreads();
+        // forward sweep, sequential, with the ratio test (free controls) and the multiplier test (fixed ones)
+        float alpha = AS_NONE, viol = 0.0f;
+        int akey = -1, vkey = -1; // (2 * stage + control) * 4 + bound hit
+        if (todo) {
+            float dx0 = Dx0, dx1 = Dx1, dx2 = Dx2;
+            for (int k = 0; k < N; ++k) {
+                float* rec = row + k * SR;
+                const float4 l0 = lds4(rec, S_B0), l1 = lds4(rec, S_B1), dd = lds4(rec, S_D), bnd = lds4(rec, S_BND),
+                             sd = lds4(rec, S_STDU), p0 = lds4(rec, S_POL0), p1 = lds4(rec, S_POL1), mu = lds4(rec, S_MU);
+                const int st0 = __float_as_int(sd.x), st1 = __float_as_int(sd.y);
+                Policy pol;
+                pol.c00 = p0.x; pol.c01 = p0.y; pol.c02 = p0.z; pol.f0 = p0.w;
+                pol.c10 = p1.x; pol.c11 = p1.y; pol.c12 = p1.z; pol.e1 = p1.w; pol.f1 = mu.z;
+                StageStep o;
+                forward_step(pol, st0, st1, dx0, dx1, dx2, bnd.x, bnd.y, bnd.z, bnd.w, o);
+                const float c0 = rec[S_SB * 4 + 3], c1 = rec[S_DX * 4 + 3];
+                int h;
+                const float r0 = asm_ratio(st0, c0, o.du0, bnd.x, bnd.y, h);
+                if (r0 < alpha) { alpha = r0; akey = (2 * k) * 4 + h; }
+                const float r1 = asm_ratio(st1, c1, o.du1, bnd.z, bnd.w, h);
+                if (r1 < alpha) { alpha = r1; akey = (2 * k + 1) * 4 + h; }
+                const float v0 = asm_violation(st0, o.mu0, bnd.x, bnd.y), v1 = asm_violation(st1, o.mu1, bnd.z, bnd.w);
+                if (v0 > viol) { viol = v0; vkey = (2 * k) * 4; }
+                if (v1 > viol) { viol = v1; vkey = (2 * k + 1) * 4; }
+                if (j == 0) {
+                    *reinterpret_cast<float2*>(rec + S_MU * 4) = make_float2(o.mu0, o.mu1);
+                    rec[S_DX * 4] = dx0; rec[S_DX * 4 + 1] = dx1; rec[S_DX * 4 + 2] = dx2;
+                    *reinterpret_cast<float2*>(rec + S_STDU * 4 + 2) = make_float2(o.du0, o.du1);
+                }
+                const float n0 = dx0 + l1.z * dx2 + l0.x * o.du0 + l0.y * o.du1 + dd.x;
+                const float n1 = dx1 + l1.w * dx2 + l0.z * o.du0 + l0.w * o.du1 + dd.y;
+                const float n2 = dx2 + l1.x * o.du0 + l1.y * o.du1 + dd.z;
+                dx0 = n0; dx1 = n1; dx2 = n2;
+            }
+            if (j == 0) {
+                float* rec = row + N * SR;
+                rec[S_DX * 4] = dx0; rec[S_DX * 4 + 1] = dx1; rec[S_DX * 4 + 2] = dx2;
+            }
+            ++it;
+        }
+        __syncthreads();
+        // one change of the working set (every lane of the group holds the same alpha / viol / keys)
+        if (todo) {
+            const bool blocked = akey >= 0;
+            const bool release = !blocked && vkey >= 0;
+            const float al = blocked ? fmaxf(alpha, 0.0f) : 1.0f;
+            if (j == 0) {
+                for (int k = 0; k < N; ++k) {
+                    float* rec = row + k * SR;
+                    const float4 sd = lds4(rec, S_STDU), bnd = lds4(rec, S_BND);
+                    int st0 = __float_as_int(sd.x), st1 = __float_as_int(sd.y);
+                    float c0 = rec[S_SB * 4 + 3], c1 = rec[S_DX * 4 + 3];
+                    if (st0 == ST_FREE) c0 += al * (sd.z - c0);
+                    if (st1 == ST_FREE) c1 += al * (sd.w - c1);
+                    if (blocked && (akey >> 3) == k) {
+                        const int hit = akey & 3;
+                        if ((akey >> 2) & 1) { c1 = (hit == ST_UPPER) ? bnd.w : bnd.z; st1 = hit; }
+                        else { c0 = (hit == ST_UPPER) ? bnd.y : bnd.x; st0 = hit; }
+                    }
+                    if (release && (vkey >> 3) == k) {
+                        if ((vkey >> 2) & 1) st1 = ST_FREE; else st0 = ST_FREE;
+                    }
+                    rec[S_SB * 4 + 3] = c0; rec[S_DX * 4 + 3] = c1;
+                    *reinterpret_cast<float2*>(rec + S_STDU * 4) = make_float2(__int_as_float(st0), __int_as_float(st1));
+                }
+            }
+            if (!blocked && !release) todo = 0;     // optimal
+            else if (it >= max_it) todo = 2;        // cap reached
+        }
+        const int more = __syncthreads_or(todo == 1 ? 1 : 0);
+        if (!more) break;
+    }
+    return it | (pd_fail ? (1 << 29) : 0) | (todo == 2 ? (1 << 30) : 0);
+}
+
 // one wavefront per workgroup, G = 64 / L problems per wavefront
 template <int L, bool STAMP>
 __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
@@ -839,10 +969,24 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             }
             if (STAMP) t_f += __builtin_amdgcn_s_memtime() - tf0;
             // wavefront-uniform continuation: any problem of this wavefront still changing?
-            const int more = __syncthreads_or((changed && it < p.max_as_iter) ? 1 : 0);
+            const int more = __syncthreads_or((changed && it < min(p.max_as_iter, AS_SWITCH)) ? 1 : 0);
             if (!more) break;
         }
         n_iter = (n_iter == 0) ? 1 : (changed ? n_iter : n_iter + 1); // + the confirming sweep
+        // not settled after AS_SWITCH sweeps (the primal-dual iteration can cycle): finish with the primal
+        // active-set method, one change of the working set per sweep
+        {
+            const bool rescue = changed && it >= AS_SWITCH && it < p.max_as_iter;
+            if (__builtin_expect(__any(rescue) ? 1 : 0, 0)) { // cold: register allocation should not pay for it
+                const int r = active_set_rescue<L>(row, N, j, rescue, Dx0, Dx1, Dx2, p.max_as_iter, it);
+                if (rescue) {
+                    changed = (r >> 30) & 1;
+                    pd_fail |= (r >> 29) & 1;
+                    it = r & 0xffffff;
+                    n_iter = it;
+                }
+            }
+        }
         status = infeasible ? RET_INIT_FAILED_INFEASIBILITY
                             : (pd_fail ? RET_INIT_FAILED_CHOLESKY : (changed ? RET_MAX_NWSR_REACHED : RET_OK));
         if (STAMP && sqp == 0) { t_stamp[2] = t_b; t_stamp[3] = t_f; t_stamp[4] = __builtin_amdgcn_s_memtime(); }

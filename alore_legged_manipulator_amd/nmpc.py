@@ -43,7 +43,7 @@ class BatchedNmpc:
     one slot per timed step so that every step reads its inputs from HBM and
     starts from the same iterate."""
 
-    def __init__(self, B: int, N: int = 20, dt: float = 0.01, device: int = 0, max_as_iter: int = 64,
+    def __init__(self, B: int, N: int = 20, dt: float = 0.01, device: int = 0, max_as_iter: int = 0,
                  lanes_per_problem: int = 0, slots: int = 1, warm_start_steps: int = -1):
         import torch  # device memory + streams
         self.torch = torch

@@ -84,6 +84,39 @@ def make_batch(B: int, N: int, seed: int = SEED, dt: float = DT, fast_tail: floa
     }
 
 
+def make_wide_batch(B: int, N: int, seed: int, dt: float = DT) -> dict:
+    """Stress distribution (not the benchmark's): far-off initial poses, references beyond the wheel-speed bounds,
+    random ICR geometry, log-uniform weights (a third of the problems with full symmetric positive definite
+    blocks), random bounds.  Exercises long working-set iterations and the active-set safeguard."""
+    r = np.random.default_rng(seed)
+    xv = r.uniform(0.0, 0.4, B); half = r.uniform(0.15, 0.5, B); skew = r.uniform(-0.05, 0.05, B)
+    od1 = np.stack([xv, -half + skew, half + skew], -1)
+    v = r.uniform(-1.0, 4.5, B); w = r.uniform(-3.0, 3.0, B)
+    t = (np.arange(N + 1) + 1.0) * dt
+    pose = arc_pose(v[:, None], w[:, None], od1[:, None, 0], t[None, :])
+    vr = v - w * od1[:, 1]; vl = v - w * od1[:, 2]
+    y = np.concatenate([pose[:, :N, :], np.broadcast_to(np.stack([vr, vl], -1)[:, None, :], (B, N, 2))], -1)
+    x0 = np.stack([r.uniform(-2, 2, B), r.uniform(-2, 2, B), r.uniform(-3, 3, B)], -1)
+    qd = 10.0 ** r.uniform(-1, 2, (B, 3)); rd = 10.0 ** r.uniform(-2, 1, (B, 2))
+    W = np.zeros((B, N, 5, 5)); WN = np.zeros((B, 3, 3))
+    for i in range(3): W[:, :, i, i] = qd[:, None, i]; WN[:, i, i] = qd[:, i] * r.uniform(0.5, 5, B)
+    for i in range(2): W[:, :, 3 + i, 3 + i] = rd[:, None, i]
+    # a third of the problems: full symmetric positive definite weights
+    full = r.random(B) < 0.33
+    for b in np.nonzero(full)[0]:
+        A = r.normal(size=(5, 5)) * 0.3
+        M = A @ A.T + np.diag(np.concatenate([qd[b], rd[b]]))
+        M[:3, 3:] = 0.0; M[3:, :3] = 0.0            # the generated code ignores state-control cross terms of the Hessian
+        W[b, :] = M
+        A3 = r.normal(size=(3, 3)); WN[b] = A3 @ A3.T + np.diag(qd[b])
+    ub = r.uniform(0.5, 5.0, (B, 1, 2)) * np.ones((B, N, 2)); lb = -r.uniform(0.5, 5.0, (B, 1, 2)) * np.ones((B, N, 2))
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    return {"x": f32(np.broadcast_to(x0[:, None, :], (B, N + 1, 3))), "u": np.zeros((B, N, 2), np.float32),
+            "od": f32(np.broadcast_to(od1[:, None, :], (B, N + 1, 3))), "y": f32(y), "yN": f32(pose[:, N, :]),
+            "W": f32(W), "WN": f32(WN), "x0": f32(x0), "lbValues": f32(lb), "ubValues": f32(ub),
+            "dual": np.zeros((B, N, 2), np.float32)}
+
+
 def problem(batch: dict, b: int) -> dict:
     """Problem b of a batch as flat reference-layout arrays."""
     return {k: np.ascontiguousarray(v[b]).reshape(-1) for k, v in batch.items()}

@@ -56,7 +56,8 @@ typedef struct {
     int N;           /* horizon (shooting intervals); reference: ACADO_N = 50, acado_common.h:65 */
     float dt;        /* interval length [s]; reference bakes 0.01 into the tableau, acado_integrator.c:255-257 */
     int device;      /* HIP device ordinal */
-    int max_as_iter; /* cap on working-set iterations per QP (<=0: default 64); the
+    int max_as_iter; /* cap on working-set sweeps per QP (<=0: default 128; after 16 primal-dual sweeps the
+                        solver continues as a primal active-set method, one change per sweep); the
                         reference caps working-set changes at 300, acado_qpoases_interface.hpp:44 */
     int lanes_per_problem; /* 0 = choose from the batch size; else 4, 8, 16, 32 or 64 */
     int warm_start_steps;  /* projected-gradient steps used to predict the working set of a QP whose

@@ -85,6 +85,8 @@ int core_rti(int N, float dt, float* x, float* u, const float* od, const float* 
     // ---- phase B
     bool pd_fail = false, changed = true;
     int it = 0, n_iter = 0, khi = N - 1;
+    bool asm_mode = false;                  // primal active-set safeguard (nmpc_core.h)
+    std::vector<float> cur0(N), cur1(N);    // its feasible point
     for (;;) {
         Value V = Vs[khi + 1];
         bool ok = true;
@@ -103,7 +105,7 @@ int core_rti(int N, float dt, float* x, float* u, const float* od, const float* 
             StageQP& s = st[k];
             StageStep o;
             forward_step(pol[k], s.st0, s.st1, dx0, dx1, dx2, lb0[k], ub0[k], lb1[k], ub1[k], o);
-            if (o.nst0 != s.st0 || o.nst1 != s.st1) new_khi = k;
+            if (!asm_mode && (o.nst0 != s.st0 || o.nst1 != s.st1)) new_khi = k;
             dxs[k * 3] = dx0; dxs[k * 3 + 1] = dx1; dxs[k * 3 + 2] = dx2;
             if (first) { sbs[k * 3] = sb0; sbs[k * 3 + 1] = sb1; sbs[k * 3 + 2] = sb2; }
             const float n0 = dx0 + s.a * dx2 + s.B00 * o.du0 + s.B01 * o.du1 + s.d0;
@@ -115,13 +117,63 @@ int core_rti(int N, float dt, float* x, float* u, const float* od, const float* 
                 sb0 = m0; sb1 = m1; sb2 = m2;
             }
             du0[k] = o.du0; du1[k] = o.du1; mu0[k] = o.mu0; mu1[k] = o.mu1;
-            s.st0 = o.nst0; s.st1 = o.nst1;
+            if (!asm_mode) { s.st0 = o.nst0; s.st1 = o.nst1; }
         }
         dxs[N * 3] = dx0; dxs[N * 3 + 1] = dx1; dxs[N * 3 + 2] = dx2;
         if (first) { sbs[N * 3] = sb0; sbs[N * 3 + 1] = sb1; sbs[N * 3 + 2] = sb2; }
         ++it;
+        if (asm_mode) {
+            // ratio test over the free controls, worst multiplier over the fixed ones
+            float alpha = AS_NONE, viol = 0.0f;
+            int ja = -1, jv = -1, hit = ST_FREE;
+            for (int k = 0; k < N; ++k) {
+                int h;
+                const float r0 = asm_ratio(st[k].st0, cur0[k], du0[k], lb0[k], ub0[k], h);
+                if (r0 < alpha) { alpha = r0; ja = 2 * k; hit = h; }
+                const float r1 = asm_ratio(st[k].st1, cur1[k], du1[k], lb1[k], ub1[k], h);
+                if (r1 < alpha) { alpha = r1; ja = 2 * k + 1; hit = h; }
+                const float v0 = asm_violation(st[k].st0, mu0[k], lb0[k], ub0[k]);
+                if (v0 > viol) { viol = v0; jv = 2 * k; }
+                const float v1 = asm_violation(st[k].st1, mu1[k], lb1[k], ub1[k]);
+                if (v1 > viol) { viol = v1; jv = 2 * k + 1; }
+            }
+            if (ja >= 0) { // blocked: move up to the bound, fix that control
+                const float al = alpha < 0.0f ? 0.0f : alpha;
+                for (int k = 0; k < N; ++k) {
+                    if (st[k].st0 == ST_FREE) cur0[k] += al * (du0[k] - cur0[k]);
+                    if (st[k].st1 == ST_FREE) cur1[k] += al * (du1[k] - cur1[k]);
+                }
+                const int k = ja >> 1;
+                if (ja & 1) { cur1[k] = (hit == ST_UPPER) ? ub1[k] : lb1[k]; st[k].st1 = hit; }
+                else { cur0[k] = (hit == ST_UPPER) ? ub0[k] : lb0[k]; st[k].st0 = hit; }
+                new_khi = k;
+            } else {
+                for (int k = 0; k < N; ++k) {
+                    if (st[k].st0 == ST_FREE) cur0[k] = du0[k];
+                    if (st[k].st1 == ST_FREE) cur1[k] = du1[k];
+                }
+                if (jv >= 0) { // full step, a multiplier has the wrong sign: release it
+                    const int k = jv >> 1;
+                    if (jv & 1) st[k].st1 = ST_FREE; else st[k].st0 = ST_FREE;
+                    new_khi = k;
+                } else {
+                    new_khi = -1; // optimal
+                }
+            }
+        }
         changed = new_khi >= 0;
         khi = new_khi;
+        if (!asm_mode && changed && it >= AS_SWITCH) {
+            // the primal-dual iteration is not settling: continue from the clipped iterate as a primal method
+            asm_mode = true;
+            for (int k = 0; k < N; ++k) {
+                cur0[k] = (lb0[k] <= ub0[k]) ? clampf(du0[k], lb0[k], ub0[k]) : du0[k];
+                cur1[k] = (lb1[k] <= ub1[k]) ? clampf(du1[k], lb1[k], ub1[k]) : du1[k];
+                st[k].st0 = (ub0[k] - lb0[k] > BOUNDTOL) ? asm_status_of(cur0[k], lb0[k], ub0[k]) : ST_LOWER;
+                st[k].st1 = (ub1[k] - lb1[k] > BOUNDTOL) ? asm_status_of(cur1[k], lb1[k], ub1[k]) : ST_LOWER;
+            }
+            khi = N - 1;
+        }
         if (changed) n_iter = it;
         if (!(changed && it < max_as_iter)) break;
     }

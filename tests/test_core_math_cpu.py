@@ -116,3 +116,27 @@ def test_core_against_golden_n50(harness, golden_dir):
             assert relerr(r["dx"], G[f"s{s}_dx"][it]) < 1e-4, (s, it)
             # continue from the reference's iterate
             p = dict(p, x=G[f"s{s}_x"][it].copy(), u=G[f"s{s}_u"][it].copy(), dual=G[f"s{s}_dual"][it].copy())
+
+
+def test_working_set_safeguard_resolves_cycling(harness):
+    """The primal-dual working-set update can cycle (period 4 on these problems: far-off poses, references beyond
+    the bounds, warm start from stale duals).  After AS_SWITCH sweeps the solver continues as a primal active-set
+    method (nmpc_core.h) and must reach the reference's solution."""
+    from alore_legged_manipulator_amd.scenarios import make_wide_batch
+    N = 20
+    batch = make_wide_batch(6000, N, 99)
+    orc = Oracle(N)
+    seen_safeguard = 0
+    for b, bad_tick in ((2734, 1), (3996, 1), (95, 2)):
+        cur = dict(problem(batch, b))
+        for k in range(bad_tick + 1):
+            orc.reset(); orc.initialize_solver(); orc.load(cur); orc.preparation_step()
+            assert orc.feedback_step() == 0
+            r = run_core_tick(harness, N, cur, max_iter=128)
+            assert r["status"] == 0, (b, k, r["n_iter"])
+            assert relerr(r["u"], orc.v["u"]) < 1e-4 and relerr(r["x"], orc.v["x"]) < 1e-4, (b, k)
+            if k == bad_tick:
+                assert r["n_iter"] > 16                      # the primal-dual phase alone did not settle
+                seen_safeguard += 1
+            cur = dict(cur); cur["x"] = orc.v["x"].copy(); cur["u"] = orc.v["u"].copy(); cur["dual"] = orc.v["dual"].copy()
+    assert seen_safeguard == 3

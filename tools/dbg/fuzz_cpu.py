@@ -1,0 +1,34 @@
+"""CPU fuzz of the working-set logic (nmpc_core.h through tests/harness/cpu_core_harness.cpp) against the oracle
+on wide random problems, K consecutive ticks each (ticks >= 1 start from stale duals)."""
+import sys, os, subprocess, ctypes as C, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from alore_legged_manipulator_amd.scenarios import make_wide_batch
+ns = {'wide_batch': make_wide_batch}
+from alore_legged_manipulator_amd.scenarios import problem
+from oracle.drivers import Oracle
+import test_core_math_cpu as T
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", T.SO, T.SRC])
+L = C.CDLL(T.SO)
+L.core_rti.argtypes = [C.c_int, C.c_float] + [T.FP] * 11 + [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), T.FP, T.FP]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 99
+batch = ns["wide_batch"](B, N, seed)
+orc = Oracle(N)
+bad = 0; worst = 0.0; iters = []
+for b in range(B):
+    cur = dict(problem(batch, b))
+    for k in range(K):
+        orc.reset(); orc.initialize_solver(); orc.load(cur); orc.preparation_step(); st = orc.feedback_step()
+        r = T.run_core_tick(L, N, cur, max_iter=128)
+        iters.append(r["n_iter"])
+        e = float(np.max(np.abs(r["u"] - orc.v["u"])) / max(1.0, np.max(np.abs(orc.v["u"]))))
+        if st != r["status"] or (st == 0 and e > 1e-4):
+            bad += 1
+            if bad <= 20: print(f"problem {b} tick {k}: oracle {st} core {r['status']} relerr {e:.2e} n_iter {r['n_iter']}")
+        elif st == 0: worst = max(worst, e)
+        cur = dict(cur); cur["x"] = orc.v["x"].copy(); cur["u"] = orc.v["u"].copy(); cur["dual"] = orc.v["dual"].copy()
+it = np.array(iters)
+print(f"{B} problems x {K} ticks (N={N}, seed {seed}): disagreements {bad}; worst agreeing rel err {worst:.2e}; n_iter mean {it.mean():.2f} max {it.max()}; >16: {(it > 16).sum()}")
