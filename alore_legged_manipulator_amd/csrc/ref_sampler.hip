@@ -42,6 +42,7 @@ __global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
     // TrajAnal::getPstate
     int index = (int)floor(tq / res);
     if (index > nc - 1) index = nc - 1;
+    if (index < 0) index = 0; // now before start_time: the reference indexes out of bounds here; extrapolate from node 0
     const double floor_t = index * res, diff_t = tq - floor_t;
     double p1[2], p2[2], p3[2], v1[2], v2[2], v3[2];
     eval_pv(dur, coef, np, floor_t, p1, v1);
