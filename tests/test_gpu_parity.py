@@ -326,3 +326,29 @@ def test_wide_problems_three_ticks_against_oracle(nmpc_mod):
         long_runs += int((out["n_iter"] > 16).sum())
         prev = out
     assert long_runs >= 3        # the safeguard ran
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,L", [(1, 20, 0), (5, 20, 0), (33, 20, 8), (5, 7, 0), (3, 50, 0), (7, 50, 16), (2, 1, 0)])
+def test_no_out_of_bounds_writes(nmpc_mod, B, N, L):
+    """Ragged batches (padding lane groups shadow the last problem) must not write outside their members: the
+    members of slot 1 sit between those of slots 0 and 2 in memory, which hold a canary pattern."""
+    import torch
+    eng = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=L, slots=3)
+    batch = make_batch(B, N, seed=5, fast_tail=0.5)
+    eng.load(batch, slot=1)
+    for k, t in eng.ts.items():
+        for s in (0, 2):
+            t[s].fill_(777 if t.dtype == torch.int32 else 12345.0)
+    eng.rti(1, slot=1)
+    eng.rti(2, slot=1)
+    if N >= 7:
+        eng.refs_init(max_pieces=4, max_checkpoints=32)
+        eng.refs_sample(0.1, np.zeros((B, 3)), np.tile([0.1, -0.3, 0.3], (B, 1)), slot=1)   # empty store: must leave slot 1 alone too
+    torch.cuda.synchronize()
+    for k, t in eng.ts.items():
+        want = 777 if t.dtype == torch.int32 else 12345.0
+        for s in (0, 2):
+            assert bool((t[s] == want).all()), (k, s)
+    out = eng.fetch(slot=1)
+    assert (out["status"] == 0).all() and np.isfinite(out["x"]).all()
