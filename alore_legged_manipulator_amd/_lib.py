@@ -50,6 +50,12 @@ class PolynomeMsg(C.Structure):
                 ("start_position", C.c_double * 3), ("ICR", C.c_double * 3), ("traj_start_time", C.c_double)]
 
 
+class PlantParams(C.Structure):
+    """alore_plant_params (include/alore_nmpc.h): the reference's simulator node constants"""
+    _fields_ = [("max_acc", C.c_double), ("max_domega", C.c_double), ("pose_pub_period", C.c_double),
+                ("state_propa_period", C.c_double), ("substeps", C.c_int)]
+
+
 class LaunchInfo(C.Structure):
     _fields_ = [("lanes_per_problem", C.c_int), ("problems_per_block", C.c_int), ("threads_per_block", C.c_int),
                 ("grid", C.c_int), ("lds_bytes_per_block", C.c_int), ("last_kernel_ms", C.c_float)]
@@ -75,6 +81,10 @@ SYMBOLS = (
                                                  C.c_double, C.c_double, C.c_double, C.c_void_p]),
     ("alore_nmpc_refs_set_polynomes", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     ("alore_nmpc_refs_download", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_plant_init", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_plant_set_state", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_plant_get_state", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_closed_loop_tick", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_double, C.c_int, C.c_void_p]),
     ("alore_nmpc_refs_sample", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p]),
     ("alore_nmpc_set_linearization_point", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

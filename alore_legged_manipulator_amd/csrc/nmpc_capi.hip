@@ -30,6 +30,10 @@ struct alore_nmpc_solver {
     double* d_icr = nullptr;  // [B][3]
     double* d_psi = nullptr;  // [B][N+1]
     int* d_goal = nullptr;    // [B]
+    // closed loop on the device (alore_nmpc_plant_*, alore_nmpc_closed_loop_tick): pose = d_est, ICR = d_icr
+    double* d_vw = nullptr;   // [B][2] current (v, omega) of the plant
+    nmpc::PlantParams plant{};
+    bool has_plant = false;
     // Polynome -> store on the device: staging + workspace for chunks of kPolyChunk messages
     static constexpr int kPolyChunk = 256;
     char* d_poly = nullptr;       // packed message arrays (layout: poly_layout)
@@ -188,6 +192,7 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->d_icr) (void)hipFree(h->d_icr);
     if (h->d_psi) (void)hipFree(h->d_psi);
     if (h->d_goal) (void)hipFree(h->d_goal);
+    if (h->d_vw) (void)hipFree(h->d_vw);
     if (h->d_poly) (void)hipFree(h->d_poly);
     if (h->d_band) (void)hipFree(h->d_band);
     if (h->d_rhs) (void)hipFree(h->d_rhs);
@@ -534,6 +539,58 @@ int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch* dev, int
         HIP_TRY(h, hipMemcpyAsync(at_goal, h->d_goal, sizeof(int) * B, hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
     }
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_plant_init(alore_nmpc_handle h, const alore_plant_params* p)
+{
+    if (!h || !h->refs.dur || !p || p->substeps < 1 || !(p->state_propa_period > 0.0) || !(p->pose_pub_period > 0.0))
+        return fail(h, ALORE_NMPC_E_INVALID, "plant_init: needs refs_init first and positive periods");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->d_vw) HIP_TRY(h, hipMalloc((void**)&h->d_vw, sizeof(double) * h->refs_B * 2));
+    HIP_TRY(h, hipMemset(h->d_vw, 0, sizeof(double) * h->refs_B * 2));
+    h->plant.max_a = p->max_acc; h->plant.max_domega = p->max_domega;
+    h->plant.pose_pub_period = p->pose_pub_period; h->plant.propa_period = p->state_propa_period;
+    h->plant.substeps = p->substeps;
+    h->has_plant = true;
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_plant_set_state(alore_nmpc_handle h, int B, const double* pose, const double* vw, const double* icr, void* stream)
+{
+    if (!h || !h->has_plant || B <= 0 || B > h->refs_B || !pose || !icr)
+        return fail(h, ALORE_NMPC_E_INVALID, "plant_set_state: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_est, pose, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_icr, icr, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
+    if (vw) HIP_TRY(h, hipMemcpyAsync(h->d_vw, vw, sizeof(double) * B * 2, hipMemcpyHostToDevice, s));
+    else HIP_TRY(h, hipMemsetAsync(h->d_vw, 0, sizeof(double) * B * 2, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_plant_get_state(alore_nmpc_handle h, int B, double* pose, double* vw, int* at_goal, void* stream)
+{
+    if (!h || !h->has_plant || B <= 0 || B > h->refs_B) return fail(h, ALORE_NMPC_E_INVALID, "plant_get_state: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (pose) HIP_TRY(h, hipMemcpyAsync(pose, h->d_est, sizeof(double) * B * 3, hipMemcpyDeviceToHost, s));
+    if (vw) HIP_TRY(h, hipMemcpyAsync(vw, h->d_vw, sizeof(double) * B * 2, hipMemcpyDeviceToHost, s));
+    if (at_goal) HIP_TRY(h, hipMemcpyAsync(at_goal, h->d_goal, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_closed_loop_tick(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, double now, int delay_num, void* stream)
+{
+    if (!h || !h->has_plant || !dev || B <= 0 || B > h->refs_B || delay_num < 0)
+        return fail(h, ALORE_NMPC_E_INVALID, "closed_loop_tick: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = h->cfg.N;
+    // CmdCallback: references from the measured pose, one real-time iteration, command = input column delay_num
+    HIP_TRY(h, nmpc::launch_ref_sample(h->refs, *dev, B, N, (double)h->cfg.dt, now, h->d_est, h->d_icr, h->d_goal, h->d_psi, 1, s));
+    const int rc = alore_nmpc_rti(h, dev, B, 1, stream);
+    if (rc != ALORE_NMPC_OK) return rc;
+    HIP_TRY(h, nmpc::launch_plant(*dev, B, N, delay_num < N ? delay_num : N - 1, h->d_icr, h->d_goal, h->d_est, h->d_vw, h->plant, s));
     return ALORE_NMPC_OK;
 }
 

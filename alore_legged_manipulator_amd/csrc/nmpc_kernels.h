@@ -67,6 +67,12 @@ struct PolyBatch {
 };
 hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, double res, int res_int, double* band_ws,
                              double* rhs_ws, int* n_panels, double* inc, int* overflow, hipStream_t st);
+struct PlantParams { // simulator.h: max_a_, max_domega_, Pose_pub_rate_ (a period), State_Propa_rate_ (a period)
+    double max_a, max_domega, pose_pub_period, propa_period;
+    int substeps; // StatePropaCallback calls per control tick
+};
+hipError_t launch_plant(const alore_nmpc_batch& b, int B, int N, int node, const double* icr, const int* at_goal,
+                        double* pose, double* vw, const PlantParams& p, hipStream_t st);
 hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now,
                              const double* est, const double* icr, int* at_goal, double* psi_scratch, int do_smooth,
                              hipStream_t st);

@@ -196,6 +196,47 @@ hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, d
     return hipGetLastError();
 }
 
+// ---- kinematic plant of the reference's simulator node, B robots (P/utils/simulator/include/simulator/
+//      simulator.h:234-275): ControlSubCallback turns the wheel-speed command into (v, vy, omega) through the
+//      ICR parameters, StatePropaCallback follows it with bounded acceleration and integrates the pose by
+//      explicit Euler steps.  The command is input column `node` of the solver's prediction, or zero once
+//      the robot is at its goal (mpc.cpp:186-194).  Deterministic: the simulator's optional Gaussian noise
+//      on v and omega (simulator.h:222-229) is not drawn.
+__global__ void plant_kernel(alore_nmpc_batch b, int B, int N, int node, const double* icr, const int* at_goal,
+                             double* pose, double* vw, PlantParams p)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    double right = (double)b.u[((size_t)r * N + node) * 2], left = (double)b.u[((size_t)r * N + node) * 2 + 1];
+    if (at_goal && at_goal[r]) { right = 0.0; left = 0.0; }
+    const double xv = icr[(size_t)r * 3], yr = icr[(size_t)r * 3 + 1], yl = icr[(size_t)r * 3 + 2];
+    const double desired_v = (left + right) / 2.0 - (right - left) / (yl - yr) * (yl + yr) / 2.0;
+    const double vy = -(right - left) / (yl - yr) * xv;
+    const double desired_w = (right - left) / (yl - yr);
+    double x = pose[(size_t)r * 3], y = pose[(size_t)r * 3 + 1], th = pose[(size_t)r * 3 + 2];
+    double v = vw[(size_t)r * 2], w = vw[(size_t)r * 2 + 1];
+    for (int s = 0; s < p.substeps; ++s) {
+        if (fabs(v - desired_v) >= p.pose_pub_period * p.max_a) v += p.pose_pub_period * p.max_a * (desired_v - v) / fabs(desired_v - v);
+        else v = desired_v;
+        if (fabs(w - desired_w) >= p.pose_pub_period * p.max_domega) w += p.pose_pub_period * p.max_domega * (desired_w - w) / fabs(desired_w - w);
+        else w = desired_w;
+        x += v * p.propa_period * cos(th);
+        y += v * p.propa_period * sin(th);
+        th += w * p.propa_period;
+        x -= vy * p.propa_period * sin(th);
+        y += vy * p.propa_period * cos(th);
+    }
+    pose[(size_t)r * 3] = x; pose[(size_t)r * 3 + 1] = y; pose[(size_t)r * 3 + 2] = th;
+    vw[(size_t)r * 2] = v; vw[(size_t)r * 2 + 1] = w;
+}
+
+hipError_t launch_plant(const alore_nmpc_batch& b, int B, int N, int node, const double* icr, const int* at_goal,
+                        double* pose, double* vw, const PlantParams& p, hipStream_t st)
+{
+    hipLaunchKernelGGL(plant_kernel, dim3((B + 127) / 128), dim3(128), 0, st, b, B, N, node, icr, at_goal, pose, vw, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now,
                              const double* est, const double* icr, int* at_goal, double* psi_scratch, int do_smooth,
                              hipStream_t st)

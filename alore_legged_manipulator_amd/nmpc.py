@@ -182,6 +182,32 @@ class BatchedNmpc:
                                                     icr.ctypes.data, 1 if smooth else 0, goal.ctypes.data, self._stream()))
         return goal.astype(bool)
 
+    # -- closed loop on the device (include/alore_nmpc.h: alore_nmpc_plant_*, alore_nmpc_closed_loop_tick)
+    def plant_init(self, max_acc: float = 2.0, max_domega: float = 4.0, pose_pub_rate: float = 100.0,
+                   state_propa_rate: float = 500.0, substeps: int = 5) -> None:
+        p = _lib.PlantParams(max_acc, max_domega, 1.0 / pose_pub_rate, 1.0 / state_propa_rate, substeps)
+        self._check(self.lib.alore_nmpc_plant_init(self.h, C.byref(p)))
+
+    def plant_set_state(self, pose, icr, vw=None) -> None:
+        pose = np.ascontiguousarray(pose, np.float64).reshape(self.B, 3)
+        icr = np.ascontiguousarray(icr, np.float64).reshape(self.B, 3)
+        vwp = None
+        if vw is not None:
+            vw = np.ascontiguousarray(vw, np.float64).reshape(self.B, 2)
+            vwp = vw.ctypes.data
+        self._check(self.lib.alore_nmpc_plant_set_state(self.h, self.B, pose.ctypes.data, vwp, icr.ctypes.data, self._stream()))
+
+    def plant_get_state(self):
+        pose = np.zeros((self.B, 3)); vw = np.zeros((self.B, 2)); goal = np.zeros(self.B, np.int32)
+        self._check(self.lib.alore_nmpc_plant_get_state(self.h, self.B, pose.ctypes.data, vw.ctypes.data, goal.ctypes.data,
+                                                        self._stream()))
+        return pose, vw, goal.astype(bool)
+
+    def closed_loop_tick(self, now: float, delay_num: int = 1, slot: int = 0) -> None:
+        """References from the plant's pose -> one real-time iteration -> command to the plant; no host sync."""
+        self._check(self.lib.alore_nmpc_closed_loop_tick(self.h, C.byref(self._batches[slot]), self.B, float(now),
+                                                         int(delay_num), self._stream()))
+
     def set_timing(self, enable: bool) -> None:
         self._check(self.lib.alore_nmpc_set_timing(self.h, 1 if enable else 0))
 

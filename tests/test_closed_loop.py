@@ -82,3 +82,75 @@ def test_closed_loop_matches_oracle_loop_and_contracts():
     # the loop the reference's weights give is slow (0.2 s horizon, heading weight 0.5): bounded, and
     # contracting on average, is what it delivers (the oracle loop behaves identically, see `gap`)
     assert last.max() < 0.3 and np.median(last) < np.median(first), (first, last)
+
+
+def plant_numpy(pose, vw, cmd, icr, max_a=2.0, max_dw=4.0, ppr=0.01, spr=0.002, substeps=5):
+    """simulator.h:234-275 in float64 (ControlSubCallback + `substeps` StatePropaCallbacks), one robot."""
+    right, left = float(cmd[0]), float(cmd[1])
+    xv, yr, yl = icr
+    dv = (left + right) / 2.0 - (right - left) / (yl - yr) * (yl + yr) / 2.0
+    vy = -(right - left) / (yl - yr) * xv
+    dw = (right - left) / (yl - yr)
+    x, y, th = pose
+    v, w = vw
+    for _ in range(substeps):
+        if abs(v - dv) >= ppr * max_a: v += ppr * max_a * (dv - v) / abs(dv - v)
+        else: v = dv
+        if abs(w - dw) >= ppr * max_dw: w += ppr * max_dw * (dw - w) / abs(dw - w)
+        else: w = dw
+        x += v * spr * math.cos(th); y += v * spr * math.sin(th); th += w * spr
+        x -= vy * spr * math.sin(th); y += vy * spr * math.cos(th)
+    return np.array([x, y, th]), np.array([v, w])
+
+
+@pytest.mark.gpu
+def test_device_closed_loop_matches_host_driven_loop():
+    """alore_nmpc_closed_loop_tick (sampling, solve and plant chained on the device, no host in the loop) against
+    the same loop driven from the host with the plant in numpy; the robots must also track their trajectories."""
+    import math as _m
+    from alore_legged_manipulator_amd.nmpc import BatchedNmpc
+    from alore_legged_manipulator_amd.host import Polynome
+    B, N, dt, T = 12, 20, 0.01, 120
+    rng = np.random.default_rng(4)
+    msgs, icr = [], []
+    for b in range(B):
+        v, w = rng.uniform(0.4, 1.2), rng.uniform(-0.8, 0.8)
+        Tp = np.array([0.5, 0.5, 0.5]); Tc = np.cumsum(Tp)
+        msgs.append(Polynome(np.stack([w * Tc[:-1], v * Tc[:-1]], 1), Tp, [0, 0, w, v, 0, 0], [w * Tc[-1], v * Tc[-1], w, v, 0, 0],
+                             [0, 0, 0], [-0.3, 0.3, 0.1], 0.0))
+        icr.append([0.1, -0.3, 0.3])
+    icr = np.array(icr)
+    pose0 = np.stack([rng.uniform(-0.05, 0.05, B), rng.uniform(-0.05, 0.05, B), rng.uniform(-0.1, 0.1, B)], 1)
+    W = np.tile(np.diag([10, 10, 0.5, 0.1, 0.1]).astype(np.float32), (B, N, 1, 1))
+    WN = np.tile(np.diag([10, 10, 0.5]).astype(np.float32), (B, 1, 1))
+
+    def fresh():
+        e = BatchedNmpc(B, N, dt)
+        e.load({"W": W, "WN": WN, "x": np.tile(pose0[:, None, :], (1, N + 1, 1)), "u": np.zeros((B, N, 2))})
+        e.refs_init(max_pieces=4, max_checkpoints=32)
+        e.refs_set_polynomes(np.arange(B), msgs)
+        return e
+
+    dev = fresh()
+    dev.plant_init()
+    dev.plant_set_state(pose0, icr)
+    for t in range(T):
+        dev.closed_loop_tick(0.01 * (t + 1), delay_num=1)
+    pose_d, vw_d, goal_d = dev.plant_get_state()
+
+    host = fresh()
+    pose, vw = pose0.copy(), np.zeros((B, 2))
+    for t in range(T):
+        goal = host.refs_sample(0.01 * (t + 1), pose, icr)
+        host.rti(1)
+        u = host.fetch(names=("u",))["u"]
+        for b in range(B):
+            cmd = (0.0, 0.0) if goal[b] else u[b, 1]
+            pose[b], vw[b] = plant_numpy(pose[b], vw[b], cmd, icr[b])
+    assert np.max(np.abs(pose_d - pose)) < 1e-6 and np.max(np.abs(vw_d - vw)) < 1e-6
+    # tracking: after 1.2 s (the robots start at rest, acceleration is bounded) every robot is near its reference arc
+    for b in range(B):
+        m = msgs[b]
+        v, w = m.init_pva[3], m.init_pva[2]
+        ref = arc_pose(v, w, 0.1, 0.01 * T)
+        assert _m.hypot(pose_d[b, 0] - ref[0], pose_d[b, 1] - ref[1]) < 0.15 and abs(pose_d[b, 2] - ref[2]) < 0.3, (b, pose_d[b], ref)
