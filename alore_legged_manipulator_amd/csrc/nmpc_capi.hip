@@ -145,7 +145,7 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     if (!h) return ALORE_NMPC_E_NOMEM;
     h->cfg = *cfg;
     if (h->cfg.max_as_iter <= 0) h->cfg.max_as_iter = 128;
-    if (h->cfg.warm_start_steps < 0) h->cfg.warm_start_steps = (h->cfg.N > 32) ? 12 : 8; // swept on MI355X (tools/dbg/pg_sweep.sh, n50_pg.sh)
+    if (h->cfg.warm_start_steps < 0) h->cfg.warm_start_steps = 6; // swept on MI355X at N = 20 and 50 (tools/dbg/bb.sh, bb2.sh)
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)prop.sharedMemPerBlock : 64 * 1024;
     if (prop.maxSharedMemoryPerMultiProcessor > (size_t)h->lds_limit)

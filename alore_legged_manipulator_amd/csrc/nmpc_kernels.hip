@@ -727,8 +727,8 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
 
         // ---- working-set prediction for cold starts (no dual information, every control free): if the
         //      clipped Jacobi step of the condensed QP hits a bound, a few projected-gradient steps
-        //      (Hessian applied stage-wise by prefix / suffix sums over the lanes, step length from a
-        //      short power iteration) predict which bounds are active, and that set is what the first
+        //      (Hessian applied stage-wise by prefix / suffix sums over the lanes, Barzilai-Borwein step
+        //      lengths) predict which bounds are active, and that set is what the first
         //      Riccati sweep starts from.  Only a guess: the sweeps below still iterate until the
         //      working set reproduces itself, so the solution is the same with or without it.
         long long t_pg = 0;
@@ -780,28 +780,21 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             const int badw = in ? ((!(R00 > 0.0f)) | (!(R11 > 0.0f))) : 0;
             const bool run = cold && (group_or<L>(hits | (badw << 1)) == 1);
             if (__any(run)) {
-                // largest eigenvalue of R^-1/2 H R^-1/2 by a short power iteration
-                const float s0 = in ? __builtin_amdgcn_rsqf(fmaxf(R00, 1e-20f)) : 0.0f,
-                            s1 = in ? __builtin_amdgcn_rsqf(fmaxf(R11, 1e-20f)) : 0.0f;
-                float v0 = msk, v1 = msk, lam = 1.0f;
-#pragma unroll 1
-                for (int t = 0; t < 2; ++t) {
-                    float h0, h1;
-                    apply(s0 * v0, s1 * v1, std::false_type{}, h0, h1);
-                    const float w0 = s0 * h0, w1 = s1 * h1;
-                    const float nn = group_total<L>(w0 * w0 + w1 * w1, j), nv = group_total<L>(v0 * v0 + v1 * v1, j);
-                    const float rn = __builtin_amdgcn_rsqf(fmaxf(nn, 1e-30f));
-                    lam = nn * rn * __builtin_amdgcn_rsqf(fmaxf(nv, 1e-30f));
-                    v0 = w0 * rn; v1 = w1 * rn;
-                }
-                const float alpha = __builtin_amdgcn_rcpf(1.15f * fmaxf(lam, 1.0f));
-                const float a0 = alpha * is0, a1 = alpha * is1;
-                float u0 = clampf(-a0 * g0, lb0, ub0), u1 = clampf(-a1 * g1, lb1, ub1); // first step from 0
+                // projected Barzilai-Borwein iteration in the R-scaled metric: the first step is the clipped
+                // Jacobi step (unit step length: the scaled Hessian is I + positive semidefinite, so the BB
+                // lengths s's / s'y lie in (0, 1]); no eigenvalue estimate is needed
+                float u0 = clampf(j0, lb0, ub0), u1 = clampf(j1, lb1, ub1);
+                float pu0 = 0.0f, pu1 = 0.0f, pg0 = g0, pg1 = g1, alpha = 1.0f;
 #pragma unroll 1
                 for (int t = 1; t < p.pg_steps; ++t) {
                     apply(u0, u1, std::true_type{}, g0, g1);
-                    u0 = __builtin_amdgcn_fmed3f(u0 - a0 * g0, lb0, ub0);
-                    u1 = __builtin_amdgcn_fmed3f(u1 - a1 * g1, lb1, ub1);
+                    const float du0 = u0 - pu0, du1 = u1 - pu1, dg0 = g0 - pg0, dg1 = g1 - pg1;
+                    const float num = group_total<L>(R00 * du0 * du0 + R11 * du1 * du1, j);
+                    const float den = group_total<L>(du0 * dg0 + du1 * dg1, j);
+                    alpha = (den > 1e-30f) ? fminf(fmaxf(num * __builtin_amdgcn_rcpf(den), 1e-3f), 1.0f) : alpha;
+                    pu0 = u0; pu1 = u1; pg0 = g0; pg1 = g1;
+                    u0 = __builtin_amdgcn_fmed3f(u0 - alpha * is0 * g0, lb0, ub0);
+                    u1 = __builtin_amdgcn_fmed3f(u1 - alpha * is1 * g1, lb1, ub1);
                 }
                 if (in && run) {
                     const int n0 = (ub0 - lb0 > BOUNDTOL) ? ((u0 <= lb0) ? ST_LOWER : ((u0 >= ub0) ? ST_UPPER : ST_FREE)) : ST_LOWER;

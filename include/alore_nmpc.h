@@ -61,7 +61,7 @@ typedef struct {
                         reference caps working-set changes at 300, acado_qpoases_interface.hpp:44 */
     int lanes_per_problem; /* 0 = choose from the batch size; else 4, 8, 16, 32 or 64 */
     int warm_start_steps;  /* projected-gradient steps used to predict the working set of a QP whose
-                              first solve hit bounds (<0: default 8, 12 for N > 32; 0: off).  Affects only the number
+                              first solve hit bounds (<0: default 6; 0: off).  Affects only the number
                               of working-set iterations, never the solution. */
 } alore_nmpc_config;
 
