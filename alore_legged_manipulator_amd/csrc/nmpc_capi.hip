@@ -284,7 +284,8 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     if (!h || !dev || B <= 0 || n_sqp < 1) return fail(h, ALORE_NMPC_E_INVALID, "rti: bad argument");
     if (!batch_complete(dev)) return fail(h, ALORE_NMPC_E_INVALID, "rti: batch has NULL members");
     nmpc::LaunchGeom g;
-    if (!nmpc::rti_geometry(B, h->cfg.N, h->cfg.lanes_per_problem, h->lds_limit, h->n_cu, &g))
+    static const int forced_wpb = getenv("ALORE_NMPC_WPB") ? atoi(getenv("ALORE_NMPC_WPB")) : 0; // diagnostic: 1 or 4
+    if (!nmpc::rti_geometry(B, h->cfg.N, h->cfg.lanes_per_problem, h->lds_limit, h->n_cu, &g, forced_wpb))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: horizon does not fit the LDS layout");
     nmpc::RtiParams p;
     p.b = *dev;
@@ -301,7 +302,7 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     p.lin_u = h->lin_u;
     hipStream_t s = (hipStream_t)stream;
     if (h->stamps) {
-        const size_t need = (size_t)g.grid * 8;
+        const size_t need = (size_t)g.grid * g.wpb * 8; // one record per wavefront
         if (need > h->stamps_cap) {
             if (h->d_stamps) (void)hipFree(h->d_stamps);
     if (h->refs.dur) (void)hipFree(h->refs.dur);
@@ -332,10 +333,14 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     h->last_geom = g;
     h->have_geom = true;
     if (h->stamps) { // diagnostic mode: synchronous, never used for timing
-        std::vector<long long> host((size_t)g.grid * 8);
+        const int n_waves = g.grid * g.wpb;
+        std::vector<long long> host((size_t)n_waves * 8);
         HIP_TRY(h, hipStreamSynchronize(s));
         HIP_TRY(h, hipMemcpy(host.data(), h->d_stamps, host.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        for (int b = 0; b < g.grid; ++b) {
+        if (const char* dump = getenv("ALORE_NMPC_STAMPS_DUMP")) { // raw per-wavefront stamps of the last launch
+            if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(host.data(), sizeof(long long), host.size(), f); std::fclose(f); }
+        }
+        for (int b = 0; b < n_waves; ++b) {
             for (int i = 0; i < 7; ++i) h->stamp_sum[i] += (double)host[(size_t)b * 8 + i];
             for (int i = 0; i < 7; ++i)
                 if ((double)host[(size_t)b * 8 + i] > h->stamp_max[i]) h->stamp_max[i] = (double)host[(size_t)b * 8 + i];
@@ -344,7 +349,7 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
                 for (int i = 0; i < 7; ++i) h->stamp_slowest[i] = (double)host[(size_t)b * 8 + i];
             }
         }
-        h->stamp_n += g.grid;
+        h->stamp_n += n_waves;
     }
     return ALORE_NMPC_OK;
 }
@@ -621,7 +626,7 @@ int alore_nmpc_get_launch_info(alore_nmpc_handle h, alore_nmpc_launch_info* out)
         h->timed_pending = false;
     }
     out->lanes_per_problem = h->last_geom.L;
-    out->problems_per_block = h->last_geom.G;
+    out->problems_per_block = h->last_geom.G * h->last_geom.wpb;
     out->threads_per_block = h->last_geom.threads;
     out->grid = h->last_geom.grid;
     out->lds_bytes_per_block = (int)h->last_geom.lds_bytes;

@@ -62,7 +62,7 @@ __host__ __device__ inline Staging staging_layout(int N)
 
 int rti_row_floats(int N) { return SR * (N + 1) + staging_layout(N).end; }
 
-bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g)
+bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int forced_wpb)
 {
     if (B <= 0 || N <= 0) return false;
     int L = forced_L;
@@ -74,7 +74,6 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
         // wavefront, which is what bounds residency).
         L = 16;
         while (L < 64 && L < N) L *= 2;
-        (void)n_cu;
     }
     if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return false;
     for (; L <= 64; L *= 2) {
@@ -87,12 +86,18 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
             if (forced_L) return false;
             continue; // more lanes per problem = fewer problems per wavefront
         }
+        // Four wavefronts per workgroup (one per SIMD: the hardware then spreads the wavefronts of a CU evenly
+        // over its SIMDs) when two such workgroups fit a CU and the batch gives every CU at least one.
+        const int cus = n_cu > 0 ? n_cu : 256;
+        const int wpb = (forced_wpb == 1 || forced_wpb == 4) ? forced_wpb
+                        : ((2L * 4 * G * row_bytes <= lds_limit_bytes && (long)B >= 4L * G * cus) ? 4 : 1);
         g->L = L;
         g->G = G;
-        g->threads = 64;
-        g->grid = (B + G - 1) / G;
+        g->wpb = wpb;
+        g->threads = 64 * wpb;
+        g->grid = (B + G * wpb - 1) / (G * wpb);
         g->RS = RS;
-        g->lds_bytes = (size_t)row_bytes * G;
+        g->lds_bytes = (size_t)row_bytes * G * wpb;
         return true;
     }
     return false;
@@ -108,6 +113,19 @@ __device__ __forceinline__ void st4(float* rec, int slot, float a, float b, floa
 {
     *reinterpret_cast<float4*>(rec + slot * 4) = make_float4(a, b, c, d);
 }
+
+// Wavefronts never share data: every problem lives in the LDS rows of its own wavefront.  With one
+// wavefront per workgroup a workgroup barrier is just a scheduling fence; with several (WPB = 4: one per
+// SIMD, which is what makes the hardware spread them evenly over the SIMDs of a CU) the barrier must NOT
+// couple them, so the kernel orders its LDS traffic per wavefront only (LDS operations of one wavefront
+// execute in program order).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int wave_or(int pred) { return __any(pred) ? 1 : 0; }
 
 // DPP quad permutes: data of another lane of the same quad, no LDS traffic
 template <int CTRL>
@@ -441,7 +459,7 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
     int pd_fail = 0;
     const int rq = j & 3, rr = (rq < 3) ? rq : 2;
     const bool is2 = (rr == 2);
-    __syncthreads();
+    wave_sync();
     if (mine && j == 0) { // start: clip the last solution into the box, fix what sits on a bound
         for (int k = 0; k < N; ++k) {
             float* rec = row + k * SR;
@@ -454,7 +472,7 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
             *reinterpret_cast<float2*>(rec + S_STDU * 4) = make_float2(__int_as_float(s0), __int_as_float(s1));
         }
     }
-    __syncthreads();
+    wave_sync();
     int todo = mine ? 1 : 0;
     for (;;) {
         // backward sweep over the whole horizon (rows over the quad lanes, as in the main loop)
@@ -480,7 +498,7 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
             }
             if (todo) pd_fail |= (ok == 0);
         }
-        __syncthreads();
+        wave_sync();
         // forward sweep, sequential, with the ratio test (free controls) and the multiplier test (fixed ones)
         float alpha = AS_NONE, viol = 0.0f;
         int akey = -1, vkey = -1; // (2 * stage + control) * 4 + bound hit
@@ -521,7 +539,7 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
             }
             ++it;
         }
-        __syncthreads();
+        wave_sync();
         // one change of the working set (every lane of the group holds the same alpha / viol / keys)
         if (todo) {
             const bool blocked = akey >= 0;
@@ -550,24 +568,26 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
             if (!blocked && !release) todo = 0;     // optimal
             else if (it >= max_it) todo = 2;        // cap reached
         }
-        const int more = __syncthreads_or(todo == 1 ? 1 : 0);
+        const int more = wave_or(todo == 1 ? 1 : 0);
         if (!more) break;
     }
     return it | (pd_fail ? (1 << 29) : 0) | (todo == 2 ? (1 << 30) : 0);
 }
 
 // one wavefront per workgroup, G = 64 / L problems per wavefront
-template <int L, bool STAMP>
-__global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
+template <int L, bool STAMP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
 {
     extern __shared__ float4 lds_raw[];
     float* lds = reinterpret_cast<float*>(lds_raw);
     const int N = p.N;
     constexpr int G = 64 / L;
-    const int grp = threadIdx.x / L;
-    const int j = threadIdx.x % L;
+    const int wave = (WPB == 1) ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int grp = wave * G + lane / L; // group index inside the workgroup
+    const int j = lane % L;
     const bool writer = (j == 0);
-    int prob = blockIdx.x * G + grp;
+    int prob = blockIdx.x * (G * WPB) + grp;
     const bool valid = prob < p.B;
     if (!valid) prob = p.B - 1; // padding groups shadow the last problem, never store
     float* row = lds + (size_t)grp * p.RS;
@@ -637,7 +657,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
     }
     const float x00 = p.b.x0[(size_t)prob * 3], x01 = p.b.x0[(size_t)prob * 3 + 1],
                 x02 = p.b.x0[(size_t)prob * 3 + 2];
-    __syncthreads();
+    wave_sync();
 
     // row role of this lane inside its quad (backward sweep)
     const int rq = j & 3;
@@ -719,7 +739,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             }
         }
         infeasible = group_or<L>(infeasible);
-        __syncthreads();
+        wave_sync();
         if (STAMP && sqp == 0) t_stamp[1] = __builtin_amdgcn_s_memtime();
 
         const float4 xfirst = lds4(row, S_X);
@@ -802,7 +822,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                     *reinterpret_cast<float2*>(rec + S_STDU * 4) = make_float2(__int_as_float(n0), __int_as_float(n1));
                 }
             }
-            __syncthreads();
+            wave_sync();
             if (STAMP) t_pg = __builtin_amdgcn_s_memtime() - tp0;
         }
 
@@ -871,7 +891,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
                 if (k == 0) step(0, sa, qa, ba);
                 pd_fail |= (ok == 0);
             }
-            __syncthreads();
+            wave_sync();
             long long tf0 = 0;
             if (STAMP) { tf0 = __builtin_amdgcn_s_memtime(); t_b += tf0 - tb0; }
 
@@ -962,7 +982,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             }
             if (STAMP) t_f += __builtin_amdgcn_s_memtime() - tf0;
             // wavefront-uniform continuation: any problem of this wavefront still changing?
-            const int more = __syncthreads_or((changed && it < min(p.max_as_iter, AS_SWITCH)) ? 1 : 0);
+            const int more = wave_or((changed && it < min(p.max_as_iter, AS_SWITCH)) ? 1 : 0);
             if (!more) break;
         }
         n_iter = (n_iter == 0) ? 1 : (changed ? n_iter : n_iter + 1); // + the confirming sweep
@@ -983,7 +1003,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
         status = infeasible ? RET_INIT_FAILED_INFEASIBILITY
                             : (pd_fail ? RET_INIT_FAILED_CHOLESKY : (changed ? RET_MAX_NWSR_REACHED : RET_OK));
         if (STAMP && sqp == 0) { t_stamp[2] = t_b; t_stamp[3] = t_f; t_stamp[4] = __builtin_amdgcn_s_memtime(); }
-        if (STAMP && sqp == 0 && threadIdx.x == 0 && p.stamps) p.stamps[(size_t)blockIdx.x * 8 + 6] = t_pg;
+        if (STAMP && sqp == 0 && lane == 0 && p.stamps) p.stamps[((size_t)blockIdx.x * WPB + wave) * 8 + 6] = t_pg;
 
         // ---- phase C (stage-parallel): KKT value (acado_getKKT), expand (acado_expand), carry the dual
         float gd = 0.0f, comp = 0.0f;
@@ -1011,7 +1031,7 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
             }
         }
         kkt = fabsf(group_sum<L>(gd)) + group_sum<L>(comp);
-        __syncthreads();
+        wave_sync();
     }
     if (STAMP) t_stamp[5] = __builtin_amdgcn_s_memtime();
 
@@ -1055,8 +1075,8 @@ __global__ __launch_bounds__(64) void rti_kernel(const RtiParams p)
         p.b.kkt[prob] = kkt;
         p.b.obj[prob] = obj;
     }
-    if (STAMP && threadIdx.x == 0 && p.stamps) {
-        long long* o = p.stamps + (size_t)blockIdx.x * 8;
+    if (STAMP && lane == 0 && p.stamps) {
+        long long* o = p.stamps + ((size_t)blockIdx.x * WPB + wave) * 8;
         const long long t_end = __builtin_amdgcn_s_memtime();
         o[0] = t_stamp[1] - t_stamp[0]; // load + phase A
         o[1] = t_stamp[2];              // backward sweeps
@@ -1075,17 +1095,20 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
     switch (g.L) {
 #define CASE(LL)                                                                                              \
     case LL: {                                                                                                \
-        static size_t configured[2] = {0, 0}; /* raise the dynamic-LDS cap once per size, not per launch */   \
-        const void* fn = stamp ? (const void*)rti_kernel<LL, true> : (const void*)rti_kernel<LL, false>;      \
-        if (g.lds_bytes > configured[stamp]) {                                                                \
+        static size_t configured[4] = {0, 0, 0, 0}; /* raise the dynamic-LDS cap once per size */             \
+        const int v = (stamp ? 1 : 0) + (g.wpb == 4 ? 2 : 0);                                                 \
+        const void* fn = v == 0   ? (const void*)rti_kernel<LL, false, 1>                                     \
+                         : v == 1 ? (const void*)rti_kernel<LL, true, 1>                                      \
+                         : v == 2 ? (const void*)rti_kernel<LL, false, 4>                                     \
+                                  : (const void*)rti_kernel<LL, true, 4>;                                     \
+        if (g.lds_bytes > configured[v]) {                                                                    \
             e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);        \
             if (e != hipSuccess) return e;                                                                    \
-            configured[stamp] = g.lds_bytes;                                                                  \
+            configured[v] = g.lds_bytes;                                                                      \
         }                                                                                                     \
-        if (stamp)                                                                                            \
-            hipLaunchKernelGGL((rti_kernel<LL, true>), grid, block, g.lds_bytes, s, p);                       \
-        else                                                                                                  \
-            hipLaunchKernelGGL((rti_kernel<LL, false>), grid, block, g.lds_bytes, s, p);                      \
+        void* args[] = {const_cast<RtiParams*>(&p)};                                                          \
+        e = hipLaunchKernel(fn, grid, block, args, g.lds_bytes, s);                                           \
+        if (e != hipSuccess) return e;                                                                        \
         break;                                                                                                \
     }
         CASE(4)
