@@ -805,8 +805,14 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 // lengths s's / s'y lie in (0, 1]); no eigenvalue estimate is needed
                 float u0 = clampf(j0, lb0, ub0), u1 = clampf(j1, lb1, ub1);
                 float pu0 = 0.0f, pu1 = 0.0f, pg0 = g0, pg1 = g1, alpha = 1.0f;
+                // pg_steps steps, then up to as many again while the predicted set of the wavefront still moves
+                const int max_steps = 2 * p.pg_steps;
+                auto at_bounds = [&](float a0_, float a1_) {
+                    return (a0_ <= lb0 ? 1 : 0) | (a0_ >= ub0 ? 2 : 0) | (a1_ <= lb1 ? 4 : 0) | (a1_ >= ub1 ? 8 : 0);
+                };
+                int bits = at_bounds(u0, u1), still = 0;
 #pragma unroll 1
-                for (int t = 1; t < p.pg_steps; ++t) {
+                for (int t = 1; t < max_steps; ++t) {
                     apply(u0, u1, std::true_type{}, g0, g1);
                     const float du0 = u0 - pu0, du1 = u1 - pu1, dg0 = g0 - pg0, dg1 = g1 - pg1;
                     const float num = group_total<L>(R00 * du0 * du0 + R11 * du1 * du1, j);
@@ -815,6 +821,10 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                     pu0 = u0; pu1 = u1; pg0 = g0; pg1 = g1;
                     u0 = __builtin_amdgcn_fmed3f(u0 - alpha * is0 * g0, lb0, ub0);
                     u1 = __builtin_amdgcn_fmed3f(u1 - alpha * is1 * g1, lb1, ub1);
+                    const int nb = at_bounds(u0, u1);
+                    still = __any(in && run && nb != bits) ? 0 : still + 1;
+                    bits = nb;
+                    if (still >= 2 && t + 1 >= p.pg_steps) break; // never fewer than pg_steps; more only while the set moves
                 }
                 if (in && run) {
                     const int n0 = (ub0 - lb0 > BOUNDTOL) ? ((u0 <= lb0) ? ST_LOWER : ((u0 >= ub0) ? ST_UPPER : ST_FREE)) : ST_LOWER;
