@@ -365,27 +365,6 @@ def main():
             del e5
         except Exception as e:  # pragma: no cover
             extras["warm_tick"] = {"error": str(e)}
-        # independent batches streamed over several HIP streams (launches may overlap: the tail of one batch
-        # runs next to the bulk of the next).  Throughput of a streaming deployment; NOT the headline, whose
-        # launches are serialised so that per-launch durations mean something.
-        try:
-            streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
-            nslots = min(slots, 60)
-            for i in range(2 * len(streams)):  # first launches on a new stream are slow
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    eng.rti(1, slot=i % nslots)
-            torch.cuda.synchronize(dev)
-            t_a = time.perf_counter()
-            for i in range(nslots):
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    eng.rti(1, slot=i)
-            torch.cuda.synchronize(dev)
-            t_b = time.perf_counter()
-            extras["streamed_batches"] = {"streams": len(streams), "launches": nslots,
-                                          "ms_per_launch": (t_b - t_a) / nslots * 1e3,
-                                          "solves_per_s": B * nslots / (t_b - t_a)}
-        except Exception as e:  # pragma: no cover
-            extras["streamed_batches"] = {"error": str(e)}
         # the whole control tick of the reference node for B robots (host controller -> C ABI -> kernels ->
         # wheel-speed commands; mpc.cpp CmdCallback): reference sampling on the host (as the reference does)
         # against reference sampling on the device
