@@ -329,7 +329,7 @@ def test_wide_problems_three_ticks_against_oracle(nmpc_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,N,L", [(1, 20, 0), (5, 20, 0), (33, 20, 8), (5, 7, 0), (3, 50, 0), (7, 50, 16), (2, 1, 0)])
+@pytest.mark.parametrize("B,N,L", [(1, 20, 0), (5, 20, 0), (33, 20, 8), (5, 7, 0), (3, 50, 0), (7, 50, 16), (2, 1, 0), (2051, 20, 0), (4101, 7, 0)])
 def test_no_out_of_bounds_writes(nmpc_mod, B, N, L):
     """Ragged batches (padding lane groups shadow the last problem) must not write outside their members: the
     members of slot 1 sit between those of slots 0 and 2 in memory, which hold a canary pattern."""
