@@ -164,6 +164,14 @@ __device__ __forceinline__ int group_or(int v)
     for (int off = L / 2; off > 0; off >>= 1) v |= __shfl_xor(v, off, L);
     return v;
 }
+// "any lane of my group": one ballot instead of a butterfly of LDS permutes (base = first lane of the group)
+template <int L>
+__device__ __forceinline__ bool group_any(bool pred, int base)
+{
+    const unsigned long long m = __ballot(pred);
+    if constexpr (L == 64) return m != 0ull;
+    else return ((m >> base) & ((1ull << L) - 1ull)) != 0ull;
+}
 __device__ __forceinline__ int wave_max(int v)
 {
 #pragma unroll
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 st4(rec, S_V + 2, w[6], w[7], w[8], q2);
             }
         }
-        infeasible = group_or<L>(infeasible);
+        infeasible = group_any<L>(infeasible != 0, lane - j) ? 1 : 0;
         wave_sync();
         if (STAMP && sqp == 0) t_stamp[1] = __builtin_amdgcn_s_memtime();
 
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                          bnd = lds4(rec, S_BND), sd = lds4(rec, S_STDU);
             const float4 q0 = lds4(recn, S_Q), q1 = lds4(recn, S_Q + 1), q2 = lds4(recn, S_Q + 2), ln = lds4(recn, S_B1);
             const int nonfree = in ? (__float_as_int(sd.x) | __float_as_int(sd.y)) : 0;
-            const bool cold = group_or<L>(nonfree) == 0;
+            const bool cold = !group_any<L>(nonfree != 0, lane - j);
             const float B00 = l0.x * msk, B01 = l0.y * msk, B10 = l0.z * msk, B11 = l0.w * msk, B20 = l1.x * msk;
             const float a = l1.z * msk, b = l1.w * msk, d0 = dd.x * msk, d1 = dd.y * msk, d2 = dd.z * msk;
             const float r0 = dd.w * msk, r1 = RR.w * msk, R00 = RR.x * msk, R01 = RR.y * msk, R11 = RR.z * msk;
@@ -798,7 +806,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
             // a control weight that is not positive: no prediction, the all-free first sweep then reports the
             // indefinite Hessian exactly where the reference's initial Cholesky does (status 31)
             const int badw = in ? ((!(R00 > 0.0f)) | (!(R11 > 0.0f))) : 0;
-            const bool run = cold && (group_or<L>(hits | (badw << 1)) == 1);
+            const bool run = cold && group_any<L>(hits != 0, lane - j) && !group_any<L>(badw != 0, lane - j);
             if (__any(run)) {
                 // projected Barzilai-Borwein iteration in the R-scaled metric: the first step is the clipped
                 // Jacobi step (unit step length: the scaled Hessian is I + positive semidefinite, so the BB
@@ -1040,7 +1048,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 st4(rec, S_UY, uy.x + du0, uy.y + du1, mu.x, mu.y);
             }
         }
-        kkt = fabsf(group_sum<L>(gd)) + group_sum<L>(comp);
+        kkt = fabsf(group_total<L>(gd, j)) + group_total<L>(comp, j);
         wave_sync();
     }
     if (STAMP) t_stamp[5] = __builtin_amdgcn_s_memtime();
@@ -1078,7 +1086,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
             ox[k * 3] = xk.x; ox[k * 3 + 1] = xk.y; ox[k * 3 + 2] = xk.z;
         }
     }
-    const float obj = 0.5f * group_sum<L>(part);
+    const float obj = 0.5f * group_total<L>(part, j);
     if (valid && writer) {
         p.b.status[prob] = status;
         p.b.n_iter[prob] = n_iter;
