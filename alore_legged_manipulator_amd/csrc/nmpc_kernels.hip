@@ -46,7 +46,7 @@ enum Slot : int {
 // loads, each sub-array padded to 16 bytes.
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 struct Staging {
-    int W, y, od, lb, ub, end; // float offsets from the start of the staging area
+    int W, y, od, lb, ub, term, end; // float offsets from the start of the staging area (term: WN[9], yN[3])
 };
 __host__ __device__ inline Staging staging_layout(int N)
 {
@@ -56,7 +56,8 @@ __host__ __device__ inline Staging staging_layout(int N)
     s.od = s.y + pad4(5 * N);
     s.lb = s.od + pad4(3 * (N + 1));
     s.ub = s.lb + pad4(2 * N);
-    s.end = s.ub + pad4(2 * N);
+    s.term = s.ub + pad4(2 * N);
+    s.end = s.term + 12;
     return s;
 }
 
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
         ldg_scl<L, UX>(gx, 3 * (N + 1), j, fx);
         ldg_scl<L, UX>(gu, 2 * N, j, fu);
         ldg_scl<L, UX>(gdual, 2 * N, j, fd);
+        const float fterm = (j < 9) ? gWN[j] : ((j < 12) ? gyN[j - 9] : 0.0f); // terminal weights and reference (L >= 12)
         if (vW) sts_vec<L, UW>(stg + SG.W, (25 * N) >> 2, j, qW);
         if (vy) sts_vec<L, UV>(stg + SG.y, (5 * N) >> 2, j, qy);
         if (vb) { sts_vec<L, UV>(stg + SG.lb, (2 * N) >> 2, j, qlb); sts_vec<L, UV>(stg + SG.ub, (2 * N) >> 2, j, qub); }
@@ -650,6 +652,8 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 rec[2] = fd[u];
             }
         }
+        if (L >= 12) { if (j < 12) stg[SG.term + j] = fterm; }
+        else { for (int i = j; i < 12; i += L) stg[SG.term + i] = (i < 9) ? gWN[i] : gyN[i - 9]; }
         // whatever the first batch did not cover
         copy_tail<L>(gW, stg + SG.W, vW ? min(25 * N, 4 * UW * L) : 0, 25 * N, j);
         copy_tail<L>(gy, stg + SG.y, vy ? min(5 * N, 4 * UV * L) : 0, 5 * N, j);
@@ -730,10 +734,11 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 st4(rec, S_STDU, __int_as_float(status_from_dual(uy.z, lb0, ub0)),
                     __int_as_float(status_from_dual(uy.w, lb1, ub1)), 0.0f, 0.0f);
             } else {
-                const float e0 = xk.x - gyN[0], e1 = xk.y - gyN[1], e2 = xk.z - gyN[2];
+                const float* tn = stg + SG.term; // WN (9), yN (3): staged with the other inputs
+                const float e0 = xk.x - tn[9], e1 = xk.y - tn[10], e2 = xk.z - tn[11];
                 float w[9];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) w[i] = gWN[i];
+                for (int i = 0; i < 9; ++i) w[i] = tn[i];
                 const float q0 = w[0] * e0 + w[1] * e1 + w[2] * e2;
                 const float q1 = w[3] * e0 + w[4] * e1 + w[5] * e2;
                 const float q2 = w[6] * e0 + w[7] * e1 + w[8] * e2;
@@ -1078,8 +1083,9 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 od[k * 2] = uy.z; od[k * 2 + 1] = uy.w;
             }
         } else { // the reference uses only the diagonal of WN here (acado_solver.c:1442-1444)
-            const float e0 = xk.x - gyN[0], e1 = xk.y - gyN[1], e2 = xk.z - gyN[2];
-            part += e0 * e0 * gWN[0] + e1 * e1 * gWN[4] + e2 * e2 * gWN[8];
+            const float* tn = stg + SG.term;
+            const float e0 = xk.x - tn[9], e1 = xk.y - tn[10], e2 = xk.z - tn[11];
+            part += e0 * e0 * tn[0] + e1 * e1 * tn[4] + e2 * e2 * tn[8];
         }
         if (valid) {
             float* ox = p.b.x + (size_t)prob * (N + 1) * 3;
