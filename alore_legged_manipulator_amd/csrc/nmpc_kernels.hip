@@ -824,6 +824,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                     return (a0_ <= lb0 ? 1 : 0) | (a0_ >= ub0 ? 2 : 0) | (a1_ <= lb1 ? 4 : 0) | (a1_ >= ub1 ? 8 : 0);
                 };
                 int bits = at_bounds(u0, u1), still = 0;
+                bool frozen = !run; // per group: its prediction has settled (so that the path of a problem never depends on its wavefront mates)
 #pragma unroll 1
                 for (int t = 1; t < max_steps; ++t) {
                     apply(u0, u1, std::true_type{}, g0, g1);
@@ -832,12 +833,16 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                     const float den = group_total<L>(du0 * dg0 + du1 * dg1, j);
                     alpha = (den > 1e-30f) ? fminf(fmaxf(num * __builtin_amdgcn_rcpf(den), 1e-3f), 1.0f) : alpha;
                     pu0 = u0; pu1 = u1; pg0 = g0; pg1 = g1;
-                    u0 = __builtin_amdgcn_fmed3f(u0 - alpha * is0 * g0, lb0, ub0);
-                    u1 = __builtin_amdgcn_fmed3f(u1 - alpha * is1 * g1, lb1, ub1);
+                    const float n0 = __builtin_amdgcn_fmed3f(u0 - alpha * is0 * g0, lb0, ub0);
+                    const float n1 = __builtin_amdgcn_fmed3f(u1 - alpha * is1 * g1, lb1, ub1);
+                    u0 = frozen ? u0 : n0;
+                    u1 = frozen ? u1 : n1;
                     const int nb = at_bounds(u0, u1);
-                    still = __any(in && run && nb != bits) ? 0 : still + 1;
+                    still = group_any<L>(in && nb != bits, lane - j) ? 0 : still + 1;
                     bits = nb;
-                    if (still >= 2 && t + 1 >= p.pg_steps) break; // never fewer than pg_steps; more only while the set moves
+                    // never fewer than pg_steps; more only while the set of this group still moves
+                    frozen = frozen || (still >= 2 && t + 1 >= p.pg_steps);
+                    if (__all(frozen)) break;
                 }
                 if (in && run) {
                     const int n0 = (ub0 - lb0 > BOUNDTOL) ? ((u0 <= lb0) ? ST_LOWER : ((u0 >= ub0) ? ST_UPPER : ST_FREE)) : ST_LOWER;
@@ -865,7 +870,12 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
             if constexpr (L == 64) kmax_v = kk;
             else if constexpr (L == 32) kmax_v = max(__float_as_int(readlane_f(__int_as_float(kk), 31)), __float_as_int(readlane_f(__int_as_float(kk), 63)));
             else kmax_v = wave_max(kk);
-            const int kmax = __builtin_amdgcn_readfirstlane(kmax_v);
+            // The loop below handles two stages per trip with two inlined copies of the step whose roundings
+            // may differ (FMA contraction); a restart keeps the parity of the full sweep so that a stage is
+            // always processed by the same copy and a problem's result does not depend on where its
+            // wavefront restarts (i.e. on its wavefront mates).
+            const int kraw = __builtin_amdgcn_readfirstlane(kmax_v);
+            const int kmax = (kraw < 0) ? -1 : kraw + ((N - 1 - kraw) & 1);
             {
                 RowValue V;
                 V.P0 = V.P1 = V.P2 = V.p = 0.0f;

@@ -352,3 +352,18 @@ def test_no_out_of_bounds_writes(nmpc_mod, B, N, L):
             assert bool((t[s] == want).all()), (k, s)
     out = eng.fetch(slot=1)
     assert (out["status"] == 0).all() and np.isfinite(out["x"]).all()
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_wavefront_mates(nmpc_mod):
+    """A problem's answer must be the same bits whatever problems share its wavefront (prediction length and sweep
+    restarts are decided per problem / parity-preserving): permute a batch that needs many working-set sweeps."""
+    from alore_legged_manipulator_amd.scenarios import make_wide_batch
+    B, N = 4096, 20
+    batch = make_wide_batch(B, N, 3)
+    perm = np.random.default_rng(0).permutation(B)
+    e1 = nmpc_mod.BatchedNmpc(B, N); e1.load(batch); e1.rti(1); o1 = e1.fetch()
+    e2 = nmpc_mod.BatchedNmpc(B, N); e2.load({k: v[perm] for k, v in batch.items()}); e2.rti(1); o2 = e2.fetch()
+    assert (o1["n_iter"] > 1).sum() > 100                      # the batch does exercise restarts
+    for k in ("x", "u", "dual", "kkt", "obj", "status", "n_iter"):
+        assert np.array_equal(o1[k][perm], o2[k]), k
