@@ -76,6 +76,7 @@ SYMBOLS = (
     ("alore_nmpc_linearize", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.POINTER(LinOut), C.c_void_p]),
     ("alore_nmpc_forward_simulate", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p]),
     ("alore_nmpc_shift", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_set_shared_members", C.c_int, [C.c_void_p, C.c_uint]),
     ("alore_nmpc_refs_init", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("alore_nmpc_refs_set_trajectory", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                  C.c_double, C.c_double, C.c_double, C.c_void_p]),

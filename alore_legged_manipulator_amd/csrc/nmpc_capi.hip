@@ -43,6 +43,7 @@ struct alore_nmpc_solver {
     int* d_overflow = nullptr;    // [1]
     double* d_inc = nullptr;      // [chunk][C * res_int][2], grown on demand
     size_t inc_doubles = 0;
+    unsigned shared = 0;          // see alore_nmpc_set_shared_members
     const float* lin_x = nullptr; // see alore_nmpc_set_linearization_point
     const float* lin_u = nullptr;
     // diagnostic phase stamps (env ALORE_NMPC_STAMPS=1): per-phase cycle shares, printed at destroy
@@ -294,6 +295,7 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     p.n_sqp = n_sqp;
     p.max_as_iter = h->cfg.max_as_iter;
     p.pg_steps = h->cfg.warm_start_steps;
+    p.shared = h->shared;
     p.RS = g.RS;
     const nmpc::IrkConst K = nmpc::make_irk(h->cfg.dt);
     p.h = K.h; p.hh = K.hh; p.c1h = K.c1h; p.c2h = K.c2h;
@@ -596,6 +598,14 @@ int alore_nmpc_closed_loop_tick(alore_nmpc_handle h, const alore_nmpc_batch* dev
     const int rc = alore_nmpc_rti(h, dev, B, 1, stream);
     if (rc != ALORE_NMPC_OK) return rc;
     HIP_TRY(h, nmpc::launch_plant(*dev, B, N, delay_num < N ? delay_num : N - 1, h->d_icr, h->d_goal, h->d_est, h->d_vw, h->plant, s));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_set_shared_members(alore_nmpc_handle h, unsigned mask)
+{
+    if (!h || (mask & ~(unsigned)(ALORE_NMPC_SHARED_W | ALORE_NMPC_SHARED_BOUNDS | ALORE_NMPC_SHARED_OD)))
+        return fail(h, ALORE_NMPC_E_INVALID, "set_shared_members: unknown bit");
+    h->shared = mask;
     return ALORE_NMPC_OK;
 }
 

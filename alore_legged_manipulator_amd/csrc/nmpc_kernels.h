@@ -21,6 +21,7 @@ struct RtiParams {
     const float* lin_x; // optional [B][(N+1)*3]: linearisation point of the first iteration (else null)
     const float* lin_u; // optional [B][N*2]
     long long* stamps; // diagnostic builds only: per-block phase cycle counts (8 per block), else null
+    unsigned shared; // ALORE_NMPC_SHARED_* bits: members that are ONE copy for the whole batch (problem stride 0)
 };
 
 struct LaunchGeom {

@@ -610,13 +610,13 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
     const float* gx = p.b.x + (size_t)prob * (N + 1) * 3;
     const float* gu = p.b.u + (size_t)prob * N * 2;
     const float* gdual = p.b.dual + (size_t)prob * N * 2;
-    const float* god = p.b.od + (size_t)prob * (N + 1) * 3;
+    const float* god = p.b.od + ((p.shared & ALORE_NMPC_SHARED_OD) ? 0 : (size_t)prob * (N + 1) * 3);
     const float* gy = p.b.y + (size_t)prob * N * 5;
     const float* gyN = p.b.yN + (size_t)prob * 3;
-    const float* gW = p.b.W + (size_t)prob * N * 25;
-    const float* gWN = p.b.WN + (size_t)prob * 9;
-    const float* glb = p.b.lbValues + (size_t)prob * N * 2;
-    const float* gub = p.b.ubValues + (size_t)prob * N * 2;
+    const float* gW = p.b.W + ((p.shared & ALORE_NMPC_SHARED_W) ? 0 : (size_t)prob * N * 25);
+    const float* gWN = p.b.WN + ((p.shared & ALORE_NMPC_SHARED_W) ? 0 : (size_t)prob * 9);
+    const float* glb = p.b.lbValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * N * 2);
+    const float* gub = p.b.ubValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * N * 2);
 
     // ---- phase 0: coalesced loads.  Read-only inputs -> staging, iterate (x, u, dual) -> records.
     const Staging SG = staging_layout(N);

@@ -208,6 +208,10 @@ class BatchedNmpc:
         self._check(self.lib.alore_nmpc_closed_loop_tick(self.h, C.byref(self._batches[slot]), self.B, float(now),
                                                          int(delay_num), self._stream()))
 
+    def set_shared_members(self, W: bool = False, bounds: bool = False, od: bool = False) -> None:
+        """Members that are ONE copy for the whole batch (row 0 of the corresponding tensors is what every problem reads)."""
+        self._check(self.lib.alore_nmpc_set_shared_members(self.h, (1 if W else 0) | (2 if bounds else 0) | (4 if od else 0)))
+
     def set_timing(self, enable: bool) -> None:
         self._check(self.lib.alore_nmpc_set_timing(self.h, 1 if enable else 0))
 

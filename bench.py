@@ -428,6 +428,27 @@ def main():
             del e7
         except Exception as e:  # pragma: no cover
             extras["device_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
+        # compact I/O (secondary figure): weights, bounds and ICR parameters shared by the batch
+        # (one object class, many poses): 4 (19 N + 19) bytes per solve instead of 4 (51 N + 28)
+        try:
+            e8 = BatchedNmpc(B, N, device=local_rank, slots=24)
+            cb = dict(batch); cb["od"] = np.broadcast_to(batch["od"][:1], batch["od"].shape).copy()
+            e8.load(cb, slot=None)
+            e8.set_shared_members(W=True, bounds=True, od=True)
+            e8.rti(1, slot=0); e8.rti(1, slot=1)
+            torch.cuda.synchronize(dev)
+            c0.record()
+            for i in range(2, 24):
+                e8.rti(1, slot=i)
+            c1.record(); torch.cuda.synchronize(dev)
+            msc = c0.elapsed_time(c1) / 22
+            cbytes = 4 * (19 * N + 19)
+            extras["compact_io"] = {"ms_per_launch": msc, "solves_per_s": B / (msc * 1e-3), "bytes_per_solve": cbytes,
+                                    "hbm_frac": cbytes * B / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "unsolved": int((e8.ts["status"][2:24] != 0).sum().item())}
+            del e8
+        except Exception as e:  # pragma: no cover
+            extras["compact_io"] = {"error": f"{type(e).__name__}: {e}"}
         # the reference's own generated horizon (N = 50), same batch size: next to the compiled reference's
         # single-core time in cpu_baseline.reference_n50_single_core_us_per_solve
         try:

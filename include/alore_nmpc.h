@@ -148,6 +148,18 @@ int alore_nmpc_forward_simulate(alore_nmpc_handle h, const alore_nmpc_batch *dev
 int alore_nmpc_shift(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int strategy, const float *xEnd,
                      const float *uEnd, void *stream);
 
+/* ---- members shared by the whole batch ----------------------------------------- */
+/* Monte-Carlo batches often share weights, bounds and ICR parameters (one object class, many poses): the
+ * members named in `mask` are then ONE copy of the per-problem layout (W [N][25] and WN [9]; lbValues and
+ * ubValues [N][2]; od [N+1][3]) that every problem reads, instead of B copies.  Results are those of the
+ * replicated layout; HBM traffic per solve drops from 4 (51 N + 28) to 4 (19 N + 19) bytes with all three
+ * ("compact variant"; reported as a secondary figure only).  Applies to alore_nmpc_rti;
+ * the per-problem members (x, u, y, yN, x0, dual, results) are unaffected. */
+#define ALORE_NMPC_SHARED_W 1u      /* W and WN */
+#define ALORE_NMPC_SHARED_BOUNDS 2u /* lbValues and ubValues */
+#define ALORE_NMPC_SHARED_OD 4u     /* od */
+int alore_nmpc_set_shared_members(alore_nmpc_handle h, unsigned mask);
+
 /* ---- reference sampling on the device -------------------------------------- */
 /* What the reference node does on the host every tick before the solver runs --
  * MpcController::getRefPoints (nmpc_controller/src/mpc.cpp:407-461, sampling TrajAnal::getPstate /

@@ -367,3 +367,24 @@ def test_results_do_not_depend_on_wavefront_mates(nmpc_mod):
     assert (o1["n_iter"] > 1).sum() > 100                      # the batch does exercise restarts
     for k in ("x", "u", "dual", "kkt", "obj", "status", "n_iter"):
         assert np.array_equal(o1[k][perm], o2[k]), k
+
+
+@pytest.mark.gpu
+def test_shared_members_give_the_replicated_results(nmpc_mod):
+    """alore_nmpc_set_shared_members: W/WN, bounds and od read from ONE copy (row 0) must give exactly what B
+    identical copies give; rows > 0 of the shared members are then never read (poisoned here)."""
+    N, B = 20, 1024
+    batch = make_batch(B, N, seed=12, fast_tail=0.2)
+    batch["od"][:] = batch["od"][0]                      # one object class for the whole batch
+    ref = nmpc_mod.BatchedNmpc(B, N); ref.load(batch); ref.rti(2); want = ref.fetch()
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    poisoned = {k: v.copy() for k, v in batch.items()}
+    for k in ("W", "WN", "lbValues", "ubValues", "od"):
+        poisoned[k][1:] = np.nan
+    eng.load(poisoned)
+    eng.set_shared_members(W=True, bounds=True, od=True)
+    eng.rti(2)
+    got = eng.fetch()
+    assert (got["status"] == 0).all()
+    for k in ("x", "u", "dual", "kkt", "obj", "n_iter"):
+        assert np.array_equal(got[k], want[k]), k
