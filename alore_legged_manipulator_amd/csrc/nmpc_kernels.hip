@@ -2,7 +2,7 @@
 //
 // Mapping.  One wavefront per workgroup; a wavefront holds G = 64 / L problems, each worked on by a
 // group of L consecutive lanes (L = 4..64, a power of two).  All per-stage data of a problem live in
-// LDS as N+1 "stage records" of 19 sixteen-byte slots (the odd slot count spreads consecutive
+// LDS as N+1 "stage records" of 21 sixteen-byte slots (the odd slot count spreads consecutive
 // records over all banks), followed by a staging copy of the read-only inputs.
 //   * load: the reference layout is contiguous per problem, so a group streams its problem in with
 //     16-byte-per-lane coalesced loads, all issued before the first LDS store (one memory round trip);
@@ -35,11 +35,12 @@ namespace nmpc {
 //   slot 4  Q00 Q01 Q02 q0       slot 11 mu0 mu1 f1  -         slot 16 x0  x1  x2  -
 //   slot 5  Q10 Q11 Q12 q1                                     slot 17 u0  u1  y0  y1
 //   slot 6  Q20 Q21 Q22 q2                                     slot 18 sb0 sb1 sb2 -
-constexpr int SLOTS = 19;
+//   slot 19 free0 free1 val0 val1 (working set as 1/0 flags + fixed values, write_fix)   slot 20 spare (odd count)
+constexpr int SLOTS = 21; // odd: consecutive records spread over all banks for 16-byte accesses
 constexpr int SR = SLOTS * 4;
 enum Slot : int {
     S_B0 = 0, S_B1 = 1, S_D = 2, S_R = 3, S_Q = 4, S_BND = 7, S_STDU = 8, S_POL0 = 9, S_POL1 = 10, S_MU = 11,
-    S_V = 12, S_DX = 15, S_X = 16, S_UY = 17, S_SB = 18
+    S_V = 12, S_DX = 15, S_X = 16, S_UY = 17, S_SB = 18, S_FIX = 19 /* slot 20 spare */
 };
 
 // After the records: a staging copy of the read-only inputs of the problem, filled by coalesced
@@ -113,6 +114,14 @@ __device__ __forceinline__ float4 lds4(const float* rec, int slot)
 __device__ __forceinline__ void st4(float* rec, int slot, float a, float b, float c, float d)
 {
     *reinterpret_cast<float4*>(rec + slot * 4) = make_float4(a, b, c, d);
+}
+
+// Working set of a stage as the backward sweep wants it: (free0, free1, fixed value 0, fixed value 1), flags as
+// 1.0 / 0.0 and the value 0 for a free control, so that the elimination needs no compares or selects.
+__device__ __forceinline__ void write_fix(float* rec, int st0, int st1, float lb0, float ub0, float lb1, float ub1)
+{
+    st4(rec, S_FIX, st0 == ST_FREE ? 1.0f : 0.0f, st1 == ST_FREE ? 1.0f : 0.0f,
+        st0 == ST_FREE ? 0.0f : (st0 == ST_UPPER ? ub0 : lb0), st1 == ST_FREE ? 0.0f : (st1 == ST_UPPER ? ub1 : lb1));
 }
 
 // Wavefronts never share data: every problem lives in the LDS rows of its own wavefront.  With one
@@ -375,8 +384,7 @@ struct RowValue {
     float P0, P1, P2, p;
 };
 struct StageBcast { // wavefront-uniform-per-group stage data (LDS broadcast reads)
-    float4 b0, b1, d, R, bnd;
-    float2 st;
+    float4 b0, b1, d, R, fix; // fix: see write_fix
 };
 struct RowPolicy {
     float c0c, c1c;     // component r of the two gain / multiplier rows
@@ -386,8 +394,7 @@ struct RowPolicy {
 __device__ __forceinline__ void load_bcast(const float* rec, StageBcast& s)
 {
     s.b0 = lds4(rec, S_B0); s.b1 = lds4(rec, S_B1); s.d = lds4(rec, S_D); s.R = lds4(rec, S_R);
-    s.bnd = lds4(rec, S_BND);
-    s.st = *reinterpret_cast<const float2*>(rec + S_STDU * 4);
+    s.fix = lds4(rec, S_FIX);
 }
 
 __device__ __forceinline__ int riccati_rows(const StageBcast& s, float4 qrow, float Br0, float Br1, bool is2,
@@ -396,9 +403,8 @@ __device__ __forceinline__ int riccati_rows(const StageBcast& s, float4 qrow, fl
     const float B00 = s.b0.x, B01 = s.b0.y, B10 = s.b0.z, B11 = s.b0.w, B20 = s.b1.x, B21 = s.b1.y;
     const float a = s.b1.z, b = s.b1.w;
     const float al = is2 ? a : 0.0f, be = is2 ? b : 0.0f;
-    const int st0 = __float_as_int(s.st.x), st1 = __float_as_int(s.st.y);
-    const float v0 = (st0 == ST_UPPER) ? s.bnd.y : s.bnd.x;
-    const float v1 = (st1 == ST_UPPER) ? s.bnd.w : s.bnd.z;
+    const float f0m = s.fix.x, f1m = s.fix.y, v0 = s.fix.z, v1 = s.fix.w; // 1 / 0 flags, fixed value (0 if free)
+    const float n0m = 1.0f - f0m, n1m = 1.0f - f1m;
 
     const float sr = V.P0 * s.d.x + V.P1 * s.d.y + V.P2 * s.d.z + V.p;     // (P d + p)[r]
     const float PB0 = V.P0 * B00 + V.P1 * B10 + V.P2 * B20;                 // (P B)[r][0]
@@ -412,28 +418,25 @@ __device__ __forceinline__ int riccati_rows(const StageBcast& s, float4 qrow, fl
     float G0c = PB0 + al * dpp<QP_BC0>(PB0) + be * dpp<QP_BC1>(PB0);
     const float G1c = PB1 + al * dpp<QP_BC0>(PB1) + be * dpp<QP_BC1>(PB1);
 
-    // eliminate control 1, then control 0 (group-uniform scalars)
-    const bool free1 = (st1 == ST_FREE);
-    const bool bad1 = free1 && !(H11 > 0.0f);
-    const float inv11 = __builtin_amdgcn_rcpf(H11); // 1 ulp, like the division it stands for
-    const float w1 = free1 ? inv11 : 0.0f;
-    const float z1 = free1 ? -hu1 * inv11 : v1;
+    // eliminate control 1, then control 0 (group-uniform scalars).  Flags as arithmetic masks: a free control
+    // has w = 1/H, z = -hu/H; a fixed one w = 0, z = its value; exact either way (the masks are 0 and 1).
+    const bool bad1 = (f1m > 0.0f) && !(H11 > 0.0f);
+    const float w1 = __builtin_amdgcn_rcpf(H11) * f1m; // reciprocal: 1 ulp, like the division it stands for
+    const float z1 = fmaf(-hu1, w1, v1);
     const float t1 = w1 * H01;
-    const float g1s = free1 ? -w1 : 1.0f;
+    const float g1s = n1m - w1;                  // -1/H if free, 1 if fixed
     pol.c1c = g1s * G1c;
     pol.e1 = g1s * H01;
-    pol.f1 = free1 ? z1 : hu1 + H11 * v1;
+    pol.f1 = fmaf(f1m, z1, n1m * fmaf(H11, v1, hu1)); // z1 if free, the multiplier's constant term if fixed
     const float H00r = H00 - t1 * H01;
     G0c -= t1 * G1c;
     hu0 += H01 * z1;
-    const bool free0 = (st0 == ST_FREE);
-    const bool bad0 = free0 && !(H00r > 0.0f);
-    const float inv00 = __builtin_amdgcn_rcpf(H00r);
-    const float w0 = free0 ? inv00 : 0.0f;
-    const float z0 = free0 ? -hu0 * inv00 : v0;
-    const float g0s = free0 ? -w0 : 1.0f;
+    const bool bad0 = (f0m > 0.0f) && !(H00r > 0.0f);
+    const float w0 = __builtin_amdgcn_rcpf(H00r) * f0m;
+    const float z0 = fmaf(-hu0, w0, v0);
+    const float g0s = n0m - w0;
     pol.c0c = g0s * G0c;
-    pol.f0 = free0 ? z0 : hu0 + H00r * v0;
+    pol.f0 = fmaf(f0m, z0, n0m * fmaf(H00r, v0, hu0));
     if (need_value) {
         // row r of Q + A' P A and of q + A' s
         const float m = a * V.P0 + b * V.P1 + V.P2; // (P A)[r][2]
@@ -479,6 +482,7 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
             const int s1 = (bnd.w - bnd.z > BOUNDTOL) ? asm_status_of(c1, bnd.z, bnd.w) : ST_LOWER;
             rec[S_SB * 4 + 3] = c0; rec[S_DX * 4 + 3] = c1;
             *reinterpret_cast<float2*>(rec + S_STDU * 4) = make_float2(__int_as_float(s0), __int_as_float(s1));
+            write_fix(rec, s0, s1, bnd.x, bnd.y, bnd.z, bnd.w);
         }
     }
     wave_sync();
@@ -572,6 +576,7 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
                     }
                     rec[S_SB * 4 + 3] = c0; rec[S_DX * 4 + 3] = c1;
                     *reinterpret_cast<float2*>(rec + S_STDU * 4) = make_float2(__int_as_float(st0), __int_as_float(st1));
+                    write_fix(rec, st0, st1, bnd.x, bnd.y, bnd.z, bnd.w);
                 }
             }
             if (!blocked && !release) todo = 0;     // optimal
@@ -731,8 +736,9 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 st4(rec, S_Q + 1, w[5], w[6], w[7], q1);
                 st4(rec, S_Q + 2, w[10], w[11], w[12], q2);
                 st4(rec, S_BND, lb0, ub0, lb1, ub1);
-                st4(rec, S_STDU, __int_as_float(status_from_dual(uy.z, lb0, ub0)),
-                    __int_as_float(status_from_dual(uy.w, lb1, ub1)), 0.0f, 0.0f);
+                const int is0_ = status_from_dual(uy.z, lb0, ub0), is1_ = status_from_dual(uy.w, lb1, ub1);
+                st4(rec, S_STDU, __int_as_float(is0_), __int_as_float(is1_), 0.0f, 0.0f);
+                write_fix(rec, is0_, is1_, lb0, ub0, lb1, ub1);
             } else {
                 const float* tn = stg + SG.term; // WN (9), yN (3): staged with the other inputs
                 const float e0 = xk.x - tn[9], e1 = xk.y - tn[10], e2 = xk.z - tn[11];
@@ -848,6 +854,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                     const int n0 = (ub0 - lb0 > BOUNDTOL) ? ((u0 <= lb0) ? ST_LOWER : ((u0 >= ub0) ? ST_UPPER : ST_FREE)) : ST_LOWER;
                     const int n1 = (ub1 - lb1 > BOUNDTOL) ? ((u1 <= lb1) ? ST_LOWER : ((u1 >= ub1) ? ST_UPPER : ST_FREE)) : ST_LOWER;
                     *reinterpret_cast<float2*>(rec + S_STDU * 4) = make_float2(__int_as_float(n0), __int_as_float(n1));
+                    write_fix(rec, n0, n1, lb0, ub0, lb1, ub1);
                 }
             }
             wave_sync();
@@ -987,6 +994,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                         *reinterpret_cast<float2*>(rec + S_MU * 4) = make_float2(o.mu0, o.mu1);
                         rec[S_DX * 4] = dx0; rec[S_DX * 4 + 1] = dx1; rec[S_DX * 4 + 2] = dx2;
                         st4(rec, S_STDU, __int_as_float(o.nst0), __int_as_float(o.nst1), o.du0, o.du1);
+                        write_fix(rec, o.nst0, o.nst1, bnd.x, bnd.y, bnd.z, bnd.w);
                     }
                     if (first) { // free response (du = 0): A is a shear, so two chained prefix sums do it
                         const float e2 = prefix_sum<L>(sc2, j);            // sum_{i<=k} d2_i
