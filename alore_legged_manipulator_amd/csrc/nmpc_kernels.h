@@ -28,6 +28,7 @@ struct LaunchGeom {
     int L;       // lanes per problem
     int G;       // problems per wavefront
     int wpb;     // wavefronts per workgroup (1 or 4)
+    int wreg;    // 1: W_k of a stage lives in the registers of its lane, not in the LDS staging area
     int threads; // = L * G, multiple of 64
     int grid;
     int RS;
@@ -35,7 +36,7 @@ struct LaunchGeom {
 };
 
 // number of LDS floats one problem needs (before padding) for horizon N
-int rti_row_floats(int N);
+int rti_row_floats(int N, bool wreg);
 // choose lanes/problem + block shape for (B, N); returns false if N does not fit
 bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int forced_wpb = 0);
 hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s);

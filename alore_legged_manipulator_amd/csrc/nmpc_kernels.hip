@@ -49,11 +49,11 @@ __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 struct Staging {
     int W, y, od, lb, ub, term, end; // float offsets from the start of the staging area (term: WN[9], yN[3])
 };
-__host__ __device__ inline Staging staging_layout(int N)
+__host__ __device__ inline Staging staging_layout(int N, bool wreg = false)
 {
     Staging s;
     s.W = 0;
-    s.y = s.W + pad4(25 * N);
+    s.y = s.W + (wreg ? 0 : pad4(25 * N)); // wreg: W only passes through (folded into the records), then lives in registers
     s.od = s.y + pad4(5 * N);
     s.lb = s.od + pad4(3 * (N + 1));
     s.ub = s.lb + pad4(2 * N);
@@ -62,7 +62,7 @@ __host__ __device__ inline Staging staging_layout(int N)
     return s;
 }
 
-int rti_row_floats(int N) { return SR * (N + 1) + staging_layout(N).end; }
+int rti_row_floats(int N, bool wreg) { return SR * (N + 1) + staging_layout(N, wreg).end; }
 
 bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int forced_wpb)
 {
@@ -80,7 +80,14 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
     if (L != 4 && L != 8 && L != 16 && L != 32 && L != 64) return false;
     for (; L <= 64; L *= 2) {
         // rows of one wavefront must start on different 16-byte bank slots: RS/4 not a multiple of 16
-        int RS = rti_row_floats(N);
+        // Long horizons: the staged copy of W (100 B per stage) is what keeps residency below two wavefronts per
+        // SIMD; with one lane per node (N + 1 <= L) the lane keeps its W_k in registers instead.
+        int RS = rti_row_floats(N, false);
+        bool wreg = false;
+        if (L >= 32 && N + 1 <= L && 8L * (64 / L) * 4 * RS > lds_limit_bytes) {
+            wreg = true;
+            RS = rti_row_floats(N, true);
+        }
         if ((RS & 63) == 0) RS += 4;
         const long row_bytes = 4L * RS;
         const int G = 64 / L; // one wavefront per workgroup
@@ -96,6 +103,7 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
         g->L = L;
         g->G = G;
         g->wpb = wpb;
+        g->wreg = wreg ? 1 : 0;
         g->threads = 64 * wpb;
         g->grid = (B + G * wpb - 1) / (G * wpb);
         g->RS = RS;
@@ -589,7 +597,7 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
 }
 
 // one wavefront per workgroup, G = 64 / L problems per wavefront
-template <int L, bool STAMP, int WPB>
+template <int L, bool STAMP, int WPB, bool WREG>
 __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
 {
     extern __shared__ float4 lds_raw[];
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
     const float* gub = p.b.ubValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * N * 2);
 
     // ---- phase 0: coalesced loads.  Read-only inputs -> staging, iterate (x, u, dual) -> records.
-    const Staging SG = staging_layout(N);
+    const Staging SG = staging_layout(N, WREG);
     float* stg = row + (N + 1) * SR;
     {
         constexpr int UW = (128 + L - 1) / L; // first batch: up to 128 float4 of W (a 20-node horizon)
@@ -641,7 +649,18 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
         ldg_scl<L, UX>(gu, 2 * N, j, fu);
         ldg_scl<L, UX>(gdual, 2 * N, j, fd);
         const float fterm = (j < 9) ? gWN[j] : ((j < 12) ? gyN[j - 9] : 0.0f); // terminal weights and reference (L >= 12)
-        if (vW) sts_vec<L, UW>(stg + SG.W, (25 * N) >> 2, j, qW);
+        auto wfold = [&](int i) { return row + (i >> 6) * SR + (i & 63); }; // WREG: float i of W in slots 0..15 of record i / 64
+        if (vW) {
+            if constexpr (WREG) {
+#pragma unroll
+                for (int u = 0; u < UW; ++u) {
+                    const int i = u * L + j;
+                    if (i < ((25 * N) >> 2)) *reinterpret_cast<float4*>(wfold(4 * i)) = qW[u];
+                }
+            } else {
+                sts_vec<L, UW>(stg + SG.W, (25 * N) >> 2, j, qW);
+            }
+        }
         if (vy) sts_vec<L, UV>(stg + SG.y, (5 * N) >> 2, j, qy);
         if (vb) { sts_vec<L, UV>(stg + SG.lb, (2 * N) >> 2, j, qlb); sts_vec<L, UV>(stg + SG.ub, (2 * N) >> 2, j, qub); }
 #pragma unroll
@@ -660,7 +679,8 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
         if (L >= 12) { if (j < 12) stg[SG.term + j] = fterm; }
         else { for (int i = j; i < 12; i += L) stg[SG.term + i] = (i < 9) ? gWN[i] : gyN[i - 9]; }
         // whatever the first batch did not cover
-        copy_tail<L>(gW, stg + SG.W, vW ? min(25 * N, 4 * UW * L) : 0, 25 * N, j);
+        if constexpr (WREG) { for (int i = (vW ? min(25 * N, 4 * UW * L) : 0) + j; i < 25 * N; i += L) *wfold(i) = gW[i]; }
+        else copy_tail<L>(gW, stg + SG.W, vW ? min(25 * N, 4 * UW * L) : 0, 25 * N, j);
         copy_tail<L>(gy, stg + SG.y, vy ? min(5 * N, 4 * UV * L) : 0, 5 * N, j);
         copy_tail<L>(glb, stg + SG.lb, vb ? min(2 * N, 4 * UV * L) : 0, 2 * N, j);
         copy_tail<L>(gub, stg + SG.ub, vb ? min(2 * N, 4 * UV * L) : 0, 2 * N, j);
@@ -675,6 +695,17 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
     const float x00 = p.b.x0[(size_t)prob * 3], x01 = p.b.x0[(size_t)prob * 3 + 1],
                 x02 = p.b.x0[(size_t)prob * 3 + 2];
     wave_sync();
+    // WREG: W_j of this lane's stage from the folded pass-through area into registers, for the whole launch
+    float wreg[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) wreg[i] = 0.0f;
+    if constexpr (WREG) {
+        if (j < N) {
+#pragma unroll
+            for (int i = 0; i < 25; ++i) wreg[i] = row[((25 * j + i) >> 6) * SR + ((25 * j + i) & 63)];
+        }
+        wave_sync(); // the records are about to overwrite the pass-through area
+    }
 
     // row role of this lane inside its quad (backward sweep)
     const int rq = j & 3;
@@ -714,10 +745,9 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 // Dy = h(x,u) - y ; gradient = W[rows] * Dy ; Hessian blocks of W
                 const float* yk = stg + SG.y + k * 5;
                 const float e0 = xk.x - yk[0], e1 = xk.y - yk[1], e2 = xk.z - yk[2], e3 = vr - yk[3], e4 = vl - yk[4];
-                const float* Wk = stg + SG.W + k * 25;
                 float w[25];
 #pragma unroll
-                for (int i = 0; i < 25; ++i) w[i] = Wk[i];
+                for (int i = 0; i < 25; ++i) w[i] = WREG ? wreg[i] : stg[SG.W + k * 25 + i]; // WREG: k == j
                 const float q0 = w[0] * e0 + w[1] * e1 + w[2] * e2 + w[3] * e3 + w[4] * e4;
                 const float q1 = w[5] * e0 + w[6] * e1 + w[7] * e2 + w[8] * e3 + w[9] * e4;
                 const float q2 = w[10] * e0 + w[11] * e1 + w[12] * e2 + w[13] * e3 + w[14] * e4;
@@ -1084,7 +1114,9 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
         if (k < N) {
             const float4 uy = lds4(rec, S_UY);
             const float* yk = stg + SG.y + k * 5;
-            const float* Wk = stg + SG.W + k * 25;
+            float Wk[25];
+#pragma unroll
+            for (int i = 0; i < 25; ++i) Wk[i] = WREG ? wreg[i] : stg[SG.W + k * 25 + i];
             float e[5] = {xk.x - yk[0], xk.y - yk[1], xk.z - yk[2], uy.x - yk[3], uy.y - yk[4]};
             float acc = 0.0f;
 #pragma unroll
@@ -1137,12 +1169,19 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
     switch (g.L) {
 #define CASE(LL)                                                                                              \
     case LL: {                                                                                                \
-        static size_t configured[4] = {0, 0, 0, 0}; /* raise the dynamic-LDS cap once per size */             \
-        const int v = (stamp ? 1 : 0) + (g.wpb == 4 ? 2 : 0);                                                 \
-        const void* fn = v == 0   ? (const void*)rti_kernel<LL, false, 1>                                     \
-                         : v == 1 ? (const void*)rti_kernel<LL, true, 1>                                      \
-                         : v == 2 ? (const void*)rti_kernel<LL, false, 4>                                     \
-                                  : (const void*)rti_kernel<LL, true, 4>;                                     \
+        static size_t configured[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* raise the dynamic-LDS cap once per size */ \
+        const int v = (stamp ? 1 : 0) + (g.wpb == 4 ? 2 : 0) + ((g.wreg && LL >= 32) ? 4 : 0);                \
+        const void* fn = nullptr;                                                                             \
+        switch (v) {                                                                                          \
+        case 0: fn = (const void*)rti_kernel<LL, false, 1, false>; break;                                     \
+        case 1: fn = (const void*)rti_kernel<LL, true, 1, false>; break;                                      \
+        case 2: fn = (const void*)rti_kernel<LL, false, 4, false>; break;                                     \
+        case 3: fn = (const void*)rti_kernel<LL, true, 4, false>; break;                                      \
+        case 4: fn = (const void*)rti_kernel<LL, false, 1, (LL >= 32)>; break;                                \
+        case 5: fn = (const void*)rti_kernel<LL, true, 1, (LL >= 32)>; break;                                 \
+        case 6: fn = (const void*)rti_kernel<LL, false, 4, (LL >= 32)>; break;                                \
+        default: fn = (const void*)rti_kernel<LL, true, 4, (LL >= 32)>; break;                                \
+        }                                                                                                     \
         if (g.lds_bytes > configured[v]) {                                                                    \
             e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);        \
             if (e != hipSuccess) return e;                                                                    \
