@@ -21,6 +21,8 @@
 // (acado_preparationStep + acado_feedbackStep, CG/acado_solver.c:1057-1077) for the whole batch.
 #include "nmpc_kernels.h"
 
+#include <cstdlib>
+
 #include <type_traits>
 
 #include "nmpc_core.h"
@@ -84,7 +86,8 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
         // SIMD; with one lane per node (N + 1 <= L) the lane keeps its W_k in registers instead.
         int RS = rti_row_floats(N, false);
         bool wreg = false;
-        if (L >= 32 && N + 1 <= L && 8L * (64 / L) * 4 * RS > lds_limit_bytes) {
+        static const int force_wreg = getenv("ALORE_NMPC_WREG") ? atoi(getenv("ALORE_NMPC_WREG")) : -1; // diagnostic
+        if (L >= 32 && N + 1 <= L && (force_wreg == 1 || (force_wreg != 0 && 8L * (64 / L) * 4 * RS > lds_limit_bytes))) {
             wreg = true;
             RS = rti_row_floats(N, true);
         }
