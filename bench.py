@@ -195,13 +195,14 @@ def main():
     run_steps(0, a.warmup)
     barrier()
 
-    # the K timed steps, captured once into a hipGraph on a single GPU (K kernel nodes, no host launch overhead
-    # inside the timed region)
+    # the K timed steps, captured once into a hipGraph (K kernel nodes, no host launch overhead inside the timed
+    # region)
     graph = None
     used_graph = False
-    # (multi-rank runs launch eagerly: measured equal to the graph on one GPU -- 33.06 vs 32.9 us per step -- and
-    #  it keeps stream capture away from the RCCL watchdog thread)
-    if not a.no_graph and world == 1 and a.steps > 0:
+    # (also on multi-rank runs: no collective is enqueued during the capture, the capture is thread-local so the
+    #  RCCL watchdog thread cannot invalidate it, and any capture failure falls back to eager launches, which are
+    #  measured equal on an idle host: 25.5 us per step either way)
+    if not a.no_graph and not do_gather and a.steps > 0:
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
