@@ -355,7 +355,14 @@ __device__ __forceinline__ void ldg_vec(const float* g, int n4, int j, float4 (&
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int i = u * L + j;
-        q[u] = (i < n4) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) {
+            // read once, never again: non-temporal (streaming) loads
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g4 + i));
+            q[u] = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 template <int L, int U>

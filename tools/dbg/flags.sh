@@ -1,0 +1,7 @@
+#!/bin/bash
+# compiler flag variants built into ab/v_*.so
+for rep in 1 2; do for v in base slp bias0 trk memclause; do
+  [ -f ab/v_$v.so ] || continue
+  export ALORE_NMPC_LIB=$PWD/ab/v_$v.so
+  echo "$v: $(python bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 5 2>&1 | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"]*1e3,2), "us")' 2>&1)"
+done; done
