@@ -117,8 +117,11 @@ void* member_ptr(const alore_nmpc_batch* b, const Member& m)
 
 bool batch_complete(const alore_nmpc_batch* b)
 {
-    for (int i = 0; i < kNumMembers; ++i)
+    for (int i = 0; i < kNumMembers; ++i) {
+        const size_t off = kMembers[i].offset;
+        if (off == offsetof(alore_nmpc_batch, kkt) || off == offsetof(alore_nmpc_batch, obj)) continue; // optional
         if (!member_ptr(b, kMembers[i])) return false;
+    }
     return true;
 }
 

@@ -607,7 +607,7 @@ __device__ __forceinline__ int active_set_rescue(float* row, int N, int j, bool 
 }
 
 // one wavefront per workgroup, G = 64 / L problems per wavefront
-template <int L, bool STAMP, int WPB, bool WREG>
+template <int L, bool STAMP, int WPB, bool WREG, bool DIAG>
 __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
 {
     extern __shared__ float4 lds_raw[];
@@ -722,6 +722,10 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
     const int rr = (rq < 3) ? rq : 2; // lane 3 shadows lane 2 (rows_sum never reads it)
     const bool is2 = (rr == 2);
 
+    // acado_getKKT / acado_getObjective are separate calls in the reference, never made by its wrapper:
+    // computed here only when the caller asks for them (non-null kkt / obj)
+    // (DIAG = false: compiled out; chosen by the launcher when both pointers are null)
+    constexpr bool want_kkt = DIAG, want_obj = DIAG;
     int status = RET_OK, n_iter = 0;
     float kkt = 0.0f;
 
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
         for (int k = j; k <= N; k += L) {
             float* rec = row + k * SR;
             const float4 dxp = lds4(rec, S_DX), sb = lds4(rec, S_SB), xk = lds4(rec, S_X);
-            if (k > 0) { // (Q_k sbar_k + q_k)' (dx_k - sbar_k)
+            if (want_kkt && k > 0) { // (Q_k sbar_k + q_k)' (dx_k - sbar_k)
                 const float4 q0 = lds4(rec, S_Q), q1 = lds4(rec, S_Q + 1), q2 = lds4(rec, S_Q + 2);
                 const float t0 = dxp.x - sb.x, t1 = dxp.y - sb.y, t2 = dxp.z - sb.z;
                 gd += (q0.x * sb.x + q0.y * sb.y + q0.z * sb.z + q0.w) * t0 +
@@ -1106,16 +1110,18 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
             if (k < N) {
                 const float4 dd = lds4(rec, S_D), R = lds4(rec, S_R), bnd = lds4(rec, S_BND), sd = lds4(rec, S_STDU),
                              mu = lds4(rec, S_MU), uy = lds4(rec, S_UY);
-                gd += dd.w * sd.z + R.w * sd.w; // r' du
-                comp += (mu.x > 1e-12f) ? fabsf(bnd.x * mu.x) : ((mu.x < -1e-12f) ? fabsf(bnd.y * mu.x) : 0.0f);
-                comp += (mu.y > 1e-12f) ? fabsf(bnd.z * mu.y) : ((mu.y < -1e-12f) ? fabsf(bnd.w * mu.y) : 0.0f);
+                if (want_kkt) {
+                    gd += dd.w * sd.z + R.w * sd.w; // r' du
+                    comp += (mu.x > 1e-12f) ? fabsf(bnd.x * mu.x) : ((mu.x < -1e-12f) ? fabsf(bnd.y * mu.x) : 0.0f);
+                    comp += (mu.y > 1e-12f) ? fabsf(bnd.z * mu.y) : ((mu.y < -1e-12f) ? fabsf(bnd.w * mu.y) : 0.0f);
+                }
                 // a free control may sit up to TOL_PRIMAL outside its box: keep the iterate feasible
                 const float du0 = (bnd.x <= bnd.y) ? clampf(sd.z, bnd.x, bnd.y) : sd.z;
                 const float du1 = (bnd.z <= bnd.w) ? clampf(sd.w, bnd.z, bnd.w) : sd.w;
                 st4(rec, S_UY, uy.x + du0, uy.y + du1, mu.x, mu.y);
             }
         }
-        kkt = fabsf(group_total<L>(gd, j)) + group_total<L>(comp, j);
+        if (want_kkt) kkt = fabsf(group_total<L>(gd, j)) + group_total<L>(comp, j);
         wave_sync();
     }
     if (STAMP) t_stamp[5] = __builtin_amdgcn_s_memtime();
@@ -1127,19 +1133,21 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
         const float4 xk = lds4(rec, S_X);
         if (k < N) {
             const float4 uy = lds4(rec, S_UY);
-            const float* yk = stg + SG.y + k * 5;
-            float Wk[25];
+            if (want_obj) {
+                const float* yk = stg + SG.y + k * 5;
+                float Wk[25];
 #pragma unroll
-            for (int i = 0; i < 25; ++i) Wk[i] = WREG ? wreg[i] : stg[SG.W + k * 25 + i];
-            float e[5] = {xk.x - yk[0], xk.y - yk[1], xk.z - yk[2], uy.x - yk[3], uy.y - yk[4]};
-            float acc = 0.0f;
+                for (int i = 0; i < 25; ++i) Wk[i] = WREG ? wreg[i] : stg[SG.W + k * 25 + i];
+                float e[5] = {xk.x - yk[0], xk.y - yk[1], xk.z - yk[2], uy.x - yk[3], uy.y - yk[4]};
+                float acc = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                const float t = e[0] * Wk[c] + e[1] * Wk[5 + c] + e[2] * Wk[10 + c] + e[3] * Wk[15 + c] +
-                                e[4] * Wk[20 + c];
-                acc += e[c] * t;
+                for (int c = 0; c < 5; ++c) {
+                    const float t = e[0] * Wk[c] + e[1] * Wk[5 + c] + e[2] * Wk[10 + c] + e[3] * Wk[15 + c] +
+                                    e[4] * Wk[20 + c];
+                    acc += e[c] * t;
+                }
+                part += acc;
             }
-            part += acc;
             if (valid) {
                 float* ou = p.b.u + (size_t)prob * N * 2;
                 float* od = p.b.dual + (size_t)prob * N * 2;
@@ -1147,21 +1155,24 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 od[k * 2] = uy.z; od[k * 2 + 1] = uy.w;
             }
         } else { // the reference uses only the diagonal of WN here (acado_solver.c:1442-1444)
-            const float* tn = stg + SG.term;
-            const float e0 = xk.x - tn[9], e1 = xk.y - tn[10], e2 = xk.z - tn[11];
-            part += e0 * e0 * tn[0] + e1 * e1 * tn[4] + e2 * e2 * tn[8];
+            if (want_obj) {
+                const float* tn = stg + SG.term;
+                const float e0 = xk.x - tn[9], e1 = xk.y - tn[10], e2 = xk.z - tn[11];
+                part += e0 * e0 * tn[0] + e1 * e1 * tn[4] + e2 * e2 * tn[8];
+            }
         }
         if (valid) {
             float* ox = p.b.x + (size_t)prob * (N + 1) * 3;
             ox[k * 3] = xk.x; ox[k * 3 + 1] = xk.y; ox[k * 3 + 2] = xk.z;
         }
     }
-    const float obj = 0.5f * group_total<L>(part, j);
+    float obj = 0.0f;
+    if (want_obj) obj = 0.5f * group_total<L>(part, j);
     if (valid && writer) {
         p.b.status[prob] = status;
         p.b.n_iter[prob] = n_iter;
-        p.b.kkt[prob] = kkt;
-        p.b.obj[prob] = obj;
+        if (want_kkt && p.b.kkt) p.b.kkt[prob] = kkt;
+        if (want_obj && p.b.obj) p.b.obj[prob] = obj;
     }
     if (STAMP && lane == 0 && p.stamps) {
         long long* o = p.stamps + ((size_t)blockIdx.x * WPB + wave) * 8;
@@ -1183,18 +1194,24 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
     switch (g.L) {
 #define CASE(LL)                                                                                              \
     case LL: {                                                                                                \
-        static size_t configured[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* raise the dynamic-LDS cap once per size */ \
-        const int v = (stamp ? 1 : 0) + (g.wpb == 4 ? 2 : 0) + ((g.wreg && LL >= 32) ? 4 : 0);                \
+        static size_t configured[16] = {0}; /* raise the dynamic-LDS cap once per size */                     \
+        constexpr bool WR = (LL >= 32);                                                                       \
+        const bool diag = stamp || p.b.kkt != nullptr || p.b.obj != nullptr;                                  \
+        const int v = (stamp ? 1 : 0) + (g.wpb == 4 ? 2 : 0) + ((g.wreg && WR) ? 4 : 0) + (diag ? 0 : 8);    \
         const void* fn = nullptr;                                                                             \
         switch (v) {                                                                                          \
-        case 0: fn = (const void*)rti_kernel<LL, false, 1, false>; break;                                     \
-        case 1: fn = (const void*)rti_kernel<LL, true, 1, false>; break;                                      \
-        case 2: fn = (const void*)rti_kernel<LL, false, 4, false>; break;                                     \
-        case 3: fn = (const void*)rti_kernel<LL, true, 4, false>; break;                                      \
-        case 4: fn = (const void*)rti_kernel<LL, false, 1, (LL >= 32)>; break;                                \
-        case 5: fn = (const void*)rti_kernel<LL, true, 1, (LL >= 32)>; break;                                 \
-        case 6: fn = (const void*)rti_kernel<LL, false, 4, (LL >= 32)>; break;                                \
-        default: fn = (const void*)rti_kernel<LL, true, 4, (LL >= 32)>; break;                                \
+        case 0: fn = (const void*)rti_kernel<LL, false, 1, false, true>; break;                               \
+        case 1: fn = (const void*)rti_kernel<LL, true, 1, false, true>; break;                                \
+        case 2: fn = (const void*)rti_kernel<LL, false, 4, false, true>; break;                               \
+        case 3: fn = (const void*)rti_kernel<LL, true, 4, false, true>; break;                                \
+        case 4: fn = (const void*)rti_kernel<LL, false, 1, WR, true>; break;                                  \
+        case 5: fn = (const void*)rti_kernel<LL, true, 1, WR, true>; break;                                   \
+        case 6: fn = (const void*)rti_kernel<LL, false, 4, WR, true>; break;                                  \
+        case 7: fn = (const void*)rti_kernel<LL, true, 4, WR, true>; break;                                   \
+        case 8: fn = (const void*)rti_kernel<LL, false, 1, false, false>; break;                              \
+        case 10: fn = (const void*)rti_kernel<LL, false, 4, false, false>; break;                             \
+        case 12: fn = (const void*)rti_kernel<LL, false, 1, WR, false>; break;                                \
+        default: fn = (const void*)rti_kernel<LL, false, 4, WR, false>; break;                                \
         }                                                                                                     \
         if (g.lds_bytes > configured[v]) {                                                                    \
             e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);        \

@@ -44,7 +44,7 @@ class BatchedNmpc:
     starts from the same iterate."""
 
     def __init__(self, B: int, N: int = 20, dt: float = 0.01, device: int = 0, max_as_iter: int = 0,
-                 lanes_per_problem: int = 0, slots: int = 1, warm_start_steps: int = -1):
+                 lanes_per_problem: int = 0, slots: int = 1, warm_start_steps: int = -1, diagnostics: bool = True):
         import torch  # device memory + streams
         self.torch = torch
         self.lib = _lib.load()  # raises if the HIP library is missing: no fallback
@@ -64,7 +64,11 @@ class BatchedNmpc:
             dt_ = torch.int32 if k in ("status", "n_iter") else torch.float32
             self.ts[k] = torch.zeros((self.slots,) + shp, dtype=dt_, device=self.device)
         self.t = {k: v[0] for k, v in self.ts.items()}
-        self._batches = [Batch(**{k: self.ts[k][s].data_ptr() for k in BATCH_MEMBERS}) for s in range(self.slots)]
+        # diagnostics=False: kkt / obj are not asked for (NULL pointers) and the kernel skips them, like the
+        # reference's tick, which never calls acado_getKKT / acado_getObjective
+        skip = () if diagnostics else ("kkt", "obj")
+        self._batches = [Batch(**{k: (None if k in skip else self.ts[k][s].data_ptr()) for k in BATCH_MEMBERS})
+                         for s in range(self.slots)]
         self._batch = self._batches[0]
         for b in self._batches:
             self._check(self.lib.alore_nmpc_batch_default_bounds(self.h, C.byref(b), self.B, self._stream()))

@@ -450,6 +450,23 @@ def main():
             del e8
         except Exception as e:  # pragma: no cover
             extras["compact_io"] = {"error": f"{type(e).__name__}: {e}"}
+        # the tick as the reference runs it: acado_getKKT / acado_getObjective are never called by its wrapper;
+        # with NULL kkt / obj the kernel skips them (the headline computes them)
+        try:
+            e9 = BatchedNmpc(B, N, device=local_rank, slots=24, diagnostics=False)
+            e9.load(batch, slot=None)
+            e9.rti(1, slot=0); e9.rti(1, slot=1)
+            torch.cuda.synchronize(dev)
+            c0.record()
+            for i in range(2, 24):
+                e9.rti(1, slot=i)
+            c1.record(); torch.cuda.synchronize(dev)
+            msd = c0.elapsed_time(c1) / 22
+            extras["without_diagnostics"] = {"ms_per_launch": msd, "solves_per_s": B / (msd * 1e-3),
+                                             "unsolved": int((e9.ts["status"][2:24] != 0).sum().item())}
+            del e9
+        except Exception as e:  # pragma: no cover
+            extras["without_diagnostics"] = {"error": f"{type(e).__name__}: {e}"}
         # the reference's own generated horizon (N = 50), same batch size: next to the compiled reference's
         # single-core time in cpu_baseline.reference_n50_single_core_us_per_solve
         try:

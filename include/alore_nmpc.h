@@ -121,8 +121,10 @@ int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch 
  * acado_preparationStep() on (x,u) followed by acado_feedbackStep()
  * (acado_solver.c:1057-1077): integrate + sensitivities, objective, QP, expand.
  * n_sqp = 1 is one reference control tick (MpcWrapper::update,
- * mpc_wrapper.cpp:279-373).  x, u, dual are updated in place; status, n_iter,
- * kkt, obj are written. */
+ * mpc_wrapper.cpp:279-373).  x, u, dual are updated in place; status, n_iter are
+ * written.  kkt and obj (acado_getKKT / acado_getObjective, acado_solver.c:1373-1450:
+ * separate calls in the reference, never made by its wrapper) are computed and written
+ * when the batch has non-NULL pointers for them, and skipped otherwise. */
 int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int n_sqp, void *stream);
 
 /* ACADO split semantics.  The reference prepares (linearises, evaluates h(x,u)) in

@@ -388,3 +388,17 @@ def test_shared_members_give_the_replicated_results(nmpc_mod):
     assert (got["status"] == 0).all()
     for k in ("x", "u", "dual", "kkt", "obj", "n_iter"):
         assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.gpu
+def test_without_diagnostics_same_solution(nmpc_mod):
+    """kkt / obj NULL in the batch: the diagnostics are skipped, everything else is bit-identical."""
+    N, B = 20, 257
+    batch = make_batch(B, N, seed=41, fast_tail=0.3)
+    a = nmpc_mod.BatchedNmpc(B, N); a.load(batch); a.rti(2); oa = a.fetch()
+    b = nmpc_mod.BatchedNmpc(B, N, diagnostics=False); b.load(batch)
+    b.t["kkt"].fill_(-7.0); b.t["obj"].fill_(-7.0)
+    b.rti(2); ob = b.fetch()
+    for k in ("x", "u", "dual", "status", "n_iter"):
+        assert np.array_equal(oa[k], ob[k]), k
+    assert (ob["kkt"] == -7.0).all() and (ob["obj"] == -7.0).all()      # untouched
