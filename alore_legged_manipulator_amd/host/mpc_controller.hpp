@@ -182,7 +182,9 @@ public:
         if (dirty_iterate_) { host.x = x_.data(); host.u = u_.data(); }
         check(alore_nmpc_batch_upload(h_, &dev_, &host, B, nullptr));
         dirty_costs_ = dirty_iterate_ = false;
-        check(alore_nmpc_rti(h_, &dev_, B, 1, nullptr));
+        alore_nmpc_batch run = dev_; // the wrapper never asks for KKT value or objective (nor does the reference's)
+        run.kkt = nullptr; run.obj = nullptr;
+        check(alore_nmpc_rti(h_, &run, B, 1, nullptr));
         alore_nmpc_batch out{};
         out.x = x_.data(); out.u = u_.data(); out.status = status_.data();
         check(alore_nmpc_batch_download(h_, &dev_, &out, B, nullptr));

@@ -406,7 +406,7 @@ def main():
             T = np.array([1.0, 1.0, 1.0]); Tc = np.cumsum(T)
             msgs = [Polynome(np.stack([w * Tc[:-1], v * Tc[:-1]], 1), T, [0, 0, w, v, 0, 0], [w * Tc[-1], v * Tc[-1], w, v, 0, 0],
                              [0, 0, 0], [-0.3, 0.3, 0.1], 0.0) for v, w in vw]
-            e7 = BatchedNmpc(B, N, device=local_rank)
+            e7 = BatchedNmpc(B, N, device=local_rank, diagnostics=False)   # like the reference's tick
             e7.load({k: batch[k] for k in ("W", "WN", "lbValues", "ubValues")})
             e7.refs_init(max_pieces=4, max_checkpoints=40)
             e7.refs_set_polynomes(np.arange(B), msgs)
