@@ -391,9 +391,10 @@ def test_shared_members_give_the_replicated_results(nmpc_mod):
 
 
 @pytest.mark.gpu
-def test_without_diagnostics_same_solution(nmpc_mod):
-    """kkt / obj NULL in the batch: the diagnostics are skipped, everything else is bit-identical."""
-    N, B = 20, 257
+@pytest.mark.parametrize("N,B", [(20, 257), (50, 70), (20, 2100), (7, 33)])
+def test_without_diagnostics_same_solution(nmpc_mod, N, B):
+    """kkt / obj NULL in the batch: the diagnostics are skipped, everything else is bit-identical (all kernel
+    variants: one / four wavefronts per workgroup, register-resident weights at N = 50)."""
     batch = make_batch(B, N, seed=41, fast_tail=0.3)
     a = nmpc_mod.BatchedNmpc(B, N); a.load(batch); a.rti(2); oa = a.fetch()
     b = nmpc_mod.BatchedNmpc(B, N, diagnostics=False); b.load(batch)
