@@ -604,6 +604,13 @@ int alore_nmpc_closed_loop_tick(alore_nmpc_handle h, const alore_nmpc_batch* dev
     return ALORE_NMPC_OK;
 }
 
+int alore_nmpc_refs_at_goal(alore_nmpc_handle h, int B, int* at_goal, void* stream)
+{
+    if (!h || !h->refs.dur || B <= 0 || B > h->refs_B || !at_goal) return fail(h, ALORE_NMPC_E_INVALID, "refs_at_goal: bad argument");
+    HIP_TRY(h, hipMemcpyAsync(at_goal, h->d_goal, sizeof(int) * B, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
 int alore_nmpc_set_shared_members(alore_nmpc_handle h, unsigned mask)
 {
     if (!h || (mask & ~(unsigned)(ALORE_NMPC_SHARED_W | ALORE_NMPC_SHARED_BOUNDS | ALORE_NMPC_SHARED_OD)))

@@ -117,6 +117,7 @@ public:
     // mpc_wrapper.cpp:267-275: reset the iterate of robot b (x <- state replicated, u <- 0)
     void resetIterate(int b, const double state[3])
     {
+        refreshStates(); // the whole mirror is uploaded with the next update: it must be current first
         for (int k = 0; k <= kSamples; ++k)
             for (int i = 0; i < 3; ++i) x_[((size_t)b * (kSamples + 1) + k) * 3 + i] = (float)state[i];
         std::fill(u_.begin() + (size_t)b * 2 * kSamples, u_.begin() + (size_t)(b + 1) * 2 * kSamples, 0.f);
@@ -166,9 +167,11 @@ public:
         check(alore_nmpc_refs_set_polynomes(h_, (int)pm.size(), robots.data(), pm.data(), state_seq_res, integral_res_int, nullptr));
     }
     // getRefPoints + smooth_yaw + setTrajectory + setICRParameters + the x0 of update() for all robots
+    // at_goal is filled by the time the next update() returns (one synchronisation per tick)
     void sampleDeviceRefs(double now, const double* est /* B x 3 */, const double* icr /* B x 3: xv yr yl */, int* at_goal)
     {
-        check(alore_nmpc_refs_sample(h_, &dev_, B, now, est, icr, 1, at_goal, nullptr));
+        check(alore_nmpc_refs_sample(h_, &dev_, B, now, est, icr, 1, nullptr, nullptr));
+        pending_goal_ = at_goal;
     }
 
     // mpc_wrapper.cpp:279-373 for all robots at once: states = B x 3
@@ -185,9 +188,11 @@ public:
         alore_nmpc_batch run = dev_; // the wrapper never asks for KKT value or objective (nor does the reference's)
         run.kkt = nullptr; run.obj = nullptr;
         check(alore_nmpc_rti(h_, &run, B, 1, nullptr));
-        alore_nmpc_batch out{};
-        out.x = x_.data(); out.u = u_.data(); out.status = status_.data();
+        alore_nmpc_batch out{}; // the tick needs the inputs and the status; the predicted states come on demand
+        out.u = u_.data(); out.status = status_.data();
+        x_stale_ = true;
         check(alore_nmpc_batch_download(h_, &dev_, &out, B, nullptr));
+        if (pending_goal_) { check(alore_nmpc_refs_at_goal(h_, B, pending_goal_, nullptr)); pending_goal_ = nullptr; }
         if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("hipStreamSynchronize");
         acado_is_prepared_ = false;
         if (do_preparation) acado_is_prepared_ = true; // the preparation is fused into the next launch
@@ -210,6 +215,7 @@ public:
     // mpc_wrapper.cpp:386-410 (double out)
     void getStates(int b, double* out /* 3 x (N+1) col-major */) const
     {
+        refreshStates();
         for (int i = 0; i < 3 * (kSamples + 1); ++i) out[i] = x_[(size_t)b * 3 * (kSamples + 1) + i];
     }
     void getInputs(int b, double* out /* 2 x N col-major */) const
@@ -221,6 +227,15 @@ public:
     double getTimestep() const { return dt_; }
 
 private:
+    void refreshStates() const
+    {
+        if (!x_stale_) return;
+        alore_nmpc_batch out{};
+        out.x = const_cast<float*>(x_.data());
+        check(alore_nmpc_batch_download(h_, &dev_, &out, B, nullptr));
+        if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("hipStreamSynchronize");
+        x_stale_ = false;
+    }
     void check(int rc) const
     {
         if (rc != ALORE_NMPC_OK) throw std::runtime_error(std::string("alore_nmpc: ") + alore_nmpc_last_error(h_));
@@ -238,6 +253,8 @@ private:
     std::vector<float> x_, u_, od_, y_, yN_, W_, WN_, x0_;
     std::vector<int> status_;
     bool acado_is_prepared_ = false, dirty_costs_ = true, dirty_iterate_ = true, device_refs_ = false;
+    mutable bool x_stale_ = false; // x_ lags the device copy (downloaded on demand)
+    int* pending_goal_ = nullptr;
     const double dt_;
 };
 
@@ -395,9 +412,9 @@ public:
     {
         const int B = mpc_wrapper_.B, N = mpc_wrapper_.kSamples;
         std::vector<double> est((size_t)B * 3, 0.0);
+        std::vector<int> goal(B, 0); // device-reference mode: at_goal flags, fetched with the results
         if (mpc_wrapper_.deviceRefs()) {
             std::vector<double> icr((size_t)B * 3, 0.0);
-            std::vector<int> goal(B, 0);
             std::vector<int> fresh_robots;
             std::vector<const Polynome*> fresh_msgs;
             for (int b = 0; b < B; ++b) {
@@ -414,9 +431,7 @@ public:
             }
             if (!fresh_robots.empty())
                 mpc_wrapper_.setDevicePolynomes(fresh_robots, fresh_msgs, state_seq_res_, integral_res_int_);
-            mpc_wrapper_.sampleDeviceRefs(now, est.data(), icr.data(), goal.data());
-            for (int b = 0; b < B; ++b)
-                if (uploaded_version_[b]) robots[b].at_goal = goal[b] != 0;
+            mpc_wrapper_.sampleDeviceRefs(now, est.data(), icr.data(), goal.data()); // goal: valid after update()
         }
         for (int b = 0; b < B && !mpc_wrapper_.deviceRefs(); ++b) {
             RefSampler& r = robots[b];
@@ -436,6 +451,9 @@ public:
             mpc_wrapper_.update(est.data(), false);
         }
         mpc_wrapper_.prepare(); // the reference's preparation thread (mpc.cpp:336, 394-403)
+        if (mpc_wrapper_.deviceRefs())
+            for (int b = 0; b < B; ++b)
+                if (uploaded_version_[b]) robots[b].at_goal = goal[b] != 0;
         for (int b = 0; b < B; ++b) {
             const int node = delay_num_ < N ? delay_num_ : N - 1;
             cmd[b * 2 + 0] = mpc_wrapper_.getInput(b, node, kVr);
