@@ -868,8 +868,8 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 // lengths s's / s'y lie in (0, 1]); no eigenvalue estimate is needed
                 float u0 = clampf(j0, lb0, ub0), u1 = clampf(j1, lb1, ub1);
                 float pu0 = 0.0f, pu1 = 0.0f, pg0 = g0, pg1 = g1, alpha = 1.0f;
-                // pg_steps steps, then up to as many again while the predicted set of the wavefront still moves
-                const int max_steps = 2 * p.pg_steps;
+                // pg_steps steps, then up to half as many again while the predicted set of the problem still moves
+                const int max_steps = p.pg_steps + p.pg_steps / 2;
                 auto at_bounds = [&](float a0_, float a1_) {
                     return (a0_ <= lb0 ? 1 : 0) | (a0_ >= ub0 ? 2 : 0) | (a1_ <= lb1 ? 4 : 0) | (a1_ >= ub1 ? 8 : 0);
                 };
