@@ -48,8 +48,8 @@ def algorithmic_bytes_per_solve(N: int) -> int:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = auto)")

@@ -38,6 +38,6 @@ int main()
 {
     float* out; long long* cyc;
     (void)hipMalloc(&out, 1024 * 4); (void)hipMalloc(&cyc, 8 * 16);
-    for (int w : {1, 2, 3, 4}) { run<1>(out, cyc, w); run<8>(out, cyc, w); }
+    for (int w : {1, 2, 3, 4}) { run<1>(out, cyc, w); run<2>(out, cyc, w); run<4>(out, cyc, w); run<8>(out, cyc, w); }
     return 0;
 }
