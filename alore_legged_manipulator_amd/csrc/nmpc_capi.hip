@@ -619,6 +619,17 @@ int alore_nmpc_set_shared_members(alore_nmpc_handle h, unsigned mask)
     return ALORE_NMPC_OK;
 }
 
+int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, double t0, double dt_tick, int n_ticks,
+                               int delay_num, void* stream)
+{
+    if (n_ticks < 0 || !(dt_tick > 0.0)) return fail(h, ALORE_NMPC_E_INVALID, "closed_loop_run: bad argument");
+    for (int t = 0; t < n_ticks; ++t) {
+        const int rc = alore_nmpc_closed_loop_tick(h, dev, B, t0 + dt_tick * t, delay_num, stream);
+        if (rc != ALORE_NMPC_OK) return rc;
+    }
+    return ALORE_NMPC_OK;
+}
+
 int alore_nmpc_set_linearization_point(alore_nmpc_handle h, const float* x_lin, const float* u_lin)
 {
     if (!h || ((x_lin == nullptr) != (u_lin == nullptr))) return fail(h, ALORE_NMPC_E_INVALID, "linearization point: bad argument");

@@ -212,6 +212,11 @@ class BatchedNmpc:
         self._check(self.lib.alore_nmpc_closed_loop_tick(self.h, C.byref(self._batches[slot]), self.B, float(now),
                                                          int(delay_num), self._stream()))
 
+    def closed_loop_run(self, t0: float, dt_tick: float, n_ticks: int, delay_num: int = 1, slot: int = 0) -> None:
+        """n_ticks closed-loop ticks at t0, t0 + dt_tick, ... enqueued back to back by the library."""
+        self._check(self.lib.alore_nmpc_closed_loop_run(self.h, C.byref(self._batches[slot]), self.B, float(t0), float(dt_tick),
+                                                        int(n_ticks), int(delay_num), self._stream()))
+
     def set_shared_members(self, W: bool = False, bounds: bool = False, od: bool = False) -> None:
         """Members that are ONE copy for the whole batch (row 0 of the corresponding tensors is what every problem reads)."""
         self._check(self.lib.alore_nmpc_set_shared_members(self.h, (1 if W else 0) | (2 if bounds else 0) | (4 if od else 0)))

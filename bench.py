@@ -417,8 +417,7 @@ def main():
             torch.cuda.synchronize(dev)
             nt = 200
             t_a = time.perf_counter()
-            for t in range(20, 20 + nt):
-                e7.closed_loop_tick(0.01 * (t + 1))
+            e7.closed_loop_run(0.01 * 21, 0.01, nt)
             torch.cuda.synchronize(dev)
             t_b = time.perf_counter()
             pose, _, goal = e7.plant_get_state()

@@ -226,6 +226,9 @@ int alore_nmpc_plant_init(alore_nmpc_handle h, const alore_plant_params *p);
 int alore_nmpc_plant_set_state(alore_nmpc_handle h, int B, const double *pose, const double *vw, const double *icr, void *stream);
 int alore_nmpc_plant_get_state(alore_nmpc_handle h, int B, double *pose, double *vw, int *at_goal, void *stream);
 int alore_nmpc_closed_loop_tick(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, double now, int delay_num, void *stream);
+/* n_ticks of them at times t0, t0 + dt_tick, ... enqueued back to back (nothing synchronises) */
+int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, double t0, double dt_tick,
+                               int n_ticks, int delay_num, void *stream);
 
 /* ---- introspection ------------------------------------------------------- */
 typedef struct {

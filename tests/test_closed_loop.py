@@ -134,8 +134,9 @@ def test_device_closed_loop_matches_host_driven_loop():
     dev = fresh()
     dev.plant_init()
     dev.plant_set_state(pose0, icr)
-    for t in range(T):
+    for t in range(T // 2):
         dev.closed_loop_tick(0.01 * (t + 1), delay_num=1)
+    dev.closed_loop_run(0.01 * (T // 2 + 1), 0.01, T - T // 2, delay_num=1)      # the rest in one call
     pose_d, vw_d, goal_d = dev.plant_get_state()
 
     host = fresh()
