@@ -10,7 +10,7 @@ from alore_legged_manipulator_amd.scenarios import make_wide_batch as wide_batch
 
 B, N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 20
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-batch = wide_batch(B, N, 99)
+batch = wide_batch(B, N, int(sys.argv[3]) if len(sys.argv) > 3 else 99)
 eng = BatchedNmpc(B, N); eng.load(batch)
 orc = Oracle(N)
 oracles = None
