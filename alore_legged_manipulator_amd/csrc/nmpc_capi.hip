@@ -246,6 +246,7 @@ static int batch_copy(alore_nmpc_handle h, const alore_nmpc_batch* dev, const al
                       void* stream, bool to_device)
 {
     if (!h || !dev || !host || B <= 0) return fail(h, ALORE_NMPC_E_INVALID, "batch copy: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < kNumMembers; ++i) {
         const Member& m = kMembers[i];
@@ -277,6 +278,7 @@ int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch*
 {
     if (!h || !dev || B <= 0 || !dev->lbValues || !dev->ubValues)
         return fail(h, ALORE_NMPC_E_INVALID, "default_bounds: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t n = (size_t)B * h->cfg.N * 2;
     HIP_TRY(h, nmpc::launch_fill(const_cast<float*>(dev->lbValues), -3.0f, n, (hipStream_t)stream));
     HIP_TRY(h, nmpc::launch_fill(const_cast<float*>(dev->ubValues), 3.0f, n, (hipStream_t)stream));
@@ -286,6 +288,7 @@ int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch*
 int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream)
 {
     if (!h || !dev || B <= 0 || n_sqp < 1) return fail(h, ALORE_NMPC_E_INVALID, "rti: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (!batch_complete(dev)) return fail(h, ALORE_NMPC_E_INVALID, "rti: batch has NULL members");
     nmpc::LaunchGeom g;
     static const int forced_wpb = getenv("ALORE_NMPC_WPB") ? atoi(getenv("ALORE_NMPC_WPB")) : 0; // diagnostic: 1 or 4
@@ -310,20 +313,8 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
         const size_t need = (size_t)g.grid * g.wpb * 8; // one record per wavefront
         if (need > h->stamps_cap) {
             if (h->d_stamps) (void)hipFree(h->d_stamps);
-    if (h->refs.dur) (void)hipFree(h->refs.dur);
-    if (h->refs.coef) (void)hipFree(h->refs.coef);
-    if (h->refs.ckpt) (void)hipFree(h->refs.ckpt);
-    if (h->refs.meta) (void)hipFree(h->refs.meta);
-    if (h->d_est) (void)hipFree(h->d_est);
-    if (h->d_icr) (void)hipFree(h->d_icr);
-    if (h->d_psi) (void)hipFree(h->d_psi);
-    if (h->d_goal) (void)hipFree(h->d_goal);
-    if (h->d_poly) (void)hipFree(h->d_poly);
-    if (h->d_band) (void)hipFree(h->d_band);
-    if (h->d_rhs) (void)hipFree(h->d_rhs);
-    if (h->d_panels) (void)hipFree(h->d_panels);
-    if (h->d_overflow) (void)hipFree(h->d_overflow);
-    if (h->d_inc) (void)hipFree(h->d_inc);
+            h->d_stamps = nullptr;
+            h->stamps_cap = 0;
             HIP_TRY(h, hipMalloc((void**)&h->d_stamps, need * sizeof(long long)));
             h->stamps_cap = need;
         }
@@ -364,6 +355,7 @@ int alore_nmpc_linearize(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B
 {
     if (!h || !dev || !out || B <= 0 || !dev->x || !dev->u || !dev->od)
         return fail(h, ALORE_NMPC_E_INVALID, "linearize: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, nmpc::launch_linearize(*dev, B, h->cfg.N, h->cfg.dt, *out, (hipStream_t)stream));
     return ALORE_NMPC_OK;
 }
@@ -372,6 +364,7 @@ int alore_nmpc_forward_simulate(alore_nmpc_handle h, const alore_nmpc_batch* dev
 {
     if (!h || !dev || B <= 0 || !dev->x || !dev->u || !dev->od)
         return fail(h, ALORE_NMPC_E_INVALID, "forward_simulate: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, nmpc::launch_forward_simulate(*dev, B, h->cfg.N, h->cfg.dt, (hipStream_t)stream));
     return ALORE_NMPC_OK;
 }
@@ -381,6 +374,7 @@ int alore_nmpc_shift(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, in
 {
     if (!h || !dev || B <= 0 || !dev->x || !dev->u || !dev->od)
         return fail(h, ALORE_NMPC_E_INVALID, "shift: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, nmpc::launch_shift(*dev, B, h->cfg.N, h->cfg.dt, strategy, xEnd, uEnd, (hipStream_t)stream));
     return ALORE_NMPC_OK;
 }
@@ -393,15 +387,31 @@ int alore_nmpc_refs_init(alore_nmpc_handle h, int B, int max_pieces, int max_che
     h->refs.P = max_pieces;
     h->refs.C = max_checkpoints;
     h->refs_B = B;
-    HIP_TRY(h, hipMalloc((void**)&h->refs.dur, sizeof(double) * B * max_pieces));
-    HIP_TRY(h, hipMalloc((void**)&h->refs.coef, sizeof(double) * B * max_pieces * 12));
-    HIP_TRY(h, hipMalloc((void**)&h->refs.ckpt, sizeof(double) * B * max_checkpoints * 2));
-    HIP_TRY(h, hipMalloc((void**)&h->refs.meta, sizeof(double) * B * 8));
-    HIP_TRY(h, hipMemset(h->refs.meta, 0, sizeof(double) * B * 8));
-    HIP_TRY(h, hipMalloc((void**)&h->d_est, sizeof(double) * B * 3));
-    HIP_TRY(h, hipMalloc((void**)&h->d_icr, sizeof(double) * B * 3));
-    HIP_TRY(h, hipMalloc((void**)&h->d_psi, sizeof(double) * B * (h->cfg.N + 1)));
-    HIP_TRY(h, hipMalloc((void**)&h->d_goal, sizeof(int) * B));
+    struct Want { void** p; size_t bytes; };
+    const Want want[] = {
+        {(void**)&h->refs.dur, sizeof(double) * B * max_pieces},
+        {(void**)&h->refs.coef, sizeof(double) * B * max_pieces * 12},
+        {(void**)&h->refs.ckpt, sizeof(double) * B * max_checkpoints * 2},
+        {(void**)&h->refs.meta, sizeof(double) * B * 8},
+        {(void**)&h->d_est, sizeof(double) * B * 3},
+        {(void**)&h->d_icr, sizeof(double) * B * 3},
+        {(void**)&h->d_psi, sizeof(double) * B * (h->cfg.N + 1)},
+        {(void**)&h->d_goal, sizeof(int) * B},
+    };
+    hipError_t e = hipSuccess;
+    for (const Want& w : want) { // everything zeroed: slots without a trajectory read as invalid / not at goal
+        e = hipMalloc(w.p, w.bytes);
+        if (e == hipSuccess) e = hipMemset(*w.p, 0, w.bytes);
+        if (e != hipSuccess) break;
+    }
+    if (e != hipSuccess) { // a retry must see "not initialised"
+        for (const Want& w : want) {
+            if (*w.p) (void)hipFree(*w.p);
+            *w.p = nullptr;
+        }
+        h->refs_B = 0;
+        return fail(h, ALORE_NMPC_E_NOMEM, "refs_init: hipMalloc", e);
+    }
     return ALORE_NMPC_OK;
 }
 
@@ -412,6 +422,7 @@ int alore_nmpc_refs_set_trajectory(alore_nmpc_handle h, int robot, int n_pieces,
     if (!h || !h->refs.dur || robot < 0 || robot >= h->refs_B || n_pieces <= 0 || n_pieces > h->refs.P || n_ckpt <= 0 ||
         n_ckpt > h->refs.C || !durations || !coeffs || !ckpt_xy || !(state_seq_res > 0.0))
         return fail(h, ALORE_NMPC_E_INVALID, "refs_set_trajectory: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     double total = 0.0;
     for (int i = 0; i < n_pieces; ++i) total += durations[i];
@@ -540,6 +551,7 @@ int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch* dev, int
 {
     if (!h || !h->refs.dur || !dev || B <= 0 || B > h->refs_B || !est || !icr || !dev->y || !dev->yN || !dev->od || !dev->x0)
         return fail(h, ALORE_NMPC_E_INVALID, "refs_sample: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipMemcpyAsync(h->d_est, est, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_icr, icr, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
@@ -570,6 +582,7 @@ int alore_nmpc_plant_set_state(alore_nmpc_handle h, int B, const double* pose, c
 {
     if (!h || !h->has_plant || B <= 0 || B > h->refs_B || !pose || !icr)
         return fail(h, ALORE_NMPC_E_INVALID, "plant_set_state: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(h, hipMemcpyAsync(h->d_est, pose, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_icr, icr, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
@@ -582,6 +595,7 @@ int alore_nmpc_plant_set_state(alore_nmpc_handle h, int B, const double* pose, c
 int alore_nmpc_plant_get_state(alore_nmpc_handle h, int B, double* pose, double* vw, int* at_goal, void* stream)
 {
     if (!h || !h->has_plant || B <= 0 || B > h->refs_B) return fail(h, ALORE_NMPC_E_INVALID, "plant_get_state: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     if (pose) HIP_TRY(h, hipMemcpyAsync(pose, h->d_est, sizeof(double) * B * 3, hipMemcpyDeviceToHost, s));
     if (vw) HIP_TRY(h, hipMemcpyAsync(vw, h->d_vw, sizeof(double) * B * 2, hipMemcpyDeviceToHost, s));
@@ -594,6 +608,7 @@ int alore_nmpc_closed_loop_tick(alore_nmpc_handle h, const alore_nmpc_batch* dev
 {
     if (!h || !h->has_plant || !dev || B <= 0 || B > h->refs_B || delay_num < 0)
         return fail(h, ALORE_NMPC_E_INVALID, "closed_loop_tick: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     const int N = h->cfg.N;
     // CmdCallback: references from the measured pose, one real-time iteration, command = input column delay_num
@@ -607,6 +622,7 @@ int alore_nmpc_closed_loop_tick(alore_nmpc_handle h, const alore_nmpc_batch* dev
 int alore_nmpc_refs_at_goal(alore_nmpc_handle h, int B, int* at_goal, void* stream)
 {
     if (!h || !h->refs.dur || B <= 0 || B > h->refs_B || !at_goal) return fail(h, ALORE_NMPC_E_INVALID, "refs_at_goal: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipMemcpyAsync(at_goal, h->d_goal, sizeof(int) * B, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return ALORE_NMPC_OK;
 }

@@ -1191,10 +1191,14 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
     dim3 grid(g.grid), block(g.threads);
     hipError_t e = hipSuccess;
     const bool stamp = p.stamps != nullptr;
+    int dev = 0; // hipFuncSetAttribute applies to the current device: the cache is per device
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    dev &= 15;
     switch (g.L) {
 #define CASE(LL)                                                                                              \
     case LL: {                                                                                                \
-        static size_t configured[16] = {0}; /* raise the dynamic-LDS cap once per size */                     \
+        static size_t configured[16][16] = {{0}}; /* raise the dynamic-LDS cap once per (device, variant) */  \
         constexpr bool WR = (LL >= 32);                                                                       \
         const bool diag = stamp || p.b.kkt != nullptr || p.b.obj != nullptr;                                  \
         const int v = (stamp ? 1 : 0) + (g.wpb == 4 ? 2 : 0) + ((g.wreg && WR) ? 4 : 0) + (diag ? 0 : 8);    \
@@ -1213,10 +1217,10 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
         case 12: fn = (const void*)rti_kernel<LL, false, 1, WR, false>; break;                                \
         default: fn = (const void*)rti_kernel<LL, false, 4, WR, false>; break;                                \
         }                                                                                                     \
-        if (g.lds_bytes > configured[v]) {                                                                    \
+        if (g.lds_bytes > configured[dev][v]) {                                                               \
             e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);        \
             if (e != hipSuccess) return e;                                                                    \
-            configured[v] = g.lds_bytes;                                                                      \
+            configured[dev][v] = g.lds_bytes;                                                                 \
         }                                                                                                     \
         void* args[] = {const_cast<RtiParams*>(&p)};                                                          \
         e = hipLaunchKernel(fn, grid, block, args, g.lds_bytes, s);                                           \

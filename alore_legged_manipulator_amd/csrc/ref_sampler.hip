@@ -29,7 +29,10 @@ __global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
     if (t >= (long)B * (N + 1)) return;
     const int r = (int)(t / (N + 1)), j = (int)(t % (N + 1));
     const double* m = s.meta + (size_t)r * 8;
-    if (m[6] == 0.0) return; // no trajectory yet: leave the references alone
+    if (m[6] == 0.0) { // no trajectory yet: leave the references alone, and the robot is not at a goal
+        if (j == 0 && at_goal) at_goal[r] = 0;
+        return;
+    }
     const double start_time = m[0], duration = m[1], xv = m[2], res = m[3];
     const int np = (int)m[4], nc = (int)m[5];
     const double* dur = s.dur + (size_t)r * s.P;

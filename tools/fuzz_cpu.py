@@ -1,7 +1,7 @@
 """CPU fuzz of the working-set logic (nmpc_core.h through tests/harness/cpu_core_harness.cpp) against the oracle
 on wide random problems, K consecutive ticks each (ticks >= 1 start from stale duals)."""
 import sys, os, subprocess, ctypes as C, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from alore_legged_manipulator_amd.scenarios import make_wide_batch
 ns = {'wide_batch': make_wide_batch}
