@@ -1,0 +1,71 @@
+// backend_kernels.h -- launch interface between backend_capi.hip and backend_kernels.hip
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/alore_backend.h"
+
+namespace backend {
+
+using Config = alore_backend_config;
+using LbfgsParam = alore_lbfgs_param;
+using Status = alore_backend_status;
+
+constexpr int MEM_MAX = 256; // L-BFGS history slots per problem (global_planning3ms.yaml: mem_size 256)
+
+enum Mode { MODE_PLAN = 0, MODE_EVAL = 1, MODE_LBFGS = 2 };
+
+struct MapView {
+    const double* dist;
+    int nx, ny;
+    double x_lo, y_lo, x_hi, y_hi, res;
+};
+
+// device copy of the FlatTrajData batch; P = piece capacity
+struct ProblemStore {
+    int P;
+    const int* M;            // [B]
+    const double* inner;     // [B][(P-1)*2]  (yaw, s)
+    const double* init_T;    // [B]
+    const double* positions; // [B][P*2]      way-points (x, y) then final (x, y)
+    const double* head;      // [B][6]        [d][p v a]
+    const double* tail;      // [B][6]
+    const double* start_xy;  // [B][2]
+    const double* final_xy;  // [B][2]
+    const int* if_cut;       // [B]
+};
+
+struct ResultStore {
+    double* inner; // [B][(P-1)*2]
+    double* T;     // [B][P]
+    double* coef;  // [B][P*12]
+    double* tail;  // [B][6]
+    int* ok;       // [B]
+    Status* status;
+};
+
+struct Params {
+    Config cfg;
+    MapView map;
+    ProblemStore prob;
+    ResultStore res;
+    double* hist; // [B][MEM_MAX][2][3P]
+    int count, mode;
+    // MODE_EVAL / MODE_LBFGS
+    int stage, max_iter;
+    double* x_io;         // [B][3P]
+    double* g_out;        // [B][3P]
+    const double* lam_in; // [B][2] or null
+    const double* rho_in;
+    double safe_dis, time_weight;
+    double* cost_out; // [B]
+    double* err_out;  // [B][2]
+    int* ret_out;     // [B][3]: ret, iterations, evaluations
+};
+
+size_t lds_bytes(int P);
+// the parameter block is copied (asynchronously, stream-ordered) into d_params and read from there by the kernel;
+// `p` must stay alive until the copy has been issued from pinned memory or has completed (callers keep it in the handle)
+hipError_t launch(const Params& p, const Params* d_params, int P, hipStream_t s);
+
+} // namespace backend

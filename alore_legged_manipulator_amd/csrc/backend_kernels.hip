@@ -1,0 +1,912 @@
+// backend_kernels.hip -- the reference's back_end optimiser (MSPlanner, P/back_end/src/optimizer.cpp) for a batch
+// of independent FlatTrajData problems: ONE WAVEFRONT PER PROBLEM, the whole optimisation inside one launch.
+//
+// What one wavefront does is MSPlanner::minco_plan (optimizer.cpp:169-220): up to safeReplanMaxTime passes of
+//   stage 1  lbfgs_optimize(costFunctionCallbackPath)                      :303-309, 1272-1591
+//   stage 2  ALM loop { lbfgs_optimize(costFunctionCallback); lambda, rho update }   :376-418, 631-1067
+//   final collision check on a dense Simpson resample                       :474-571
+// in float64.  Inside a cost evaluation the 64 lanes work on
+//   - the knot system of the minimum-jerk spline (csrc/minco_spline.h: SPD 2 x 2 block-tridiagonal instead
+//     of the reference's 6M x 6M band LU; lanes 0/1 = the two flat dimensions),
+//   - (piece, dimension) for the Hermite coefficients, the energy and the adjoint,
+//   - the M x 17 Simpson nodes for everything in attachPenaltyFunctional (lane = node, 64 per round),
+//   - wave prefix / suffix scans for the pose integration (every pose depends on all earlier Simpson panels)
+//     and for the chain rule back through it (optimizer.cpp:944-947, 1054-1066),
+//   - (piece, power, dimension) for the reduction of node terms into the coefficient gradient.
+// All sums are taken in a fixed order (butterfly reductions, ascending node order): results are bit-reproducible.
+// L-BFGS (lbfgs.hpp:440-756, Lewis-Overton line search :276-396) keeps x, g, d in LDS, lane = variable; the
+// (s, y) history (mem_size = 256 pairs, 3M - 1 doubles each) lives in HBM, one contiguous slab per problem.
+// Control flow is wave-uniform by construction (every decision is taken on a butterfly-reduced value).
+#include <hip/hip_runtime.h>
+
+#include "backend_kernels.h"
+#include "minco_spline.h"
+
+namespace backend {
+
+namespace {
+
+constexpr int NS = 17; // Simpson nodes per piece (sparseResolution 8)
+constexpr int RES = 8;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ double uni(double v) // value known to be wave-uniform -> SGPR pair
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ void smoothed_l1(double eps, double x, double& f, double& df)
+{
+    if (x < eps) {
+        const double f3 = 1.0 / (eps * eps), f4 = -0.5 * f3 / eps;
+        f = (f4 * x + f3) * x * x * x;
+        df = (4.0 * f4 * x + 3.0 * f3) * x * x;
+    } else {
+        f = x - 0.5 * eps;
+        df = 1.0;
+    }
+}
+__device__ __forceinline__ double t_of_tau(double v) { return v > 0.0 ? ((0.5 * v + 1.0) * v + 1.0) : 1.0 / ((0.5 * v - 1.0) * v + 1.0); }
+__device__ __forceinline__ double tau_of_t(double t) { return t > 1.0 ? (sqrt(2.0 * t - 1.0) - 1.0) : (1.0 - sqrt(2.0 / t - 1.0)); }
+__device__ __forceinline__ double dt_dtau(double v)
+{
+    if (v > 0) return v + 1.0;
+    const double den = (0.5 * v - 1.0) * v + 1.0;
+    return (1.0 - v) / (den * den);
+}
+
+// SDFmap::getDistWithGradBilinear(pos, grad, mindis) (sdf_map.cpp:796-834) and (pos) (:836-861, want_grad = false)
+__device__ __forceinline__ double esdf(const MapView& m, double x, double y, bool want_grad, double mindis, double& gx, double& gy)
+{
+    gx = 0.0; gy = 0.0;
+    if (x < m.x_lo || y < m.y_lo || x > m.x_hi || y > m.y_hi) return 1e10;
+    const double inv = 1.0 / m.res;
+    int ix = (int)((x - m.x_lo) * inv - 0.5), iy = (int)((y - m.y_lo) * inv - 0.5);
+    ix = min(max(ix, 0), m.nx - 1);
+    iy = min(max(iy, 0), m.ny - 1);
+    if (ix >= m.nx - 1 || iy >= m.ny - 1) return 1e10;
+    const double fx = (x - ((ix + 0.5) * m.res + m.x_lo)) * inv, fy = (y - ((iy + 0.5) * m.res + m.y_lo)) * inv;
+    const double* c = m.dist + (size_t)ix * m.ny + iy;
+    const double v00 = c[0], v01 = c[1], v10 = c[m.ny], v11 = c[m.ny + 1];
+    const double lo = (1 - fx) * v00 + fx * v10, hi = (1 - fx) * v01 + fx * v11;
+    const double dist = (1 - fy) * lo + fy * hi;
+    if (!want_grad || dist > mindis) return dist;
+    gy = (hi - lo) * inv;
+    gx = ((1 - fy) * (v10 - v00) + fy * (v11 - v01)) * inv;
+    return dist;
+}
+
+// everything a cost evaluation needs besides x; lives in LDS (wave-uniform, written by lane 0 + barrier or by
+// all lanes with the same value)
+struct EvalCtx {
+    int M, n, stage, evals;
+    double lam[2], rho[2], safe_dis, time_weight;
+    const double* positions; // [M][2] way-points + final (stage 1)
+    double head[2][3], tail[2][3], start_xy[2], final_xy[2];
+    double xy_err[2]; // out
+};
+
+template <int P>
+struct Lds {
+    EvalCtx e;
+    double T[P];
+    double kp[2][P + 1], kv[2][P + 1], ka[2][P + 1]; // knot states per flat dimension
+    minco::Sym2 sinv[P];
+    double y[2][P][2];                                // knot system right-hand side / solution per dimension
+    double coef[P * 12];                              // (6 i + q) * 2 + d
+    double gdC[P * 12];
+    double gdT[P];
+    double gk[2][P + 1][3];                           // gradient w.r.t. the knot states
+    double cy[P * NS], sy[P * NS], fx[P * NS], fy[P * NS]; // fx / fy become the chain coefficients
+    double E[P * NS * 6];                             // node terms of the coefficient gradient [node][E0 E1 E2][d]
+    double nodeT[P * NS];
+    double posx[RES * P + 1], posy[RES * P + 1];      // pose at the Simpson panel ends
+    double x[3 * P], g[3 * P], d[3 * P], xp[3 * P], gp[3 * P];
+    double ys[MEM_MAX], alpha[MEM_MAX];
+    double pf[16];
+};
+
+extern __shared__ __align__(16) unsigned char lds_raw[];
+template <int P>
+__device__ __forceinline__ Lds<P>& lds() { return *reinterpret_cast<Lds<P>*>(lds_raw); }
+
+// One cost callback.  x in L.x, gradient to L.g.  Returns the cost (wave-uniform).  *skipped is set when the
+// reference's norm guard fires (cost 0, gradient untouched).
+template <int P>
+__device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__ gp, bool* skipped)
+{
+    const Params& prm = *gp;
+    const Config& c = prm.cfg;
+    Lds<P>& L = lds<P>();
+    EvalCtx& e = L.e;
+    const int lane = threadIdx.x, M = uni(e.M), n = uni(e.n), NN = M * NS;
+    const double xvI = c.standard_diff ? 0.0 : c.icr_xv;
+    __syncthreads();
+    if (lane == 0) ++e.evals;
+    // ---- norm guard (optimizer.cpp:635-636: `inf` is the macro 1 >> 30 = 0)
+    double part = 0.0;
+    for (int v = lane; v < n; v += 64) part += L.x[v] * L.x[v];
+    if (sqrt(uni(wave_sum(part))) > 1e4) { *skipped = true; return 0.0; }
+    *skipped = false;
+
+    // ---- durations, knot positions
+    double tpart = 0.0;
+    for (int i = lane; i < M; i += 64) {
+        const double T = t_of_tau(L.x[2 * (M - 1) + 1 + i]);
+        L.T[i] = T;
+        tpart += T;
+    }
+    const double sumT = uni(wave_sum(tpart));
+    for (int k = lane; k <= M; k += 64)
+        for (int d = 0; d < 2; ++d) {
+            double p;
+            if (k == 0) p = e.head[d][0];
+            else if (k == M) p = (d == 1) ? L.x[2 * (M - 1)] : e.tail[d][0];
+            else p = L.x[2 * (k - 1) + d];
+            L.kp[d][k] = p;
+            if (k == 0) { L.kv[d][0] = e.head[d][1]; L.ka[d][0] = e.head[d][2]; }
+            if (k == M) { L.kv[d][M] = e.tail[d][1]; L.ka[d][M] = e.tail[d][2]; }
+        }
+    __syncthreads();
+    // ---- knot system: right-hand sides (lane = (knot, dim)), factorisation + solves (lanes 0, 1)
+    for (int t = lane; t < 2 * (M - 1); t += 64) {
+        const int k = 1 + (t >> 1), d = t & 1;
+        const minco::InvT l(L.T[k - 1]), r(L.T[k]);
+        double rr[2];
+        minco::knot_rhs(l, r, L.kp[d][k - 1], L.kp[d][k], L.kp[d][k + 1], rr);
+        if (k == 1) {
+            const minco::Mat2 u = minco::knot_upper(l);
+            rr[0] -= u.a * L.kv[d][0] + u.c * L.ka[d][0];
+            rr[1] -= u.b * L.kv[d][0] + u.d * L.ka[d][0];
+        }
+        if (k == M - 1) {
+            const minco::Mat2 u = minco::knot_upper(r);
+            rr[0] -= u.a * L.kv[d][M] + u.b * L.ka[d][M];
+            rr[1] -= u.c * L.kv[d][M] + u.d * L.ka[d][M];
+        }
+        L.y[d][k - 1][0] = rr[0];
+        L.y[d][k - 1][1] = rr[1];
+    }
+    __syncthreads();
+    if (lane == 0) minco::knot_factor(M, L.T, L.sinv);
+    __syncthreads();
+    if (lane < 2) {
+        minco::knot_solve(M, L.T, L.sinv, &L.y[lane][0][0]);
+        for (int k = 1; k < M; ++k) { L.kv[lane][k] = L.y[lane][k - 1][0]; L.ka[lane][k] = L.y[lane][k - 1][1]; }
+    }
+    __syncthreads();
+    // ---- coefficients, energy and its partial gradients: lane = (piece, dim)
+    double epart = 0.0;
+    for (int t = lane; t < 2 * M; t += 64) {
+        const int i = t >> 1, d = t & 1;
+        const double T = L.T[i];
+        const minco::InvT q(T);
+        double cc[6];
+        minco::hermite(T, q, L.kp[d][i], L.kv[d][i], L.ka[d][i], L.kp[d][i + 1], L.kv[d][i + 1], L.ka[d][i + 1], cc, nullptr);
+        for (int k = 0; k < 6; ++k) L.coef[(6 * i + k) * 2 + d] = cc[k];
+        const double w = c.energy_w[d], t2 = T * T, t3 = t2 * T, t4 = t2 * t2, t5 = t4 * T;
+        const double c3 = cc[3], c4 = cc[4], c5 = cc[5];
+        epart += w * (36.0 * c3 * c3 * T + 144.0 * c4 * c3 * t2 + 192.0 * c4 * c4 * t3 + 240.0 * c5 * c3 * t3 + 720.0 * c5 * c4 * t4 +
+                      720.0 * c5 * c5 * t5);
+        L.gdC[(6 * i + 0) * 2 + d] = 0.0; L.gdC[(6 * i + 1) * 2 + d] = 0.0; L.gdC[(6 * i + 2) * 2 + d] = 0.0;
+        L.gdC[(6 * i + 3) * 2 + d] = w * (72.0 * c3 * T + 144.0 * c4 * t2 + 240.0 * c5 * t3);
+        L.gdC[(6 * i + 4) * 2 + d] = w * (144.0 * c3 * t2 + 384.0 * c4 * t3 + 720.0 * c5 * t4);
+        L.gdC[(6 * i + 5) * 2 + d] = w * (240.0 * c3 * t3 + 720.0 * c4 * t4 + 1440.0 * c5 * t5);
+        double gt = w * (36.0 * c3 * c3 + 288.0 * c4 * c3 * T + 576.0 * c4 * c4 * t2 + 720.0 * c5 * c3 * t2 + 2880.0 * c5 * c4 * t3 +
+                         3600.0 * c5 * c5 * t4);
+        gt += __shfl_xor(gt, 1); // the two dimensions of a piece sit on neighbouring lanes
+        if (d == 0) L.gdT[i] = gt;
+    }
+    double cost_part = epart;
+    __syncthreads();
+
+    // ---- pass A over the nodes: flat state, Simpson integrands, pose-independent penalties
+    const double w_mom = e.stage == 1 ? c.p_moment : c.w_moment, w_acc = e.stage == 1 ? c.p_acc : c.w_acc,
+                 w_dom = e.stage == 1 ? c.p_domega : c.w_domega;
+    for (int node = lane; node < NN; node += 64) {
+        const int i = node / NS, j = node - i * NS;
+        const double T = L.T[i], step = T / RES, t = j * (step / 2.0);
+        const double* ci = L.coef + 12 * i;
+        double sg[2], d1[2], d2[2], d3[2];
+        for (int d = 0; d < 2; ++d) {
+            const double c0 = ci[d], c1 = ci[2 + d], c2 = ci[4 + d], c3 = ci[6 + d], c4 = ci[8 + d], c5 = ci[10 + d];
+            sg[d] = ((((c5 * t + c4) * t + c3) * t + c2) * t + c1) * t + c0;
+            d1[d] = (((5.0 * c5 * t + 4.0 * c4) * t + 3.0 * c3) * t + 2.0 * c2) * t + c1;
+            d2[d] = ((20.0 * c5 * t + 12.0 * c4) * t + 6.0 * c3) * t + 2.0 * c2;
+            d3[d] = (60.0 * c5 * t + 24.0 * c4) * t + 6.0 * c3;
+        }
+        double sy, cy;
+        sincos(sg[0], &sy, &cy);
+        L.cy[node] = cy;
+        L.sy[node] = sy;
+        L.fx[node] = d1[1] * cy + d1[0] * xvI * sy;
+        L.fy[node] = d1[1] * sy - d1[0] * xvI * cy;
+        double gb[3][2] = {{0, 0}, {0, 0}, {0, 0}}, gT = 0.0;
+        if ((j & 1) == 0) {
+            const double alpha = (double)(j >> 1) / RES, omg = (j == 0 || j == NS - 1) ? 0.5 : 1.0, ws = omg * step;
+            double f, df, v;
+#define PENALISE(viol, weight, dviol_dt, apply)                           \
+    if ((v = (viol)) > 0.0) {                                             \
+        smoothed_l1(c.smooth_eps, v, f, df);                              \
+        apply;                                                            \
+        gT += omg * (weight) * (df * (dviol_dt) * step + f / RES);        \
+        cost_part += ws * (weight) * f;                                   \
+    }
+            PENALISE(d2[1] * d2[1] - c.max_acc * c.max_acc, w_acc, 2.0 * alpha * d2[1] * d3[1], gb[2][1] += ws * w_acc * df * 2.0 * d2[1]);
+            PENALISE(d2[0] * d2[0] - c.max_domega * c.max_domega, w_dom, 2.0 * alpha * d2[0] * d3[0],
+                     gb[2][0] += ws * w_dom * df * 2.0 * d2[0]);
+            if (e.stage == 2 && c.direct_v_omega) {
+                PENALISE(d1[1] * d1[1] - c.max_vel * c.max_vel, w_mom, 2.0 * alpha * d1[1] * d2[1], gb[1][1] += ws * w_mom * df * 2.0 * d1[1]);
+                PENALISE(d1[0] * d1[0] - c.max_omega * c.max_omega, w_mom, 2.0 * alpha * d1[0] * d2[0],
+                         gb[1][0] += ws * w_mom * df * 2.0 * d1[0]);
+            } else {
+                for (int sym = -1; sym <= 1; sym += 2)
+                    PENALISE(sym * c.max_vel * d1[0] + c.max_omega * d1[1] - c.max_vel * c.max_omega, w_mom,
+                             alpha * (sym * c.max_vel * d2[0] + c.max_omega * d2[1]),
+                             (gb[1][0] += ws * w_mom * df * sym * c.max_vel, gb[1][1] += ws * w_mom * df * c.max_omega));
+                for (int sym = -1; sym <= 1; sym += 2)
+                    PENALISE(sym * -c.min_vel * d1[0] - c.max_omega * d1[1] + c.min_vel * c.max_omega, w_mom,
+                             alpha * (sym * -c.min_vel * d2[0] - c.max_omega * d2[1]),
+                             (gb[1][0] += ws * w_mom * df * sym * -c.min_vel, gb[1][1] -= ws * w_mom * df * c.max_omega));
+            }
+            if (e.stage == 2)
+                PENALISE(d1[0] * d1[0] * d1[1] * d1[1] - c.max_cen_acc * c.max_cen_acc, c.w_cen_acc,
+                         2.0 * alpha * (d1[0] * d1[1] * d1[1] * d2[0] + d1[1] * d1[0] * d1[0] * d2[1]),
+                         (gb[1][0] += ws * c.w_cen_acc * df * (2 * d1[0] * d1[1] * d1[1]),
+                          gb[1][1] += ws * c.w_cen_acc * df * (2 * d1[0] * d1[0] * d1[1])));
+        }
+        double* E = L.E + node * 6;
+        E[0] = gb[0][0]; E[1] = gb[0][1]; E[2] = gb[1][0]; E[3] = gb[1][1]; E[4] = gb[2][0]; E[5] = gb[2][1];
+        L.nodeT[node] = gT;
+    }
+    __syncthreads();
+
+    // ---- Simpson panels and the running pose: prefix scan over the 8 M panels
+    {
+        double carry_x = e.start_xy[0], carry_y = e.start_xy[1];
+        if (lane == 0) { L.posx[0] = carry_x; L.posy[0] = carry_y; }
+        const int NP = RES * M;
+        for (int base = 0; base < NP; base += 64) {
+            const int p = base + lane;
+            double ix = 0.0, iy = 0.0;
+            if (p < NP) {
+                const int i = p / RES, q = p - i * RES, n0 = i * NS + 2 * q;
+                const double cint = L.T[i] / (RES * 6);
+                // the reference accumulates  cint f0 + 4 cint f1 + cint f2  into a zeroed sum, in this order
+                ix = cint * L.fx[n0]; ix += 4.0 * cint * L.fx[n0 + 1]; ix += cint * L.fx[n0 + 2];
+                iy = cint * L.fy[n0]; iy += 4.0 * cint * L.fy[n0 + 1]; iy += cint * L.fy[n0 + 2];
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double tx = __shfl_up(ix, o), ty = __shfl_up(iy, o);
+                if (lane >= o) { ix += tx; iy += ty; }
+            }
+            if (p < NP) { L.posx[p + 1] = carry_x + ix; L.posy[p + 1] = carry_y + iy; }
+            carry_x += __shfl(ix, 63);
+            carry_y += __shfl(iy, 63);
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        e.xy_err[0] = L.posx[RES * M] - e.final_xy[0];
+        e.xy_err[1] = L.posy[RES * M] - e.final_xy[1];
+    }
+    __syncthreads(); // fx / fy are consumed; they now carry the position gradients of the chain rule
+    for (int node = lane; node < NN; node += 64) { L.fx[node] = 0.0; L.fy[node] = 0.0; }
+    __syncthreads();
+
+    // ---- pose-dependent terms
+    if (e.stage == 2) { // obstacle clearance at the even nodes
+        for (int en = lane; en < (RES + 1) * M; en += 64) {
+            const int i = en / (RES + 1), je = en - i * (RES + 1), j = 2 * je, node = i * NS + j;
+            const double T = L.T[i], step = T / RES, alpha = (double)je / RES, omg = (j == 0 || j == NS - 1) ? 0.5 : 1.0, ws = omg * step;
+            const double px = L.posx[RES * i + je], py = L.posy[RES * i + je], cy = L.cy[node], sy = L.sy[node];
+            const double* ci = L.coef + 12 * i;
+            const double t = j * (step / 2.0);
+            const double d1th = (((5.0 * ci[10] * t + 4.0 * ci[8]) * t + 3.0 * ci[6]) * t + 2.0 * ci[4]) * t + ci[2];
+            double gpx = 0.0, gpy = 0.0, gb0 = 0.0, gT = 0.0;
+            for (int q = 0; q < c.n_check; ++q) {
+                const double bx = c.check_pts[q][0], by = c.check_pts[q][1];
+                double gx, gy;
+                const double sd = esdf(prm.map, px + cy * bx - sy * by, py + sy * bx + cy * by, true, e.safe_dis, gx, gy);
+                const double viol = e.safe_dis - sd;
+                if (viol > 0.0) {
+                    double f, df;
+                    smoothed_l1(c.smooth_eps, viol, f, df);
+                    const double rot = gx * (-sy * bx - cy * by) + gy * (cy * bx - sy * by);
+                    gpx -= ws * c.w_collision * df * gx;
+                    gpy -= ws * c.w_collision * df * gy;
+                    gb0 -= ws * c.w_collision * df * rot;
+                    gT += omg * c.w_collision * (df * (-alpha * d1th * rot) * step + f / RES);
+                    cost_part += ws * c.w_collision * f;
+                }
+            }
+            L.fx[node] = gpx;
+            L.fy[node] = gpy;
+            L.E[node * 6 + 0] += gb0;
+            L.nodeT[node] += gT;
+        }
+    } else { // way-point attraction at the end of every piece
+        for (int i = lane; i < M; i += 64) {
+            const double ex = L.posx[RES * (i + 1)] - e.positions[2 * i], ey = L.posy[RES * (i + 1)] - e.positions[2 * i + 1];
+            cost_part += c.p_bigpath * (ex * ex + ey * ey);
+            L.fx[i * NS + NS - 1] = c.p_bigpath * 2.0 * ex;
+            L.fy[i * NS + NS - 1] = c.p_bigpath * 2.0 * ey;
+        }
+    }
+    __syncthreads();
+    // ---- chain coefficients: inclusive suffix sums over the nodes (+ the ALM terminal term)
+    {
+        double add_x = 0.0, add_y = 0.0;
+        if (e.stage == 2) {
+            const double ax = e.xy_err[0] + e.lam[0] / e.rho[0], ay = e.xy_err[1] + e.lam[1] / e.rho[1];
+            if (lane == 0) cost_part += 0.5 * (e.rho[0] * ax * ax + e.rho[1] * ay * ay);
+            add_x = e.rho[0] * ax;
+            add_y = e.rho[1] * ay;
+        }
+        double carry_x = 0.0, carry_y = 0.0;
+        const int rounds = (NN + 63) / 64;
+        for (int r = rounds - 1; r >= 0; --r) {
+            const int node = r * 64 + lane;
+            double vx = node < NN ? L.fx[node] : 0.0, vy = node < NN ? L.fy[node] : 0.0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double tx = __shfl_down(vx, o), ty = __shfl_down(vy, o);
+                if (lane + o < 64) { vx += tx; vy += ty; }
+            }
+            if (node < NN) { L.fx[node] = vx + carry_x + add_x; L.fy[node] = vy + carry_y + add_y; }
+            carry_x += __shfl(vx, 0);
+            carry_y += __shfl(vy, 0);
+        }
+    }
+    __syncthreads();
+    // ---- pass C: chain rule through the Simpson sums into the node terms
+    for (int node = lane; node < NN; node += 64) {
+        const int i = node / NS, j = node - i * NS;
+        const double T = L.T[i], step = T / RES, t = j * (step / 2.0), cint = T / (RES * 6), ialpha = (double)j / (2 * RES);
+        const double sw = (j == 0 || j == NS - 1) ? 1.0 : ((j & 1) ? 4.0 : 2.0);
+        const double cx = L.fx[node] * sw, cyy = L.fy[node] * sw, cy = L.cy[node], sy = L.sy[node];
+        const double* ci = L.coef + 12 * i;
+        double d1[2], d2[2];
+        for (int d = 0; d < 2; ++d) {
+            const double c1 = ci[2 + d], c2 = ci[4 + d], c3 = ci[6 + d], c4 = ci[8 + d], c5 = ci[10 + d];
+            d1[d] = (((5.0 * c5 * t + 4.0 * c4) * t + 3.0 * c3) * t + 2.0 * c2) * t + c1;
+            d2[d] = ((20.0 * c5 * t + 12.0 * c4) * t + 6.0 * c3) * t + 2.0 * c2;
+        }
+        const double fxv = d1[1] * cy + d1[0] * xvI * sy, fyv = d1[1] * sy - d1[0] * xvI * cy;
+        // d(dx)/d(theta coefficients) = b0 (-s' sin + th' xv cos) + b1 xv sin ; d(dy)/.. = b0 (s' cos - th' xv sin) - b1 xv cos
+        // (the reference's sign of the th' xv sin term, optimizer.cpp:822; exact would be +)
+        double* E = L.E + node * 6;
+        E[0] += cint * ((-d1[1] * sy + d1[0] * xvI * cy) * cx + (d1[1] * cy - d1[0] * xvI * sy) * cyy);
+        E[2] += cint * xvI * (sy * cx - cy * cyy);
+        E[3] += cint * (cy * cx + sy * cyy);
+        const double XT = (d2[1] * cy - d1[1] * d1[0] * sy + d2[0] * xvI * sy + d1[0] * d1[0] * xvI * cy) * ialpha * cint + fxv / (RES * 6);
+        const double YT = (d2[1] * sy + d1[1] * d1[0] * cy - d2[0] * xvI * cy + d1[0] * d1[0] * xvI * sy) * ialpha * cint + fyv / (RES * 6);
+        L.nodeT[node] += XT * cx + YT * cyy;
+    }
+    __syncthreads();
+    // ---- node terms -> coefficient gradient: lane = (piece, power, dim); time gradient: lane = piece
+    for (int t = lane; t < 12 * M; t += 64) {
+        const int i = t / 12, r = t - i * 12, q = r >> 1, d = r & 1;
+        const double half = L.T[i] / (2 * RES);
+        double acc = 0.0;
+        for (int j = 0; j < NS; ++j) {
+            const double* E = L.E + (i * NS + j) * 6;
+            const double tt = j * half;
+            double p0 = 1.0, p1 = 0.0, p2 = 0.0; // t^q, q t^(q-1), q (q-1) t^(q-2)
+            if (q >= 1) { double pw = 1.0; for (int s = 1; s < q; ++s) pw *= tt; p1 = q * pw; p0 = pw * tt; }
+            if (q >= 2) { double pw = 1.0; for (int s = 2; s < q; ++s) pw *= tt; p2 = q * (q - 1) * pw; }
+            acc += p0 * E[d] + p1 * E[2 + d] + p2 * E[4 + d];
+        }
+        L.gdC[t] += acc; // gdC index (6 i + q) * 2 + d = 12 i + r
+    }
+    for (int i = lane; i < M; i += 64) {
+        double acc = 0.0;
+        for (int j = 0; j < NS; ++j) acc += L.nodeT[i * NS + j];
+        L.gdT[i] += acc;
+    }
+    __syncthreads();
+    // ---- adjoint of the spline: coefficient gradient -> knot-state gradient -> knot system -> variables
+    // phase 1: every (piece, dim) lane turns its coefficient gradient into the gradients of its two knot states;
+    // the start knot is written directly, the end knot goes through a staging slot (E is free by now)
+    for (int t = lane; t < 2 * M; t += 64) {
+        const int i = t >> 1, d = t & 1;
+        const minco::InvT q(L.T[i]);
+        double G[6], g0[3], g1[3];
+        for (int k = 0; k < 6; ++k) G[k] = L.gdC[(6 * i + k) * 2 + d];
+        minco::hermite_adjoint(q, G, g0, g1);
+        for (int k = 0; k < 3; ++k) { L.gk[d][i][k] = g0[k]; L.E[t * 3 + k] = g1[k]; }
+        if (i == M - 1) for (int k = 0; k < 3; ++k) L.gk[d][M][k] = 0.0;
+    }
+    __syncthreads();
+    for (int t = lane; t < 2 * M; t += 64) {
+        const int i = t >> 1, d = t & 1;
+        for (int k = 0; k < 3; ++k) L.gk[d][i + 1][k] += L.E[t * 3 + k];
+    }
+    __syncthreads();
+    for (int t = lane; t < 2 * (M - 1); t += 64) {
+        const int k = 1 + (t >> 1), d = t & 1;
+        L.y[d][k - 1][0] = L.gk[d][k][1];
+        L.y[d][k - 1][1] = L.gk[d][k][2];
+    }
+    __syncthreads();
+    if (lane < 2) minco::knot_solve(M, L.T, L.sinv, &L.y[lane][0][0]); // K is symmetric: the same sweep
+    __syncthreads();
+    // way-point and tail gradients: lane = (knot 1..M, dim)
+    for (int t = lane; t < 2 * M; t += 64) {
+        const int k = 1 + (t >> 1), d = t & 1;
+        double val = L.gk[d][k][0];
+        // - sum_k' mu_k' . dF_k'/dp_k ; dF_k'/dp: from knot k'+... (see minco_spline.h knot_rhs)
+        if (k + 1 <= M - 1) { // F_{k+1} depends on p_k as its left neighbour: dF/dp = (360 l4, -60 l3), l = T_k
+            const minco::InvT l(L.T[k]);
+            val -= L.y[d][k][0] * (360.0 * l.i4) + L.y[d][k][1] * (-60.0 * l.i3);
+        }
+        if (k <= M - 1) { // F_k on its own position: -(360 l4 - 360 r4... ) see below
+            const minco::InvT l(L.T[k - 1]), r(L.T[k]);
+            val -= L.y[d][k - 1][0] * (-360.0 * l.i4 + 360.0 * r.i4) + L.y[d][k - 1][1] * (60.0 * l.i3 + 60.0 * r.i3);
+        }
+        if (k - 1 >= 1) { // F_{k-1} depends on p_k as its right neighbour: dF/dp = (-360 r4, -60 r3), r = T_{k-1}
+            const minco::InvT r(L.T[k - 1]);
+            val -= L.y[d][k - 2][0] * (-360.0 * r.i4) + L.y[d][k - 2][1] * (-60.0 * r.i3);
+        }
+        if (k <= M - 1) L.g[2 * (k - 1) + d] = val;
+        else if (d == 1) L.g[2 * (M - 1)] = val;
+    }
+    // duration gradients: lane = (piece, dim)
+    for (int t = lane; t < 2 * M; t += 64) {
+        const int i = t >> 1, d = t & 1;
+        const double T = L.T[i];
+        const minco::InvT q(T);
+        double cc[6], dc[6], dE0[2], dE1[2];
+        minco::hermite(T, q, L.kp[d][i], L.kv[d][i], L.ka[d][i], L.kp[d][i + 1], L.kv[d][i + 1], L.ka[d][i + 1], cc, dc);
+        minco::piece_end_rows(T, cc, dc, dE0, dE1);
+        double val = 0.0;
+        for (int k = 3; k < 6; ++k) val += L.gdC[(6 * i + k) * 2 + d] * dc[k];
+        if (i + 1 <= M - 1) val -= L.y[d][i][0] * dE1[0] + L.y[d][i][1] * dE1[1];
+        if (i >= 1) val += L.y[d][i - 1][0] * dE0[0] + L.y[d][i - 1][1] * dE0[1];
+        val += __shfl_xor(val, 1);
+        if (d == 0) {
+            const double tau = L.x[2 * (M - 1) + 1 + i];
+            L.g[2 * (M - 1) + 1 + i] = (L.gdT[i] + val + e.time_weight) * dt_dtau(tau);
+        }
+    }
+    __syncthreads();
+    double cost = uni(wave_sum(cost_part));
+    cost += (e.stage == 1 ? c.p_time : e.time_weight) * sumT;
+    return cost;
+}
+
+// ---- L-BFGS -----------------------------------------------------------------------------------------
+enum { LB_CONVERGENCE = 0, LB_STOP = 1, LBE_INVALID_FUNCVAL = -1012, LBE_MINIMUMSTEP = -1011, LBE_MAXIMUMSTEP = -1010,
+       LBE_MAXIMUMLINESEARCH = -1009, LBE_MAXIMUMITERATION = -1008, LBE_WIDTHTOOSMALL = -1007, LBE_INVALIDPARAMETERS = -1006,
+       LBE_INCREASEGRADIENT = -1005 };
+
+template <int P>
+__device__ double vdot(const double* a, const double* b, int n)
+{
+    double s = 0.0;
+    for (int v = threadIdx.x; v < n; v += 64) s += a[v] * b[v];
+    return uni(wave_sum(s));
+}
+template <int P>
+__device__ double vmaxabs(const double* a, int n)
+{
+    double s = 0.0;
+    for (int v = threadIdx.x; v < n; v += 64) s = fmax(s, fabs(a[v]));
+    return uni(wave_max(s));
+}
+
+// line_search_lewisoverton: x, g in L.x / L.g; s = L.d; xp, gp in L.xp / L.gp
+template <int P>
+__device__ int line_search(const Params* __restrict__ gp, const LbfgsParam& pr, double& f, double& stp, double stpmin, double stpmax)
+{
+    Lds<P>& L = lds<P>();
+    const int n = uni(L.e.n), lane = threadIdx.x;
+    int count = 0;
+    bool brackt = false, touched = false;
+    double mu = 0.0, nu = stpmax;
+    if (!(stp > 0.0)) return LBE_INVALIDPARAMETERS;
+    const double dginit = vdot<P>(L.gp, L.d, n);
+    if (0.0 < dginit) return LBE_INCREASEGRADIENT;
+    const double finit = f, dgtest = pr.f_dec_coeff * dginit, dstest = pr.s_curv_coeff * dginit;
+    for (;;) {
+        for (int v = lane; v < n; v += 64) L.x[v] = L.xp[v] + stp * L.d[v];
+        __syncthreads();
+        bool skipped;
+        f = eval_cost<P>(gp, &skipped);
+        ++count;
+        if (isinf(f) || isnan(f)) return LBE_INVALID_FUNCVAL;
+        if (pr.past > 0 && fabs(finit - f) / (fabs(finit) + 1.0) < pr.delta / pr.past) return count;
+        if (f > finit + stp * dgtest) {
+            nu = stp;
+            brackt = true;
+        } else if (vdot<P>(L.g, L.d, n) < dstest) {
+            mu = stp;
+        } else {
+            return count;
+        }
+        if (pr.max_linesearch <= count) return LBE_MAXIMUMLINESEARCH;
+        if (brackt && (nu - mu) < pr.machine_prec * nu) return LBE_WIDTHTOOSMALL;
+        stp = brackt ? 0.5 * (mu + nu) : stp * 2.0;
+        if (stp < stpmin) return LBE_MINIMUMSTEP;
+        if (stp > stpmax) {
+            if (touched) return LBE_MAXIMUMSTEP;
+            touched = true;
+            stp = stpmax;
+        }
+    }
+}
+
+// lbfgs_optimize.  hist: [mem][2][nstride] doubles of this problem.  iter_cap > 0 limits the iterations.
+template <int P>
+__device__ __attribute__((noinline)) int lbfgs(const Params* __restrict__ gp, const LbfgsParam pr, double* hist, int nstride, int iter_cap,
+                                               double& f_out, int& k_out)
+{
+    Lds<P>& L = lds<P>();
+    const int n = uni(L.e.n), lane = threadIdx.x, m = pr.mem_size;
+    int ret, k = 1, end = 0, bound = 0;
+    bool skipped;
+    double fx = eval_cost<P>(gp, &skipped);
+    if (lane == 0) L.pf[0] = fx;
+    for (int v = lane; v < n; v += 64) L.d[v] = -L.g[v];
+    __syncthreads();
+    double gn = vmaxabs<P>(L.g, n), xn = vmaxabs<P>(L.x, n);
+    if (gn / fmax(1.0, xn) < pr.g_epsilon) {
+        ret = LB_CONVERGENCE;
+    } else {
+        double step = 1.0 / sqrt(vdot<P>(L.d, L.d, n));
+        for (;;) {
+            for (int v = lane; v < n; v += 64) { L.xp[v] = L.x[v]; L.gp[v] = L.g[v]; }
+            __syncthreads();
+            const int ls = line_search<P>(gp, pr, fx, step, pr.min_step, pr.max_step);
+            if (ls < 0) {
+                for (int v = lane; v < n; v += 64) { L.x[v] = L.xp[v]; L.g[v] = L.gp[v]; }
+                __syncthreads();
+                ret = ls;
+                break;
+            }
+            gn = vmaxabs<P>(L.g, n);
+            xn = vmaxabs<P>(L.x, n);
+            if (gn / fmax(1.0, xn) < pr.g_epsilon) { ret = LB_CONVERGENCE; break; }
+            if (pr.past > 0) {
+                if (pr.past <= k) {
+                    const double rate = fabs(uni(L.pf[k % pr.past]) - fx) / fmax(1.0, fabs(fx));
+                    if (rate < pr.delta) { ret = LB_STOP; break; }
+                }
+                __syncthreads();
+                if (lane == 0) L.pf[k % pr.past] = fx;
+                __syncthreads();
+            }
+            if ((pr.max_iterations != 0 && pr.max_iterations <= k) || (iter_cap > 0 && iter_cap <= k)) { ret = LBE_MAXIMUMITERATION; break; }
+            ++k;
+            double* sk = hist + (size_t)end * 2 * nstride;
+            double* yk = sk + nstride;
+            double pys = 0.0, pyy = 0.0, pss = 0.0, pgg = 0.0;
+            for (int v = lane; v < n; v += 64) {
+                const double s = L.x[v] - L.xp[v], y = L.g[v] - L.gp[v];
+                sk[v] = s;
+                yk[v] = y;
+                pys += y * s; pyy += y * y; pss += s * s; pgg += L.gp[v] * L.gp[v];
+                L.d[v] = -L.g[v];
+            }
+            const double ys = uni(wave_sum(pys)), yy = uni(wave_sum(pyy));
+            const double cau = uni(wave_sum(pss)) * sqrt(uni(wave_sum(pgg))) * pr.cautious_factor;
+            if (lane == 0) L.ys[end] = ys;
+            __syncthreads();
+            if (ys > cau) {
+                ++bound;
+                if (bound > m) bound = m;
+                end = (end + 1) % m;
+                int j = end;
+                for (int i = 0; i < bound; ++i) {
+                    j = (j + m - 1) % m;
+                    const double* sj = hist + (size_t)j * 2 * nstride;
+                    const double* yj = sj + nstride;
+                    double p = 0.0;
+                    for (int v = lane; v < n; v += 64) p += sj[v] * L.d[v];
+                    const double a = uni(wave_sum(p)) / L.ys[j];
+                    if (lane == 0) L.alpha[j] = a;
+                    for (int v = lane; v < n; v += 64) L.d[v] += (-a) * yj[v];
+                }
+                const double sc = ys / yy;
+                for (int v = lane; v < n; v += 64) L.d[v] *= sc;
+                __syncthreads();
+                for (int i = 0; i < bound; ++i) {
+                    const double* sj = hist + (size_t)j * 2 * nstride;
+                    const double* yj = sj + nstride;
+                    double p = 0.0;
+                    for (int v = lane; v < n; v += 64) p += yj[v] * L.d[v];
+                    const double beta = uni(wave_sum(p)) / L.ys[j];
+                    const double a = L.alpha[j];
+                    for (int v = lane; v < n; v += 64) L.d[v] += (a - beta) * sj[v];
+                    j = (j + 1) % m;
+                }
+            }
+            __syncthreads();
+            step = 1.0;
+        }
+    }
+    f_out = fx;
+    k_out = k;
+    return ret;
+}
+
+// final collision check (optimizer.cpp:474-571): 16 Simpson panels per piece, ESDF at the panel ends
+template <int P>
+__device__ __attribute__((noinline)) bool final_collision(const Params* __restrict__ gp, double& min_dist)
+{
+    const Params& prm = *gp;
+    const Config& c = prm.cfg;
+    Lds<P>& L = lds<P>();
+    const EvalCtx& e = L.e;
+    const int lane = threadIdx.x, M = uni(e.M), R = c.final_check_num, NP = R * M;
+    const double xvI = c.standard_diff ? 0.0 : c.icr_xv;
+    double carry_x = e.start_xy[0], carry_y = e.start_xy[1], mind = 1.79769313486231570815e+308;
+    int first_hit = 0x7fffffff;
+    for (int base = 0; base < NP; base += 64) {
+        const int p = base + lane;
+        double ix = 0.0, iy = 0.0;
+        if (p < NP) {
+            const int i = p / R, q = p - i * R;
+            const double T = L.T[i], half = T / R / 2.0, cint = T / R / 6.0;
+            const double* ci = L.coef + 12 * i;
+            for (int s = 0; s < 3; ++s) {
+                const double t = (2 * q + s) * half;
+                double sg, d1[2];
+                sg = ((((ci[10] * t + ci[8]) * t + ci[6]) * t + ci[4]) * t + ci[2]) * t + ci[0];
+                for (int d = 0; d < 2; ++d)
+                    d1[d] = (((5.0 * ci[10 + d] * t + 4.0 * ci[8 + d]) * t + 3.0 * ci[6 + d]) * t + 2.0 * ci[4 + d]) * t + ci[2 + d];
+                double sy, cy;
+                sincos(sg, &sy, &cy);
+                const double w = (s == 1) ? 4.0 * cint : cint;
+                ix += w * (d1[1] * cy + d1[0] * xvI * sy);
+                iy += w * (d1[1] * sy - d1[0] * xvI * cy);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double tx = __shfl_up(ix, o), ty = __shfl_up(iy, o);
+            if (lane >= o) { ix += tx; iy += ty; }
+        }
+        if (p < NP) {
+            double gx, gy;
+            const double sd = esdf(prm.map, carry_x + ix, carry_y + iy, false, 0.0, gx, gy);
+            if (sd < c.final_min_safe_dis && p < first_hit) first_hit = p;
+            L.nodeT[lane] = sd; // staging for the ordered minimum below
+        }
+        __syncthreads();
+        // the reference stops at the first hit: its reported minimum covers the panels up to and including it
+        int hit = first_hit;
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) hit = min(hit, __shfl_xor(hit, mm));
+        double local = (p < NP && p <= hit) ? L.nodeT[lane] : 1.79769313486231570815e+308;
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) local = fmin(local, __shfl_xor(local, mm));
+        mind = fmin(mind, local);
+        carry_x += __shfl(ix, 63);
+        carry_y += __shfl(iy, 63);
+        first_hit = hit;
+        __syncthreads();
+        if (hit != 0x7fffffff) break;
+    }
+    min_dist = uni(mind);
+    return uni(first_hit) != 0x7fffffff;
+}
+
+template <int P>
+__device__ void load_problem(const Params& prm, int b)
+{
+    Lds<P>& L = lds<P>();
+    EvalCtx& e = L.e;
+    const ProblemStore& s = prm.prob;
+    if (threadIdx.x == 0) {
+        e.M = s.M[b];
+        e.n = 3 * e.M - 1;
+        for (int d = 0; d < 2; ++d)
+            for (int k = 0; k < 3; ++k) { e.head[d][k] = s.head[(size_t)b * 6 + d * 3 + k]; e.tail[d][k] = s.tail[(size_t)b * 6 + d * 3 + k]; }
+        e.start_xy[0] = s.start_xy[(size_t)b * 2]; e.start_xy[1] = s.start_xy[(size_t)b * 2 + 1];
+        e.final_xy[0] = s.final_xy[(size_t)b * 2]; e.final_xy[1] = s.final_xy[(size_t)b * 2 + 1];
+        e.positions = s.positions + (size_t)b * s.P * 2;
+        e.evals = 0;
+        e.xy_err[0] = e.xy_err[1] = 0.0;
+    }
+    __syncthreads();
+}
+
+} // namespace
+
+template <int P>
+__global__ __launch_bounds__(64) void backend_kernel(const Params* __restrict__ gp)
+{
+    const Params& prm = *gp;
+    Lds<P>& L = lds<P>();
+    EvalCtx& e = L.e;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= prm.count) return;
+    const Config& c = prm.cfg;
+    load_problem<P>(prm, b);
+    const int M = uni(e.M), n = uni(e.n), nstride = 3 * prm.prob.P;
+    double* hist = prm.hist + (size_t)b * MEM_MAX * 2 * nstride;
+    const bool cut = prm.prob.if_cut[b] != 0;
+
+    if (prm.mode == MODE_EVAL || prm.mode == MODE_LBFGS) {
+        for (int v = lane; v < n; v += 64) L.x[v] = prm.x_io[(size_t)b * nstride + v];
+        for (int v = lane; v < n; v += 64) L.g[v] = 0.0;
+        if (lane == 0) {
+            for (int q = 0; q < 2; ++q) {
+                e.lam[q] = prm.lam_in ? prm.lam_in[(size_t)b * 2 + q] : (cut ? c.cut_lam0[q] : c.lam0[q]);
+                e.rho[q] = prm.rho_in ? prm.rho_in[(size_t)b * 2 + q] : (cut ? c.cut_rho0[q] : c.rho0[q]);
+            }
+            e.stage = prm.stage;
+            e.safe_dis = prm.safe_dis;
+            e.time_weight = prm.time_weight;
+        }
+        __syncthreads();
+        double cost;
+        int ret = 0, iters = 0;
+        if (prm.mode == MODE_EVAL) {
+            bool skipped;
+            cost = eval_cost<P>(gp, &skipped);
+        } else {
+            LbfgsParam pr = prm.stage == 1 ? c.path_lbfgs : c.lbfgs;
+            if (prm.stage == 1 && fabs(e.tail[1][0]) < c.shot_path_horizon) pr.past = c.shot_path_past;
+            ret = lbfgs<P>(gp, pr, hist, nstride, prm.max_iter, cost, iters);
+        }
+        __syncthreads();
+        for (int v = lane; v < n; v += 64) {
+            prm.g_out[(size_t)b * nstride + v] = L.g[v];
+            prm.x_io[(size_t)b * nstride + v] = L.x[v];
+        }
+        if (lane == 0) {
+            prm.cost_out[b] = cost;
+            prm.err_out[(size_t)b * 2] = e.xy_err[0];
+            prm.err_out[(size_t)b * 2 + 1] = e.xy_err[1];
+            prm.ret_out[(size_t)b * 3] = ret;
+            prm.ret_out[(size_t)b * 3 + 1] = iters;
+            prm.ret_out[(size_t)b * 3 + 2] = e.evals;
+        }
+        return;
+    }
+
+    // ---- MODE_PLAN: MSPlanner::minco_plan
+    double safe;
+    { // getDistanceReal(start) * 0.85 (nearest cell, sdf_map.cpp:865-871)
+        const MapView& m = prm.map;
+        double dr = 10000.0;
+        const double x = e.start_xy[0], y = e.start_xy[1];
+        if (!(x < m.x_lo || y < m.y_lo || x > m.x_hi || y > m.y_hi)) {
+            const double inv = 1.0 / m.res;
+            const int ix = min(max((int)((x - m.x_lo) * inv), 0), m.nx - 1), iy = min(max((int)((y - m.y_lo) * inv), 0), m.ny - 1);
+            dr = m.dist[(size_t)ix * m.ny + iy];
+        }
+        safe = fmin(dr * 0.85, c.safe_dis);
+    }
+    double tw = c.w_time, cost = 0.0, min_dist = 0.0;
+    int attempts = 0, alm_rounds = 0, lb_ret = 0, path_ret = 0, total_evals = 0;
+    bool collision = true;
+    const double tol = cut ? c.cut_tol : c.tol;
+    const double tail_s0 = prm.prob.tail[(size_t)b * 6 + 3];
+    while (attempts < c.safe_replan_max) {
+        // get_state + the initial decision vector (optimizer.cpp:222-249, 277-286)
+        __syncthreads();
+        for (int v = lane; v < 2 * (M - 1); v += 64) L.x[v] = prm.prob.inner[(size_t)b * (prm.prob.P - 1) * 2 + v];
+        const double tau0 = tau_of_t(prm.prob.init_T[b]);
+        for (int i = lane; i < M; i += 64) L.x[2 * (M - 1) + 1 + i] = tau0;
+        if (lane == 0) {
+            L.x[2 * (M - 1)] = tail_s0;
+            e.tail[1][0] = tail_s0;
+            for (int q = 0; q < 2; ++q) { e.lam[q] = cut ? c.cut_lam0[q] : c.lam0[q]; e.rho[q] = cut ? c.cut_rho0[q] : c.rho0[q]; }
+            e.safe_dis = safe;
+            e.time_weight = tw;
+            e.evals = 0;
+            e.stage = 1;
+        }
+        __syncthreads();
+        // stage 1
+        LbfgsParam pp = c.path_lbfgs;
+        if (fabs(tail_s0) < c.shot_path_horizon) pp.past = c.shot_path_past;
+        int iters;
+        path_ret = lbfgs<P>(gp, pp, hist, nstride, 0, cost, iters);
+        // stage 2: augmented-Lagrangian loop
+        __syncthreads();
+        if (lane == 0) e.stage = 2;
+        __syncthreads();
+        alm_rounds = 0;
+        for (;;) {
+            lb_ret = lbfgs<P>(gp, c.lbfgs, hist, nstride, 0, cost, iters);
+            ++alm_rounds;
+            __syncthreads();
+            const double ex = uni(e.xy_err[0]), ey = uni(e.xy_err[1]);
+            if (sqrt(ex * ex + ey * ey) < tol) break;
+            if (alm_rounds >= c.max_alm_rounds) break;
+            __syncthreads();
+            if (lane == 0)
+                for (int q = 0; q < 2; ++q) {
+                    e.lam[q] += e.rho[q] * e.xy_err[q];
+                    e.rho[q] = fmin((1 + (cut ? c.cut_gamma[q] : c.gamma[q])) * e.rho[q], cut ? c.cut_rho_max[q] : c.rho_max[q]);
+                }
+            __syncthreads();
+        }
+        __syncthreads();
+        total_evals += uni(e.evals);
+        ++attempts;
+        // final trajectory: setParameters(finalInnerpoints, finalpieceTime) -- one more pass leaves T and the
+        // coefficients of the final x in LDS (its cost and gradient are not used)
+        {
+            bool skipped;
+            (void)eval_cost<P>(gp, &skipped);
+        }
+        __syncthreads();
+        collision = final_collision<P>(gp, min_dist);
+        if (!collision) break;
+        tw *= 0.75;
+    }
+    // ---- results
+    __syncthreads();
+    const ResultStore& r = prm.res;
+    for (int v = lane; v < 2 * (M - 1); v += 64) r.inner[(size_t)b * (prm.prob.P - 1) * 2 + v] = L.x[v];
+    for (int i = lane; i < M; i += 64) r.T[(size_t)b * prm.prob.P + i] = L.T[i];
+    for (int v = lane; v < 12 * M; v += 64) r.coef[(size_t)b * prm.prob.P * 12 + v] = L.coef[v];
+    if (lane == 0) {
+        Status& st = r.status[b];
+        st.ok = collision ? 0 : 1;
+        st.attempts = attempts;
+        st.alm_rounds = alm_rounds;
+        st.evals = total_evals;
+        st.lbfgs_ret = lb_ret;
+        st.path_ret = path_ret;
+        st.collision = collision ? 1 : 0;
+        st.n_pieces = M;
+        st.cost = cost;
+        st.xy_err[0] = e.xy_err[0];
+        st.xy_err[1] = e.xy_err[1];
+        st.min_dist = min_dist;
+        st.tail_s = L.x[2 * (M - 1)];
+        r.ok[b] = collision ? 0 : 1;
+        for (int d = 0; d < 2; ++d)
+            for (int k = 0; k < 3; ++k) r.tail[(size_t)b * 6 + d * 3 + k] = (d == 1 && k == 0) ? L.x[2 * (M - 1)] : e.tail[d][k];
+    }
+}
+
+size_t lds_bytes(int P)
+{
+    return P <= 16 ? sizeof(Lds<16>) : sizeof(Lds<32>);
+}
+
+hipError_t launch(const Params& p, const Params* d_params, int P, hipStream_t s)
+{
+    const void* fn = P <= 16 ? (const void*)backend_kernel<16> : (const void*)backend_kernel<32>;
+    const size_t lds = lds_bytes(P);
+    static size_t configured[16][2] = {{0}};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    dev &= 15;
+    const int v = P <= 16 ? 0 : 1;
+    if (lds > configured[dev][v]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[dev][v] = lds;
+    }
+    e = hipMemcpyAsync(const_cast<Params*>(d_params), &p, sizeof(Params), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    void* args[] = {&d_params};
+    e = hipLaunchKernel(fn, dim3(p.count), dim3(64), args, lds, s);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+} // namespace backend

@@ -10,7 +10,6 @@
 
 #include "nmpc_kernels.h"
 #include "nmpc_core.h"
-#include "minco_core.h"
 
 struct alore_nmpc_solver {
     alore_nmpc_config cfg;
@@ -37,8 +36,7 @@ struct alore_nmpc_solver {
     // Polynome -> store on the device: staging + workspace for chunks of kPolyChunk messages
     static constexpr int kPolyChunk = 256;
     char* d_poly = nullptr;       // packed message arrays (layout: poly_layout)
-    double* d_band = nullptr;     // [chunk][band_doubles(P)]
-    double* d_rhs = nullptr;      // [chunk][rhs_doubles(P)]
+    double* d_knot = nullptr;     // [chunk][2][traj_ws_doubles(P)] workspace of the spline kernel
     int* d_panels = nullptr;      // [chunk]
     int* d_overflow = nullptr;    // [1]
     double* d_inc = nullptr;      // [chunk][C * res_int][2], grown on demand
@@ -198,8 +196,7 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->d_goal) (void)hipFree(h->d_goal);
     if (h->d_vw) (void)hipFree(h->d_vw);
     if (h->d_poly) (void)hipFree(h->d_poly);
-    if (h->d_band) (void)hipFree(h->d_band);
-    if (h->d_rhs) (void)hipFree(h->d_rhs);
+    if (h->d_knot) (void)hipFree(h->d_knot);
     if (h->d_panels) (void)hipFree(h->d_panels);
     if (h->d_overflow) (void)hipFree(h->d_overflow);
     if (h->d_inc) (void)hipFree(h->d_inc);
@@ -468,8 +465,7 @@ int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int* rob
     const PolyLayout L = poly_layout(CH, P);
     if (!h->d_poly) {
         HIP_TRY(h, hipMalloc((void**)&h->d_poly, L.end));
-        HIP_TRY(h, hipMalloc((void**)&h->d_band, sizeof(double) * CH * minco::band_doubles(P)));
-        HIP_TRY(h, hipMalloc((void**)&h->d_rhs, sizeof(double) * CH * minco::rhs_doubles(P)));
+        HIP_TRY(h, hipMalloc((void**)&h->d_knot, sizeof(double) * CH * 2 * nmpc::traj_ws_doubles(P)));
         HIP_TRY(h, hipMalloc((void**)&h->d_panels, sizeof(int) * CH));
         HIP_TRY(h, hipMalloc((void**)&h->d_overflow, sizeof(int)));
     }
@@ -522,7 +518,7 @@ int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int* rob
         pb.icr = reinterpret_cast<const double*>(h->d_poly + L.icr);
         pb.t0 = reinterpret_cast<const double*>(h->d_poly + L.t0);
         pb.P = P;
-        HIP_TRY(h, nmpc::launch_traj_build(h->refs, pb, n, state_seq_res, integral_res_int, h->d_band, h->d_rhs, h->d_panels,
+        HIP_TRY(h, nmpc::launch_traj_build(h->refs, pb, n, state_seq_res, integral_res_int, h->d_knot, h->d_panels,
                                            h->d_inc, h->d_overflow, s));
         HIP_TRY(h, hipStreamSynchronize(s)); // `pack` is reused by the next chunk
     }

@@ -68,8 +68,11 @@ struct PolyBatch {
     const double* t0;      // [count]      traj_start_time
     int P;
 };
-hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, double res, int res_int, double* band_ws,
-                             double* rhs_ws, int* n_panels, double* inc, int* overflow, hipStream_t st);
+// workspace doubles per (message, dimension) thread of the spline kernel: knot positions P + 1, inverted Schur
+// blocks 3 P, right-hand side 2 P, coefficients 6 P
+inline __host__ __device__ int traj_ws_doubles(int P) { return 12 * P + 1; }
+hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, double res, int res_int, double* knot_ws,
+                             int* n_panels, double* inc, int* overflow, hipStream_t st);
 struct PlantParams { // simulator.h: max_a_, max_domega_, Pose_pub_rate_ (a period), State_Propa_rate_ (a period)
     double max_a, max_domega, pose_pub_period, propa_period;
     int substeps; // StatePropaCallback calls per control tick

@@ -14,7 +14,7 @@
 // as in MpcWrapper::setTrajectory.
 #include "nmpc_kernels.h"
 
-#include "minco_core.h"
+#include "minco_spline.h"
 
 namespace nmpc {
 
@@ -105,36 +105,44 @@ __global__ void ref_unwrap_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
 
 // ---- Polynome messages -> trajectory store, on the device (TrajAnal::setTraj: setConditions /
 //      setParameters / getTrajectory, then getSeq; traj_anal.hpp:36-95).  Three kernels:
-//      spline (one thread per message: 6M x 6M banded LU, sequential by nature), Simpson panels (one thread
-//      per (message, panel): independent), checkpoints (one thread per message: the running sum, in the
-//      reference's order so that the result is the host's to the last bits).
-__global__ void traj_spline_kernel(RefStore s, PolyBatch m, int count, double res, int res_int, double* band_ws,
-                                   double* rhs_ws, int* n_panels, int* overflow)
+//      spline (one thread per (message, flat dimension): the SPD knot system of csrc/minco_spline.h, O(M) with
+//      2 x 2 blocks, instead of the reference's 6M x 6M band LU), Simpson panels (one thread per (message,
+//      panel): independent), checkpoints (one thread per message: the running sum in the reference's order).
+__global__ void traj_spline_kernel(RefStore s, PolyBatch m, int count, double res, int res_int, double* knot_ws,
+                                   int* n_panels, int* overflow)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 2 * count) return;
+    const int t = g >> 1, d = g & 1; // the two dimensions of a message sit on neighbouring lanes
     const int r = m.robot[t], M = m.n_pieces[t];
     double* meta = s.meta + (size_t)r * 8;
-    n_panels[t] = 0;
-    if (M < 1 || M > s.P) { meta[6] = 0.0; atomicOr(overflow, 1); return; }
+    if (d == 0) n_panels[t] = 0;
+    if (M < 1 || M > s.P) {
+        if (d == 0) { meta[6] = 0.0; atomicOr(overflow, 1); }
+        return;
+    }
     const double* T = m.t_pts + (size_t)t * m.P;
     const double* pva = m.pva + (size_t)t * 12; // init p0 p1 v0 v1 a0 a1, tail p0 p1 v0 v1 a0 a1
-    double head[2][3], tail[2][3];
-    for (int d = 0; d < 2; ++d) {
-        head[d][0] = pva[d]; head[d][1] = pva[2 + d]; head[d][2] = pva[4 + d];
-        tail[d][0] = pva[6 + d]; tail[d][1] = pva[8 + d]; tail[d][2] = pva[10 + d];
-    }
-    double* band = band_ws + (size_t)t * minco::band_doubles(m.P);
-    double* rhs = rhs_ws + (size_t)t * minco::rhs_doubles(m.P);
-    minco::spline_solve(M, T, m.inner + (size_t)t * (m.P > 1 ? m.P - 1 : 1) * 2, head, tail, band, rhs);
-    double* dur = s.dur + (size_t)r * s.P;
+    // workspace of this thread: knot positions [P + 1], inverted Schur blocks [P] (3 doubles), rhs [2 P], coefficients [6 P]
+    double* ws = knot_ws + (size_t)g * traj_ws_doubles(m.P);
+    double* kp = ws;
+    minco::Sym2* sinv = reinterpret_cast<minco::Sym2*>(ws + (m.P + 1));
+    double* y = ws + (m.P + 1) + 3 * m.P;
+    double* cf = y + 2 * m.P;
+    const double* inner = m.inner + (size_t)t * (m.P > 1 ? m.P - 1 : 1) * 2;
+    kp[0] = pva[d];
+    for (int k = 1; k < M; ++k) kp[k] = inner[(k - 1) * 2 + d];
+    kp[M] = pva[6 + d];
+    minco::spline_1d(M, T, kp, pva[2 + d], pva[4 + d], pva[8 + d], pva[10 + d], sinv, y, cf);
     double* coef = s.coef + (size_t)r * s.P * 12;
+    for (int i = 0; i < M; ++i)
+        for (int k = 0; k < 6; ++k) coef[(size_t)i * 12 + d * 6 + k] = cf[6 * i + k];
+    if (d != 0) return;
+    double* dur = s.dur + (size_t)r * s.P;
     double total = 0.0;
     for (int i = 0; i < M; ++i) {
         dur[i] = T[i];
         total += T[i];
-        for (int d = 0; d < 2; ++d)
-            for (int k = 0; k < 6; ++k) coef[(size_t)i * 12 + d * 6 + k] = rhs[(6 * i + k) * 2 + d];
     }
     const double fine = res / res_int;
     const int seq = (int)floor(total / fine);
@@ -185,12 +193,12 @@ __global__ void traj_checkpoint_kernel(RefStore s, PolyBatch m, int count, int r
     }
 }
 
-hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, double res, int res_int, double* band_ws,
-                             double* rhs_ws, int* n_panels, double* inc, int* overflow, hipStream_t st)
+hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, double res, int res_int, double* knot_ws,
+                             int* n_panels, double* inc, int* overflow, hipStream_t st)
 {
     const int max_panels = s.C * res_int;
-    hipLaunchKernelGGL(traj_spline_kernel, dim3((count + 63) / 64), dim3(64), 0, st, s, m, count, res, res_int, band_ws,
-                       rhs_ws, n_panels, overflow);
+    hipLaunchKernelGGL(traj_spline_kernel, dim3((2 * count + 63) / 64), dim3(64), 0, st, s, m, count, res, res_int, knot_ws,
+                       n_panels, overflow);
     const long total = (long)count * max_panels;
     hipLaunchKernelGGL(traj_panel_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st, s, m, count, res, res_int,
                        n_panels, max_panels, inc);

@@ -301,3 +301,25 @@ def test_obstacle_is_avoided(orc):
     nodes = orc.eval(grid, ft, 2, x, want_nodes=True)["nodes"][::2]
     # body check points keep (almost) safe_dis from the disc; the penalty is soft
     assert np.min(np.hypot(nodes[:, 0] - 3.0, nodes[:, 1] - 1.3) - 0.9) > orc.cfg.safe_dis - 0.35
+
+
+def test_optimiser_is_sensitive_to_the_last_digits(orc):
+    """Documents why whole plans cannot be compared digit for digit with ANY other implementation (another
+    compiler, another libm, the GPU): perturbing the inputs in the 14th digit changes the iteration on which the
+    reference's stopping rule fires, and with it the final cost by 1e-3..5e-2."""
+    import copy
+    grid = EsdfGrid.free(half=20.0)
+    rng = np.random.default_rng(0)
+    dev, same = [], 0
+    for ft in monte_carlo_goals(24, seed=20260206):
+        a = orc.minco_plan(grid, ft)
+        f2 = copy.deepcopy(ft)
+        f2.traj_pts = ft.traj_pts * (1 + 1e-14 * rng.standard_normal(ft.traj_pts.shape))
+        b = orc.minco_plan(grid, f2)
+        dev.append(abs(a["cost"] - b["cost"]) / abs(a["cost"]))
+        same += a["evals"] == b["evals"]
+        assert np.hypot(*b["xy_err"]) < orc.cfg.tol
+    dev = np.array(dev)
+    assert same < len(dev)          # some runs end on a different iteration
+    assert dev.max() > 1e-4         # ... with a visibly different final cost
+    assert dev.max() < 0.2          # ... that is still the same valley
