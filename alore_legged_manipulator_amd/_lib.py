@@ -87,6 +87,8 @@ SYMBOLS = (
     ("alore_nmpc_plant_get_state", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("alore_nmpc_closed_loop_tick", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_double, C.c_int, C.c_void_p]),
     ("alore_nmpc_refs_at_goal", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_refs_eval", C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_closed_loop_reset", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p, C.c_void_p]),
     ("alore_nmpc_closed_loop_run", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]),
     ("alore_nmpc_refs_sample", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p]),

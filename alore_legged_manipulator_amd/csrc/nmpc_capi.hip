@@ -31,6 +31,8 @@ struct alore_nmpc_solver {
     int* d_goal = nullptr;    // [B]
     // closed loop on the device (alore_nmpc_plant_*, alore_nmpc_closed_loop_tick): pose = d_est, ICR = d_icr
     double* d_vw = nullptr;   // [B][2] current (v, omega) of the plant
+    double* d_flat = nullptr; // [B][4] alore_nmpc_refs_eval output
+    unsigned char* d_mask = nullptr; // [B] alore_nmpc_closed_loop_reset
     nmpc::PlantParams plant{};
     bool has_plant = false;
     // Polynome -> store on the device: staging + workspace for chunks of kPolyChunk messages
@@ -195,6 +197,8 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->d_psi) (void)hipFree(h->d_psi);
     if (h->d_goal) (void)hipFree(h->d_goal);
     if (h->d_vw) (void)hipFree(h->d_vw);
+    if (h->d_flat) (void)hipFree(h->d_flat);
+    if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_poly) (void)hipFree(h->d_poly);
     if (h->d_knot) (void)hipFree(h->d_knot);
     if (h->d_panels) (void)hipFree(h->d_panels);
@@ -560,6 +564,18 @@ int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch* dev, int
     return ALORE_NMPC_OK;
 }
 
+int alore_nmpc_refs_eval(alore_nmpc_handle h, int B, double now, double* out, void* stream)
+{
+    if (!h || !h->refs.dur || B <= 0 || B > h->refs_B || !out) return fail(h, ALORE_NMPC_E_INVALID, "refs_eval: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->d_flat) HIP_TRY(h, hipMalloc((void**)&h->d_flat, sizeof(double) * h->refs_B * 4));
+    HIP_TRY(h, nmpc::launch_ref_eval(h->refs, B, now, h->d_flat, s));
+    HIP_TRY(h, hipMemcpyAsync(out, h->d_flat, sizeof(double) * B * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return ALORE_NMPC_OK;
+}
+
 int alore_nmpc_plant_init(alore_nmpc_handle h, const alore_plant_params* p)
 {
     if (!h || !h->refs.dur || !p || p->substeps < 1 || !(p->state_propa_period > 0.0) || !(p->pose_pub_period > 0.0))
@@ -597,6 +613,23 @@ int alore_nmpc_plant_get_state(alore_nmpc_handle h, int B, double* pose, double*
     if (vw) HIP_TRY(h, hipMemcpyAsync(vw, h->d_vw, sizeof(double) * B * 2, hipMemcpyDeviceToHost, s));
     if (at_goal) HIP_TRY(h, hipMemcpyAsync(at_goal, h->d_goal, sizeof(int) * B, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_closed_loop_reset(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, const unsigned char* mask, void* stream)
+{
+    if (!h || !h->has_plant || !dev || !dev->x || !dev->u || B <= 0 || B > h->refs_B)
+        return fail(h, ALORE_NMPC_E_INVALID, "closed_loop_reset: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* d_mask = nullptr;
+    if (mask) {
+        if (!h->d_mask) HIP_TRY(h, hipMalloc((void**)&h->d_mask, (size_t)h->refs_B));
+        HIP_TRY(h, hipMemcpyAsync(h->d_mask, mask, (size_t)B, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipStreamSynchronize(s)); // `mask` may go away after return
+        d_mask = h->d_mask;
+    }
+    HIP_TRY(h, nmpc::launch_iterate_reset(*dev, B, h->cfg.N, h->d_est, d_mask, s));
     return ALORE_NMPC_OK;
 }
 

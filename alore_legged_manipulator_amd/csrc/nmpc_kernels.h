@@ -73,6 +73,8 @@ struct PolyBatch {
 inline __host__ __device__ int traj_ws_doubles(int P) { return 12 * P + 1; }
 hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, double res, int res_int, double* knot_ws,
                              int* n_panels, double* inc, int* overflow, hipStream_t st);
+hipError_t launch_iterate_reset(const alore_nmpc_batch& b, int B, int N, const double* pose, const unsigned char* mask, hipStream_t st);
+hipError_t launch_ref_eval(const RefStore& s, int B, double now, double* out /* [B][4] */, hipStream_t st);
 struct PlantParams { // simulator.h: max_a_, max_domega_, Pose_pub_rate_ (a period), State_Propa_rate_ (a period)
     double max_a, max_domega, pose_pub_period, propa_period;
     int substeps; // StatePropaCallback calls per control tick

@@ -103,6 +103,26 @@ __global__ void ref_unwrap_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
     }
 }
 
+// TrajAnal::getVstate / getAstate at t_cur for every robot (the if_mpc = false branch of CmdCallback)
+__global__ void ref_eval_kernel(RefStore s, int B, double now, double* out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    const double* m = s.meta + (size_t)r * 8;
+    double v[2] = {0, 0}, a[2] = {0, 0}, p[2];
+    if (m[6] != 0.0) {
+        const double t = now - m[0];
+        eval_pv(s.dur + (size_t)r * s.P, s.coef + (size_t)r * s.P * 12, (int)m[4], t, p, v);
+        minco::eval_a(s.dur + (size_t)r * s.P, s.coef + (size_t)r * s.P * 12, (int)m[4], t, a);
+    }
+    out[(size_t)r * 4] = v[0]; out[(size_t)r * 4 + 1] = v[1]; out[(size_t)r * 4 + 2] = a[0]; out[(size_t)r * 4 + 3] = a[1];
+}
+hipError_t launch_ref_eval(const RefStore& s, int B, double now, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(ref_eval_kernel, dim3((B + 127) / 128), dim3(128), 0, st, s, B, now, out);
+    return hipGetLastError();
+}
+
 // ---- Polynome messages -> trajectory store, on the device (TrajAnal::setTraj: setConditions /
 //      setParameters / getTrajectory, then getSeq; traj_anal.hpp:36-95).  Three kernels:
 //      spline (one thread per (message, flat dimension): the SPD knot system of csrc/minco_spline.h, O(M) with
@@ -239,6 +259,24 @@ __global__ void plant_kernel(alore_nmpc_batch b, int B, int N, int node, const d
     }
     pose[(size_t)r * 3] = x; pose[(size_t)r * 3 + 1] = y; pose[(size_t)r * 3 + 2] = th;
     vw[(size_t)r * 2] = v; vw[(size_t)r * 2 + 1] = w;
+}
+
+// MpcWrapper::solve's reset (mpc_wrapper.cpp:267-275) from the plant's pose: one thread per (robot, node)
+__global__ void iterate_reset_kernel(alore_nmpc_batch b, int B, int N, const double* pose, const unsigned char* mask)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * (N + 1)) return;
+    const int r = (int)(t / (N + 1)), k = (int)(t % (N + 1));
+    if (mask && !mask[r]) return;
+    float* x = b.x + ((size_t)r * (N + 1) + k) * 3;
+    x[0] = (float)pose[(size_t)r * 3]; x[1] = (float)pose[(size_t)r * 3 + 1]; x[2] = (float)pose[(size_t)r * 3 + 2];
+    if (k < N) { b.u[((size_t)r * N + k) * 2] = 0.f; b.u[((size_t)r * N + k) * 2 + 1] = 0.f; }
+}
+hipError_t launch_iterate_reset(const alore_nmpc_batch& b, int B, int N, const double* pose, const unsigned char* mask, hipStream_t st)
+{
+    const long total = (long)B * (N + 1);
+    hipLaunchKernelGGL(iterate_reset_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st, b, B, N, pose, mask);
+    return hipGetLastError();
 }
 
 hipError_t launch_plant(const alore_nmpc_batch& b, int B, int N, int node, const double* icr, const int* at_goal,

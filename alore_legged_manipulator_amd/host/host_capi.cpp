@@ -1,122 +1,108 @@
-// host_capi.cpp -- C entry points over the C++ host layer (traj_anal.hpp, mpc_controller.hpp) so that
-// tests and Python callers can drive it through ctypes.  Plain pointers and sizes only.
+// host_capi.cpp -- C entry points (include/alore_nmpc_host.h) over the C++ host layer (mpc_controller.hpp) so that
+// tests and Python callers can drive the batched controller through ctypes.  Plain pointers and sizes only.
 #include <new>
 
+#include "../../include/alore_nmpc_host.h"
 #include "mpc_controller.hpp"
 
 using namespace alore;
 
 namespace {
-Polynome make_polynome(double traj_start_time, int n_pieces, const double* innerpoints /* (n-1) x 2 */,
-                       const double* t_pts, const double* init_pva /* [p0 p1 v0 v1 a0 a1] */,
-                       const double* tail_pva, const double* start_position, const double* ICR)
-{
-    Polynome m;
-    m.traj_start_time = traj_start_time;
-    for (int i = 0; i < n_pieces - 1; ++i) m.innerpoints.push_back({innerpoints[i * 2], innerpoints[i * 2 + 1]});
-    m.t_pts.assign(t_pts, t_pts + n_pieces);
-    for (int d = 0; d < 2; ++d) {
-        m.init_p[d] = init_pva[d]; m.init_v[d] = init_pva[2 + d]; m.init_a[d] = init_pva[4 + d];
-        m.tail_p[d] = tail_pva[d]; m.tail_v[d] = tail_pva[2 + d]; m.tail_a[d] = tail_pva[4 + d];
-    }
-    for (int i = 0; i < 3; ++i) { m.start_position[i] = start_position[i]; m.ICR[i] = ICR[i]; }
-    return m;
+BatchedMpcController* C(void* c) { return static_cast<BatchedMpcController*>(c); }
 }
-} // namespace
 
 extern "C" {
 
-// ---- RefSampler (host only, no GPU) ------------------------------------------------------------
-void* alore_host_sampler_create(int N, double dt, double state_seq_res, double integral_res_int)
+void alore_host_default_params(alore_host_mpc_params* p)
 {
-    try { return new RefSampler(N, dt, state_seq_res, integral_res_int); } catch (...) { return nullptr; }
+    const MpcParams d;
+    p->max_omega = d.max_omega; p->max_domega = d.max_domega; p->max_vel = d.max_vel; p->min_vel = d.min_vel; p->max_acc = d.max_acc;
+    p->cmd_timer_rate = d.cmd_timer_rate; p->max_mpc_time = d.max_mpc_time; p->if_mpc = d.if_mpc ? 1 : 0; p->delay_num = d.delay_num;
+    p->state_seq_res = d.state_seq_res; p->Integral_appr_resInt = d.Integral_appr_resInt;
+    for (int i = 0; i < 3; ++i) p->matrix_q[i] = d.matrix_q[i];
+    for (int i = 0; i < 2; ++i) p->matrix_r[i] = d.matrix_r[i];
 }
-void alore_host_sampler_destroy(void* s) { delete static_cast<RefSampler*>(s); }
-int alore_host_sampler_traj(void* s, double traj_start_time, int n_pieces, const double* innerpoints, const double* t_pts,
-                            const double* init_pva, const double* tail_pva, const double* start_position, const double* ICR)
-{
-    try {
-        static_cast<RefSampler*>(s)->TrajCallback(
-            make_polynome(traj_start_time, n_pieces, innerpoints, t_pts, init_pva, tail_pva, start_position, ICR));
-        return 0;
-    } catch (...) { return -1; }
-}
-void alore_host_sampler_odom(void* s, double x, double y, double yaw) { static_cast<RefSampler*>(s)->OdomCallback(x, y, yaw); }
-void alore_host_sampler_icr(void* s, double yr, double yl, double xv) { static_cast<RefSampler*>(s)->ICRCallback(yr, yl, xv); }
-// one CmdCallback worth of reference handling: swap in the pending trajectory, sample, unwrap yaw
-int alore_host_sampler_refs(void* s_, double now, int do_smooth, double* ref_states /* 3 x (N+1) */,
-                            double* ref_inputs /* 2 x (N+1) */, int* at_goal)
-{
-    RefSampler* s = static_cast<RefSampler*>(s_);
-    try {
-        s->swapInNewTraj(now);
-        s->getRefPoints(now);
-        if (do_smooth) s->smooth_yaw();
-    } catch (...) { return -1; }
-    for (size_t i = 0; i < s->reference_states_.size(); ++i) ref_states[i] = s->reference_states_[i];
-    for (size_t i = 0; i < s->reference_inputs_.size(); ++i) ref_inputs[i] = s->reference_inputs_[i];
-    *at_goal = s->at_goal ? 1 : 0;
-    return 0;
-}
-int alore_host_sampler_at_goal(void* s) { return static_cast<RefSampler*>(s)->at_goal ? 1 : 0; }
-double alore_host_sampler_duration(void* s) { return static_cast<RefSampler*>(s)->new_traj_.get_traj_duration(); }
-// direct TrajAnal queries on the pending (latest) trajectory
-int alore_host_sampler_state(void* s_, double t, double* p3, double* v2, double* a2)
-{
-    RefSampler* s = static_cast<RefSampler*>(s_);
-    try {
-        s->new_traj_.getPstate(t, p3);
-        s->new_traj_.getVstate(t, v2);
-        s->new_traj_.getAstate(t, a2);
-        return 0;
-    } catch (...) { return -1; }
-}
-int alore_host_sampler_flat(void* s_, double t, double* pos2, double* vel2, double* acc2)
-{
-    RefSampler* s = static_cast<RefSampler*>(s_);
-    s->new_traj_.trajectory().getPos(t, pos2);
-    s->new_traj_.trajectory().getVel(t, vel2);
-    s->new_traj_.trajectory().getAcc(t, acc2);
-    return 0;
-}
-int alore_host_sampler_sequence(void* s_, double* out4, int max_rows)
-{
-    const auto& seq = static_cast<RefSampler*>(s_)->new_traj_.get_state_sequence_();
-    const int n = (int)seq.size() < max_rows ? (int)seq.size() : max_rows;
-    for (int i = 0; i < n; ++i)
-        for (int k = 0; k < 4; ++k) out4[i * 4 + k] = seq[i][k];
-    return (int)seq.size();
-}
-void alore_host_normlize_theta(double* th) { RefSampler::normlize_theta(*th); }
 
-// ---- BatchedMpcController (needs the GPU library) ----------------------------------------------
-void* alore_host_controller_create(int B, int N, double dt, const double* matrix_q, const double* matrix_r, int delay_num,
-                                   double state_seq_res, double integral_res_int, int device)
+void* alore_host_controller_create(int B, int N, double dt, const alore_host_mpc_params* p, int device, int max_pieces,
+                                   int max_checkpoints)
 {
     try {
-        return new BatchedMpcController(B, N, dt, matrix_q, matrix_r, delay_num, state_seq_res, integral_res_int, device);
+        MpcParams m;
+        m.max_omega = p->max_omega; m.max_domega = p->max_domega; m.max_vel = p->max_vel; m.min_vel = p->min_vel; m.max_acc = p->max_acc;
+        m.cmd_timer_rate = p->cmd_timer_rate; m.max_mpc_time = p->max_mpc_time; m.if_mpc = p->if_mpc != 0; m.delay_num = p->delay_num;
+        m.state_seq_res = p->state_seq_res; m.Integral_appr_resInt = p->Integral_appr_resInt;
+        for (int i = 0; i < 3; ++i) m.matrix_q[i] = p->matrix_q[i];
+        for (int i = 0; i < 2; ++i) m.matrix_r[i] = p->matrix_r[i];
+        return new BatchedMpcController(B, N, dt, m, device, max_pieces, max_checkpoints);
     } catch (...) { return nullptr; }
 }
-void alore_host_controller_destroy(void* c) { delete static_cast<BatchedMpcController*>(c); }
-int alore_host_controller_device_refs(void* c, int max_pieces, int max_checkpoints, int build_on_device)
+void alore_host_controller_destroy(void* c) { delete C(c); }
+
+int alore_host_controller_odom(void* c, int b, double x, double y, double yaw)
 {
-    try { static_cast<BatchedMpcController*>(c)->useDeviceReferences(max_pieces, max_checkpoints, build_on_device != 0); return 0; } catch (...) { return -1; }
+    try { C(c)->robots.at((size_t)b).OdomCallback(x, y, yaw); return 0; } catch (...) { return -1; }
 }
-void* alore_host_controller_robot(void* c, int b) { return &static_cast<BatchedMpcController*>(c)->robots.at(b); }
-int alore_host_controller_tick(void* c, double now, double* cmd)
+int alore_host_controller_icr(void* c, int b, double yr, double yl, double xv)
 {
-    try { static_cast<BatchedMpcController*>(c)->tick(now, cmd); return 0; } catch (...) { return -1; }
+    try { C(c)->robots.at((size_t)b).ICRCallback(yr, yl, xv); return 0; } catch (...) { return -1; }
 }
-// the references the solver saw on the last tick (device copies): y B x N x 5, yN B x 3, od B x (N+1) x 3, x0 B x 3
-int alore_host_controller_references(void* c_, float* y, float* yN, float* od, float* x0)
+int alore_host_controller_traj(void* c, int b, double traj_start_time, int n_pieces, const double* innerpoints, const double* t_pts,
+                               const double* init_pva, const double* tail_pva, const double* start_position, const double* ICR)
 {
-    try { static_cast<BatchedMpcController*>(c_)->mpc_wrapper_.downloadReferences(y, yN, od, x0); return 0; } catch (...) { return -1; }
+    try {
+        Polynome m;
+        m.traj_start_time = traj_start_time;
+        for (int i = 0; i < n_pieces - 1; ++i) m.innerpoints.push_back({innerpoints[i * 2], innerpoints[i * 2 + 1]});
+        m.t_pts.assign(t_pts, t_pts + n_pieces);
+        for (int d = 0; d < 2; ++d) {
+            m.init_p[d] = init_pva[d]; m.init_v[d] = init_pva[2 + d]; m.init_a[d] = init_pva[4 + d];
+            m.tail_p[d] = tail_pva[d]; m.tail_v[d] = tail_pva[2 + d]; m.tail_a[d] = tail_pva[4 + d];
+        }
+        for (int i = 0; i < 3; ++i) { m.start_position[i] = start_position[i]; m.ICR[i] = ICR[i]; }
+        C(c)->robots.at((size_t)b).TrajCallback(m);
+        return 0;
+    } catch (...) { return -1; }
 }
-void alore_host_controller_prediction(void* c_, int b, double* states /* 3 x (N+1) */, double* inputs /* 2 x N */, int* status)
+int alore_host_controller_emergency_stop(void* c, int b)
 {
-    BatchedMpcController* c = static_cast<BatchedMpcController*>(c_);
-    c->mpc_wrapper_.getStates(b, states);
-    c->mpc_wrapper_.getInputs(b, inputs);
-    *status = c->mpc_wrapper_.getStatus(b);
+    try { C(c)->emergencyStop(b); return 0; } catch (...) { return -1; }
+}
+int alore_host_controller_robot_state(void* c, int b, int* at_goal, int* receive_traj, int* has_odom)
+{
+    try {
+        const RobotNode& r = C(c)->robots.at((size_t)b);
+        if (at_goal) *at_goal = r.at_goal ? 1 : 0;
+        if (receive_traj) *receive_traj = r.receive_traj_ ? 1 : 0;
+        if (has_odom) *has_odom = r.has_odom ? 1 : 0;
+        return 0;
+    } catch (...) { return -1; }
+}
+int alore_host_controller_tick(void* c, double now, alore_host_command* cmd)
+{
+    try {
+        BatchedMpcController* k = C(c);
+        std::vector<RobotCommand> out((size_t)k->mpc_wrapper_.B);
+        k->tick(now, out.data());
+        for (size_t b = 0; b < out.size(); ++b) {
+            cmd[b].right_wheel_ome = out[b].right_wheel_ome; cmd[b].left_wheel_ome = out[b].left_wheel_ome;
+            cmd[b].v = out[b].v; cmd[b].omega = out[b].omega; cmd[b].a = out[b].a; cmd[b].alpha = out[b].alpha;
+            cmd[b].wheel_published = out[b].wheel_published ? 1 : 0;
+            cmd[b].state_published = out[b].state_published ? 1 : 0;
+        }
+        return 0;
+    } catch (...) { return -1; }
+}
+int alore_host_controller_references(void* c, float* y, float* yN, float* od, float* x0)
+{
+    try { C(c)->mpc_wrapper_.downloadReferences(y, yN, od, x0); return 0; } catch (...) { return -1; }
+}
+int alore_host_controller_prediction(void* c, int b, double* states, double* inputs, int* status)
+{
+    try {
+        C(c)->mpc_wrapper_.getStates(b, states);
+        C(c)->mpc_wrapper_.getInputs(b, inputs);
+        *status = C(c)->mpc_wrapper_.getStatus(b);
+        return 0;
+    } catch (...) { return -1; }
 }
 }

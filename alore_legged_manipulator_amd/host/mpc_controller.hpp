@@ -4,18 +4,19 @@
 //   MpcWrapper        P/nmpc_controller/include/nmpc_controller/mpc_wrapper.h:43-141,
 //                     P/nmpc_controller/src/mpc_wrapper.cpp:33-410
 //   MpcController     P/nmpc_controller/include/nmpc_controller/mpc.h:83-200,
-//                     P/nmpc_controller/src/mpc.cpp:6-98 (parameters), :124-171 (callbacks),
-//                     :173-240 (CmdCallback), :243-277 (normlize_theta, smooth_yaw),
-//                     :296-350 (run), :407-461 (getRefPoints), :502-509 (cmdPub)
+//                     P/nmpc_controller/src/mpc.cpp:6-98 (parameters), :112-171 (callbacks),
+//                     :173-240 (CmdCallback), :279-294 (emergencyStop), :296-350 (run), :502-509 (cmdPub)
 // with P = /root/reference/planning_ddr_opt.  Same method names and argument meaning; every robot of
 // the batch is one instance of the reference node.  ROS time is replaced by an explicit `now`
-// argument, messages by plain structs (traj_anal.hpp: Polynome).  The numerics run on the GPU through
-// include/alore_nmpc.h; this layer only does what the reference does in double precision on the host.
+// argument, messages by plain structs (polynome.hpp).  All numerics run on the GPU through
+// include/alore_nmpc.h: the solver AND what the reference does on the host before it -- turning a
+// Polynome into a spline with Simpson checkpoints (TrajAnal::setTraj / getSeq), sampling it
+// (getRefPoints), unwrapping the heading (smooth_yaw).  This layer only keeps the per-robot message
+// state and the tick logic.  (A float64 host restatement of the sampling exists as a checker:
+// oracle/traj_oracle.hpp -- test infrastructure, not included here.)
 #pragma once
 
-#ifndef ALORE_HOST_SAMPLER_ONLY // (tests/harness/sanitize_driver.cpp builds the GPU-free part alone)
 #include <hip/hip_runtime_api.h>
-#endif
 
 #include <cmath>
 #include <cstring>
@@ -24,7 +25,7 @@
 #include <vector>
 
 #include "../../include/alore_nmpc.h"
-#include "traj_anal.hpp"
+#include "polynome.hpp"
 
 namespace alore {
 
@@ -36,7 +37,26 @@ struct CarICR { // mpc.h:76-81
     double yr = -0.2, yl = 0.2, xv = 0.0;
 };
 
-#ifndef ALORE_HOST_SAMPLER_ONLY
+// The node's private parameters (mpc.cpp:11-20, 32-33, 69-70; values of
+// P/nmpc_controller/config/mpc3ms.yaml where the file sets them, the nh.param defaults otherwise)
+struct MpcParams {
+    double max_omega = -1.0, max_domega = -1.0, max_vel = -1.0, min_vel = -1.0, max_acc = -1.0;
+    double cmd_timer_rate = 100.0, max_mpc_time = 10.0;
+    bool if_mpc = true;
+    int delay_num = 0;
+    double state_seq_res = 1.0;
+    int Integral_appr_resInt = 10;
+    double matrix_q[3] = {10.0, 10.0, 0.5};
+    double matrix_r[2] = {0.1, 0.1};
+};
+
+// what one tick publishes for one robot: ~wheel_cmd (CarControl) and ~cmd (CarState)
+struct RobotCommand {
+    double right_wheel_ome = 0.0, left_wheel_ome = 0.0; // carstatemsgs/CarControl
+    double v = 0.0, omega = 0.0, a = 0.0, alpha = 0.0;  // carstatemsgs/CarState (v, omega, a, alpha; js = jyaw = 0)
+    bool wheel_published = false, state_published = false;
+};
+
 // ---- A10: batched MpcWrapper -------------------------------------------------------------------
 class BatchedMpcWrapper {
 public:
@@ -130,20 +150,6 @@ public:
         device_refs_ = true;
     }
     bool deviceRefs() const { return device_refs_; }
-    // the trajectory robot b tracks from `start_time` on (TrajAnal as prepared by TrajCallback)
-    void setDeviceTrajectory(int b, const TrajAnal& traj, double start_time)
-    {
-        const auto& pieces = traj.trajectory().pieces;
-        const auto& seq = traj.get_state_sequence_();
-        std::vector<double> dur(pieces.size()), coef(pieces.size() * 12), ck(seq.size() * 2);
-        for (size_t i = 0; i < pieces.size(); ++i) {
-            dur[i] = pieces[i].duration;
-            std::memcpy(&coef[i * 12], pieces[i].c, sizeof(double) * 12);
-        }
-        for (size_t i = 0; i < seq.size(); ++i) { ck[i * 2] = seq[i][0]; ck[i * 2 + 1] = seq[i][1]; }
-        check(alore_nmpc_refs_set_trajectory(h_, b, (int)pieces.size(), dur.data(), coef.data(), (int)seq.size(), ck.data(),
-                                             start_time, traj.state_seq_res(), traj.icr_xv(), nullptr));
-    }
     // the same store filled on the device from the planner messages themselves
     void setDevicePolynomes(const std::vector<int>& robots, const std::vector<const Polynome*>& msgs, double state_seq_res,
                             int integral_res_int)
@@ -165,6 +171,12 @@ public:
             q.traj_start_time = m.traj_start_time;
         }
         check(alore_nmpc_refs_set_polynomes(h_, (int)pm.size(), robots.data(), pm.data(), state_seq_res, integral_res_int, nullptr));
+    }
+    // flat velocity / acceleration (theta', s', theta'', s'') of every robot's trajectory at now (the if_mpc = false
+    // branch of CmdCallback, mpc.cpp:211-234); robots without a trajectory get zeros
+    void flatStateAt(double now, double* out /* B x 4 */)
+    {
+        check(alore_nmpc_refs_eval(h_, B, now, out, nullptr));
     }
     // getRefPoints + smooth_yaw + setTrajectory + setICRParameters + the x0 of update() for all robots
     // at_goal is filled by the time the next update() returns (one synchronisation per tick)
@@ -258,211 +270,133 @@ private:
     const double dt_;
 };
 
-#endif // ALORE_HOST_SAMPLER_ONLY
-
-// ---- A11: reference sampling + tick logic, one entry per robot -------------------------------------
-// Pure host code (no GPU): usable and tested on its own.
-class RefSampler {
-public:
-    TrajAnal traj_, new_traj_;
-    double new_traj_start_time_ = 0.0, start_time = -1.0, traj_duration = 0.0;
-    bool receive_traj_ = false, at_goal = false, has_odom = false;
-    unsigned traj_version = 0; // bumped whenever traj_ is replaced (device copies follow it)
-    // build_on_device: the spline and the Simpson checkpoints of a new message are computed by the GPU
-    // (alore_nmpc_refs_set_polynomes); the host only keeps the message and its duration
-    bool build_on_device = false;
+// ---- A11: per-robot message state + the tick ---------------------------------------------------------
+// What MpcController keeps between callbacks, for one robot.
+struct RobotNode {
+    bool has_odom = false, receive_traj_ = false, at_goal = false;
+    bool solve_from_scratch_ = true;          // mpc.cpp:317-320: the first solve of THIS robot resets its iterate
+    bool pending = false;                     // new_traj_.if_get_traj_
+    double new_traj_start_time_ = 0.0, start_time = -1.0, traj_duration = 0.0, new_duration_ = 0.0;
     Polynome msg_, new_msg_;
-    double new_duration_ = 0.0;
+    unsigned traj_version = 0, uploaded_version = 0; // the device store follows traj_version
     CarICR car_icr_;
     double est_state_[3] = {0, 0, 0};
-    int N_;
-    double dt_;
-    std::vector<double> reference_states_; // 3 x (N+1), column-major (Eigen layout)
-    std::vector<double> reference_inputs_; // 2 x (N+1)
+    double last_input_[2] = {0, 0};           // predicted_inputs_(., delay_num_) of the last solve
 
-    RefSampler(int N, double dt, double state_seq_res = 0.1, double Integral_appr_resInt = 4) : N_(N), dt_(dt)
+    void OdomCallback(double x, double y, double yaw) { has_odom = true; est_state_[0] = x; est_state_[1] = y; est_state_[2] = yaw; } // mpc.cpp:112-122
+    void ICRCallback(double yr, double yl, double xv) { car_icr_.yr = yr; car_icr_.yl = yl; car_icr_.xv = xv; }                         // :124-128
+    void TrajCallback(const Polynome& msg) // :130-171
     {
-        traj_.setRes(state_seq_res, Integral_appr_resInt);
-        new_traj_.setRes(state_seq_res, Integral_appr_resInt);
-        reference_states_.assign((size_t)3 * (N + 1), 0.0);
-        reference_inputs_.assign((size_t)2 * (N + 1), 0.0);
-    }
-    // mpc.cpp:112-122
-    void OdomCallback(double x, double y, double yaw) { has_odom = true; est_state_[0] = x; est_state_[1] = y; est_state_[2] = yaw; }
-    // mpc.cpp:124-128: point.x = yr, point.y = yl, point.z = xv
-    void ICRCallback(double yr, double yl, double xv) { car_icr_.yr = yr; car_icr_.yl = yl; car_icr_.xv = xv; }
-    // mpc.cpp:130-171
-    void TrajCallback(const Polynome& msg)
-    {
-        if (new_traj_.if_get_traj_) promote();
-        if (build_on_device) {
-            new_msg_ = msg;
-            new_duration_ = 0.0;
-            for (double t : msg.t_pts) new_duration_ += t;
-        } else {
-            new_traj_.setTraj(msg);
-        }
+        if (pending) promote();
+        new_msg_ = msg;
+        new_duration_ = 0.0;
+        for (double t : msg.t_pts) new_duration_ += t;
         new_traj_start_time_ = msg.traj_start_time;
-        new_traj_.if_get_traj_ = true;
+        pending = true;
         receive_traj_ = true;
         at_goal = false;
     }
-    // mpc.cpp:177-182
-    void swapInNewTraj(double now)
-    {
-        if (new_traj_.if_get_traj_ && now > new_traj_start_time_) promote();
-    }
-    // the pending trajectory becomes the tracked one (mpc.cpp:139-144, 177-182)
+    void emergencyStop() { receive_traj_ = false; start_time = -1.0; } // :279-294 (the zero CarState is published by the controller)
+    void swapInNewTraj(double now) { if (pending && now > new_traj_start_time_) promote(); } // :177-182
     void promote()
     {
-        if (build_on_device) {
-            msg_ = new_msg_;
-            traj_duration = new_duration_;
-        } else {
-            traj_ = new_traj_;
-            traj_duration = traj_.get_traj_duration();
-        }
+        msg_ = new_msg_;
+        traj_duration = new_duration_;
         ++traj_version;
         start_time = new_traj_start_time_;
-        new_traj_.if_get_traj_ = false;
-    }
-    static void normlize_theta(double& th) // mpc.cpp:243-246
-    {
-        while (th > M_PI) th -= 2 * M_PI;
-        while (th < -M_PI) th += 2 * M_PI;
-    }
-    // mpc.cpp:407-461
-    void getRefPoints(double now)
-    {
-        const int T = N_;
-        const double dt = dt_;
-        const double t_cur = now - start_time;
-        at_goal = (t_cur > traj_duration + 1.0);
-        int j = 0;
-        for (double temp_t = t_cur + dt; j <= T; ++j, temp_t += dt) {
-            double P[3], V[2];
-            const bool inside = temp_t <= traj_duration;
-            const double tq = inside ? temp_t : traj_duration;
-            traj_.getPstate(tq, P);
-            traj_.getVstate(tq, V);
-            reference_states_[j * 3 + kX] = P[0];
-            reference_states_[j * 3 + kY] = P[1];
-            reference_states_[j * 3 + kPsi] = P[2];
-            reference_inputs_[j * 2 + kVl] = inside ? V[1] - V[0] * car_icr_.yl : 0.0;
-            reference_inputs_[j * 2 + kVr] = inside ? V[1] - V[0] * car_icr_.yr : 0.0;
-            normlize_theta(reference_states_[j * 3 + kPsi]);
-        }
-    }
-    // mpc.cpp:248-277
-    void smooth_yaw()
-    {
-        auto psi = [&](int i) -> double& { return reference_states_[i * 3 + kPsi]; };
-        double dyaw = psi(0) - est_state_[kPsi];
-        while (dyaw >= M_PI / 2) { psi(0) -= M_PI * 2; dyaw = psi(0) - est_state_[kPsi]; }
-        while (dyaw <= -M_PI / 2) { psi(0) += M_PI * 2; dyaw = psi(0) - est_state_[kPsi]; }
-        for (int i = 0; i < N_; ++i) {
-            dyaw = psi(i + 1) - psi(i);
-            while (dyaw >= M_PI / 2) { psi(i + 1) -= M_PI * 2; dyaw = psi(i + 1) - psi(i); }
-            while (dyaw <= -M_PI / 2) { psi(i + 1) += M_PI * 2; dyaw = psi(i + 1) - psi(i); }
-        }
+        pending = false;
     }
 };
 
-#ifndef ALORE_HOST_SAMPLER_ONLY
 // The ROS-free control tick of the reference node for B robots (mpc.cpp:173-240 CmdCallback + :296-350
-// run + :502-509 cmdPub).  `tick(now)` returns, per robot, the wheel-speed command
-// (right_wheel_ome, left_wheel_ome) = predicted input column `delay_num`.
+// run + :502-509 cmdPub).
 class BatchedMpcController {
 public:
     BatchedMpcWrapper mpc_wrapper_;
-    std::vector<RefSampler> robots;
-    int delay_num_ = 1;
-    bool solve_from_scratch_ = true;
-    std::vector<unsigned> uploaded_version_; // device-reference mode: traj_version last sent per robot
-    double state_seq_res_ = 0.1;
-    int integral_res_int_ = 4;
+    std::vector<RobotNode> robots;
+    MpcParams params_;
 
-    BatchedMpcController(int B, int N, double dt, const double matrix_q[3], const double matrix_r[2], int delay_num = 1,
-                         double state_seq_res = 0.1, double Integral_appr_resInt = 4, int device = 0)
-        : mpc_wrapper_(B, N, dt, device), delay_num_(delay_num), state_seq_res_(state_seq_res),
-          integral_res_int_((int)Integral_appr_resInt)
+    BatchedMpcController(int B, int N, double dt, const MpcParams& prm, int device = 0, int max_pieces = 64, int max_checkpoints = 1024)
+        : mpc_wrapper_(B, N, dt, device), robots((size_t)B), params_(prm)
     {
         // mpc.cpp:67-85: diagonal weights from ~matrix_q / ~matrix_r
-        const double Q[9] = {matrix_q[0], 0, 0, 0, matrix_q[1], 0, 0, 0, matrix_q[2]};
-        const double R[4] = {matrix_r[0], 0, 0, matrix_r[1]};
+        const double Q[9] = {prm.matrix_q[0], 0, 0, 0, prm.matrix_q[1], 0, 0, 0, prm.matrix_q[2]};
+        const double R[4] = {prm.matrix_r[0], 0, 0, prm.matrix_r[1]};
         mpc_wrapper_.setCosts(Q, R);
-        robots.reserve(B);
-        for (int b = 0; b < B; ++b) robots.emplace_back(N, dt, state_seq_res, Integral_appr_resInt);
-    }
-    // Sample the references on the GPU from now on (alore_nmpc_refs_*): a tick then uploads the
-    // odometry and ICR of every robot (48 bytes each) instead of its 5N+3 reference floats.
-    // build_on_device: new Polynome messages are also turned into splines + checkpoints by the GPU, all
-    // robots whose trajectory changed in one call (otherwise the host does it, as the reference's TrajCallback)
-    void useDeviceReferences(int max_pieces = 64, int max_checkpoints = 1024, bool build_on_device = true)
-    {
         mpc_wrapper_.enableDeviceRefs(max_pieces, max_checkpoints);
-        uploaded_version_.assign(robots.size(), 0u);
-        for (auto& r : robots) {
-            if (r.receive_traj_ && build_on_device) throw std::logic_error("useDeviceReferences: call before the first trajectory");
-            r.build_on_device = build_on_device;
-        }
     }
-    // cmd: B x 2 (right, left).  Robots without odometry / trajectory keep a zero command.
-    void tick(double now, double* cmd)
+    // /planner/emergency_stop (mpc.cpp:22, 279-294): the robot forgets its trajectory; `out` (optional) gets the
+    // zero CarState the reference publishes from the callback
+    void emergencyStop(int b, RobotCommand* out = nullptr)
+    {
+        robots.at((size_t)b).emergencyStop();
+        if (out) { *out = RobotCommand{}; out->state_published = true; }
+    }
+    // One CmdCallback for every robot.  cmd: B entries.  A robot without odometry or trajectory publishes nothing.
+    void tick(double now, RobotCommand* cmd)
     {
         const int B = mpc_wrapper_.B, N = mpc_wrapper_.kSamples;
-        std::vector<double> est((size_t)B * 3, 0.0);
-        std::vector<int> goal(B, 0); // device-reference mode: at_goal flags, fetched with the results
-        if (mpc_wrapper_.deviceRefs()) {
-            std::vector<double> icr((size_t)B * 3, 0.0);
-            std::vector<int> fresh_robots;
-            std::vector<const Polynome*> fresh_msgs;
-            for (int b = 0; b < B; ++b) {
-                RefSampler& r = robots[b];
-                icr[(size_t)b * 3] = r.car_icr_.xv; icr[(size_t)b * 3 + 1] = r.car_icr_.yr; icr[(size_t)b * 3 + 2] = r.car_icr_.yl;
-                if (!r.has_odom || !r.receive_traj_) continue;
-                r.swapInNewTraj(now);
-                if (r.traj_version != uploaded_version_[b]) {
-                    if (r.build_on_device) { fresh_robots.push_back(b); fresh_msgs.push_back(&r.msg_); }
-                    else mpc_wrapper_.setDeviceTrajectory(b, r.traj_, r.start_time);
-                    uploaded_version_[b] = r.traj_version;
-                }
-                for (int i = 0; i < 3; ++i) est[(size_t)b * 3 + i] = r.est_state_[i];
-            }
-            if (!fresh_robots.empty())
-                mpc_wrapper_.setDevicePolynomes(fresh_robots, fresh_msgs, state_seq_res_, integral_res_int_);
-            mpc_wrapper_.sampleDeviceRefs(now, est.data(), icr.data(), goal.data()); // goal: valid after update()
-        }
-        for (int b = 0; b < B && !mpc_wrapper_.deviceRefs(); ++b) {
-            RefSampler& r = robots[b];
+        const int node = params_.delay_num < N ? params_.delay_num : N - 1;
+        std::vector<double> est((size_t)B * 3, 0.0), icr((size_t)B * 3, 0.0);
+        std::vector<int> goal(B, 0), fresh_robots;
+        std::vector<const Polynome*> fresh_msgs;
+        std::vector<char> solving(B, 0);
+        for (int b = 0; b < B; ++b) {
+            RobotNode& r = robots[b];
+            cmd[b] = RobotCommand{};
+            icr[(size_t)b * 3] = r.car_icr_.xv; icr[(size_t)b * 3 + 1] = r.car_icr_.yr; icr[(size_t)b * 3 + 2] = r.car_icr_.yl;
+            for (int i = 0; i < 3; ++i) est[(size_t)b * 3 + i] = r.est_state_[i];
             if (!r.has_odom || !r.receive_traj_) continue;
             r.swapInNewTraj(now);
-            r.getRefPoints(now);
-            r.smooth_yaw();
-            const double icr[3] = {r.car_icr_.xv, r.car_icr_.yr, r.car_icr_.yl}; // mpc.cpp:305-310
-            mpc_wrapper_.setICRParameters(b, icr);
-            mpc_wrapper_.setTrajectory(b, r.reference_states_.data(), r.reference_inputs_.data());
-            for (int i = 0; i < 3; ++i) est[(size_t)b * 3 + i] = r.est_state_[i];
+            if (r.traj_version != r.uploaded_version) {
+                fresh_robots.push_back(b);
+                fresh_msgs.push_back(&r.msg_);
+                r.uploaded_version = r.traj_version;
+            }
+            if (r.at_goal) { // mpc.cpp:184-203: zero CarState, the last predicted input once more, then idle
+                cmd[b].state_published = cmd[b].wheel_published = true;
+                cmd[b].right_wheel_ome = r.last_input_[kVr];
+                cmd[b].left_wheel_ome = r.last_input_[kVl];
+                r.receive_traj_ = false;
+                r.start_time = -1.0;
+                continue;
+            }
+            solving[b] = 1;
         }
-        if (solve_from_scratch_) { // mpc.cpp:317-320
-            mpc_wrapper_.solve(est.data());
-            solve_from_scratch_ = false;
-        } else {
-            mpc_wrapper_.update(est.data(), false);
+        if (!fresh_robots.empty())
+            mpc_wrapper_.setDevicePolynomes(fresh_robots, fresh_msgs, params_.state_seq_res, params_.Integral_appr_resInt);
+        if (!params_.if_mpc) { // open-loop replay of the planned flat velocities (mpc.cpp:211-234)
+            std::vector<double> flat((size_t)B * 4, 0.0);
+            mpc_wrapper_.flatStateAt(now, flat.data());
+            for (int b = 0; b < B; ++b) {
+                if (!solving[b]) continue;
+                RobotNode& r = robots[b];
+                if (now - r.start_time > r.traj_duration) r.at_goal = true;
+                cmd[b].state_published = true;
+                cmd[b].omega = flat[(size_t)b * 4]; cmd[b].v = flat[(size_t)b * 4 + 1];
+                cmd[b].alpha = flat[(size_t)b * 4 + 2]; cmd[b].a = flat[(size_t)b * 4 + 3];
+            }
+            return;
         }
+        mpc_wrapper_.sampleDeviceRefs(now, est.data(), icr.data(), goal.data()); // goal: valid after update()
+        for (int b = 0; b < B; ++b) // mpc.cpp:317-320, per robot: x <- est replicated, u <- 0 on its first solve
+            if (solving[b] && robots[b].solve_from_scratch_) {
+                mpc_wrapper_.resetIterate(b, &est[(size_t)b * 3]);
+                robots[b].solve_from_scratch_ = false;
+            }
+        mpc_wrapper_.update(est.data(), false);
         mpc_wrapper_.prepare(); // the reference's preparation thread (mpc.cpp:336, 394-403)
-        if (mpc_wrapper_.deviceRefs())
-            for (int b = 0; b < B; ++b)
-                if (uploaded_version_[b]) robots[b].at_goal = goal[b] != 0;
         for (int b = 0; b < B; ++b) {
-            const int node = delay_num_ < N ? delay_num_ : N - 1;
-            cmd[b * 2 + 0] = mpc_wrapper_.getInput(b, node, kVr);
-            cmd[b * 2 + 1] = mpc_wrapper_.getInput(b, node, kVl);
-            if (robots[b].at_goal || !robots[b].has_odom || !robots[b].receive_traj_) { cmd[b * 2] = 0.0; cmd[b * 2 + 1] = 0.0; }
+            if (!solving[b]) continue;
+            RobotNode& r = robots[b];
+            r.at_goal = goal[b] != 0; // getRefPoints sets it; the NEXT tick acts on it
+            r.last_input_[kVr] = mpc_wrapper_.getInput(b, node, kVr);
+            r.last_input_[kVl] = mpc_wrapper_.getInput(b, node, kVl);
+            cmd[b].wheel_published = true; // cmdPub
+            cmd[b].right_wheel_ome = r.last_input_[kVr];
+            cmd[b].left_wheel_ome = r.last_input_[kVl];
         }
     }
 };
-
-#endif // ALORE_HOST_SAMPLER_ONLY
 
 } // namespace alore

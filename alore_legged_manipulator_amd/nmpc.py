@@ -207,6 +207,18 @@ class BatchedNmpc:
                                                         self._stream()))
         return pose, vw, goal.astype(bool)
 
+    def closed_loop_reset(self, mask=None, slot: int = 0) -> None:
+        """MpcWrapper::solve's cold start from the plant's pose (x <- pose replicated, u <- 0) for the masked robots."""
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self.lib.alore_nmpc_closed_loop_reset(self.h, C.byref(self._batches[slot]), self.B,
+                                                          None if m is None else m.ctypes.data, self._stream()))
+
+    def refs_eval(self, now: float) -> np.ndarray:
+        """(B, 4): theta', s', theta'', s'' of every stored trajectory at `now` (zeros without a trajectory)."""
+        out = np.zeros((self.B, 4))
+        self._check(self.lib.alore_nmpc_refs_eval(self.h, self.B, float(now), out.ctypes.data, self._stream()))
+        return out
+
     def closed_loop_tick(self, now: float, delay_num: int = 1, slot: int = 0) -> None:
         """References from the plant's pose -> one real-time iteration -> command to the plant; no host sync."""
         self._check(self.lib.alore_nmpc_closed_loop_tick(self.h, C.byref(self._batches[slot]), self.B, float(now),

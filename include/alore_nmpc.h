@@ -203,6 +203,11 @@ int alore_nmpc_refs_download(alore_nmpc_handle h, int robot, double *meta8, doub
 int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, double now, const double *est,
                            const double *icr, int do_smooth, int *at_goal, void *stream);
 
+/* flat velocity and acceleration (theta', s', theta'', s'') of every stored trajectory at time `now` -- what the
+ * reference node publishes with if_mpc = false (TrajAnal::getVstate / getAstate at t_cur, mpc.cpp:211-234);
+ * out [B][4] HOST pointer, zeros for slots without a trajectory.  Synchronises the stream. */
+int alore_nmpc_refs_eval(alore_nmpc_handle h, int B, double now, double *out, void *stream);
+
 /* at_goal flags of the last alore_nmpc_refs_sample, copied asynchronously on `stream` (no synchronisation here:
  * lets a caller pass at_goal = NULL to the sampling call and pay for one synchronisation per tick only) */
 int alore_nmpc_refs_at_goal(alore_nmpc_handle h, int B, int *at_goal, void *stream);
@@ -225,6 +230,11 @@ int alore_nmpc_plant_init(alore_nmpc_handle h, const alore_plant_params *p);
 /* pose [B][3] (x, y, theta), vw [B][2] (v, omega; NULL = at rest), icr [B][3] (xv, yr, yl): host pointers */
 int alore_nmpc_plant_set_state(alore_nmpc_handle h, int B, const double *pose, const double *vw, const double *icr, void *stream);
 int alore_nmpc_plant_get_state(alore_nmpc_handle h, int B, double *pose, double *vw, int *at_goal, void *stream);
+/* cold start of the loop: what MpcWrapper::solve does before its first update (mpc_wrapper.cpp:267-275) for
+ * every robot with mask[b] != 0 (mask: HOST pointer, NULL = all): x <- the plant's pose replicated over the
+ * horizon, u <- 0 (the multipliers are left alone, as the reference leaves acadoWorkspace.y).  Call it once
+ * before the first alore_nmpc_closed_loop_tick and whenever a robot gets a new trajectory after standing still. */
+int alore_nmpc_closed_loop_reset(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, const unsigned char *mask, void *stream);
 int alore_nmpc_closed_loop_tick(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, double now, int delay_num, void *stream);
 /* n_ticks of them at times t0, t0 + dt_tick, ... enqueued back to back (nothing synchronises) */
 int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, double t0, double dt_tick,

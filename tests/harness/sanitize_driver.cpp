@@ -1,20 +1,43 @@
-// sanitize_driver.cpp -- AddressSanitizer + UBSan pass over the CPU-compilable parts of the product
-// (GPU sanitizers are not available on the pool): the host layer's trajectory code (traj_anal.hpp:
-// banded LU, minimum-jerk spline, Simpson sequence, getPstate) and reference sampling
-// (mpc_controller.hpp: RefSampler), and the device numerics header (csrc/nmpc_core.h) run on the host.
+// sanitize_driver.cpp -- AddressSanitizer + UBSan pass over the CPU-compilable parts (GPU sanitizers are not
+// available on the pool): the device numerics headers run on the host -- csrc/nmpc_core.h (solver algebra) and
+// csrc/minco_spline.h (knot-state spline, evaluation, Simpson panels) -- and the trajectory checker
+// (oracle/traj_oracle.hpp: banded LU, Simpson sequence, getPstate, getRefPoints, smooth_yaw).
 // Built and run by tests/test_sanitizers.py; exits 0 when every sanitiser stayed silent.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "../../alore_legged_manipulator_amd/csrc/nmpc_core.h"
-#include "../../alore_legged_manipulator_amd/host/traj_anal.hpp"
+#include "../../alore_legged_manipulator_amd/csrc/minco_spline.h"
+#include "../../oracle/traj_oracle.hpp"
 
-// RefSampler only (mpc_controller.hpp also pulls the GPU wrapper in; the sampler is self-contained)
-#define ALORE_HOST_SAMPLER_ONLY 1
-#include "../../alore_legged_manipulator_amd/host/mpc_controller.hpp"
+using namespace alore_oracle;
 
-using namespace alore;
+// the product's spline header against the checker's banded solve, all piece counts
+static double spline_header_pass()
+{
+    double acc = 0.0;
+    for (int M = 1; M <= 24; ++M) {
+        std::vector<double> T(M), p(M + 1), y(2 * (M > 1 ? M - 1 : 1)), cf(6 * M);
+        std::vector<minco::Sym2> sinv(M);
+        for (int i = 0; i < M; ++i) T[i] = 0.3 + 0.05 * ((i * 7) % 9);
+        for (int k = 0; k <= M; ++k) p[k] = 0.4 * k + 0.1 * ((k * 5) % 3);
+        minco::spline_1d(M, T.data(), p.data(), 0.3, -0.2, 0.1, 0.05, sinv.data(), y.data(), cf.data());
+        std::vector<double> dur(T), coef((size_t)M * 12);
+        for (int i = 0; i < M; ++i)
+            for (int k = 0; k < 6; ++k) coef[(size_t)i * 12 + k] = coef[(size_t)i * 12 + 6 + k] = cf[6 * i + k];
+        double total = 0.0;
+        for (double t : T) total += t;
+        for (double t : {0.0, 0.5 * total, total, total + 0.2}) {
+            double pp[2], vv[2], aa[2], dx, dy;
+            minco::eval_pv(dur.data(), coef.data(), M, t, pp, vv);
+            minco::eval_a(dur.data(), coef.data(), M, t, aa);
+            minco::simpson_panel(dur.data(), coef.data(), M, 0.1, t, 0.025, dx, dy);
+            acc += pp[0] + vv[1] + aa[0] + dx + dy;
+        }
+    }
+    return acc;
+}
 
 static Polynome arc(double v, double w, double th0, const std::vector<double>& pieces, double xv, double t0)
 {
@@ -37,7 +60,7 @@ static Polynome arc(double v, double w, double th0, const std::vector<double>& p
 
 int main()
 {
-    double acc = 0.0;
+    double acc = spline_header_pass();
     // host layer: several piece counts, sampling before the start, inside, across the end, long after
     for (int pieces = 1; pieces <= 6; ++pieces) {
         for (int N : {1, 7, 20, 50}) {

@@ -34,6 +34,41 @@ def test_library_exports_every_declared_symbol():
         assert name in bound, f"{name} is declared in the header but not bound in _lib.SYMBOLS"
 
 
+def test_backend_and_host_headers_are_exported_too():
+    """include/alore_backend.h (libalore_nmpc.so) and include/alore_nmpc_host.h (libalore_nmpc_host.so)"""
+    from alore_legged_manipulator_amd import _lib, backend
+    lib = _lib.load()
+    backend._bind(lib)
+    for hdr, prefix, so in (("alore_backend.h", "alore_backend_", lib),):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", hdr)).read(), flags=re.S)
+        names = sorted(set(re.findall(r"\b(%s[a-z_]+)\s*\(" % prefix, src)))
+        assert len(names) >= 12
+        for n in names:
+            assert hasattr(so, n), f"{n} declared in {hdr} but not exported"
+    host_so = os.path.join(ROOT, "alore_legged_manipulator_amd", "libalore_nmpc_host.so")
+    syms = os.popen(f"nm -D --defined-only {host_so}").read()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "alore_nmpc_host.h")).read(), flags=re.S)
+    for n in sorted(set(re.findall(r"\b(alore_host_[a-z_]+)\s*\(", src))):
+        assert f" {n}\n" in syms, f"{n} declared in alore_nmpc_host.h but not exported"
+    # ctypes mirrors have the C sizes (checked against a C compiler)
+    import subprocess, tempfile
+    code = '#include <stdio.h>\n#include "alore_backend.h"\nint main(){printf("%zu %zu %zu", sizeof(alore_backend_config), sizeof(alore_backend_status), sizeof(alore_flat_traj));}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(code)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    assert sizes == [C.sizeof(backend.BackendConfig), C.sizeof(backend.StatusC), C.sizeof(backend.FlatTrajC)]
+
+
+def test_no_backend_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from alore_legged_manipulator_amd.backend import BackendError, BatchedMSPlanner
+    with pytest.raises(BackendError):
+        BatchedMSPlanner(4, 16)
+
+
 def test_no_cpu_fallback_behind_the_abi():
     import torch
     if torch.cuda.is_available():

@@ -26,9 +26,11 @@ def test_closed_loop_matches_oracle_loop_and_contracts():
     """150 ticks in closed loop: the GPU-backed controller and an oracle-driven loop (same reference
     sampling, same plant) must stay together (errors accumulate over ticks: 2 mm), and the tracking
     error must stay bounded."""
-    from alore_legged_manipulator_amd.host import BatchedMpcController, RefSampler
+    from alore_legged_manipulator_amd.host import BatchedMpcController
     from oracle.drivers import Oracle
-    from tests.test_host_layer import arc_polynome, exact_pose
+    from oracle.traj_driver import RefSampler
+    from tests.test_host_layer import as_host_msg
+    from tests.test_traj_oracle import arc_polynome, exact_pose
     B, N, dt = 8, 20, 0.01
     rng = np.random.default_rng(0)
     ctl = BatchedMpcController(B, N, dt, delay_num=0)
@@ -38,7 +40,7 @@ def test_closed_loop_matches_oracle_loop_and_contracts():
         v, w, xv = rng.uniform(0.6, 1.6), rng.uniform(-0.8, 0.8), rng.uniform(0.0, 0.25)
         yr, yl = -rng.uniform(0.25, 0.35), rng.uniform(0.25, 0.35)
         m = arc_polynome(v, w, 0.0, [1.0, 1.0, 1.0], xv=xv, t0=0.0)
-        ctl.robots[b].traj(m); ctl.robots[b].icr(yr, yl, xv)
+        ctl.robots[b].traj(as_host_msg(m)); ctl.robots[b].icr(yr, yl, xv)
         s = RefSampler(N, dt); s.traj(m); s.icr(yr, yl, xv)
         samplers.append(s)
         o = Oracle(N); o.reset(); o.initialize_solver()

@@ -1,134 +1,42 @@
-"""Host layer (C++: alore_legged_manipulator_amd/host/): the controller-side rows of the hot path --
-MINCO spline solve, quintic evaluation, TrajAnal Simpson integration, getRefPoints, smooth_yaw.
-
-The reference code for these needs Eigen + ROS (absent here), so there is no compiled oracle: parity is
-UNPINNED and the restatement is pinned by analytic known answers instead:
-minimum-jerk splines reproduce linear motion exactly, constant-twist arcs have a closed-form pose,
-spline continuity / boundary conditions, yaw unwrapping cases."""
+"""Host layer (C++: alore_legged_manipulator_amd/host/, C entry points include/alore_nmpc_host.h) and the
+device-side reference path (csrc/ref_sampler.hip) against
+  * the float64 host restatement of the reference's sampling (oracle/traj_oracle.hpp, pinned by
+    tests/test_traj_oracle.py), and
+  * golden trajectories computed with NumPy / SciPy only (tests/golden/traj_polynomes.npz), so that the device
+    spline (csrc/minco_spline.h: knot-state system) is checked against something that shares no code with it."""
 import math
+import os
 
 import numpy as np
 import pytest
 
-from alore_legged_manipulator_amd.host import Polynome, RefSampler, normlize_theta
-from alore_legged_manipulator_amd.scenarios import arc_pose
+from tests.test_traj_oracle import arc_polynome, exact_pose, golden_messages
+
+pytestmark = pytest.mark.gpu
 
 
-def arc_polynome(v, w, theta0, pieces, start=(0.0, 0.0), xv=0.1, t0=0.0):
-    """theta(t) = theta0 + w t, s(t) = v t over the given piece durations."""
-    T = np.cumsum(pieces)
-    inner = np.stack([theta0 + w * T[:-1], v * T[:-1]], 1)
-    init = [theta0, 0.0, w, v, 0.0, 0.0]
-    tail = [theta0 + w * T[-1], v * T[-1], w, v, 0.0, 0.0]
-    return Polynome(inner, pieces, init, tail, [start[0], start[1], theta0], [-0.3, 0.3, xv], t0)
+def as_host_msg(m):
+    from alore_legged_manipulator_amd.host import Polynome
+    return Polynome(m.innerpoints, m.t_pts, m.init_pva, m.tail_pva, m.start_position, m.ICR, m.traj_start_time)
 
 
-def exact_pose(v, w, theta0, start, xv, t):
-    p = arc_pose(v, w, xv, t)
-    c, s = math.cos(theta0), math.sin(theta0)
-    return np.array([start[0] + c * p[..., 0] - s * p[..., 1], start[1] + s * p[..., 0] + c * p[..., 1], theta0 + p[..., 2]])
+def wiggly_polynome(rng, pieces, t0=0.0):
+    """A trajectory that is not a constant-twist arc: random inner points, boundary velocities and accelerations."""
+    from oracle.traj_driver import Polynome
+    M = len(pieces)
+    th = np.cumsum(rng.uniform(-0.6, 0.6, M + 1)) + rng.uniform(-3, 3)
+    sl = np.cumsum(rng.uniform(0.1, 0.8, M + 1))
+    inner = np.stack([th[1:M], sl[1:M]], 1)
+    init = [th[0], sl[0], rng.uniform(-1, 1), rng.uniform(0.2, 1.5), rng.uniform(-1, 1), rng.uniform(-1, 1)]
+    tail = [th[M], sl[M], rng.uniform(-1, 1), rng.uniform(0.2, 1.5), rng.uniform(-1, 1), rng.uniform(-1, 1)]
+    return Polynome(inner, pieces, init, tail, rng.uniform(-1, 1, 3), [-0.3, 0.3, rng.uniform(0, 0.3)], t0)
 
 
-def test_minimum_jerk_reproduces_linear_motion():
-    s = RefSampler(20)
-    s.traj(arc_polynome(1.3, -0.7, 0.4, [0.5, 0.8, 0.3, 1.1]))
-    assert abs(s.duration() - 2.7) < 1e-12
-    for t in np.linspace(0, 2.7, 37):
-        p, v, a = s.flat(t)
-        assert abs(p[0] - (0.4 - 0.7 * t)) < 1e-10 and abs(p[1] - 1.3 * t) < 1e-10
-        assert abs(v[0] + 0.7) < 1e-9 and abs(v[1] - 1.3) < 1e-9 and np.max(np.abs(a)) < 1e-8
-
-
-@pytest.mark.parametrize("v,w,th0,xv", [(1.0, 0.0, 0.0, 0.0), (1.5, 0.9, -0.6, 0.2), (0.4, -1.4, 2.5, 0.3)])
-def test_pstate_matches_closed_form_arc(v, w, th0, xv):
-    s = RefSampler(20)
-    start = (0.7, -1.2)
-    s.traj(arc_polynome(v, w, th0, [0.6, 0.6, 0.6, 0.6, 0.6], start=start, xv=xv))
-    for t in (0.0, 0.013, 0.1, 0.55, 1.234, 2.999):
-        p, vel, _ = s.state(t)
-        ref = exact_pose(v, w, th0, start, xv, t)
-        assert np.max(np.abs(p - ref)) < 2e-8, (t, p, ref)   # Simpson: last panel up to 0.1 s wide, error ~ (w h)^4 h
-        assert abs(vel[0] - w) < 1e-9 and abs(vel[1] - v) < 1e-9
-    seq = s.sequence()
-    assert abs(seq[1, 3] - 0.1) < 1e-12 and abs(seq[-1, 3] - 3.0) < 1e-9 and len(seq) == 31
-    k = 17
-    assert np.max(np.abs(seq[k, :3] - exact_pose(v, w, th0, start, xv, seq[k, 3]))) < 1e-9
-
-
-def test_spline_conditions_general():
-    rng = np.random.default_rng(4)
-    M = 5
-    pieces = rng.uniform(0.3, 0.9, M)
-    inner = rng.normal(size=(M - 1, 2))
-    init = rng.normal(size=6); tail = rng.normal(size=6)
-    s = RefSampler(20)
-    s.traj(Polynome(inner, pieces, init, tail, [0, 0, init[0]], [-0.3, 0.3, 0.0]))
-    T = np.concatenate([[0], np.cumsum(pieces)])
-    p, v, a = s.flat(0.0)
-    assert np.allclose(p, init[0:2], atol=1e-10) and np.allclose(v, init[2:4], atol=1e-9) and np.allclose(a, init[4:6], atol=1e-8)
-    p, v, a = s.flat(T[-1])
-    assert np.allclose(p, tail[0:2], atol=1e-8) and np.allclose(v, tail[2:4], atol=1e-7) and np.allclose(a, tail[4:6], atol=1e-6)
-    eps = 1e-6
-    for i in range(1, M):
-        pl, vl, al = s.flat(T[i] - eps)
-        pr, vr, ar = s.flat(T[i] + eps)
-        assert np.allclose(s.flat(T[i])[0], inner[i - 1], atol=1e-9)          # passes through the inner point
-        assert np.allclose(pl, pr, atol=1e-4) and np.allclose(vl, vr, atol=1e-3) and np.allclose(al, ar, atol=1e-2)
-    # beyond the end the last piece is extrapolated (Trajectory::locatePieceIdx)
-    pe, _, _ = s.flat(T[-1] + 0.05)
-    assert np.all(np.isfinite(pe))
-
-
-def test_get_ref_points_sampling_clamp_and_wheel_speeds():
-    N, dt = 20, 0.01
-    v, w, xv = 1.2, 0.8, 0.15
-    s = RefSampler(N, dt)
-    s.odom(0.0, 0.0, 0.0)
-    s.icr(-0.31, 0.29, xv)
-    m = arc_polynome(v, w, 0.0, [0.5, 0.5], xv=xv, t0=10.0)
-    s.traj(m)
-    now = 10.0 + 0.37
-    rs, ri, at_goal = s.refs(now, smooth=False)
-    assert not at_goal
-    for j in range(N + 1):
-        t = 0.37 + (j + 1) * dt          # mpc.cpp:432: temp_t starts at t_cur + dt
-        ref = exact_pose(v, w, 0.0, (0, 0), xv, t)
-        assert np.max(np.abs(rs[j] - ref)) < 2e-8
-        assert abs(ri[j, 0] - (v - w * (-0.31))) < 1e-9     # kVr = v - w*yr
-        assert abs(ri[j, 1] - (v - w * 0.29)) < 1e-9        # kVl = v - w*yl
-    # past the end: pose clamps to the final pose, wheel speeds to zero; at_goal one second later
-    rs, ri, at_goal = s.refs(10.0 + 0.95, smooth=False)
-    end = exact_pose(v, w, 0.0, (0, 0), xv, 1.0)
-    assert np.max(np.abs(rs[-1] - end)) < 2e-8 and np.all(ri[-1] == 0.0) and not at_goal
-    assert np.any(ri[0] != 0.0)
-    _, _, at_goal = s.refs(10.0 + 2.01, smooth=False)
-    assert at_goal
-
-
-def test_smooth_yaw_and_normalise():
-    assert abs(normlize_theta(3.5) - (3.5 - 2 * math.pi)) < 1e-12
-    assert abs(normlize_theta(-7.0) - (-7.0 + 2 * math.pi)) < 1e-12
-    N = 20
-    s = RefSampler(N, 0.01)
-    # heading crosses +pi inside the horizon: getRefPoints wraps it to (-pi, pi], smooth_yaw unwraps
-    s.traj(arc_polynome(0.5, 2.0, math.pi - 0.2, [1.0], t0=0.0))
-    s.odom(0, 0, math.pi - 0.25)
-    raw, _, _ = s.refs(0.05, smooth=False)
-    assert np.max(np.abs(np.diff(raw[:, 2]))) > 6.0            # the 2 pi jump is there
-    rs, _, _ = s.refs(0.05, smooth=True)
-    assert np.max(np.abs(np.diff(rs[:, 2]))) < 0.1
-    assert abs(rs[0, 2] - (math.pi - 0.25)) < math.pi / 2
-    # estimated yaw on the other branch: the whole reference shifts by 2 pi
-    s.odom(0, 0, -math.pi + 0.1)
-    rs2, _, _ = s.refs(0.05, smooth=True)
-    assert abs(rs2[0, 2] - (-math.pi + 0.1)) < math.pi / 2 and np.max(np.abs(np.diff(rs2[:, 2]))) < 0.1
-
-
-@pytest.mark.gpu
 def test_controller_tick_matches_oracle_pipeline():
-    """BatchedMpcController.tick == (RefSampler refs -> MpcWrapper::solve semantics -> oracle tick)."""
+    """BatchedMpcController.tick == (oracle RefSampler refs -> MpcWrapper::solve semantics -> oracle RTI tick)."""
     from alore_legged_manipulator_amd.host import BatchedMpcController
     from oracle.drivers import Oracle
+    from oracle.traj_driver import RefSampler
     B, N, dt = 6, 20, 0.01
     rng = np.random.default_rng(9)
     ctl = BatchedMpcController(B, N, dt, delay_num=1)
@@ -138,8 +46,8 @@ def test_controller_tick_matches_oracle_pipeline():
         m = arc_polynome(v, w, 0.0, [0.4, 0.4, 0.4], xv=xv, t0=0.0)
         yr, yl = -rng.uniform(0.2, 0.35), rng.uniform(0.2, 0.35)
         od = (rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(-0.3, 0.3))
-        for r in (ctl.robots[b],):
-            r.traj(m); r.odom(*od); r.icr(yr, yl, xv)
+        r = ctl.robots[b]
+        r.traj(as_host_msg(m)); r.odom(*od); r.icr(yr, yl, xv)
         s = RefSampler(N, dt); s.traj(m); s.odom(*od); s.icr(yr, yl, xv)
         lone.append((s, od, (xv, yr, yl)))
     cmd = ctl.tick(0.123)
@@ -161,22 +69,15 @@ def test_controller_tick_matches_oracle_pipeline():
         assert st == 0 and np.max(np.abs(ps.reshape(-1) - orc.v["x"])) < 1e-4 * max(1.0, np.max(np.abs(orc.v["x"])))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("build_on_device", [False, True])
-def test_device_reference_sampling_matches_host_sampler(build_on_device):
-    """alore_nmpc_refs_* (ref_sampler.hip) against the float64 host RefSampler: y, yN, od, x0 as float32,
+def test_device_reference_sampling_matches_oracle_sampler():
+    """alore_nmpc_refs_* (ref_sampler.hip) against the float64 oracle RefSampler: y, yN, od, x0 as float32,
     across heading wrap-around, the end of the trajectory, a trajectory swap and a robot without trajectory."""
     from alore_legged_manipulator_amd.host import BatchedMpcController
+    from oracle.traj_driver import RefSampler
     B, N, dt = 9, 20, 0.01
     rng = np.random.default_rng(31)
-    host = BatchedMpcController(B, N, dt)
-    dev = BatchedMpcController(B, N, dt)
-    dev.use_device_references(max_pieces=8, max_checkpoints=64, build_on_device=build_on_device)
+    dev = BatchedMpcController(B, N, dt, max_pieces=8, max_checkpoints=64)
     lone = [RefSampler(N, dt) for _ in range(B)]
-
-    def feed(b, fn):
-        for r in (host.robots[b], dev.robots[b], lone[b]):
-            fn(r)
 
     spec = []
     for b in range(B - 1):                       # robot B-1 never gets a trajectory
@@ -188,15 +89,15 @@ def test_device_reference_sampling_matches_host_sampler(build_on_device):
         m = arc_polynome(v, w, th0, pieces, xv=xv, t0=0.0)
         yr, yl = -rng.uniform(0.2, 0.35), rng.uniform(0.2, 0.35)
         od = (rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), th0 + rng.uniform(-0.3, 0.3))
-        feed(b, lambda r: (r.traj(m), r.odom(*od), r.icr(yr, yl, xv)))
+        dev.robots[b].traj(as_host_msg(m)); dev.robots[b].odom(*od); dev.robots[b].icr(yr, yl, xv)
+        lone[b].traj(m); lone[b].odom(*od); lone[b].icr(yr, yl, xv)
         spec.append((od, (xv, yr, yl)))
-    feed(B - 1, lambda r: r.odom(0.1, 0.2, 0.3))
+    dev.robots[B - 1].odom(0.1, 0.2, 0.3)
 
-    def check(now):
-        ch, cd = host.tick(now), dev.tick(now)
-        yh, yNh, odh, x0h = host.references()
+    def check(now, active=range(B - 1)):
+        cd = dev.tick(now)
         yd, yNd, odd, x0d = dev.references()
-        for b in range(B - 1):
+        for b in active:
             rs, ri, goal = lone[b].refs(now, smooth=True)
             want = np.concatenate([rs[:N], ri[:N]], 1).astype(np.float32)
             tol = 2e-6 * max(1.0, float(np.max(np.abs(want))))
@@ -204,49 +105,59 @@ def test_device_reference_sampling_matches_host_sampler(build_on_device):
             assert np.max(np.abs(yNd[b] - rs[N].astype(np.float32))) <= tol
             assert np.array_equal(odd[b], np.tile(np.float32(spec[b][1]), (N + 1, 1)))
             assert np.array_equal(x0d[b], np.float32(spec[b][0]))
-            assert np.max(np.abs(yd[b] - yh[b])) <= tol and np.max(np.abs(yNd[b] - yNh[b])) <= tol
-            assert dev.robots[b].at_goal == goal == host.robots[b].at_goal
-        # same references -> same commands (the solver is deterministic; refs may differ in the last ulp)
-        assert np.max(np.abs(ch - cd)) < 1e-4
+            assert dev.robots[b].at_goal == goal
         assert np.all(cd[B - 1] == 0.0)
+        return cd
 
     check(0.123)                                  # first tick (solve from scratch)
     check(0.133)                                  # warm tick
     check(0.35)                                   # horizons of the 1-piece robots run past the end (0.4 s)
     # a new trajectory arrives for robot 2, starting in the future: old one keeps being tracked until then
     m2 = arc_polynome(1.1, -0.7, 0.4, [0.5, 0.5], xv=0.1, t0=0.5)
-    feed(2, lambda r: r.traj(m2))
+    dev.robots[2].traj(as_host_msg(m2)); lone[2].traj(m2)
     check(0.45)
     check(0.55)                                   # swapped in
-    check(5.0)                                    # everybody is at the goal: zero commands
-    assert np.all(dev.tick(5.01) == 0.0)
+    cd = check(5.0)                               # every trajectory ended more than 1 s ago: at_goal gets set ...
+    assert all(dev.robots[b].at_goal for b in range(B - 1)) and np.any(cd[:B - 1] != 0.0)
+    full = dev.tick_full(5.01)                    # ... and the NEXT tick publishes the zero CarState, the last wheel command
+    for b in range(B - 1):                        # once more (mpc.cpp:184-203), and forgets the trajectory
+        assert full[b].state_published and full[b].v == 0.0 and full[b].omega == 0.0
+        assert full[b].wheel_published and abs(full[b].right_wheel_ome - cd[b, 0]) < 1e-12
+        assert not dev.robots[b].receive_traj
+    assert np.all(dev.tick(5.02) == 0.0)          # nothing is published any more
 
 
-def wiggly_polynome(rng, pieces, t0=0.0):
-    """A trajectory that is not a constant-twist arc: random inner points, boundary velocities and accelerations."""
-    M = len(pieces)
-    th = np.cumsum(rng.uniform(-0.6, 0.6, M + 1)) + rng.uniform(-3, 3)
-    sl = np.cumsum(rng.uniform(0.1, 0.8, M + 1))
-    inner = np.stack([th[1:M], sl[1:M]], 1)
-    init = [th[0], sl[0], rng.uniform(-1, 1), rng.uniform(0.2, 1.5), rng.uniform(-1, 1), rng.uniform(-1, 1)]
-    tail = [th[M], sl[M], rng.uniform(-1, 1), rng.uniform(0.2, 1.5), rng.uniform(-1, 1), rng.uniform(-1, 1)]
-    return Polynome(inner, pieces, init, tail, rng.uniform(-1, 1, 3), [-0.3, 0.3, rng.uniform(0, 0.3)], t0)
-
-
-@pytest.mark.gpu
-def test_device_built_trajectory_store_matches_host_trajanal():
-    """alore_nmpc_refs_set_polynomes (spline + Simpson checkpoints on the GPU, csrc/minco_core.h compiled by
-    hipcc) against the host TrajAnal (the same header compiled by g++): coefficients through evaluation,
-    checkpoints directly, float64; then the sampled references (float32) against the host getRefPoints."""
+def test_device_built_trajectory_store_matches_golden_and_oracle():
+    """alore_nmpc_refs_set_polynomes (knot-state spline + Simpson checkpoints on the GPU) against (i) the golden
+    trajectories (NumPy dense solve, SciPy quadrature: no shared code) and (ii) the oracle TrajAnal (same Simpson
+    rule: checkpoints to 1e-11); then the sampled references (float32) against the oracle getRefPoints."""
     from alore_legged_manipulator_amd.nmpc import BatchedNmpc
-    B, N, dt = 300, 20, 0.01                     # > one chunk of 256 messages
+    from oracle.traj_driver import RefSampler
+    N, dt = 20, 0.01
+    gold = golden_messages()
     rng = np.random.default_rng(5)
+    extra = [wiggly_polynome(rng, list(rng.uniform(0.3, 0.7, int(rng.integers(1, 13)))), t0=float(rng.uniform(0, 0.05)))
+             for _ in range(300 - len(gold))]        # > one chunk of 256 messages
+    msgs = [m for m, _ in gold] + extra
+    B = len(msgs)
     eng = BatchedNmpc(B, N, dt)
     eng.refs_init(max_pieces=12, max_checkpoints=80)
-    msgs = [wiggly_polynome(rng, list(rng.uniform(0.3, 0.7, int(rng.integers(1, 13)))), t0=float(rng.uniform(0, 0.05)))
-            for _ in range(B)]
     order = rng.permutation(B)                   # store slots need not follow message order
     eng.refs_set_polynomes(order, msgs)
+    # (i) golden
+    for i, (m, ans) in enumerate(gold):
+        d = eng.refs_download(int(order[i]))
+        M = len(m.t_pts)
+        assert d["valid"] and np.array_equal(d["durations"], m.t_pts)
+        ref = np.transpose(ans["coef"], (0, 2, 1))
+        assert np.max(np.abs(d["coeffs"][:M] - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))), i
+        # checkpoints (every 0.1 s) against the exact integral at those times
+        edges = np.concatenate([[0.0], np.cumsum(m.t_pts)])
+        for k, t in enumerate(ans["times"]):
+            j = int(np.floor(t / 0.1 + 1e-9))
+            if abs(j * 0.1 - t) < 1e-12 and j < d["checkpoints"].shape[0]:
+                assert np.max(np.abs(d["checkpoints"][j] - ans["xy"][k])) < 2e-5
+    # (ii) oracle TrajAnal
     hosts = {}
     for i in (0, 1, 2, 17, 255, 256, B - 1):
         r = int(order[i]); m = msgs[i]
@@ -254,18 +165,11 @@ def test_device_built_trajectory_store_matches_host_trajanal():
         hosts[r] = (s, m)
         d = eng.refs_download(r)
         assert d["valid"] and abs(d["duration"] - m.t_pts.sum()) < 1e-12 and d["xv"] == m.ICR[2]
-        assert np.array_equal(d["durations"], m.t_pts)
         seq = s.sequence()
         assert d["checkpoints"].shape[0] == seq.shape[0]
-        assert np.max(np.abs(d["checkpoints"] - seq[:, :2])) < 1e-11
-        edges = np.concatenate([[0.0], np.cumsum(m.t_pts)])
-        for t in np.linspace(0.0, edges[-1], 23):
-            k = min(int(np.searchsorted(edges, t, side="left")) - 1, len(m.t_pts) - 1) if t > 0 else 0
-            k = max(k, 0)
-            tl = t - edges[k]
-            pw = tl ** np.arange(6)
-            p, v, _ = s.flat(t)
-            assert np.max(np.abs(d["coeffs"][k] @ pw - p)) < 1e-10 * max(1.0, np.max(np.abs(p)))
+        assert np.max(np.abs(d["checkpoints"] - seq[:, :2])) < 1e-10
+        _, coef = s.coefficients()
+        assert np.max(np.abs(d["coeffs"][:len(m.t_pts)] - coef)) <= 1e-9 * max(1.0, np.max(np.abs(coef)))
     # sampled references
     est = rng.uniform(-0.3, 0.3, (B, 3)); icr = np.tile([0.1, -0.3, 0.3], (B, 1))
     now = 0.21
@@ -287,3 +191,69 @@ def test_device_built_trajectory_store_matches_host_trajanal():
     with pytest.raises(NmpcError):
         eng.refs_set_polynomes([1], [wiggly_polynome(rng, [0.9] * 10)])           # 9 s -> 91 checkpoints > 80
     assert not eng.refs_download(1)["valid"]
+
+
+def test_cold_start_is_per_robot_and_emergency_stop_forgets_the_trajectory():
+    """A robot whose odometry / trajectory arrives later is reset (x <- pose, u <- 0) on ITS first solve
+    (mpc.cpp:317-320), exactly like a robot that was there from the start; /planner/emergency_stop makes a robot
+    idle until the next trajectory (mpc.cpp:279-294)."""
+    from alore_legged_manipulator_amd.host import BatchedMpcController
+    B, N, dt = 3, 20, 0.01
+    m = arc_polynome(1.2, 0.6, 0.2, [0.5, 0.5, 0.5], xv=0.1, t0=0.0)
+    od = (0.05, -0.1, 0.25)
+    late = BatchedMpcController(B, N, dt)
+    alone = BatchedMpcController(1, N, dt)
+    for r in (late.robots[0], late.robots[2]):
+        r.traj(as_host_msg(m)); r.odom(*od); r.icr(-0.3, 0.3, 0.1)
+    for t in (0.10, 0.11, 0.12):                     # robot 1 is silent: nothing published, others run
+        cmd = late.tick_full(t)
+        assert not cmd[1].wheel_published and cmd[0].wheel_published
+    # robot 1 wakes up at t = 0.13; a lone controller started at the same time must give the same command
+    late.robots[1].traj(as_host_msg(m)); late.robots[1].odom(*od); late.robots[1].icr(-0.3, 0.3, 0.1)
+    alone.robots[0].traj(as_host_msg(m)); alone.robots[0].odom(*od); alone.robots[0].icr(-0.3, 0.3, 0.1)
+    for t in (0.13, 0.14, 0.15):
+        a, b = late.tick(t), alone.tick(t)
+        assert np.array_equal(a[1], b[0]), (t, a[1], b[0])
+    # emergency stop
+    late.robots[0].emergency_stop()
+    assert not late.robots[0].receive_traj
+    cmd = late.tick_full(0.16)
+    assert not cmd[0].wheel_published and cmd[1].wheel_published and cmd[2].wheel_published
+    late.robots[0].traj(as_host_msg(arc_polynome(0.8, -0.3, 0.2, [0.6, 0.6], xv=0.1, t0=0.0)))
+    assert late.tick_full(0.17)[0].wheel_published
+
+
+def test_open_loop_replay_without_mpc():
+    """if_mpc = false (mpc.cpp:211-234): the planned flat velocities and accelerations at t_cur are republished."""
+    from alore_legged_manipulator_amd.host import BatchedMpcController, default_params
+    gold = golden_messages()[:4]
+    ctl = BatchedMpcController(len(gold), 20, 0.01, params=default_params(if_mpc=0, state_seq_res=0.1, Integral_appr_resInt=4),
+                               max_pieces=12, max_checkpoints=80)
+    for b, (m, _) in enumerate(gold):
+        ctl.robots[b].traj(as_host_msg(m)); ctl.robots[b].odom(0, 0, 0)
+    for b, (m, ans) in enumerate(gold):
+        t = float(ans["times"][7])
+        cmd = ctl.tick_full(m.traj_start_time + t)
+        v, a = ans["flat"][7][1], ans["flat"][7][2]
+        assert cmd[b].state_published and not cmd[b].wheel_published
+        assert abs(cmd[b].omega - v[0]) < 1e-8 and abs(cmd[b].v - v[1]) < 1e-8
+        assert abs(cmd[b].alpha - a[0]) < 1e-7 and abs(cmd[b].a - a[1]) < 1e-7
+
+
+def test_phase_stamps_do_not_disturb_the_trajectory_store(monkeypatch):
+    """ALORE_NMPC_STAMPS=1 (diagnostic build path) with device references in use: the stamp buffer growth must
+    leave the trajectory store alone (it once freed it)."""
+    monkeypatch.setenv("ALORE_NMPC_STAMPS", "1")
+    from alore_legged_manipulator_amd.host import BatchedMpcController
+    B = 5
+    m = arc_polynome(1.0, 0.5, 0.0, [0.5, 0.5], xv=0.1, t0=0.0)
+    stamped = BatchedMpcController(B, 20, 0.01)
+    for r in stamped.robots:
+        r.traj(as_host_msg(m)); r.odom(0.0, 0.0, 0.0); r.icr(-0.3, 0.3, 0.1)
+    a = [stamped.tick(0.1 + 0.01 * k) for k in range(3)]
+    monkeypatch.delenv("ALORE_NMPC_STAMPS")
+    plain = BatchedMpcController(B, 20, 0.01)
+    for r in plain.robots:
+        r.traj(as_host_msg(m)); r.odom(0.0, 0.0, 0.0); r.icr(-0.3, 0.3, 0.1)
+    b = [plain.tick(0.1 + 0.01 * k) for k in range(3)]
+    assert np.array_equal(np.array(a), np.array(b)) and np.any(np.array(a) != 0.0)
