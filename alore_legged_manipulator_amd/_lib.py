@@ -81,6 +81,7 @@ SYMBOLS = (
     ("alore_nmpc_refs_set_trajectory", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                  C.c_double, C.c_double, C.c_double, C.c_void_p]),
     ("alore_nmpc_refs_set_polynomes", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
+    ("alore_nmpc_refs_set_from_backend", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     ("alore_nmpc_refs_download", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("alore_nmpc_plant_init", C.c_int, [C.c_void_p, C.c_void_p]),
     ("alore_nmpc_plant_set_state", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

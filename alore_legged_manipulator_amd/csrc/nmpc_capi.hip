@@ -10,6 +10,7 @@
 
 #include "nmpc_kernels.h"
 #include "nmpc_core.h"
+#include "../../include/alore_backend.h"
 
 struct alore_nmpc_solver {
     alore_nmpc_config cfg;
@@ -42,6 +43,8 @@ struct alore_nmpc_solver {
     int* d_panels = nullptr;      // [chunk]
     int* d_overflow = nullptr;    // [1]
     double* d_inc = nullptr;      // [chunk][C * res_int][2], grown on demand
+    int* d_panels_be = nullptr;   // [count] panels per plan (alore_nmpc_refs_set_from_backend)
+    size_t panels_cap = 0;
     size_t inc_doubles = 0;
     unsigned shared = 0;          // see alore_nmpc_set_shared_members
     const float* lin_x = nullptr; // see alore_nmpc_set_linearization_point
@@ -204,6 +207,7 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->d_panels) (void)hipFree(h->d_panels);
     if (h->d_overflow) (void)hipFree(h->d_overflow);
     if (h->d_inc) (void)hipFree(h->d_inc);
+    if (h->d_panels_be) (void)hipFree(h->d_panels_be);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -531,6 +535,41 @@ int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int* rob
     HIP_TRY(h, hipStreamSynchronize(s));
     if (ov & 1) return fail(h, ALORE_NMPC_E_INVALID, "refs_set_polynomes: a message has more pieces than max_pieces (or none)");
     if (ov & 2) return fail(h, ALORE_NMPC_E_INVALID, "refs_set_polynomes: a trajectory needs more checkpoints than max_checkpoints");
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_refs_set_from_backend(alore_nmpc_handle h, const void* view, int count, double traj_start_time, double xv,
+                                     double state_seq_res, int integral_res_int, void* stream)
+{
+    const alore_backend_device_view* v = static_cast<const alore_backend_device_view*>(view);
+    if (!h || !h->refs.dur || !v || count < 1 || count > h->refs_B || !(state_seq_res > 0.0) || integral_res_int < 1)
+        return fail(h, ALORE_NMPC_E_INVALID, "refs_set_from_backend: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->d_overflow) HIP_TRY(h, hipMalloc((void**)&h->d_overflow, sizeof(int)));
+    if ((size_t)count > h->panels_cap) {
+        if (h->d_panels_be) (void)hipFree(h->d_panels_be);
+        h->d_panels_be = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&h->d_panels_be, sizeof(int) * count));
+        h->panels_cap = count;
+    }
+    const size_t need = (size_t)count * h->refs.C * integral_res_int * 2;
+    if (need > h->inc_doubles) {
+        if (h->d_inc) (void)hipFree(h->d_inc);
+        h->d_inc = nullptr;
+        h->inc_doubles = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->d_inc, sizeof(double) * need));
+        h->inc_doubles = need;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(int), s));
+    const nmpc::BackendView bv{v->max_pieces, v->n_pieces, v->T, v->coef, v->start_xytheta, v->ok};
+    HIP_TRY(h, nmpc::launch_traj_from_backend(h->refs, bv, count, traj_start_time, state_seq_res, integral_res_int, xv, h->d_panels_be,
+                                              h->d_inc, h->d_overflow, s));
+    int ov = 0;
+    HIP_TRY(h, hipMemcpyAsync(&ov, h->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (ov & 1) return fail(h, ALORE_NMPC_E_INVALID, "refs_set_from_backend: a plan has more pieces than max_pieces");
+    if (ov & 2) return fail(h, ALORE_NMPC_E_INVALID, "refs_set_from_backend: a trajectory needs more checkpoints than max_checkpoints");
     return ALORE_NMPC_OK;
 }
 

@@ -75,6 +75,17 @@ hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, d
                              int* n_panels, double* inc, int* overflow, hipStream_t st);
 hipError_t launch_iterate_reset(const alore_nmpc_batch& b, int B, int N, const double* pose, const unsigned char* mask, hipStream_t st);
 hipError_t launch_ref_eval(const RefStore& s, int B, double now, double* out /* [B][4] */, hipStream_t st);
+// the planner's device-resident results (mirror of alore_backend_device_view, include/alore_backend.h)
+struct BackendView {
+    int P;
+    const int* n_pieces;
+    const double* T;
+    const double* coef;
+    const double* start_xytheta;
+    const int* ok;
+};
+hipError_t launch_traj_from_backend(const RefStore& s, const BackendView& v, int count, double t0, double res, int res_int, double xv,
+                                    int* n_panels, double* inc, int* overflow, hipStream_t st);
 struct PlantParams { // simulator.h: max_a_, max_domega_, Pose_pub_rate_ (a period), State_Propa_rate_ (a period)
     double max_a, max_domega, pose_pub_period, propa_period;
     int substeps; // StatePropaCallback calls per control tick

@@ -183,7 +183,7 @@ __global__ void traj_panel_kernel(RefStore s, PolyBatch m, int count, double res
     if (g >= (long)count * max_panels) return;
     const int t = (int)(g / max_panels), i = (int)(g % max_panels);
     if (i >= n_panels[t]) return;
-    const int r = m.robot[t];
+    const int r = m.robot ? m.robot[t] : t;
     const double* meta = s.meta + (size_t)r * 8;
     const double fine = res / res_int;
     double dx, dy;
@@ -198,8 +198,9 @@ __global__ void traj_checkpoint_kernel(RefStore s, PolyBatch m, int count, int r
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const int n = n_panels[t];
-    if (n <= 0 && s.meta[(size_t)m.robot[t] * 8 + 6] == 0.0) return;
-    double* ck = s.ckpt + (size_t)m.robot[t] * s.C * 2;
+    const int r = m.robot ? m.robot[t] : t;
+    if (n <= 0 && s.meta[(size_t)r * 8 + 6] == 0.0) return;
+    double* ck = s.ckpt + (size_t)r * s.C * 2;
     double x = ck[0], y = ck[1];
     const double* in = inc + (size_t)t * max_panels * 2;
     for (int i = 0; i < n; ++i) {
@@ -224,6 +225,59 @@ hipError_t launch_traj_build(const RefStore& s, const PolyBatch& m, int count, d
                        n_panels, max_panels, inc);
     hipLaunchKernelGGL(traj_checkpoint_kernel, dim3((count + 63) / 64), dim3(64), 0, st, s, m, count, res_int, n_panels,
                        max_panels, inc);
+    return hipGetLastError();
+}
+
+// ---- the planner's result slabs (alore_backend_device_view) -> trajectory store, device to device: what the
+//      reference does with a process boundary in between (MSPlanner result -> PlanManager::MPCPathPub ->
+//      Polynome -> MpcController::TrajCallback -> TrajAnal::setTraj re-solves the spline): the coefficients the
+//      optimiser ended with ARE that spline (same knot system, tests/test_backend_gpu.py), so they are copied, and
+//      only the Simpson checkpoints are built.  One thread per (problem, piece) for the copy.
+__global__ void traj_from_backend_kernel(RefStore s, BackendView v, int count, double t0, double res, int res_int, double xv,
+                                         int* n_panels, int* overflow)
+{
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long)count * v.P) return;
+    const int t = (int)(g / v.P), i = (int)(g % v.P);
+    const int M = v.n_pieces[t];
+    double* meta = s.meta + (size_t)t * 8;
+    const bool ok = v.ok[t] != 0 && M >= 1 && M <= s.P;
+    if (i == 0) {
+        n_panels[t] = 0;
+        if (!ok) { meta[6] = 0.0; if (v.ok[t] != 0) atomicOr(overflow, 1); }
+    }
+    if (!ok || i >= M) return;
+    s.dur[(size_t)t * s.P + i] = v.T[(size_t)t * v.P + i];
+    const double* c = v.coef + ((size_t)t * v.P + i) * 12; // (6 i + q) * 2 + d
+    double* o = s.coef + ((size_t)t * s.P + i) * 12;       // [d][q]
+    for (int q = 0; q < 6; ++q) { o[q] = c[q * 2]; o[6 + q] = c[q * 2 + 1]; }
+    if (i != 0) return;
+    double total = 0.0;
+    for (int k = 0; k < M; ++k) total += v.T[(size_t)t * v.P + k];
+    const double fine = res / res_int;
+    const int seq = (int)floor(total / fine);
+    const int nck = 1 + seq / res_int;
+    if (nck > s.C) { meta[6] = 0.0; atomicOr(overflow, 2); return; }
+    n_panels[t] = seq;
+    meta[0] = t0; meta[1] = total; meta[2] = xv; meta[3] = res;
+    meta[4] = (double)M; meta[5] = (double)nck; meta[6] = 1.0; meta[7] = 0.0;
+    s.ckpt[(size_t)t * s.C * 2] = v.start_xytheta[(size_t)t * 3];
+    s.ckpt[(size_t)t * s.C * 2 + 1] = v.start_xytheta[(size_t)t * 3 + 1];
+}
+
+hipError_t launch_traj_from_backend(const RefStore& s, const BackendView& v, int count, double t0, double res, int res_int, double xv,
+                                    int* n_panels, double* inc, int* overflow, hipStream_t st)
+{
+    const int max_panels = s.C * res_int;
+    const long threads = (long)count * v.P;
+    hipLaunchKernelGGL(traj_from_backend_kernel, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st, s, v, count, t0, res, res_int,
+                       xv, n_panels, overflow);
+    PolyBatch m{};
+    m.robot = nullptr; // identity: problem t -> store slot t
+    const long total = (long)count * max_panels;
+    hipLaunchKernelGGL(traj_panel_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, st, s, m, count, res, res_int, n_panels,
+                       max_panels, inc);
+    hipLaunchKernelGGL(traj_checkpoint_kernel, dim3((count + 63) / 64), dim3(64), 0, st, s, m, count, res_int, n_panels, max_panels, inc);
     return hipGetLastError();
 }
 

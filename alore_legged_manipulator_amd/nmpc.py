@@ -145,6 +145,14 @@ class BatchedNmpc:
         self._refs_shape = (int(max_pieces), int(max_checkpoints))
         self._check(self.lib.alore_nmpc_refs_init(self.h, self.B, max_pieces, max_checkpoints))
 
+    def refs_set_from_backend(self, planner, count: int | None = None, traj_start_time: float = 0.0, xv: float = 0.0,
+                              state_seq_res: float = 0.1, integral_res_int: int = 4) -> None:
+        """Trajectory store <- the plans of a BatchedMSPlanner on the same GPU, device to device (problem t -> slot t)."""
+        view = planner.device_view()
+        self._check(self.lib.alore_nmpc_refs_set_from_backend(self.h, C.addressof(view), int(count or planner.count),
+                                                              float(traj_start_time), float(xv), float(state_seq_res),
+                                                              int(integral_res_int), self._stream()))
+
     def refs_set_polynomes(self, robots, msgs, state_seq_res: float = 0.1, integral_res_int: int = 4) -> None:
         """msgs: objects with the fields of Polynome.msg (alore_legged_manipulator_amd.host.Polynome)."""
         n = len(msgs)

@@ -194,6 +194,15 @@ typedef struct alore_polynome {
 } alore_polynome;
 int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int *robots, const alore_polynome *msgs,
                                   double state_seq_res, int integral_res_int, void *stream);
+/* The store filled straight from the planner on the same GPU: `view` is an alore_backend_device_view
+ * (include/alore_backend.h, passed as const void* to keep this header self-contained) after alore_backend_plan;
+ * problem t goes to slot t for t < count.  Replaces the reference's process boundary MSPlanner ->
+ * PlanManager::MPCPathPub (plan_manager.hpp:784-831) -> ~traj -> MpcController::TrajCallback -> TrajAnal::setTraj:
+ * the optimiser's final coefficients are that spline, so they are copied and only the Simpson checkpoints are
+ * built.  xv = ICR.z of the message (0 for the standard differential model).  Problems the planner rejected
+ * (ok = 0) leave their slot invalid.  Synchronises the stream; errors as alore_nmpc_refs_set_polynomes. */
+int alore_nmpc_refs_set_from_backend(alore_nmpc_handle h, const void *view, int count, double traj_start_time, double xv,
+                                     double state_seq_res, int integral_res_int, void *stream);
 /* read one slot back (tests, logging): meta8 = start_time, duration, xv, state_seq_res, n_pieces, n_ckpt,
  * valid, 0; durations [max_pieces]; coeffs [max_pieces][2][6]; ckpt_xy [max_checkpoints][2]; any may be NULL */
 int alore_nmpc_refs_download(alore_nmpc_handle h, int robot, double *meta8, double *durations, double *coeffs,

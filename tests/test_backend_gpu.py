@@ -178,7 +178,7 @@ def test_results_are_bit_reproducible_and_independent_of_batch_mates(orc):
 
 def test_long_paths_use_the_32_piece_kernel(orc):
     grid = free_grid(40.0)
-    ft = waypoint_path([[-15.0, -10.0], [0.0, -2.0], [14.0, 9.0]], 0.0, 1.0)
+    ft = waypoint_path([[-6.0, -4.0], [0.0, -1.0], [6.0, 4.0]], 0.0, 1.0)
     assert 16 < ft.pieces <= 32
     pl = planner_for(grid, 1, max_pieces=32)
     pl.set_problems([ft])
@@ -194,7 +194,7 @@ def test_long_paths_use_the_32_piece_kernel(orc):
 def test_too_many_pieces_is_refused():
     from alore_legged_manipulator_amd.backend import BackendError, BatchedMSPlanner
     grid = free_grid(40.0)
-    ft = waypoint_path([[-15.0, -10.0], [0.0, -2.0], [14.0, 9.0]], 0.0, 1.0)
+    ft = waypoint_path([[-6.0, -4.0], [0.0, -1.0], [6.0, 4.0]], 0.0, 1.0)
     pl = BatchedMSPlanner(1, 16)
     pl.set_map(grid.dist, grid.x_lo, grid.y_lo, grid.res)
     with pytest.raises(BackendError):

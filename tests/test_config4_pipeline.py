@@ -1,0 +1,82 @@
+"""BASELINE configs[4] end to end on one GPU: a mixed multi-object batch -- 4 object classes (ICR parameters and
+weights of SURVEY.md section 8(d)) x Monte-Carlo start poses -- planned by the batched back_end, handed to the NMPC
+on the device (no host copy of the trajectories), tracked in closed loop by the kinematic plant.
+Checked against the CPU chain oracle back_end -> oracle TrajAnal / getRefPoints -> oracle RTI on a sample."""
+import numpy as np
+import pytest
+
+from alore_legged_manipulator_amd.flat_traj import monte_carlo_goals
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = [(0.0, -0.3, 0.3), (0.2, -0.3, 0.3), (0.1, -0.25, 0.25), (0.3, -0.35, 0.35)]  # (xv, yr, yl) per object class
+
+
+def test_backend_plans_warm_start_the_nmpc_on_the_device():
+    from alore_legged_manipulator_amd.backend import BatchedMSPlanner
+    from alore_legged_manipulator_amd.nmpc import BatchedNmpc
+    from oracle.backend_driver import BackendOracle, EsdfGrid
+    from oracle.drivers import Oracle
+    from oracle.traj_driver import Polynome, RefSampler
+    poses_per_class, N, dt = 64, 20, 0.01
+    B = 4 * poses_per_class
+    fts = monte_carlo_goals(B, seed=44)
+    grid = EsdfGrid.free(half=20.0)
+    pl = BatchedMSPlanner(B, 16)
+    pl.set_map(grid.dist, grid.x_lo, grid.y_lo, grid.res)
+    res = pl.minco_plan(fts)
+    assert np.all(res["ok"] == 1)
+
+    icr = np.array([CLASSES[b % 4] for b in range(B)])
+    pose0 = np.array([ft.start_xytheta for ft in fts])
+    W = np.tile(np.diag([10, 10, 0.5, 0.1, 0.1]).astype(np.float32), (B, N, 1, 1))
+    WN = np.tile(np.diag([10, 10, 0.5]).astype(np.float32), (B, 1, 1))
+    eng = BatchedNmpc(B, N, dt)
+    eng.load({"W": W, "WN": WN})
+    eng.refs_init(max_pieces=16, max_checkpoints=128)
+    eng.refs_set_from_backend(pl)                                   # device -> device
+    # (i) the store equals what the reference's message path builds: Polynome -> TrajAnal on the host
+    msgs = pl.polynomes(fts, res)
+    for b in (0, 1, 2, 3, 77, B - 1):
+        m = msgs[b]
+        pm = Polynome(m["innerpoints"], m["t_pts"], m["init_pva"], m["tail_pva"], m["start_position"], m["ICR"], 0.0)
+        s = RefSampler(N, dt); s.traj(pm)
+        d = eng.refs_download(b)
+        seq = s.sequence()
+        assert d["valid"] and d["checkpoints"].shape[0] == seq.shape[0]
+        assert np.max(np.abs(d["checkpoints"] - seq[:, :2])) < 1e-9
+        _, coef = s.coefficients()
+        assert np.max(np.abs(d["coeffs"][:len(m["t_pts"])] - coef)) <= 1e-8 * max(1.0, np.max(np.abs(coef)))
+    # (ii) first tick against the oracle chain (cold start from the start pose)
+    eng.plant_init()
+    eng.plant_set_state(pose0, icr)
+    eng.closed_loop_reset()
+    eng.closed_loop_tick(0.05, delay_num=1)
+    out = eng.fetch(names=("x", "u", "y", "yN", "status"))
+    assert np.all(out["status"] == 0)
+    orc = Oracle(N)
+    for b in (0, 1, 2, 3, 77, B - 1):
+        m = msgs[b]
+        pm = Polynome(m["innerpoints"], m["t_pts"], m["init_pva"], m["tail_pva"], m["start_position"], m["ICR"], 0.0)
+        s = RefSampler(N, dt); s.traj(pm); s.odom(*pose0[b]); s.icr(icr[b, 1], icr[b, 2], icr[b, 0])
+        rs, ri, _ = s.refs(0.05, smooth=True)
+        p = {"x": np.tile(np.float32(pose0[b]), N + 1), "u": np.zeros(2 * N, np.float32), "od": np.tile(np.float32(icr[b]), N + 1),
+             "y": np.concatenate([rs[:N], ri[:N]], 1).astype(np.float32).reshape(-1), "yN": rs[N].astype(np.float32),
+             "W": W[b].reshape(-1), "WN": WN[b].reshape(-1), "x0": np.float32(pose0[b])}
+        orc.reset(); orc.initialize_solver(); orc.load(p)
+        orc.preparation_step()
+        assert orc.feedback_step() == 0
+        for k in ("x", "u"):
+            ref = orc.v[k]
+            assert np.max(np.abs(out[k][b].reshape(-1) - ref)) <= 1e-4 * max(1.0, np.max(np.abs(ref))), (b, k)
+    # (iii) closed loop to the end of the plans: every robot ends near its goal
+    Tmax = float(res["T"].sum(1).max())
+    ticks = int((Tmax + 1.5) / dt)
+    eng.closed_loop_run(0.06, dt, ticks, delay_num=1)
+    pose, vw, goal = eng.plant_get_state()
+    final = np.array([ft.final_xytheta for ft in fts])
+    dist = np.hypot(pose[:, 0] - final[:, 0], pose[:, 1] - final[:, 1])
+    # the reference's tuning (0.2 s horizon, weights 10 / 10 / 0.5, command dropped 1 s after the plan ends) lags plans
+    # that run at up to 3 m/s: the robots stop near, not on, their goals (3 - 8 m away from the start)
+    assert np.all(goal) and np.median(dist) < 0.3 and dist.max() < 1.0, (np.median(dist), dist.max())
+    assert np.max(np.abs(vw)) < 0.2

@@ -20,7 +20,25 @@ IN_KEYS = ("x", "u", "od", "y", "yN", "W", "WN", "x0", "lbValues", "ubValues", "
 
 
 def relerr(a, b):
+    """element-wise relative error with an absolute floor of 1: max_i |a_i - b_i| / max(1, |b_i|)  (never smaller than
+    the vector-norm figure max|a - b| / max(1, max|b|), which `relerr_vec` reports)"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def relerr_vec(a, b):
     return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
+
+
+def exact_box_qp(H, g, lb, ub):
+    """float64 minimiser of 0.5 x'Hx + g'x in [lb, ub]: bounded-variable least squares on the Cholesky factor
+    (scipy.optimize.lsq_linear, BVLS: an exact active-set method)."""
+    from scipy.optimize import lsq_linear
+    H = np.asarray(H, np.float64); H = 0.5 * (H + H.T)
+    L = np.linalg.cholesky(H)
+    rhs = -np.linalg.solve(L, np.asarray(g, np.float64))
+    r = lsq_linear(L.T, rhs, bounds=(np.asarray(lb, np.float64), np.asarray(ub, np.float64)), method="bvls", tol=1e-15, max_iter=2000)
+    return r.x
 
 
 def oracle_tick(orc, p):
@@ -299,9 +317,10 @@ def test_config3_whole_batch_on_one_gpu(nmpc_mod):
 def test_wide_problems_three_ticks_against_oracle(nmpc_mod):
     """Stress distribution (scenarios.make_wide_batch): 6000 problems x 3 consecutive ticks (ticks 1, 2 start from
     stale duals).  Every problem must be solved -- three of them make the primal-dual working-set iteration cycle
-    and are finished by the active-set safeguard -- and agree with the oracle.  Tolerance 2e-4 here: on this
-    distribution (cond(H) ~ 2e3) the reference's float32 homotopy is itself up to 3e-4 away from the float64
-    solution of its own QP, the kernel ~8e-5."""
+    and are finished by the active-set safeguard -- and agree with the oracle.
+    Tolerance: 1e-4 (BASELINE.json) wherever the reference's own float32 answer is that close to the float64
+    solution of its QP; where it is not (cond(H) ~ 2e3: the reference's homotopy is up to 3.5e-4 off), the kernel
+    must be CLOSER to the float64 solution than the reference is -- proven here per problem, not assumed."""
     from alore_legged_manipulator_amd.scenarios import make_wide_batch
     N, B = 20, 6000
     batch = make_wide_batch(B, N, 99)
@@ -310,7 +329,9 @@ def test_wide_problems_three_ticks_against_oracle(nmpc_mod):
     orc = Oracle(N)
     prev = None
     long_runs = 0
+    err_k, err_r, loose = [], [], 0
     for k in range(3):
+        u_in = eng.fetch(names=("u",))["u"].copy()
         eng.rti(1)
         out = eng.fetch()
         assert (out["status"] == 0).all(), (k, np.nonzero(out["status"])[0][:8], out["status"][out["status"] != 0][:8])
@@ -321,10 +342,24 @@ def test_wide_problems_three_ticks_against_oracle(nmpc_mod):
                 p["x"] = prev["x"][b].reshape(-1); p["u"] = prev["u"][b].reshape(-1); p["dual"] = prev["dual"][b].reshape(-1)
             orc.reset(); orc.initialize_solver(); orc.load(p); orc.preparation_step()
             assert orc.feedback_step() == 0
-            assert relerr(out["u"][b].reshape(-1), orc.v["u"]) < 2e-4, (k, b)
-            assert relerr(out["x"][b].reshape(-1), orc.v["x"]) < 2e-4, (k, b)
+            eu, ex = relerr(out["u"][b].reshape(-1), orc.v["u"]), relerr(out["x"][b].reshape(-1), orc.v["x"])
+            assert eu < 2e-4 and ex < 2e-4, (k, b, eu, ex)
+            # the float64 solution of the reference's own condensed QP (its float32 H, g, bounds)
+            n = 2 * N
+            du_true = exact_box_qp(orc.v["H"].reshape(n, n), orc.v["g"], orc.v["lb"], orc.v["ub"])
+            scale = max(1.0, float(np.max(np.abs(orc.v["u"]))))
+            ek = float(np.max(np.abs((out["u"][b].reshape(-1).astype(np.float64) - u_in[b].reshape(-1)) - du_true))) / scale
+            er = float(np.max(np.abs(orc.v["dx"].astype(np.float64) - du_true))) / scale
+            err_k.append(ek); err_r.append(er)
+            if max(eu, ex) >= 1e-4:          # beyond BASELINE's tolerance against the reference: then the reference is the
+                loose += 1                   # one that is off, and the kernel is the closer of the two to the true minimiser
+                assert ek < er and ek < 1e-4, (k, b, eu, ex, ek, er)
         long_runs += int((out["n_iter"] > 16).sum())
         prev = out
+    err_k, err_r = np.array(err_k), np.array(err_r)
+    print(f"wide: {len(err_k)} QPs; vs float64 truth: kernel max {err_k.max():.2e} median {np.median(err_k):.2e}; "
+          f"reference max {err_r.max():.2e} median {np.median(err_r):.2e}; beyond 1e-4 of the reference: {loose}")
+    assert err_k.max() < 1e-4 and err_k.max() <= err_r.max()
     assert long_runs >= 3        # the safeguard ran
 
 

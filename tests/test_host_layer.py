@@ -226,18 +226,22 @@ def test_cold_start_is_per_robot_and_emergency_stop_forgets_the_trajectory():
 def test_open_loop_replay_without_mpc():
     """if_mpc = false (mpc.cpp:211-234): the planned flat velocities and accelerations at t_cur are republished."""
     from alore_legged_manipulator_amd.host import BatchedMpcController, default_params
-    gold = golden_messages()[:4]
-    ctl = BatchedMpcController(len(gold), 20, 0.01, params=default_params(if_mpc=0, state_seq_res=0.1, Integral_appr_resInt=4),
-                               max_pieces=12, max_checkpoints=80)
-    for b, (m, _) in enumerate(gold):
-        ctl.robots[b].traj(as_host_msg(m)); ctl.robots[b].odom(0, 0, 0)
-    for b, (m, ans) in enumerate(gold):
-        t = float(ans["times"][7])
-        cmd = ctl.tick_full(m.traj_start_time + t)
-        v, a = ans["flat"][7][1], ans["flat"][7][2]
-        assert cmd[b].state_published and not cmd[b].wheel_published
-        assert abs(cmd[b].omega - v[0]) < 1e-8 and abs(cmd[b].v - v[1]) < 1e-8
-        assert abs(cmd[b].alpha - a[0]) < 1e-7 and abs(cmd[b].a - a[1]) < 1e-7
+    prm = default_params(if_mpc=0, state_seq_res=0.1, Integral_appr_resInt=4)
+    for m, ans in golden_messages()[:4]:
+        ctl = BatchedMpcController(1, 20, 0.01, params=prm, max_pieces=12, max_checkpoints=80)
+        ctl.robots[0].traj(as_host_msg(m)); ctl.robots[0].odom(0, 0, 0)
+        for k in (3, 7, 15):
+            t = float(ans["times"][k])
+            cmd = ctl.tick_full(m.traj_start_time + t)[0]
+            v, a = ans["flat"][k][1], ans["flat"][k][2]
+            assert cmd.state_published and not cmd.wheel_published
+            assert abs(cmd.omega - v[0]) < 1e-8 and abs(cmd.v - v[1]) < 1e-8
+            assert abs(cmd.alpha - a[0]) < 1e-7 and abs(cmd.a - a[1]) < 1e-7
+        # past the end the robot is flagged at_goal and the next tick publishes the stop
+        ctl.tick_full(m.traj_start_time + float(m.t_pts.sum()) + 0.01)
+        assert ctl.robots[0].at_goal
+        stop = ctl.tick_full(m.traj_start_time + float(m.t_pts.sum()) + 0.02)[0]
+        assert stop.state_published and stop.v == 0.0 and stop.omega == 0.0 and not ctl.robots[0].receive_traj
 
 
 def test_phase_stamps_do_not_disturb_the_trajectory_store(monkeypatch):
