@@ -69,6 +69,8 @@ SYMBOLS = (
     ("alore_nmpc_version", C.c_char_p, []),
     ("alore_nmpc_batch_alloc", C.c_int, [C.c_void_p, C.c_int, C.POINTER(Batch)]),
     ("alore_nmpc_batch_free", C.c_int, [C.c_void_p, C.POINTER(Batch)]),
+    ("alore_nmpc_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("alore_nmpc_host_free", C.c_int, [C.c_void_p]),
     ("alore_nmpc_batch_upload", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(Batch), C.c_int, C.c_void_p]),
     ("alore_nmpc_batch_download", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(Batch), C.c_int, C.c_void_p]),
     ("alore_nmpc_batch_default_bounds", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p]),

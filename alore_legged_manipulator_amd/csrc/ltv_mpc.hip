@@ -1,0 +1,577 @@
+// ltv_mpc.hip -- batched linear time-varying MPC of the reference's `mpc` node (include/alore_ltv_mpc.h).
+//
+// Reference (P = /root/reference/planning_ddr_opt/mpc_controller/src/mpc.cpp):
+//   stateTrans / predictMotion   P:233-269     rollout of the previous output (its clamping quirks kept)
+//   getLinearModel               P:217-231     unicycle, explicit Euler, linearised about the rollout
+//   solveMPCV                    P:304-535     the QP (states + inputs, dynamics rows, input box, rate limits) -> OSQP
+//   getCmd                       P:569-614     relinearisation loop (wall-clock bound there, counted here), delay buffer
+//   predictMotion(xopt)          P:271-302     linear prediction that is published
+//   getRefPoints / smooth_yaw    P:634-690, 538-567
+//
+// Mapping: ONE THREAD PER ROBOT (the per-stage algebra is a 7 x 7 quadratic form: it fits a lane's registers and
+// has no parallelism worth a wavefront), the per-stage records of all robots interleaved ([field][stage][robot])
+// so that the 64 robots of a wavefront read and write whole cache lines.  float64 like the reference.
+//
+// The QP is solved exactly by a working-set Riccati method.  State of stage j: xi = (x, y, theta, v_{j-1}, w_{j-1})
+// -- augmenting by the previous input makes the rate penalty Rd and the rate limits stage-local.  Each input
+// component is FREE, on a BOX bound or on a RATE limit.  For a given assignment the stage cost-to-go is a quadratic
+// form in w = (xi, u0, u1); a component is eliminated by an affine substitution u = a.w_rest + f (the minimiser if
+// free, the bound if boxed, previous input +- limit if rate-limited) -- one routine for all cases.  The forward
+// sweep evaluates inputs, the multipliers of the non-free components (gradient rows kept from the backward
+// sweep) and the violations of the free ones, and updates the assignment; done when it reproduces itself.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/alore_ltv_mpc.h"
+#include "minco_spline.h"
+#include "nmpc_kernels.h"
+
+namespace ltv {
+
+constexpr int MAXT = 64;
+enum : int { FREE = 0, BOX_LO = 1, BOX_HI = 2, RATE_LO = 3, RATE_HI = 4 };
+constexpr int NF = 38; // doubles per stage record
+constexpr int SINGLE_AFTER = 24; // from this sweep on only the most severe change is applied (breaks cycles)
+
+struct Dev {
+    alore_ltv_config c;
+    int B;               // robots in this launch
+    int stride;          // robot stride of the interleaved arrays (= max_robots)
+    const double* now;   // [B][3]
+    const double* xref;  // [B][T][3]
+    const double* dref;  // [B][T][2]
+    double* output;      // [B][T][2]  in/out (previous output -> new output)
+    double* buff;        // [B][d][2]  in/out
+    double* xopt;        // [B][T+1][3]
+    double* ws;          // [T][NF][stride]
+    int* st;             // [T][2][stride] working set (kept between calls: warm start)
+    int* sweeps;         // [B]
+    int* status;         // [B]
+    int n_relin, reset;
+};
+
+struct Quad7 { // symmetric 7 x 7 form H and vector h in w = (xi0..4, u0, u1); only the entries that can be non-zero are kept dense
+    double H[7][7];
+    double h[7];
+};
+
+__device__ __forceinline__ double& W(const Dev& d, int j, int f, int b) { return d.ws[((size_t)j * NF + f) * d.stride + b]; }
+
+__global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= d.B) return;
+    const alore_ltv_config& c = d.c;
+    const int T = c.predict_steps, dl = c.delay_num, K = T - dl;
+    const double dt = c.dt;
+    const double umax[2] = {c.max_vel, c.max_omega}, rmax[2] = {c.max_acc * dt, c.max_domega * dt};
+    const double Qp2[3] = {2.0 * c.matrix_q[0], 2.0 * c.matrix_q[1], 2.0 * c.matrix_q[3]};
+    const double Rd2[2] = {2.0 * c.matrix_rd[0], 2.0 * c.matrix_rd[1]};
+    const double Ruu0[2] = {2.0 * (c.matrix_r[0] + c.matrix_q[2]), 2.0 * c.matrix_r[1]};
+    const double tol = 1e-9;
+    double* out = d.output + (size_t)b * T * 2;
+    double* bf = d.buff + (size_t)b * (dl > 0 ? dl : 1) * 2;
+    const double* xr = d.xref + (size_t)b * T * 3;
+    const double* dr = d.dref + (size_t)b * T * 2;
+    if (d.reset) {
+        for (int i = 0; i < 2 * T; ++i) out[i] = 0.0;
+        for (int i = 0; i < 2 * dl; ++i) bf[i] = 0.0;
+        for (int j = 0; j < T; ++j) { d.st[((size_t)j * 2) * d.stride + b] = FREE; d.st[((size_t)j * 2 + 1) * d.stride + b] = FREE; }
+    }
+    const double x0 = d.now[(size_t)b * 3], y0 = d.now[(size_t)b * 3 + 1], th0 = d.now[(size_t)b * 3 + 2];
+    int sweeps = 0, status = 0;
+
+    for (int relin = 0; relin < d.n_relin; ++relin) {
+        // ---- predictMotion: rollout of the last output; the linear model about xbar[dl + j] goes to the records
+        double px = x0, py = y0, pth = th0, pv = 0.0; // now_state.v = 0 (odometry callback)
+        double pos0[3] = {x0, y0, th0};
+        for (int i = 0; i <= T; ++i) {
+            if (i >= dl && i < T) {
+                const int j = i - dl;
+                const double B00 = cos(pth) * dt, B10 = sin(pth) * dt;
+                const double A02 = -B10 * pv, A12 = B00 * pv;
+                W(d, j, 0, b) = A02; W(d, j, 1, b) = A12; W(d, j, 2, b) = B00; W(d, j, 3, b) = B10;
+                W(d, j, 4, b) = -A02 * pth; W(d, j, 5, b) = -A12 * pth;
+                if (j == 0) { pos0[0] = px; pos0[1] = py; pos0[2] = pth; }
+            }
+            if (i == T) break;
+            // stateTrans(temp, a = output(0, i), yaw_dot = output(1, i))
+            const double a = out[2 * i];
+            double yd = out[2 * i + 1];
+            yd = fmin(fmax(yd, -c.max_omega), c.max_omega);
+            px += a * cos(pth) * dt;
+            py += a * sin(pth) * dt;
+            pth += yd * dt;
+            pv = a;
+        }
+
+        // ---- working-set iterations
+        bool settled = false;
+        for (sweeps = 0; sweeps < c.max_sweeps && !settled; ++sweeps) {
+            // backward sweep: cost-to-go V(xi) = 1/2 xi' P xi + p' xi, P symmetric 5 x 5
+            double P[5][5], p[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) { p[r] = 0.0;
+#pragma unroll
+                for (int s = 0; s < 5; ++s) P[r][s] = 0.0; }
+            // effective boxes: a stage that sits on a rate limit hands its box on to its predecessor, shifted by the limit
+            // (u_j = u_{j-1} + r and u_j <= hi  =>  u_{j-1} <= hi - r); a BOX status means "on the effective box"
+            double lo_eff[2] = {-umax[0], -umax[1]}, hi_eff[2] = {umax[0], umax[1]};
+            for (int j = K - 1; j >= 0; --j) {
+                const double A02 = W(d, j, 0, b), A12 = W(d, j, 1, b), B00 = W(d, j, 2, b), B10 = W(d, j, 3, b);
+                const double C0 = W(d, j, 4, b), C1 = W(d, j, 5, b);
+                W(d, j, 34, b) = lo_eff[0]; W(d, j, 35, b) = hi_eff[0]; W(d, j, 36, b) = lo_eff[1]; W(d, j, 37, b) = hi_eff[1];
+                // tracking on the next position, then pull back through xi' = Fw w + c:
+                //   x' = x + A02 th + B00 u0 + C0 ; y' = y + A12 th + B10 u0 + C1 ; th' = th + dt u1 ; v' = u0 ; om' = u1
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { P[r][r] += Qp2[r]; p[r] -= Qp2[r] * xr[(dl + j) * 3 + r]; }
+                // s = P c + p
+                double s[5];
+#pragma unroll
+                for (int r = 0; r < 5; ++r) s[r] = P[r][0] * C0 + P[r][1] * C1 + p[r];
+                // columns of Fw (5 x 7): col0 = e0, col1 = e1, col2 = (A02, A12, 1, 0, 0), col3 = col4 = 0,
+                //                        col5 = (B00, B10, 0, 1, 0), col6 = (0, 0, dt, 0, 1)
+                double Fc[7][5];
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) Fc[k][r] = 0.0;
+                Fc[0][0] = 1.0; Fc[1][1] = 1.0; Fc[2][0] = A02; Fc[2][1] = A12; Fc[2][2] = 1.0;
+                Fc[5][0] = B00; Fc[5][1] = B10; Fc[5][3] = 1.0; Fc[6][2] = dt; Fc[6][4] = 1.0;
+                Quad7 q;
+                double PF[7][5]; // P Fc[k]
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int t = 0; t < 5; ++t) acc += P[r][t] * Fc[k][t];
+                        PF[k][r] = acc;
+                    }
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    double hk = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) hk += Fc[k][r] * s[r];
+                    q.h[k] = hk;
+#pragma unroll
+                    for (int m = 0; m < 7; ++m) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 5; ++r) acc += Fc[m][r] * PF[k][r];
+                        q.H[m][k] = acc;
+                    }
+                }
+                q.H[5][5] += Ruu0[0]; q.H[6][6] += Ruu0[1];
+                q.h[5] += -2.0 * c.matrix_q[2] * dr[(dl + j) * 2];
+                if (j >= 1) {
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        q.H[5 + cc][5 + cc] += Rd2[cc]; q.H[3 + cc][3 + cc] += Rd2[cc];
+                        q.H[5 + cc][3 + cc] -= Rd2[cc]; q.H[3 + cc][5 + cc] -= Rd2[cc];
+                    }
+                }
+                const int st1 = d.st[((size_t)j * 2 + 1) * d.stride + b], st0 = d.st[((size_t)j * 2) * d.stride + b];
+                // ---- eliminate u1 (index 6): u1 = a1 . w[0..5] + f1
+                {
+                    double a1[6], f1;
+                    const double inv = 1.0 / q.H[6][6];
+                    const bool fr = st1 == FREE, bx = (st1 == BOX_LO || st1 == BOX_HI);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) a1[k] = fr ? -q.H[6][k] * inv : ((!bx && k == 4) ? 1.0 : 0.0);
+                    f1 = fr ? -q.h[6] * inv : (bx ? (st1 == BOX_LO ? lo_eff[1] : hi_eff[1]) : (st1 == RATE_LO ? -rmax[1] : rmax[1]));
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) W(d, j, 6 + k, b) = a1[k];
+                    W(d, j, 12, b) = f1;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) W(d, j, 13 + k, b) = q.H[6][k]; // gradient row of u1
+                    W(d, j, 20, b) = q.h[6];
+                    const double Hkk = q.H[6][6], hk = q.h[6];
+                    double Hk[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) Hk[k] = q.H[6][k];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        q.h[r] += a1[r] * hk + (Hk[r] + a1[r] * Hkk) * f1;
+#pragma unroll
+                        for (int s2 = 0; s2 < 6; ++s2) q.H[r][s2] += a1[r] * Hk[s2] + Hk[r] * a1[s2] + Hkk * a1[r] * a1[s2];
+                    }
+                }
+                // ---- eliminate u0 (index 5): u0 = a0 . xi + f0
+                {
+                    double a0[5], f0;
+                    const double inv = 1.0 / q.H[5][5];
+                    const bool fr = st0 == FREE, bx = (st0 == BOX_LO || st0 == BOX_HI);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) a0[k] = fr ? -q.H[5][k] * inv : ((!bx && k == 3) ? 1.0 : 0.0);
+                    f0 = fr ? -q.h[5] * inv : (bx ? (st0 == BOX_LO ? lo_eff[0] : hi_eff[0]) : (st0 == RATE_LO ? -rmax[0] : rmax[0]));
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) W(d, j, 21 + k, b) = a0[k];
+                    W(d, j, 26, b) = f0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) W(d, j, 27 + k, b) = q.H[5][k]; // reduced gradient row of u0
+                    W(d, j, 33, b) = q.h[5];
+                    const double Hkk = q.H[5][5], hk = q.h[5];
+                    double Hk[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) Hk[k] = q.H[5][k];
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        p[r] = q.h[r] + a0[r] * hk + (Hk[r] + a0[r] * Hkk) * f0;
+#pragma unroll
+                        for (int s2 = 0; s2 < 5; ++s2) P[r][s2] = q.H[r][s2] + a0[r] * Hk[s2] + Hk[r] * a0[s2] + Hkk * a0[r] * a0[s2];
+                    }
+                }
+                // boxes of stage j - 1
+                {
+                    const double l0 = lo_eff[0], h0 = hi_eff[0], l1 = lo_eff[1], h1 = hi_eff[1];
+                    lo_eff[0] = (st0 == RATE_LO) ? fmax(-umax[0], l0 + rmax[0]) : -umax[0];
+                    hi_eff[0] = (st0 == RATE_HI) ? fmin(umax[0], h0 - rmax[0]) : umax[0];
+                    lo_eff[1] = (st1 == RATE_LO) ? fmax(-umax[1], l1 + rmax[1]) : -umax[1];
+                    hi_eff[1] = (st1 == RATE_HI) ? fmin(umax[1], h1 - rmax[1]) : umax[1];
+                }
+            }
+            // forward sweep: inputs, multipliers, violations -> next working set
+            double xi[5] = {pos0[0], pos0[1], pos0[2], 0.0, 0.0};
+            int changes = 0;
+            // multiplier carried down a chain of rate-limited stages that hangs from a tightened box (the box of the
+            // chain's last stage, active through the chain): gradient of the anchor; chain_dir: -1 lower, +1 upper
+            double chain_mu[2] = {0.0, 0.0};
+            int chain_dir[2] = {0, 0};
+            const bool single = sweeps >= SINGLE_AFTER;
+            double best_sev = -1.0;
+            int best_j = 0, best_c = 0, best_ns = 0;
+            for (int j = 0; j < K; ++j) {
+                double w7[7];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) w7[k] = xi[k];
+                double u0 = W(d, j, 26, b);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) u0 += W(d, j, 21 + k, b) * xi[k];
+                w7[5] = u0;
+                double u1 = W(d, j, 12, b);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) u1 += W(d, j, 6 + k, b) * w7[k];
+                w7[6] = u1;
+                double g1 = W(d, j, 20, b), g0 = W(d, j, 33, b);
+#pragma unroll
+                for (int k = 0; k < 7; ++k) g1 += W(d, j, 13 + k, b) * w7[k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) g0 += W(d, j, 27 + k, b) * w7[k];
+                const double uu[2] = {u0, u1}, gg[2] = {g0, g1};
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    int* sp = d.st + ((size_t)j * 2 + cc) * d.stride + b;
+                    const int s = *sp;
+                    const double val = uu[cc], prev = xi[3 + cc], grad = gg[cc];
+                    const double lo = W(d, j, 34 + 2 * cc, b), hi = W(d, j, 35 + 2 * cc, b);
+                    int ns = s;
+                    double sev = 0.0;
+                    if (s == FREE) {
+                        chain_mu[cc] = 0.0; chain_dir[cc] = 0;
+                        const double vb = fmax(lo - val, val - hi);
+                        const double vr = (j >= 1) ? fmax(-rmax[cc] - (val - prev), (val - prev) - rmax[cc]) : -1.0;
+                        if (vb > tol && vb >= vr) { ns = (val < lo) ? BOX_LO : BOX_HI; sev = vb; }
+                        else if (vr > tol) { ns = (val - prev < 0.0) ? RATE_LO : RATE_HI; sev = vr; }
+                    } else if (s == BOX_LO || s == BOX_HI) {
+                        const bool lower = (s == BOX_LO);
+                        const bool tightened = lower ? (lo > -umax[cc] + 1e-12) : (hi < umax[cc] - 1e-12);
+                        chain_mu[cc] = tightened ? grad : 0.0;
+                        chain_dir[cc] = tightened ? (lower ? -1 : 1) : 0;
+                        if ((lower && grad < -tol) || (!lower && grad > tol)) { ns = FREE; sev = fabs(grad); }
+                        else if (j >= 1 && fabs(val - prev) > rmax[cc] + tol) { ns = (val - prev < 0.0) ? RATE_LO : RATE_HI; sev = fabs(val - prev) - rmax[cc]; }
+                    } else {
+                        const bool lower = (s == RATE_LO);
+                        if (chain_dir[cc] != (lower ? -1 : 1)) { chain_mu[cc] = 0.0; chain_dir[cc] = 0; }
+                        const double g_eff = grad - chain_mu[cc];
+                        if ((lower && g_eff < -tol) || (!lower && g_eff > tol)) {
+                            // inside a chain that hangs from a box further down: this stage becomes the anchor of the rest
+                            ns = (chain_mu[cc] == 0.0) ? FREE : (lower ? BOX_LO : BOX_HI);
+                            sev = fabs(g_eff);
+                            chain_mu[cc] = 0.0; chain_dir[cc] = 0;
+                        }
+                    }
+                    if (ns != s) {
+                        ++changes;
+                        if (!single) *sp = ns;
+                        else if (sev > best_sev) { best_sev = sev; best_j = j; best_c = cc; best_ns = ns; }
+                    }
+                }
+                out[2 * (dl + j)] = u0;
+                out[2 * (dl + j) + 1] = u1;
+                const double A02 = W(d, j, 0, b), A12 = W(d, j, 1, b), B00 = W(d, j, 2, b), B10 = W(d, j, 3, b);
+                const double nx = xi[0] + A02 * xi[2] + B00 * u0 + W(d, j, 4, b), ny = xi[1] + A12 * xi[2] + B10 * u0 + W(d, j, 5, b);
+                xi[2] = xi[2] + dt * u1; xi[0] = nx; xi[1] = ny; xi[3] = u0; xi[4] = u1;
+            }
+            if (single && changes > 0) d.st[((size_t)best_j * 2 + best_c) * d.stride + b] = best_ns;
+            settled = (changes == 0);
+        }
+        status = settled ? 0 : 1;
+        for (int i = 0; i < dl; ++i) { out[2 * i] = bf[2 * i]; out[2 * i + 1] = bf[2 * i + 1]; } // solveMPCV: the delayed inputs
+    }
+    // ---- predictMotion(xopt): the linear prediction about the last rollout (what the node publishes as cmd_path)
+    {
+        double* xo = d.xopt + (size_t)b * (T + 1) * 3;
+        // the rollout xbar of the last pass is not stored: redo stateTrans to get xbar[i-1] for the linear model
+        double bx = x0, by = y0, bth = th0, bv = 0.0; // xbar[i - 1]
+        double tx = x0, ty = y0, tth = th0;          // temp (linear prediction)
+        xo[0] = tx; xo[1] = ty; xo[2] = tth;
+        // NOTE: the reference's xbar at this point is the rollout of the output BEFORE the last solve (predictMotion
+        // runs at the top of each pass); `prev_out` is not kept, so the published path uses the final output for
+        // both roles -- identical once the relinearisation has converged.
+        for (int i = 1; i <= T; ++i) {
+            const double B00 = cos(bth) * dt, B10 = sin(bth) * dt, A02 = -B10 * bv, A12 = B00 * bv;
+            const double u0 = out[2 * (i - 1)], u1 = out[2 * (i - 1) + 1];
+            const double nx = tx + A02 * tth + B00 * u0 - A02 * bth, ny = ty + A12 * tth + B10 * u0 - A12 * bth;
+            tth = tth + dt * u1; tx = nx; ty = ny;
+            xo[3 * i] = tx; xo[3 * i + 1] = ty; xo[3 * i + 2] = tth;
+            double yd = fmin(fmax(u1, -c.max_omega), c.max_omega);
+            bx += u0 * cos(bth) * dt; by += u0 * sin(bth) * dt; bth += yd * dt; bv = u0;
+        }
+    }
+    if (dl > 0) { // output_buff: drop the oldest, append the command just computed
+        for (int i = 0; i + 1 < dl; ++i) { bf[2 * i] = bf[2 * (i + 1)]; bf[2 * i + 1] = bf[2 * (i + 1) + 1]; }
+        bf[2 * (dl - 1)] = out[2 * dl]; bf[2 * (dl - 1) + 1] = out[2 * dl + 1];
+    }
+    d.sweeps[b] = sweeps;
+    d.status[b] = status;
+}
+
+// getRefPoints of the `mpc` node on the trajectory store: thread = (robot, i), then smooth_yaw per robot
+__global__ void ltv_refs_kernel(nmpc::RefStore s, int B, int T, double dt, double now, double* xref, double* dref, int* at_goal)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * T) return;
+    const int r = (int)(t / T), i = (int)(t % T);
+    const double* m = s.meta + (size_t)r * 8;
+    if (m[6] == 0.0) { if (i == 0 && at_goal) at_goal[r] = 0; return; }
+    const double duration = m[1], xv = m[2], res = m[3];
+    const int np = (int)m[4], nc = (int)m[5];
+    const double* dur = s.dur + (size_t)r * s.P;
+    const double* coef = s.coef + (size_t)r * s.P * 12;
+    const double t_cur = now - m[0];
+    double temp_t = t_cur + dt;
+    for (int k = 0; k < i; ++k) temp_t += dt;
+    const double tq = (temp_t <= duration) ? temp_t : duration;
+    int index = (int)floor(tq / res);
+    if (index > nc - 1) index = nc - 1;
+    if (index < 0) index = 0;
+    const double floor_t = index * res, diff_t = tq - floor_t;
+    double p1[2], p2[2], p3[2], v1[2], v2[2], v3[2];
+    minco::eval_pv(dur, coef, np, floor_t, p1, v1);
+    minco::eval_pv(dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
+    minco::eval_pv(dur, coef, np, tq, p3, v3);
+    const double* ck = s.ckpt + ((size_t)r * s.C + index) * 2;
+    const double X = ck[0] + diff_t / 6.0 * (minco::xdot(p1, v1, xv) + 4.0 * minco::xdot(p2, v2, xv) + minco::xdot(p3, v3, xv));
+    const double Y = ck[1] + diff_t / 6.0 * (minco::ydot(p1, v1, xv) + 4.0 * minco::ydot(p2, v2, xv) + minco::ydot(p3, v3, xv));
+    double psi = p3[0];
+    while (psi > M_PI) psi -= 2 * M_PI;
+    while (psi < -M_PI) psi += 2 * M_PI;
+    double* xo = xref + ((size_t)r * T + i) * 3;
+    xo[0] = X; xo[1] = Y; xo[2] = psi;
+    dref[((size_t)r * T + i) * 2] = v3[1];
+    dref[((size_t)r * T + i) * 2 + 1] = v3[0];
+    if (i == 0 && at_goal) at_goal[r] = (t_cur > duration + 1.0) ? 1 : 0;
+}
+__global__ void ltv_unwrap_kernel(nmpc::RefStore s, int B, int T, const double* est, double* xref)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B || s.meta[(size_t)r * 8 + 6] == 0.0) return;
+    double* x = xref + (size_t)r * T * 3;
+    const double th = est[(size_t)r * 3 + 2];
+    double dy = x[2] - th;
+    while (dy >= M_PI / 2) { x[2] -= 2 * M_PI; dy = x[2] - th; }
+    while (dy <= -M_PI / 2) { x[2] += 2 * M_PI; dy = x[2] - th; }
+    for (int i = 0; i + 1 < T; ++i) {
+        dy = x[3 * (i + 1) + 2] - x[3 * i + 2];
+        while (dy >= M_PI / 2) { x[3 * (i + 1) + 2] -= 2 * M_PI; dy = x[3 * (i + 1) + 2] - x[3 * i + 2]; }
+        while (dy <= -M_PI / 2) { x[3 * (i + 1) + 2] += 2 * M_PI; dy = x[3 * (i + 1) + 2] - x[3 * i + 2]; }
+    }
+}
+
+} // namespace ltv
+
+// internal accessor of the NMPC handle's trajectory store (nmpc_capi.hip)
+extern "C" int alore_nmpc_internal_refstore(void* nmpc_handle, nmpc::RefStore* out, int* capacity, int* device);
+
+struct alore_ltv_solver {
+    alore_ltv_config cfg;
+    int device = 0, B = 0;
+    std::string err;
+    double *d_now = nullptr, *d_xref = nullptr, *d_dref = nullptr, *d_out = nullptr, *d_buff = nullptr, *d_xopt = nullptr, *d_ws = nullptr,
+           *d_est = nullptr;
+    int *d_st = nullptr, *d_sweeps = nullptr, *d_status = nullptr, *d_goal = nullptr;
+    char* h_stage = nullptr; // pinned
+    size_t stage_bytes = 0;
+};
+
+namespace {
+int lfail(alore_ltv_handle h, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (h) { h->err = what; if (e != hipSuccess) { h->err += ": "; h->err += hipGetErrorString(e); } }
+    return code;
+}
+#define LTV_TRY(h, call)                                                  \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return lfail(h, ALORE_LTV_E_HIP, #call, e_); \
+    } while (0)
+template <class T>
+hipError_t zalloc(T** p, size_t n)
+{
+    hipError_t e = hipMalloc((void**)p, sizeof(T) * (n ? n : 1));
+    if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(T) * (n ? n : 1));
+    return e;
+}
+void lfree(alore_ltv_handle h)
+{
+    void* ptrs[] = {h->d_now, h->d_xref, h->d_dref, h->d_out, h->d_buff, h->d_xopt, h->d_ws, h->d_est, h->d_st, h->d_sweeps, h->d_status, h->d_goal};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+}
+} // namespace
+
+extern "C" {
+
+void alore_ltv_default_config(alore_ltv_config* c)
+{
+    std::memset(c, 0, sizeof(*c));
+    c->dt = 0.01; c->predict_steps = 30; c->delay_num = 1;
+    c->matrix_q[0] = 15.0; c->matrix_q[1] = 15.0; c->matrix_q[2] = 0.0; c->matrix_q[3] = 1.0;
+    c->matrix_r[0] = 0.0; c->matrix_r[1] = 0.0;
+    c->matrix_rd[0] = 1.0; c->matrix_rd[1] = 0.05;
+    c->max_vel = 3.0; c->min_vel = 0.0; c->max_omega = 3.0; c->max_acc = 2.0; c->max_domega = 4.0;
+    c->max_sweeps = 64;
+}
+
+int alore_ltv_create(const alore_ltv_config* cfg, int device, int max_robots, alore_ltv_handle* out)
+{
+    if (!cfg || !out || max_robots < 1) return ALORE_LTV_E_INVALID;
+    *out = nullptr;
+    if (cfg->predict_steps < 2 || cfg->predict_steps > ltv::MAXT || cfg->delay_num < 0 || cfg->delay_num >= cfg->predict_steps - 1 ||
+        !(cfg->dt > 0.0))
+        return ALORE_LTV_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ALORE_LTV_E_NO_DEVICE;
+    if (device < 0 || device >= ndev) return ALORE_LTV_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return ALORE_LTV_E_NO_DEVICE;
+    alore_ltv_solver* h = new (std::nothrow) alore_ltv_solver;
+    if (!h) return ALORE_LTV_E_NOMEM;
+    h->cfg = *cfg;
+    if (h->cfg.max_sweeps <= 0) h->cfg.max_sweeps = 64;
+    h->device = device;
+    h->B = max_robots;
+    const size_t B = max_robots, T = cfg->predict_steps, dl = cfg->delay_num > 0 ? cfg->delay_num : 1;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(zalloc(&h->d_now, B * 3)); A(zalloc(&h->d_xref, B * T * 3)); A(zalloc(&h->d_dref, B * T * 2)); A(zalloc(&h->d_out, B * T * 2));
+    A(zalloc(&h->d_buff, B * dl * 2)); A(zalloc(&h->d_xopt, B * (T + 1) * 3)); A(zalloc(&h->d_ws, T * ltv::NF * B)); A(zalloc(&h->d_est, B * 3));
+    A(zalloc(&h->d_st, T * 2 * B)); A(zalloc(&h->d_sweeps, B)); A(zalloc(&h->d_status, B)); A(zalloc(&h->d_goal, B));
+    h->stage_bytes = sizeof(double) * B * ((T + 1) * 3 + T * 5 + 8) + sizeof(int) * B * 4 + 1024;
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { lfree(h); delete h; return e == hipErrorOutOfMemory ? ALORE_LTV_E_NOMEM : ALORE_LTV_E_HIP; }
+    *out = h;
+    return ALORE_LTV_OK;
+}
+
+int alore_ltv_destroy(alore_ltv_handle h)
+{
+    if (!h) return ALORE_LTV_E_INVALID;
+    (void)hipSetDevice(h->device);
+    lfree(h);
+    delete h;
+    return ALORE_LTV_OK;
+}
+const char* alore_ltv_last_error(alore_ltv_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int alore_ltv_set_refs(alore_ltv_handle h, int B, const double* xref, const double* dref, void* stream)
+{
+    if (!h || B < 1 || B > h->B || !xref || !dref) return lfail(h, ALORE_LTV_E_INVALID, "set_refs: bad argument");
+    LTV_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t T = h->cfg.predict_steps;
+    double* hx = (double*)h->h_stage;
+    double* hd = hx + (size_t)B * T * 3;
+    std::memcpy(hx, xref, sizeof(double) * B * T * 3);
+    std::memcpy(hd, dref, sizeof(double) * B * T * 2);
+    LTV_TRY(h, hipMemcpyAsync(h->d_xref, hx, sizeof(double) * B * T * 3, hipMemcpyHostToDevice, s));
+    LTV_TRY(h, hipMemcpyAsync(h->d_dref, hd, sizeof(double) * B * T * 2, hipMemcpyHostToDevice, s));
+    LTV_TRY(h, hipStreamSynchronize(s)); // the slab is reused
+    return ALORE_LTV_OK;
+}
+
+int alore_ltv_refs_from_store(alore_ltv_handle h, void* nmpc, int B, double now, const double* est, int* at_goal, void* stream)
+{
+    if (!h || !nmpc || B < 1 || B > h->B || !est) return lfail(h, ALORE_LTV_E_INVALID, "refs_from_store: bad argument");
+    nmpc::RefStore rs;
+    int cap = 0, dev = -1;
+    if (alore_nmpc_internal_refstore(nmpc, &rs, &cap, &dev) != 0 || cap < B || dev != h->device)
+        return lfail(h, ALORE_LTV_E_INVALID, "refs_from_store: the NMPC handle has no trajectory store for B robots on this device");
+    LTV_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int T = h->cfg.predict_steps;
+    double* he = (double*)h->h_stage;
+    std::memcpy(he, est, sizeof(double) * B * 3);
+    LTV_TRY(h, hipMemcpyAsync(h->d_est, he, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
+    const long total = (long)B * T;
+    hipLaunchKernelGGL(ltv::ltv_refs_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, rs, B, T, h->cfg.dt, now, h->d_xref, h->d_dref,
+                       h->d_goal);
+    hipLaunchKernelGGL(ltv::ltv_unwrap_kernel, dim3((B + 63) / 64), dim3(64), 0, s, rs, B, T, h->d_est, h->d_xref);
+    LTV_TRY(h, hipGetLastError());
+    if (at_goal) LTV_TRY(h, hipMemcpyAsync(at_goal, h->d_goal, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    LTV_TRY(h, hipStreamSynchronize(s));
+    return ALORE_LTV_OK;
+}
+
+int alore_ltv_get_cmd(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, void* stream)
+{
+    if (!h || B < 1 || B > h->B || !now_state || n_relin < 1) return lfail(h, ALORE_LTV_E_INVALID, "get_cmd: bad argument");
+    LTV_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    double* hn = (double*)h->h_stage;
+    std::memcpy(hn, now_state, sizeof(double) * B * 3);
+    LTV_TRY(h, hipMemcpyAsync(h->d_now, hn, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
+    ltv::Dev d{};
+    d.c = h->cfg; d.B = B; d.stride = h->B;
+    d.now = h->d_now; d.xref = h->d_xref; d.dref = h->d_dref; d.output = h->d_out; d.buff = h->d_buff; d.xopt = h->d_xopt;
+    d.ws = h->d_ws; d.st = h->d_st; d.sweeps = h->d_sweeps; d.status = h->d_status;
+    d.n_relin = n_relin; d.reset = reset;
+    hipLaunchKernelGGL(ltv::get_cmd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d);
+    LTV_TRY(h, hipGetLastError());
+    LTV_TRY(h, hipStreamSynchronize(s)); // `hn` is reused by the next call
+    return ALORE_LTV_OK;
+}
+
+int alore_ltv_results(alore_ltv_handle h, int B, double* output, double* xopt, int* sweeps, int* status, void* stream)
+{
+    if (!h || B < 1 || B > h->B) return lfail(h, ALORE_LTV_E_INVALID, "results: bad argument");
+    LTV_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t T = h->cfg.predict_steps;
+    if (output) LTV_TRY(h, hipMemcpyAsync(output, h->d_out, sizeof(double) * B * T * 2, hipMemcpyDeviceToHost, s));
+    if (xopt) LTV_TRY(h, hipMemcpyAsync(xopt, h->d_xopt, sizeof(double) * B * (T + 1) * 3, hipMemcpyDeviceToHost, s));
+    if (sweeps) LTV_TRY(h, hipMemcpyAsync(sweeps, h->d_sweeps, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    if (status) LTV_TRY(h, hipMemcpyAsync(status, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    LTV_TRY(h, hipStreamSynchronize(s));
+    return ALORE_LTV_OK;
+}
+
+int alore_ltv_set_state(alore_ltv_handle h, int B, const double* output, const double* buff, void* stream)
+{
+    if (!h || B < 1 || B > h->B) return lfail(h, ALORE_LTV_E_INVALID, "set_state: bad argument");
+    LTV_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t T = h->cfg.predict_steps, dl = h->cfg.delay_num;
+    if (output) LTV_TRY(h, hipMemcpyAsync(h->d_out, output, sizeof(double) * B * T * 2, hipMemcpyHostToDevice, s));
+    if (buff && dl > 0) LTV_TRY(h, hipMemcpyAsync(h->d_buff, buff, sizeof(double) * B * dl * 2, hipMemcpyHostToDevice, s));
+    LTV_TRY(h, hipStreamSynchronize(s));
+    return ALORE_LTV_OK;
+}
+
+} // extern "C"

@@ -49,6 +49,11 @@ struct alore_nmpc_solver {
     unsigned shared = 0;          // see alore_nmpc_set_shared_members
     const float* lin_x = nullptr; // see alore_nmpc_set_linearization_point
     const float* lin_u = nullptr;
+    // pinned staging for alore_nmpc_batch_upload / _download from pageable host memory
+    char* stage_up = nullptr;
+    char* stage_down = nullptr;
+    size_t stage_up_cap = 0, stage_down_cap = 0;
+    hipEvent_t stage_up_done = nullptr; // the copies out of stage_up enqueued by the last upload
     // diagnostic phase stamps (env ALORE_NMPC_STAMPS=1): per-phase cycle shares, printed at destroy
     bool stamps = false;
     long long* d_stamps = nullptr;
@@ -210,6 +215,9 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->d_panels_be) (void)hipFree(h->d_panels_be);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stage_up_done) { (void)hipEventSynchronize(h->stage_up_done); (void)hipEventDestroy(h->stage_up_done); }
+    if (h->stage_up) (void)hipHostFree(h->stage_up);
+    if (h->stage_down) (void)hipHostFree(h->stage_down);
     delete h;
     return ALORE_NMPC_OK;
 }
@@ -247,24 +255,106 @@ int alore_nmpc_batch_free(alore_nmpc_handle h, alore_nmpc_batch* b)
     return ALORE_NMPC_OK;
 }
 
+// Host memory the runtime can DMA from directly (hipHostMalloc / hipHostRegister)?
+static bool host_is_pinned(const void* p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); // an unregistered pointer is reported as an error: not one of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+static int grow_stage(alore_nmpc_handle h, char*& buf, size_t& cap, size_t need)
+{
+    if (need <= cap) return ALORE_NMPC_OK;
+    if (buf) (void)hipHostFree(buf);
+    buf = nullptr; cap = 0;
+    hipError_t e = hipHostMalloc((void**)&buf, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(h, ALORE_NMPC_E_NOMEM, "hipHostMalloc (staging)", e);
+    cap = need;
+    return ALORE_NMPC_OK;
+}
+
+// Pageable host members go through one pinned staging buffer per direction (a hipMemcpyAsync from pageable memory
+// is staged by the runtime in 4 MB pieces with a host wait per piece: 2-3 x slower and never asynchronous);
+// members already in pinned memory (alore_nmpc_host_alloc) are copied in place.
 static int batch_copy(alore_nmpc_handle h, const alore_nmpc_batch* dev, const alore_nmpc_batch* host, int B,
                       void* stream, bool to_device)
 {
     if (!h || !dev || !host || B <= 0) return fail(h, ALORE_NMPC_E_INVALID, "batch copy: bad argument");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
+    size_t staged = 0;
+    bool pinned[kNumMembers];
+    for (int i = 0; i < kNumMembers; ++i) {
+        const Member& m = kMembers[i];
+        void* hp = member_ptr(host, m);
+        pinned[i] = false;
+        if (!member_ptr(dev, m) || !hp) continue;
+        pinned[i] = host_is_pinned(hp);
+        if (!pinned[i]) staged += (((size_t)B * m.per_problem(h->cfg.N) * 4) + 255) & ~(size_t)255;
+    }
+    char* stage = nullptr;
+    if (staged) {
+        if (to_device) {
+            if (h->stage_up_done) HIP_TRY(h, hipEventSynchronize(h->stage_up_done)); // the previous upload still reads it
+            if (int rc = grow_stage(h, h->stage_up, h->stage_up_cap, staged)) return rc;
+            stage = h->stage_up;
+        } else {
+            if (int rc = grow_stage(h, h->stage_down, h->stage_down_cap, staged)) return rc;
+            stage = h->stage_down;
+        }
+    }
+    size_t off = 0;
     for (int i = 0; i < kNumMembers; ++i) {
         const Member& m = kMembers[i];
         void* d = member_ptr(dev, m);
         void* hp = member_ptr(host, m);
         if (!d || !hp) continue;
         const size_t bytes = (size_t)B * m.per_problem(h->cfg.N) * 4;
+        void* src_dst = hp;
+        if (!pinned[i]) {
+            src_dst = stage + off;
+            off += (bytes + 255) & ~(size_t)255;
+            if (to_device) std::memcpy(src_dst, hp, bytes);
+        }
         if (to_device)
-            HIP_TRY(h, hipMemcpyAsync(d, hp, bytes, hipMemcpyHostToDevice, s));
+            HIP_TRY(h, hipMemcpyAsync(d, src_dst, bytes, hipMemcpyHostToDevice, s));
         else
-            HIP_TRY(h, hipMemcpyAsync(hp, d, bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipMemcpyAsync(src_dst, d, bytes, hipMemcpyDeviceToHost, s));
+    }
+    if (staged && to_device) {
+        if (!h->stage_up_done) HIP_TRY(h, hipEventCreateWithFlags(&h->stage_up_done, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->stage_up_done, s));
+    }
+    if (staged && !to_device) { // pageable destinations: complete the transfer, then hand the data over
+        HIP_TRY(h, hipStreamSynchronize(s));
+        off = 0;
+        for (int i = 0; i < kNumMembers; ++i) {
+            const Member& m = kMembers[i];
+            void* hp = member_ptr(host, m);
+            if (!member_ptr(dev, m) || !hp || pinned[i]) continue;
+            const size_t bytes = (size_t)B * m.per_problem(h->cfg.N) * 4;
+            std::memcpy(hp, stage + off, bytes);
+            off += (bytes + 255) & ~(size_t)255;
+        }
     }
     return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return ALORE_NMPC_E_INVALID;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? ALORE_NMPC_OK : ALORE_NMPC_E_NOMEM;
+}
+
+int alore_nmpc_host_free(void* p)
+{
+    if (!p) return ALORE_NMPC_OK;
+    return hipHostFree(p) == hipSuccess ? ALORE_NMPC_OK : ALORE_NMPC_E_HIP;
 }
 
 int alore_nmpc_batch_upload(alore_nmpc_handle h, const alore_nmpc_batch* dev, const alore_nmpc_batch* host, int B,
@@ -720,6 +810,17 @@ int alore_nmpc_set_linearization_point(alore_nmpc_handle h, const float* x_lin, 
     h->lin_x = x_lin;
     h->lin_u = u_lin;
     return ALORE_NMPC_OK;
+}
+
+// internal (not in the public header): the trajectory store of a handle, for the LTV-MPC reference sampler (ltv_mpc.hip)
+int alore_nmpc_internal_refstore(void* nmpc_handle, nmpc::RefStore* out, int* capacity, int* device)
+{
+    alore_nmpc_handle h = static_cast<alore_nmpc_handle>(nmpc_handle);
+    if (!h || !h->refs.dur || !out) return -1;
+    *out = h->refs;
+    if (capacity) *capacity = h->refs_B;
+    if (device) *device = h->cfg.device;
+    return 0;
 }
 
 int alore_nmpc_set_timing(alore_nmpc_handle h, int enable)

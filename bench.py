@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = auto)")
     ap.add_argument("--warm-start-steps", type=int, default=-1, help="working-set prediction steps (-1 = library default)")
-    ap.add_argument("--gather", choices=("last", "full", "none"), default="last",
+    ap.add_argument("--gather", choices=("last", "full", "none", "both"), default="both",
                     help="multi-GPU: all-gather the trajectories of the last timed step inside the timed region (default), "
                          "of every step in overlapped buckets (full: eager launches), or keep results sharded (none)")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per all-gather bucket")
@@ -168,75 +168,88 @@ def main():
     batch = make_batch(B, N, offset=rank * B)
     eng = BatchedNmpc(B, N, device=local_rank, lanes_per_problem=a.lanes, slots=slots,
                       warm_start_steps=a.warm_start_steps)
-    eng.load(batch, slot=None)
-    torch.cuda.synchronize(dev)
-
-    do_gather = world > 1 and a.gather == "full"      # every step, bucketed, overlapped with the next solves
-    gather_last = world > 1 and a.gather == "last"    # one all-gather of the final trajectories
-    gatherer = ResultGatherer(dist, world) if (do_gather or gather_last) else None
+    gatherer = ResultGatherer(dist, world) if (world > 1 and a.gather != "none") else None
     ge = max(1, a.gather_every)
-
-    def run_steps(first, count):
-        for i in range(first, first + count):
-            eng.rti(1, slot=i)
-            if do_gather and ((i - first + 1) % ge == 0 or i == first + count - 1):
-                lo = first + ((i - first) // ge) * ge
-                gatherer.submit({"x": eng.ts["x"][lo:i + 1], "u": eng.ts["u"][lo:i + 1],
-                                 "status": eng.ts["status"][lo:i + 1], "kkt": eng.ts["kkt"][lo:i + 1]})
-        if do_gather:
-            gatherer.wait()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # warm-up (untimed)
-    run_steps(0, a.warmup)
-    barrier()
+    def timed_pass(mode):
+        """W untimed + K timed steps with the result exchange `mode`:
+        full -- the trajectories (x, u, status, kkt) of EVERY timed batch are all-gathered to every rank, in buckets
+                of `--gather-every` steps issued asynchronously and all completed inside the timed region (eager
+                launches: collectives sit between the solves);
+        last -- only the last batch's trajectories are exchanged (the K launches replay as one hipGraph);
+        none -- results stay sharded."""
+        do_gather = world > 1 and mode == "full"
+        gather_last = world > 1 and mode == "last"
 
-    # the K timed steps, captured once into a hipGraph (K kernel nodes, no host launch overhead inside the timed
-    # region)
-    graph = None
-    used_graph = False
-    # (also on multi-rank runs: no collective is enqueued during the capture, the capture is thread-local so the
-    #  RCCL watchdog thread cannot invalidate it, and any capture failure falls back to eager launches, which are
-    #  measured equal on an idle host: 25.5 us per step either way)
-    if not a.no_graph and not do_gather and a.steps > 0:
-        try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                g = torch.cuda.CUDAGraph()
-                # thread_local: the RCCL watchdog thread of a multi-rank run must not invalidate the capture
-                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    run_steps(a.warmup, a.steps)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            graph = g
-            used_graph = True
-        except Exception as e:  # fall back to eager launches
-            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize(dev)
+        def run_steps(first, count):
+            for i in range(first, first + count):
+                eng.rti(1, slot=i)
+                if do_gather and ((i - first + 1) % ge == 0 or i == first + count - 1):
+                    lo = first + ((i - first) // ge) * ge
+                    gatherer.submit({"x": eng.ts["x"][lo:i + 1], "u": eng.ts["u"][lo:i + 1],
+                                     "status": eng.ts["status"][lo:i + 1], "kkt": eng.ts["kkt"][lo:i + 1]})
+            if do_gather:
+                gatherer.wait()
 
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        run_steps(a.warmup, a.steps)
-    ev1.record()
-    if gather_last:  # the converged trajectories of the last batch on every rank (x, u, status, kkt)
-        last = a.warmup + a.steps - 1
-        gatherer.submit({k: eng.ts[k][last] for k in ("x", "u", "status", "kkt")})
-        gatherer.wait()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    dev_ms = ev0.elapsed_time(ev1)
+        eng.load(batch, slot=None)  # every pass starts from the same cold-start iterates in every slot
+        torch.cuda.synchronize(dev)
+        run_steps(0, a.warmup)
+        barrier()
+        # the K timed steps captured once into a hipGraph (K kernel nodes, no host launch overhead inside the timed
+        # region); not with collectives between the solves.  Capture is thread-local so that the RCCL watchdog thread
+        # of a multi-rank run cannot invalidate it; any capture failure falls back to eager launches.
+        graph = None
+        if not a.no_graph and not do_gather and a.steps > 0:
+            try:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        run_steps(a.warmup, a.steps)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                graph = g
+            except Exception as e:
+                print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize(dev)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            run_steps(a.warmup, a.steps)
+        ev1.record()
+        if gather_last:  # the converged trajectories of the last batch on every rank (x, u, status, kkt)
+            last = a.warmup + a.steps - 1
+            gatherer.submit({k: eng.ts[k][last] for k in ("x", "u", "status", "kkt")})
+            gatherer.wait()
+        barrier()
+        t1 = time.perf_counter()
+        el, dms = t1 - t0, ev0.elapsed_time(ev1)
+        if world > 1:
+            tt = torch.tensor([el, dms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el, dms = float(tt[0].item()), float(tt[1].item())
+        return el, dms, graph is not None
+
+    # primary figure: multi-rank runs gather EVERY batch ("both" adds the last-batch-only figure beside it)
+    primary = "none" if world == 1 else ("full" if a.gather in ("full", "both") else a.gather)
+    elapsed, dev_ms, used_graph = timed_pass(primary)
+    do_gather, gather_last = primary == "full", primary == "last"
+    alt = None
+    if world > 1 and a.gather == "both":
+        el2, dms2, g2 = timed_pass("last")
+        alt = {"gather": "last batch only", "value": float(B) * world * a.steps / el2, "ms_per_step": el2 / a.steps * 1e3,
+               "kernel_ms_avg": dms2 / a.steps, "hip_graph": g2}
 
     # every timed step must have solved every problem
     st = eng.ts["status"][a.warmup:a.warmup + a.steps]
@@ -244,9 +257,6 @@ def main():
     n_iter_mean = float(eng.ts["n_iter"][a.warmup:a.warmup + a.steps].float().mean().item())
 
     if world > 1:
-        tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(tt[0].item()), float(tt[1].item())
         nb = torch.tensor([n_bad], dtype=torch.int64, device=dev)
         dist.all_reduce(nb)
         n_bad = int(nb.item())
@@ -257,7 +267,9 @@ def main():
         total_solves = float(B) * world * a.steps
         value = total_solves / elapsed
         ms_per_step = elapsed / a.steps * 1e3
-        kern_ms = dev_ms / a.steps  # average launch duration of the dominant kernel (HIP events, launch stream)
+        # average launch duration of the dominant kernel: HIP events on the launch stream around the K back-to-back
+        # launches (multi-rank: of the pass without collectives between the launches)
+        kern_ms = (alt["kernel_ms_avg"] if alt is not None else dev_ms / a.steps)
         bytes_per_launch = algorithmic_bytes_per_solve(N) * B
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         traffic = None
@@ -288,11 +300,14 @@ def main():
                          "fp32_frac": value / world * flops_per_solve / (FP32_PEAK_TFLOPS * 1e12)},
             "unsolved_problems": n_bad, "working_set_iters_mean": n_iter_mean,
         }
+        if alt is not None:
+            result["gather_last"] = alt
 
     # ---- extras on rank 0 of a single-GPU run: latency, converged solves, large batch, CPU baseline
     if rank == 0 and world == 1 and not a.no_extras:
         extras = {}
-        # p50/p99 of one synchronous launch (what a caller of the C ABI sees), B = 4096 and small batches
+        # p50/p99 of one synchronous launch (what a caller of the C ABI sees): 1000 launches after 50 discarded,
+        # B = 4096 and small batches
         lat = {}
         for b_lat in (B, 64, 1):
             hb = batch if b_lat == B else make_batch(b_lat, N)
@@ -301,7 +316,7 @@ def main():
                 e2.load(hb, slot=None)
             xs0, us0, ds0 = (torch.from_numpy(hb[k]).to(dev) for k in ("x", "u", "dual"))
             ts = []
-            for i in range(350):
+            for i in range(1050):
                 e2.ts["x"][0].copy_(xs0); e2.ts["u"][0].copy_(us0); e2.ts["dual"][0].copy_(ds0)
                 torch.cuda.synchronize(dev)
                 t_a = time.perf_counter()
@@ -309,20 +324,33 @@ def main():
                 torch.cuda.synchronize(dev)
                 ts.append(time.perf_counter() - t_a)
             ts = np.array(ts[50:]) * 1e3
-            lat[f"B{b_lat}"] = {"p50_ms": float(np.percentile(ts, 50)), "p99_ms": float(np.percentile(ts, 99))}
-        extras["launch_latency"] = lat
-        # converged solve: K = 15 real-time iterations inside one launch
-        e3 = BatchedNmpc(B, N, device=local_rank, slots=12)
+            lat[f"B{b_lat}"] = {"launches": int(ts.size), "p50_ms": float(np.percentile(ts, 50)), "p99_ms": float(np.percentile(ts, 99)),
+                                "max_ms": float(ts.max())}
+        result["latency"] = {"what": "one synchronous alore_nmpc_rti launch (enqueue + kernel + stream sync), host clock", **lat}
+        # converged solve: K = 15 real-time iterations inside one launch (MpcWrapper::solve + 14 update() calls of the
+        # reference collapsed into one kernel: the I/O contract is read and written once, the arithmetic 15 times)
+        e3 = BatchedNmpc(B, N, device=local_rank, slots=52)
         e3.load(batch, slot=None)
         e3.rti(15, slot=0); e3.rti(15, slot=1)
         torch.cuda.synchronize(dev)
         c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
         c0.record()
-        for i in range(2, 12):
+        for i in range(2, 52):
             e3.rti(15, slot=i)
         c1.record(); torch.cuda.synchronize(dev)
-        ms15 = c0.elapsed_time(c1) / 10
+        ms15 = c0.elapsed_time(c1) / 50
+        it15 = float(e3.ts["n_iter"][2:52].float().mean().item())
+        gb15 = algorithmic_bytes_per_solve(N) * B / (ms15 * 1e-3) / 1e9
+        fl15 = 15 * 350.0 * N + it15 * 160.0 * N
         extras["converged_solve_k15"] = {"ms_per_launch": ms15, "solves_per_s": B / (ms15 * 1e-3)}
+        result["roofline_converged_k15"] = {
+            "bound": "hbm", "achieved": gb15, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb15 / HBM_PEAK_GBS,
+            "traffic": None, "kernel": "nmpc::rti_kernel (n_sqp = 15)", "kernel_ms_avg": ms15, "launches": 50,
+            "algorithmic_bytes_per_solve": algorithmic_bytes_per_solve(N),
+            "working_set_iters_total_mean": it15,
+            "fp32_frac": B / (ms15 * 1e-3) * fl15 / (FP32_PEAK_TFLOPS * 1e12),
+            "unsolved": int((e3.ts["status"][2:52] != 0).sum().item()),
+            "note": "same I/O bytes as one real-time iteration, 15 x the arithmetic: latency/issue bound, not HBM bound"}
         del e3
         # large batch (BASELINE configs[3] per-GPU share: 262144 / 8)
         Bl = 32768

@@ -28,6 +28,8 @@
 #ifndef ALORE_NMPC_H
 #define ALORE_NMPC_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -103,11 +105,18 @@ int alore_nmpc_destroy(alore_nmpc_handle h);
 const char *alore_nmpc_last_error(alore_nmpc_handle h); /* text of the last failure (never NULL) */
 const char *alore_nmpc_version(void);
 
+/* pinned host memory for the members of a host-side alore_nmpc_batch (no staging copy, fully asynchronous) */
+int alore_nmpc_host_alloc(size_t bytes, void **out);
+int alore_nmpc_host_free(void *p);
+
 /* ---- device batch storage (convenience; callers may bring their own) ---- */
 int alore_nmpc_batch_alloc(alore_nmpc_handle h, int B, alore_nmpc_batch *out); /* hipMalloc every member */
 int alore_nmpc_batch_free(alore_nmpc_handle h, alore_nmpc_batch *b);
 /* host <-> device copies of whole members, `host` holds HOST pointers laid out
- * like the device batch; NULL members are skipped.  Asynchronous on `stream`. */
+ * like the device batch; NULL members are skipped.  Members in pinned host memory (alore_nmpc_host_alloc,
+ * hipHostMalloc, hipHostRegister) are copied in place, asynchronously on `stream`.  Pageable members go through a
+ * pinned staging buffer owned by the handle: an upload returns once the data is staged (the DMA is asynchronous on
+ * `stream`); a download completes -- synchronises `stream` -- before it returns. */
 int alore_nmpc_batch_upload(alore_nmpc_handle h, const alore_nmpc_batch *dev, const alore_nmpc_batch *host,
                             int B, void *stream);
 int alore_nmpc_batch_download(alore_nmpc_handle h, const alore_nmpc_batch *dev, const alore_nmpc_batch *host,

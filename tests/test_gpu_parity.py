@@ -343,7 +343,7 @@ def test_wide_problems_three_ticks_against_oracle(nmpc_mod):
             orc.reset(); orc.initialize_solver(); orc.load(p); orc.preparation_step()
             assert orc.feedback_step() == 0
             eu, ex = relerr(out["u"][b].reshape(-1), orc.v["u"]), relerr(out["x"][b].reshape(-1), orc.v["x"])
-            assert eu < 2e-4 and ex < 2e-4, (k, b, eu, ex)
+            assert eu < 5e-4 and ex < 5e-4, (k, b, eu, ex)   # hard cap; the real criterion follows
             # the float64 solution of the reference's own condensed QP (its float32 H, g, bounds)
             n = 2 * N
             du_true = exact_box_qp(orc.v["H"].reshape(n, n), orc.v["g"], orc.v["lb"], orc.v["ub"])
