@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -198,6 +199,35 @@ int acado_integrate(real_t* const eta, int)
     for (int i = 0; i < 9; ++i) eta[3 + i] = gx[i];
     for (int i = 0; i < 6; ++i) eta[12 + i] = gu[i];
     return 0;
+}
+
+// The ICR differential-drive model (host; the kernels carry their own copy in nmpc_kernels.hip):
+//   v = (u_r yl - u_l yr) / (yl - yr),  w = (u_r - u_l) / (yl - yr),
+//   xdot = v cos(th) + xv w sin(th),  ydot = v sin(th) - xv w cos(th),  thdot = w
+void acado_rhs(const real_t* in, real_t* out)
+{
+    const real_t th = in[2], ur = in[3], ul = in[4], xv = in[5], yr = in[6], yl = in[7];
+    const real_t span = yl - yr, c = (real_t)std::cos((double)th), s = (real_t)std::sin((double)th); // double libm, as the generated C
+    const real_t v = (ur * yl - ul * yr) / span, lat = ((ur - ul) * xv) / span;
+    out[0] = v * c + lat * s;
+    out[1] = v * s - lat * c;
+    out[2] = (ur - ul) / span;
+}
+
+void acado_diffs(const real_t* in, real_t* out)
+{
+    const real_t th = in[2], ur = in[3], ul = in[4], xv = in[5], yr = in[6], yl = in[7];
+    const real_t span = yl - yr, inv = real_t(1) / span, c = (real_t)std::cos((double)th), s = (real_t)std::sin((double)th);
+    const real_t v = (ur * yl - ul * yr) / span, lat = ((ur - ul) * xv) / span;
+    for (int i = 0; i < 15; ++i) out[i] = real_t(0);
+    out[2] = v * -s + lat * c;                       // d xdot / d theta
+    out[3] = (yl * inv) * c + (xv * inv) * s;        // d xdot / d u_r
+    out[4] = (-yr * inv) * c + (-xv * inv) * s;      // d xdot / d u_l
+    out[7] = v * c - lat * -s;                       // d ydot / d theta
+    out[8] = (yl * inv) * s - (xv * inv) * c;
+    out[9] = (-yr * inv) * s - (-xv * inv) * c;
+    out[13] = inv;
+    out[14] = -inv;
 }
 
 int acado_solve(void) { return 29; } // the dense condensed QP is never formed (RET_INIT_FAILED)

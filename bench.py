@@ -347,7 +347,7 @@ def main():
             "bound": "hbm", "achieved": gb15, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb15 / HBM_PEAK_GBS,
             "traffic": None, "kernel": "nmpc::rti_kernel (n_sqp = 15)", "kernel_ms_avg": ms15, "launches": 50,
             "algorithmic_bytes_per_solve": algorithmic_bytes_per_solve(N),
-            "working_set_iters_total_mean": it15,
+            "working_set_iters_last_iteration_mean": it15,
             "fp32_frac": B / (ms15 * 1e-3) * fl15 / (FP32_PEAK_TFLOPS * 1e12),
             "unsolved": int((e3.ts["status"][2:52] != 0).sum().item()),
             "note": "same I/O bytes as one real-time iteration, 15 x the arithmetic: latency/issue bound, not HBM bound"}
@@ -395,36 +395,99 @@ def main():
         except Exception as e:  # pragma: no cover
             extras["warm_tick"] = {"error": str(e)}
         # the whole control tick of the reference node for B robots (host controller -> C ABI -> kernels ->
-        # wheel-speed commands; mpc.cpp CmdCallback): reference sampling on the host (as the reference does)
-        # against reference sampling on the device
+        # wheel-speed commands; mpc.cpp CmdCallback); trajectories live in the device store, references are
+        # sampled there
         try:
             from alore_legged_manipulator_amd.host import BatchedMpcController, Polynome
-            ticks = {}
             rng = np.random.default_rng(7)
             vw = rng.uniform([0.5, -1.0], [1.8, 1.0], (B, 2))
-            for mode in ("host_refs", "device_refs"):
-                ctl = BatchedMpcController(B, N, 0.01, device=local_rank)
-                if mode == "device_refs":
-                    ctl.use_device_references(max_pieces=8, max_checkpoints=64, build_on_device=True)
-                for b in range(B):
-                    v, w = vw[b]
-                    T = np.array([0.5, 0.5, 0.5, 0.5]); Tc = np.cumsum(T)
-                    ctl.robots[b].traj(Polynome(np.stack([w * Tc[:-1], v * Tc[:-1]], 1), T, [0, 0, w, v, 0, 0],
-                                                [w * Tc[-1], v * Tc[-1], w, v, 0, 0], [0, 0, 0], [-0.3, 0.3, 0.1], 0.0))
-                    ctl.robots[b].odom(0.01, -0.01, 0.02)
-                    ctl.robots[b].icr(-0.3, 0.3, 0.1)
-                ctl.tick(0.05); ctl.tick(0.06)
-                t_a = time.perf_counter()
-                nt = 30
-                for i in range(nt):
-                    ctl.tick(0.07 + 0.01 * i)
-                t_b = time.perf_counter()
-                ticks[mode] = {"ms_per_tick": (t_b - t_a) / nt * 1e3, "robot_ticks_per_s": B * nt / (t_b - t_a)}
-                del ctl
-            ticks["robots"] = B
-            extras["controller_tick"] = ticks
+            ctl = BatchedMpcController(B, N, 0.01, device=local_rank, max_pieces=8, max_checkpoints=64)
+            t_a = time.perf_counter()
+            for b in range(B):
+                v, w = vw[b]
+                T = np.array([0.5, 0.5, 0.5, 0.5]); Tc = np.cumsum(T)
+                ctl.robots[b].traj(Polynome(np.stack([w * Tc[:-1], v * Tc[:-1]], 1), T, [0, 0, w, v, 0, 0],
+                                            [w * Tc[-1], v * Tc[-1], w, v, 0, 0], [0, 0, 0], [-0.3, 0.3, 0.1], 0.0))
+                ctl.robots[b].odom(0.01, -0.01, 0.02)
+                ctl.robots[b].icr(-0.3, 0.3, 0.1)
+            ctl.tick(0.05)
+            t_first = time.perf_counter() - t_a   # includes the B trajectory messages -> device store
+            ctl.tick(0.06)
+            t_a = time.perf_counter()
+            nt = 30
+            for i in range(nt):
+                ctl.tick(0.07 + 0.01 * i)
+            t_b = time.perf_counter()
+            extras["controller_tick"] = {"robots": B, "ms_per_tick": (t_b - t_a) / nt * 1e3,
+                                         "robot_ticks_per_s": B * nt / (t_b - t_a),
+                                         "first_tick_with_trajectory_messages_ms": t_first * 1e3}
+            del ctl
         except Exception as e:  # pragma: no cover
             extras["controller_tick"] = {"error": f"{type(e).__name__}: {e}"}
+        # back_end: B_be Monte-Carlo goals planned in one launch (MSPlanner::minco_plan per problem), then handed to
+        # the NMPC store device-to-device and tracked for 100 closed-loop ticks (BASELINE configs[4], one GPU's share)
+        try:
+            from alore_legged_manipulator_amd.backend import BatchedMSPlanner
+            from alore_legged_manipulator_amd.flat_traj import monte_carlo_goals
+            Bb = 2048
+            fts = monte_carlo_goals(Bb, seed=44)
+            pl = BatchedMSPlanner(Bb, 16, device=local_rank)
+            pl.set_free_map(half=20.0)
+            pl.set_problems(fts)
+            pl.plan(); torch.cuda.synchronize(dev)
+            t_a = time.perf_counter()
+            pl.plan()
+            res = pl.results()
+            t_b = time.perf_counter()
+            be = {"problems": Bb, "ms_per_launch_device": pl.last_plan_ms(), "ms_wall_incl_results": (t_b - t_a) * 1e3,
+                  "plans_per_s": Bb / (pl.last_plan_ms() * 1e-3), "ok": int(res["ok"].sum()),
+                  "cost_evaluations_mean": float(res["evals"].mean()), "pieces_mean": float(res["n_pieces"].mean())}
+            e10 = BatchedNmpc(Bb, N, device=local_rank, diagnostics=False)
+            e10.load({k: batch[k][:Bb] for k in ("W", "WN", "lbValues", "ubValues")})
+            e10.refs_init(max_pieces=16, max_checkpoints=128)
+            t_a = time.perf_counter()
+            e10.refs_set_from_backend(pl)
+            torch.cuda.synchronize(dev)
+            be["handover_to_nmpc_store_ms"] = (time.perf_counter() - t_a) * 1e3
+            icr = np.array([[(0.0, -0.3, 0.3), (0.2, -0.3, 0.3), (0.1, -0.25, 0.25), (0.3, -0.35, 0.35)][b % 4] for b in range(Bb)])
+            e10.plant_init()
+            e10.plant_set_state(np.array([ft.start_xytheta for ft in fts]), icr)
+            e10.closed_loop_reset()
+            e10.closed_loop_tick(0.05)
+            torch.cuda.synchronize(dev)
+            t_a = time.perf_counter()
+            e10.closed_loop_run(0.06, 0.01, 100)
+            torch.cuda.synchronize(dev)
+            be["closed_loop_100_ticks_ms"] = (time.perf_counter() - t_a) * 1e3
+            be["unsolved_last_tick"] = int((e10.t["status"] != 0).sum().item())
+            extras["backend_to_nmpc_pipeline"] = be
+            del e10, pl
+        except Exception as e:  # pragma: no cover
+            extras["backend_to_nmpc_pipeline"] = {"error": f"{type(e).__name__}: {e}"}
+        # LTV-MPC class (the `mpc` node): getCmd for B robots, 5 relinearisation passes, cold and warm working sets
+        try:
+            from alore_legged_manipulator_amd.ltv_mpc import BatchedLtvMpc
+            rng = np.random.default_rng(11)
+            lt = BatchedLtvMpc(B, device=local_rank)
+            T = lt.cfg.predict_steps
+            vv, ww = rng.uniform(0.5, 2.5, B), rng.uniform(-1.5, 1.5, B)
+            ts_ = (np.arange(T) + 1) * lt.cfg.dt
+            xr = np.stack([vv[:, None] / ww[:, None] * np.sin(ww[:, None] * ts_), vv[:, None] / ww[:, None] * (1 - np.cos(ww[:, None] * ts_)),
+                           ww[:, None] * ts_], 2)
+            dr = np.stack([np.repeat(vv[:, None], T, 1), np.repeat(ww[:, None], T, 1)], 2)
+            st0 = rng.uniform(-0.1, 0.1, (B, 3))
+            lt.set_refs(xr, dr)
+            t_a = time.perf_counter(); g0 = lt.get_cmd(st0, n_relin=5, reset=True); t_cold = time.perf_counter() - t_a
+            t_a = time.perf_counter()
+            for i in range(10):
+                g1 = lt.get_cmd(st0, n_relin=5)
+            t_warm = (time.perf_counter() - t_a) / 10
+            extras["ltv_mpc"] = {"robots": B, "relinearisations": 5, "cold_ms": t_cold * 1e3, "warm_ms": t_warm * 1e3,
+                                 "robot_ticks_per_s_warm": B / t_warm, "sweeps_last_qp_cold_mean": float(g0["sweeps"].mean()),
+                                 "sweeps_last_qp_warm_mean": float(g1["sweeps"].mean()), "unsettled": int((g1["status"] != 0).sum())}
+            del lt
+        except Exception as e:  # pragma: no cover
+            extras["ltv_mpc"] = {"error": f"{type(e).__name__}: {e}"}
         # Monte-Carlo closed-loop rollout with no host in the loop: per tick, references from the plant's pose ->
         # one real-time iteration -> command into the simulator plant (alore_nmpc_closed_loop_tick)
         try:

@@ -11,7 +11,7 @@
  *
  * Served from the GPU: acado_initializeSolver, acado_initializeNodesByForwardSimulation,
  * acado_preparationStep, acado_feedbackStep, acado_shiftStates, acado_shiftControls, acado_getKKT,
- * acado_getObjective, acado_getNWSR, acado_integrate, acado_getErrorString.
+ * acado_getObjective, acado_getNWSR, acado_integrate, acado_rhs, acado_diffs, acado_getErrorString.
  * Workspace members kept up to date: d, evGx, evGu (preparation), Dx0, lb, ub, x (= delta u), y (= dual).
  * The dense condensed QP (H, g, E, ...) is never formed, so acado_solve() reports RET_INIT_FAILED.
  */
@@ -93,6 +93,10 @@ real_t acado_getKKT(void);                              /* :1373 */
 real_t acado_getObjective(void);                        /* :1393 */
 int acado_integrate(real_t *const rk_eta, int resetIntegrator); /* acado_integrator.c:261 */
 int acado_solve(void);                                  /* acado_qpoases_interface.cpp:39 */
+/* The model's symbolic functions (host, pure): in = [x y theta | u_r u_l | xv yr yl];
+ * acado_rhs -> out[3] = (xdot, ydot, thetadot); acado_diffs -> out[15] = d rhs / d (x, y, theta, u_r, u_l), row major. */
+void acado_rhs(const real_t *in, real_t *out);          /* acado_integrator.c:62 */
+void acado_diffs(const real_t *in, real_t *out);        /* acado_integrator.c:84 */
 int acado_getNWSR(void);                                /* :62 */
 const char *acado_getErrorString(int error);            /* :67 */
 

@@ -96,3 +96,36 @@ def test_struct_layouts_match_the_header():
     cfg = re.sub(r"/\*.*?\*/", "", cfg, flags=re.S)
     cfg_members = re.findall(r"(?:int|float)\s+([A-Za-z0-9_]+)\s*;", cfg)
     assert cfg_members == [n for n, _ in _lib.Config._fields_]
+
+
+def test_compat_library_exports_the_model_functions():
+    """acado_rhs / acado_diffs of libalore_acado_compat.so (host, no GPU needed) against the oracle's restatement
+    and, where it was built, the compiled reference: bit-exact."""
+    import numpy as np
+    pkg = os.path.join(ROOT, "alore_legged_manipulator_amd")
+    import subprocess, tempfile
+    C.CDLL(os.path.join(pkg, "libalore_nmpc.so"), mode=C.RTLD_GLOBAL)
+    # the two process-global structs are the CALLER's (mpc_wrapper.cpp:27-28 defines them in the reference)
+    tmp = tempfile.mkdtemp()
+    open(os.path.join(tmp, "g.c"), "w").write('#include "alore_acado_compat.h"\nACADOvariables acadoVariables;\nACADOworkspace acadoWorkspace;\n')
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), os.path.join(tmp, "g.c"), "-o", os.path.join(tmp, "libg.so")])
+    C.CDLL(os.path.join(tmp, "libg.so"), mode=C.RTLD_GLOBAL)
+    S = C.CDLL(os.path.join(pkg, "libalore_acado_compat.so"))
+    O = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_nmpc.so"))
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libacado_ref.so")
+    R = C.CDLL(ref_so) if os.path.exists(ref_so) else None
+    FP = C.POINTER(C.c_float)
+    rng = np.random.default_rng(12)
+    for _ in range(200):
+        xin = np.concatenate([rng.uniform(-5, 5, 2), rng.uniform(-7, 7, 1), rng.uniform(-20, 20, 2),
+                              [rng.uniform(-0.3, 0.3), rng.uniform(-0.5, -0.1), rng.uniform(0.1, 0.5)]]).astype(np.float32)
+        outs = []
+        for lib, names in ((S, ("acado_rhs", "acado_diffs")), (O, ("orc_rhs", "orc_diffs")), (R, ("acado_rhs", "acado_diffs"))):
+            if lib is None:
+                continue
+            r, d = np.zeros(3, np.float32), np.zeros(15, np.float32)
+            getattr(lib, names[0])(xin.ctypes.data_as(FP), r.ctypes.data_as(FP))
+            getattr(lib, names[1])(xin.ctypes.data_as(FP), d.ctypes.data_as(FP))
+            outs.append(np.concatenate([r, d]))
+        for o in outs[1:]:
+            assert np.array_equal(outs[0], o)
