@@ -1,0 +1,303 @@
+"""oracle/wb_oracle.py -- TEST INFRASTRUCTURE ONLY (float64 NumPy restatement; never imported by the product).
+
+Whole-body class (SURVEY.md 8(a) row A-RB, BASELINE configs[2]): B2 + Z1, floating base + 18 revolute joints.
+THE REFERENCE HAS NO IMPLEMENTATION OF THIS CLASS (no RNEA / ABA / CRBA, no whole-body OCP; Pinocchio is not installed
+here either): PARITY UNPINNED.  The only reference artefact is the URDF, turned into numbers by
+tools/gen_b2z1_model.py.  This oracle is written in 6-D spatial algebra (Featherstone, "Rigid Body Dynamics
+Algorithms", 2008: RNEA table 5.1, CRBA table 6.2, ABA table 7.1 with a floating base as in section 9.4) -- a
+different formulation from the kernels (3-D Newton-Euler vectors, mass matrix from unit accelerations, Cholesky) --
+and is pinned by the physics identities of SURVEY.md 8(c) (tests/test_wb_oracle.py): gravity torques against the
+gradient of the potential energy, CRBA against RNEA columns, symmetry / positive definiteness, ABA o RNEA = identity,
+energy and momentum conservation of passive rollouts.
+
+Conventions (shared with include/alore_wb.h):
+  configuration  q = [p (3, world) | rpy (3, ZYX: R = Rz(yaw) Ry(pitch) Rx(roll)) | joint angles (18)]
+  velocity       v = [omega (3, base frame) | v_lin (3, velocity of the base origin, base frame) | joint rates (18)]
+  acceleration   a = d/dt of the components of v (= spatial acceleration of the base in base coordinates)
+  inputs         tau (18 joint torques), f (4 x 3 foot forces, WORLD frame, applied at the foot points)
+  spatial vectors are [angular; linear]."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODEL_JSON = os.path.join(ROOT, "alore_legged_manipulator_amd", "data", "b2z1_model.json")
+
+
+def skew(a):
+    return np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0.0]])
+
+
+def rot_axis(axis, q):
+    """rotation about coordinate axis `axis` by q: maps child-frame coordinates to parent-frame coordinates"""
+    c, s = np.cos(q), np.sin(q)
+    if axis == 0:
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    if axis == 1:
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+def rpy_matrix(rpy):
+    return rot_axis(2, rpy[2]) @ rot_axis(1, rpy[1]) @ rot_axis(0, rpy[0])
+
+
+def rpy_rates(rpy):
+    """E with d(rpy)/dt = E omega_body"""
+    r, p = rpy[0], rpy[1]
+    sr, cr, cp, tp = np.sin(r), np.cos(r), np.cos(p), np.tan(p)
+    return np.array([[1, sr * tp, cr * tp], [0, cr, -sr], [0, sr / cp, cr / cp]])
+
+
+def crm(v):
+    """spatial cross product matrix for motion vectors"""
+    w, l = skew(v[:3]), skew(v[3:])
+    return np.block([[w, np.zeros((3, 3))], [l, w]])
+
+
+def crf(v):
+    return -crm(v).T
+
+
+def plucker(E, r):
+    """motion transform: coordinates in frame A -> frame B, where B's origin is at r (A coordinates) and E = R_B^T R_A"""
+    return np.block([[E, np.zeros((3, 3))], [-E @ skew(r), E]])
+
+
+class Model:
+    def __init__(self, path=MODEL_JSON):
+        m = json.load(open(path))
+        self.raw = m
+        self.g = m["gravity"]
+        b = m["bodies"]
+        self.nb = len(b)
+        self.nj = self.nb - 1
+        self.nv = 6 + self.nj
+        self.parent = [x["parent"] for x in b]
+        self.axis = [x["axis"] for x in b]
+        self.origin = [np.array(x["origin"], float) for x in b]
+        self.mass = np.array([x["mass"] for x in b])
+        self.com = [np.array(x["com"], float) for x in b]
+        self.Ic = []
+        self.I = []  # 6 x 6 spatial inertias about the body origins
+        for x in b:
+            i = x["inertia"]
+            Ic = np.array([[i[0], i[1], i[2]], [i[1], i[3], i[4]], [i[2], i[4], i[5]]])
+            c, mm = np.array(x["com"], float), x["mass"]
+            cx = skew(c)
+            self.Ic.append(Ic)
+            self.I.append(np.block([[Ic + mm * cx @ cx.T, mm * cx], [mm * cx.T, mm * np.eye(3)]]))
+        self.lower = np.array([x["lower"] for x in b[1:]])
+        self.upper = np.array([x["upper"] for x in b[1:]])
+        self.effort = np.array([x["effort"] for x in b[1:]])
+        self.foot_body = [f["body"] for f in m["feet"]]
+        self.foot_point = [np.array(f["point"], float) for f in m["feet"]]
+        self.total_mass = m["total_mass"]
+
+    def S(self, i):
+        s = np.zeros(6)
+        s[self.axis[i]] = 1.0
+        return s
+
+    # ---- kinematics ----------------------------------------------------------------------------------------------
+    def transforms(self, q):
+        """X[i]: parent -> body i motion transform; Rw[i]: body i -> world rotation; pw[i]: body origins in the world"""
+        X, Rw, pw = [None] * self.nb, [None] * self.nb, [None] * self.nb
+        Rw[0] = rpy_matrix(q[3:6])
+        pw[0] = np.array(q[:3], float)
+        for i in range(1, self.nb):
+            R = rot_axis(self.axis[i], q[5 + i])
+            X[i] = plucker(R.T, self.origin[i])
+            p = self.parent[i]
+            Rw[i] = Rw[p] @ R
+            pw[i] = pw[p] + Rw[p] @ self.origin[i]
+        return X, Rw, pw
+
+    def ext_forces(self, q, f_world, Rw=None):
+        """foot forces (4 x 3, world) -> spatial forces on the calf bodies, body coordinates"""
+        if Rw is None:
+            _, Rw, _ = self.transforms(q)
+        fx = [np.zeros(6) for _ in range(self.nb)]
+        if f_world is not None:
+            f_world = np.asarray(f_world, float).reshape(4, 3)
+            for k in range(4):
+                b = self.foot_body[k]
+                fb = Rw[b].T @ f_world[k]
+                fx[b] = fx[b] + np.concatenate([np.cross(self.foot_point[k], fb), fb])
+        return fx
+
+    def foot_positions(self, q):
+        _, Rw, pw = self.transforms(q)
+        return np.array([pw[self.foot_body[k]] + Rw[self.foot_body[k]] @ self.foot_point[k] for k in range(4)])
+
+    # ---- RNEA (Featherstone table 5.1, floating base: the base's 6 "joint forces" are its net spatial force) -----
+    def rnea(self, q, v, a, f_world=None, gravity=True):
+        X, Rw, _ = self.transforms(q)
+        fx = self.ext_forces(q, f_world, Rw)
+        vel, acc, f = [None] * self.nb, [None] * self.nb, [None] * self.nb
+        vel[0] = np.array(v[:6], float)
+        acc[0] = np.array(a[:6], float)
+        if gravity:
+            acc[0] = acc[0] + np.concatenate([np.zeros(3), Rw[0].T @ np.array([0, 0, self.g])])
+        f[0] = self.I[0] @ acc[0] + crf(vel[0]) @ (self.I[0] @ vel[0]) - fx[0]
+        for i in range(1, self.nb):
+            S = self.S(i)
+            vJ = S * v[5 + i]
+            vel[i] = X[i] @ vel[self.parent[i]] + vJ
+            acc[i] = X[i] @ acc[self.parent[i]] + S * a[5 + i] + crm(vel[i]) @ vJ
+            f[i] = self.I[i] @ acc[i] + crf(vel[i]) @ (self.I[i] @ vel[i]) - fx[i]
+        tau = np.zeros(self.nv)
+        for i in range(self.nb - 1, 0, -1):
+            tau[5 + i] = self.S(i) @ f[i]
+            f[self.parent[i]] = f[self.parent[i]] + X[i].T @ f[i]
+        tau[:6] = f[0]
+        return tau
+
+    # ---- CRBA (table 6.2 + floating base, section 9.4) ----------------------------------------------------------
+    def crba(self, q):
+        X, _, _ = self.transforms(q)
+        Ic = [I.copy() for I in self.I]
+        for i in range(self.nb - 1, 0, -1):
+            Ic[self.parent[i]] = Ic[self.parent[i]] + X[i].T @ Ic[i] @ X[i]
+        M = np.zeros((self.nv, self.nv))
+        M[:6, :6] = Ic[0]
+        for i in range(1, self.nb):
+            S = self.S(i)
+            F = Ic[i] @ S
+            M[5 + i, 5 + i] = S @ F
+            j = i
+            while self.parent[j] > 0:
+                F = X[j].T @ F
+                j = self.parent[j]
+                M[5 + i, 5 + j] = M[5 + j, 5 + i] = F @ self.S(j)
+            F = X[j].T @ F
+            M[:6, 5 + i] = F
+            M[5 + i, :6] = F
+        return M
+
+    # ---- ABA (table 7.1, floating base) -------------------------------------------------------------------------
+    def aba(self, q, v, tau, f_world=None, gravity=True):
+        X, Rw, _ = self.transforms(q)
+        fx = self.ext_forces(q, f_world, Rw)
+        nb = self.nb
+        vel, c, IA, pA = [None] * nb, [None] * nb, [None] * nb, [None] * nb
+        U, d, u = [None] * nb, [None] * nb, [None] * nb
+        vel[0] = np.array(v[:6], float)
+        IA[0] = self.I[0].copy()
+        pA[0] = crf(vel[0]) @ (self.I[0] @ vel[0]) - fx[0]
+        for i in range(1, nb):
+            S = self.S(i)
+            vJ = S * v[5 + i]
+            vel[i] = X[i] @ vel[self.parent[i]] + vJ
+            c[i] = crm(vel[i]) @ vJ
+            IA[i] = self.I[i].copy()
+            pA[i] = crf(vel[i]) @ (self.I[i] @ vel[i]) - fx[i]
+        for i in range(nb - 1, 0, -1):
+            S = self.S(i)
+            U[i] = IA[i] @ S
+            d[i] = S @ U[i]
+            u[i] = tau[i - 1] - S @ pA[i]
+            Ia = IA[i] - np.outer(U[i], U[i]) / d[i]
+            pa = pA[i] + Ia @ c[i] + U[i] * u[i] / d[i]
+            p = self.parent[i]
+            IA[p] = IA[p] + X[i].T @ Ia @ X[i]
+            pA[p] = pA[p] + X[i].T @ pa
+        acc = [None] * nb
+        a0 = -np.linalg.solve(IA[0], pA[0])          # includes the fictitious gravity acceleration ...
+        acc[0] = a0
+        out = np.zeros(self.nv)
+        for i in range(1, nb):
+            S = self.S(i)
+            ap = X[i] @ acc[self.parent[i]] + c[i]
+            qdd = (u[i] - U[i] @ ap) / d[i]
+            out[5 + i] = qdd
+            acc[i] = ap + S * qdd
+        out[:6] = a0
+        if gravity:                                   # ... which is removed from the reported base acceleration
+            out[3:6] -= Rw[0].T @ np.array([0, 0, self.g])
+        return out
+
+    def forward_dynamics(self, q, v, tau, f_world=None):
+        """a = M^-1 ([0; tau] - RNEA(q, v, 0, f))  (what the kernels do)"""
+        b = self.rnea(q, v, np.zeros(self.nv), f_world)
+        rhs = np.concatenate([np.zeros(6), tau]) - b
+        return np.linalg.solve(self.crba(q), rhs)
+
+    # ---- energies / momentum (identity tests) ------------------------------------------------------------------
+    def potential(self, q):
+        _, Rw, pw = self.transforms(q)
+        return sum(self.mass[i] * self.g * (pw[i] + Rw[i] @ self.com[i])[2] for i in range(self.nb))
+
+    def kinetic(self, q, v):
+        return 0.5 * v @ self.crba(q) @ v
+
+    def world_momentum(self, q, v):
+        """spatial momentum about the world origin, world coordinates [angular; linear]"""
+        M = self.crba(q)
+        h = (M @ v)[:6]                                   # base coordinates, about the base origin
+        R, p = rpy_matrix(q[3:6]), np.asarray(q[:3], float)
+        lin = R @ h[3:]
+        return np.concatenate([R @ h[:3] + np.cross(p, lin), lin])
+
+    def qdot(self, q, v):
+        """d q / dt from the generalised velocity"""
+        R = rpy_matrix(q[3:6])
+        return np.concatenate([R @ v[3:6], rpy_rates(q[3:6]) @ v[:3], v[6:]])
+
+
+# ---- the OCP of the class (builder-defined; include/alore_wb.h states the same) ------------------------------------
+NQ, NVV, NX, NU = 24, 24, 48, 30
+
+
+def step(model, x, u, dt):
+    """semi-implicit Euler: v+ = v + dt a(q, v, u);  q+ = q + dt qdot(q, v+)"""
+    q, v = x[:NQ], x[NQ:]
+    a = model.forward_dynamics(q, v, u[:18], u[18:].reshape(4, 3))
+    vn = v + dt * a
+    return np.concatenate([q + dt * model.qdot(q, vn), vn])
+
+
+def linearize(model, x, u, dt, h=1e-6):
+    """A = d step / d x, B = d step / d u by central differences (float64)"""
+    A = np.zeros((NX, NX)); B = np.zeros((NX, NU))
+    for j in range(NX):
+        e = np.zeros(NX); e[j] = h
+        A[:, j] = (step(model, x + e, u, dt) - step(model, x - e, u, dt)) / (2 * h)
+    for j in range(NU):
+        e = np.zeros(NU); e[j] = h * 10
+        B[:, j] = (step(model, x, u + e, dt) - step(model, x, u - e, dt)) / (20 * h)
+    return A, B
+
+
+def solve_lq(A, B, d, Q, R, QN, gx, gu, gN, dx0):
+    """The equality-constrained QP of one real-time iteration, solved as ONE dense KKT system (numpy.linalg):
+         min sum_k 1/2 dx_k' Q dx_k + gx_k' dx_k + 1/2 du_k' R du_k + gu_k' du_k  + terminal
+         s.t. dx_{k+1} = A_k dx_k + B_k du_k + d_k,  dx_0 given.
+       Returns dx (N+1, nx), du (N, nu)."""
+    N = len(A); nx, nu = B[0].shape
+    nz = (N + 1) * nx + N * nu
+    H = np.zeros((nz, nz)); g = np.zeros(nz)
+    ox = lambda k: k * (nx + nu)
+    ou = lambda k: k * (nx + nu) + nx
+    for k in range(N):
+        H[ox(k):ox(k) + nx, ox(k):ox(k) + nx] = Q
+        H[ou(k):ou(k) + nu, ou(k):ou(k) + nu] = R
+        g[ox(k):ox(k) + nx] = gx[k]; g[ou(k):ou(k) + nu] = gu[k]
+    H[ox(N):ox(N) + nx, ox(N):ox(N) + nx] = QN
+    g[ox(N):ox(N) + nx] = gN
+    ne = (N + 1) * nx
+    C = np.zeros((ne, nz)); c = np.zeros(ne)
+    C[:nx, :nx] = np.eye(nx); c[:nx] = dx0
+    for k in range(N):
+        r = (k + 1) * nx
+        C[r:r + nx, ox(k):ox(k) + nx] = -A[k]
+        C[r:r + nx, ou(k):ou(k) + nu] = -B[k]
+        C[r:r + nx, ox(k + 1):ox(k + 1) + nx] = np.eye(nx)
+        c[r:r + nx] = d[k]
+    K = np.block([[H, C.T], [C, np.zeros((ne, ne))]])
+    sol = np.linalg.solve(K, np.concatenate([-g, c]))
+    z = sol[:nz]
+    dx = np.array([z[ox(k):ox(k) + nx] for k in range(N + 1)])
+    du = np.array([z[ou(k):ou(k) + nu] for k in range(N)])
+    return dx, du
