@@ -1,0 +1,720 @@
+// wb_kernels.hip -- whole-body NMPC class (include/alore_wb.h): linearisation and Riccati kernels + C ABI.
+//
+// No reference code exists for this class (SURVEY.md 8(a) row A-RB); the OCP is stated in include/alore_wb.h.
+//
+// Kernel 1, stage_kernel: ONE WAVEFRONT PER (problem, stage).  Lanes are independent RNEA evaluations
+// (wb_dynamics.h) that differ by a unit vector or a perturbation:
+//   round 1   24 lanes: columns of M(q) (unit accelerations, no gravity) | 1 lane: bias RNEA(q, v, 0, f) |
+//             12 lanes: columns of -J_c' (unit foot forces)
+//   Cholesky of M in LDS, a = M^-1 ([0; tau] - bias)
+//   round 2   45 lanes: d RNEA(q, v, a, f) / d (rpy, joints, v) by central differences (2 evaluations each)
+//   75 lanes (2 rounds): M^-1 times the 75 right-hand sides -> da/dq, da/dv, da/du
+//   assembly of A_k (48 x 48), B_k (48 x 30) and f(x_k, u_k) for the semi-implicit Euler step, written to HBM
+//   (float32 for the Riccati kernel, float64 on request).
+// Kernel 2, riccati_kernel: one workgroup (4 wavefronts) per problem, float32 MFMA 16x16x4 on the dense blocks.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/alore_wb.h"
+#include "wb_dynamics.h"
+
+namespace wb {
+
+constexpr int NQ = 24, NV = 24, NX = 48, NU = 30, NUP = 32; // NUP: input dimension padded to the MFMA tile
+constexpr int NCOL = 75;                                     // 21 (rpy, joints) + 24 (v) + 18 (tau) + 12 (f)
+constexpr double HQ = 1e-5, HV = 1e-3;                       // central-difference steps (RNEA is quadratic in v)
+
+struct StageArgs {
+    const double* x; // [B][N+1][48]
+    const double* u; // [B][N][30]
+    int N;           // stages per problem
+    int n_items;     // B * N
+    double dt;
+    float* A32;      // [n][48][48]
+    float* B32;      // [n][48][32]
+    double* next;    // [n][48]
+    double* A64;     // optional [n][48][48]
+    double* B64;     // optional [n][48][30]
+    double* M64;     // optional [n][24][24]
+    double* a64;     // optional [n][24]
+};
+
+constexpr int MS = 25; // row stride of M / column stride of D in LDS (doubles)
+
+struct StageLds {
+    double q[NQ], v[NV], u[NU], a[NV], zero[NV];
+    double M[NV * MS];
+    double bias[NV];
+    double D[NCOL * MS]; // D[col][i]
+    double vn[NV];       // v+
+    double R0[9], E[9], Gq[3][6];
+};
+
+// x <- (L L')^-1 x, in place in LDS (x: one column of D, or a scratch vector); L = lower Cholesky factor, row stride MS.
+// Loops stay rolled: the vector lives in LDS, not in 48 registers, and the reads of L are wavefront broadcasts.
+__device__ __forceinline__ void chol_solve(const double* L, double* x)
+{
+#pragma unroll 1
+    for (int i = 0; i < NV; ++i) {
+        double s = x[i];
+#pragma unroll 4
+        for (int j = 0; j < i; ++j) s -= L[i * MS + j] * x[j];
+        x[i] = s / L[i * MS + i];
+    }
+#pragma unroll 1
+    for (int i = NV - 1; i >= 0; --i) {
+        double s = x[i];
+#pragma unroll 4
+        for (int j = i + 1; j < NV; ++j) s -= L[j * MS + i] * x[j];
+        x[i] = s / L[i * MS + i];
+    }
+}
+
+__global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
+{
+    __shared__ StageLds S;
+    const int item = blockIdx.x;
+    if (item >= g.n_items) return;
+    const int lane = threadIdx.x;
+    const int b = item / g.N, k = item % g.N;
+    const double* xk = g.x + ((size_t)b * (g.N + 1) + k) * NX;
+    const double* uk = g.u + ((size_t)b * g.N + k) * NU;
+    if (lane < NQ) { S.q[lane] = xk[lane]; S.v[lane] = xk[NQ + lane]; S.zero[lane] = 0.0; }
+    if (lane < NU) S.u[lane] = uk[lane];
+    __syncthreads();
+
+    // Three passes over ONE inlined copy of the RNEA (the loop is kept rolled): pass 0 = round 1 (M columns, bias,
+    // foot-force columns), passes 1 and 2 = the +h and -h evaluations of round 2.  Outputs go straight to LDS.
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        Eval e{S.q, S.v, S.zero, S.u + 18, 0.0, 0.0, 0.0, -1, -1, -1, -1, 0.0, 0.0, 0.0, 0.0, 0.0};
+        Sink sink{S.D + lane * MS, 1, 1.0, 0};
+        bool active;
+        if (pass == 0) {
+            active = lane < 37;
+            if (lane < 24) { e.ua = lane; e.da = 1.0; sink.out = S.M + lane; sink.stride = MS; }
+            else if (lane == 24) { e.sv = 1.0; e.sf = 1.0; e.g = b2z1::GRAVITY; sink.out = S.bias; }
+            else { e.uf = lane - 25; e.df = 1.0; sink.out = S.D + (63 + lane - 25) * MS; sink.scale = -1.0; } // RNEA = ... - J_c' f
+        } else {
+            active = lane < 45;
+            const double hh = lane < 21 ? HQ : HV, h = pass == 1 ? hh : -hh;
+            e.a = S.a; e.sv = 1.0; e.sa = 1.0; e.sf = 1.0; e.g = b2z1::GRAVITY;
+            if (lane < 21) { e.uq = 3 + lane; e.dq = h; } else { e.uv = lane - 21; e.dv = h; }
+            if (pass == 2) { sink.mode = 1; sink.scale = -0.5 / hh; } // D = -(tau+ - tau-) / 2h
+        }
+        if (active) rnea(e, sink);
+        if (pass == 0) {
+            if (lane >= 37 && lane < 37 + 18) { // right-hand sides of da / dtau: unit vectors on the joint rows
+                const int j = lane - 37;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) S.D[(45 + j) * MS + i] = (i == 6 + j) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            if (g.M64 && lane < 24)
+                for (int i = 0; i < NV; ++i) g.M64[((size_t)item * NV + i) * NV + lane] = S.M[i * MS + lane];
+            // ---- Cholesky M = L L' in place (lower triangle), lanes = rows
+            for (int c = 0; c < NV; ++c) {
+                if (lane == c) S.M[c * MS + c] = sqrt(S.M[c * MS + c]);
+                __syncthreads();
+                if (lane > c && lane < NV) S.M[lane * MS + c] /= S.M[c * MS + c];
+                __syncthreads();
+                if (lane > c && lane < NV) {
+                    const double lic = S.M[lane * MS + c];
+                    for (int j = c + 1; j <= lane; ++j) S.M[lane * MS + j] -= lic * S.M[j * MS + c];
+                }
+                __syncthreads();
+            }
+            // ---- a = M^-1 ([0; tau] - bias)
+            if (lane < NV) S.a[lane] = (lane >= 6 ? S.u[lane - 6] : 0.0) - S.bias[lane];
+            __syncthreads();
+            if (lane == 0) chol_solve(S.M, S.a);
+            __syncthreads();
+            if (g.a64 && lane < NV) g.a64[(size_t)item * NV + lane] = S.a[lane];
+            if (lane < NV) S.vn[lane] = S.v[lane] + g.dt * S.a[lane];
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (lane >= 45 && lane < 48) { // derivative of the kinematic map G(q) v+ with respect to rpy (v+ fixed)
+        const int c = lane - 45;
+        const V3 wn = {S.vn[0], S.vn[1], S.vn[2]}, vl = {S.vn[3], S.vn[4], S.vn[5]};
+        const double h = 1e-6;
+        const double h0 = c == 0 ? h : 0.0, h1 = c == 1 ? h : 0.0, h2 = c == 2 ? h : 0.0;
+        BaseRot Rp, Rm;
+        Rp.set(S.q[3] + h0, S.q[4] + h1, S.q[5] + h2);
+        Rm.set(S.q[3] - h0, S.q[4] - h1, S.q[5] - h2);
+        const V3 dp = (0.5 / h) * (Rp.toWorld(vl) - Rm.toWorld(vl)), dr = (0.5 / h) * (Rp.rates(wn) - Rm.rates(wn));
+        S.Gq[c][0] = dp.x; S.Gq[c][1] = dp.y; S.Gq[c][2] = dp.z; S.Gq[c][3] = dr.x; S.Gq[c][4] = dr.y; S.Gq[c][5] = dr.z;
+    } else if (lane == 48) {
+        BaseRot R;
+        R.set(S.q[3], S.q[4], S.q[5]);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const V3 em = {m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0};
+            const V3 cw = R.toWorld(em), ce = R.rates(em);
+            S.R0[0 * 3 + m] = cw.x; S.R0[1 * 3 + m] = cw.y; S.R0[2 * 3 + m] = cw.z;
+            S.E[0 * 3 + m] = ce.x; S.E[1 * 3 + m] = ce.y; S.E[2 * 3 + m] = ce.z;
+        }
+    }
+    __syncthreads();
+
+    // ---- M^-1 times the 75 columns
+    for (int col = lane; col < NCOL; col += 64) chol_solve(S.M, S.D + col * MS);
+    __syncthreads();
+
+    // ---- assembly.  Z(var, i) = d a_i / d var;  dvn_i / d var = dt Z + [var is v_i]
+    const double dt = g.dt;
+    auto zcol = [](int c) -> int { return c < 3 ? -1 : (c < 24 ? c - 3 : (c < 48 ? 21 + c - 24 : 45 + c - 48)); }; // c: 0..77
+    auto dvn = [&](int i, int c, int zc) -> double { return (zc >= 0 ? dt * S.D[zc * MS + i] : 0.0) + ((c == 24 + i) ? 1.0 : 0.0); };
+    float* A32 = g.A32 + (size_t)item * NX * NX;
+    float* B32 = g.B32 + (size_t)item * NX * NUP;
+    for (int idx = lane; idx < NX * (NX + NUP); idx += 64) {
+        const int r = idx / (NX + NUP), cc = idx % (NX + NUP);
+        if (cc >= NX + NU) { B32[r * NUP + (cc - NX)] = 0.0f; continue; }
+        const int c = cc, zc = zcol(c);
+        double val;
+        if (r >= 24) val = dvn(r - 24, c, zc);
+        else if (r >= 6) val = ((r == c) ? 1.0 : 0.0) + dt * dvn(r, c, zc);
+        else {
+            const double* Gm = (r < 3) ? (S.R0 + 3 * r) : (S.E + 3 * (r - 3));
+            const int off = (r < 3) ? 3 : 0; // p rows use v_lin (3..5), rpy rows use omega (0..2)
+            double acc = Gm[0] * dvn(off, c, zc) + Gm[1] * dvn(off + 1, c, zc) + Gm[2] * dvn(off + 2, c, zc);
+            if (c >= 3 && c < 6) acc += S.Gq[c - 3][r];
+            val = ((r == c) ? 1.0 : 0.0) + dt * acc;
+        }
+        if (c < NX) {
+            A32[r * NX + c] = (float)val;
+            if (g.A64) g.A64[((size_t)item * NX + r) * NX + c] = val;
+        } else {
+            B32[r * NUP + (c - NX)] = (float)val;
+            if (g.B64) g.B64[((size_t)item * NX + r) * NU + (c - NX)] = val;
+        }
+    }
+    if (lane < NX) { // f(x_k, u_k)
+        double val;
+        const int r = lane;
+        if (r >= 24) val = S.vn[r - 24];
+        else if (r >= 6) val = S.q[r] + dt * S.vn[r];
+        else {
+            const double* Gm = (r < 3) ? (S.R0 + 3 * r) : (S.E + 3 * (r - 3));
+            const int off = (r < 3) ? 3 : 0;
+            val = S.q[r] + dt * (Gm[0] * S.vn[off] + Gm[1] * S.vn[off + 1] + Gm[2] * S.vn[off + 2]);
+        }
+        g.next[(size_t)item * NX + r] = val;
+    }
+}
+
+// one lane per evaluation point (alore_wb_rnea)
+__global__ __launch_bounds__(64) void rnea_kernel(int n, const double* q, const double* v, const double* a, const double* f, double grav, double* tau)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Eval e{q + (size_t)t * NQ, v + (size_t)t * NV, a + (size_t)t * NV, f ? f + (size_t)t * 12 : q, 1.0, 1.0, f ? 1.0 : 0.0,
+           -1, -1, -1, -1, 0.0, 0.0, 0.0, 0.0, grav};
+    rnea(e, Sink{tau + (size_t)t * NV, 1, 1.0, 0});
+}
+
+
+// =====================================================================================================================
+// Kernel 2: Riccati sweep of the LQ problem of one real-time iteration.  One workgroup (4 wavefronts) per problem, all
+// matrices of the current stage in LDS (float32), the dense products on the matrix cores:
+//   v_mfma_f32_16x16x4_f32:  lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives
+//   C[4 (l >> 4) + r][l & 15], r = 0..3  (cdna_hip_programming.md, "A/B operands ... 16x16x4").
+// Backward, stage k = N-1 .. 0 (P, p: cost-to-go 1/2 dx' P dx + p' dx of stage k + 1):
+//   PA = P A, PB = P B, s = P d + p                              (15 output tiles)
+//   Qxx = Q + A' PA, Qux = B' PA, Quu = R + B' PB, qx, qu        (19 tiles)
+//   Quu = L L' (Cholesky, 30 x 30), K = -Quu^-1 Qux, kff = -Quu^-1 qu   -> HBM (used by the forward sweep)
+//   P <- Qxx + Qux' K, p <- qx + Qux' kff                        (9 tiles)
+// Forward: dx_0 = x0 - x_0, du_k = K_k dx_k + kff_k, dx_{k+1} = A_k dx_k + B_k du_k + d_k; then x += dx, u += du with
+// the joint torques clipped to the URDF effort limits.
+// =====================================================================================================================
+constexpr int LDX = 49;  // row stride of the 48-column matrices in LDS (floats): 49 keeps column walks off one bank
+constexpr int LDU = 33;  // row stride of the 32-column matrices
+
+struct RicArgs {
+    const float* A32;    // [B][N][48][48]
+    const float* B32;    // [B][N][48][32]
+    const double* next;  // [B][N][48]
+    double* x;           // [B][N+1][48]  in/out
+    double* u;           // [B][N][30]    in/out
+    const double* x0;    // [B][48]
+    const double* xref;  // [B][N+1][48]
+    const double* uref;  // [B][N][30]
+    const double* w;     // Q[48] R[30] QN[48]
+    float* K;            // [B][N][32][48] workspace
+    float* kff;          // [B][N][32]
+    double* dx;          // [B][N+1][48]
+    double* du;          // [B][N][30]
+    int N;
+    int apply;           // 1: x += dx, u += du (clipped)
+};
+
+struct RicLds {
+    float P[48 * LDX], A[48 * LDX], PA[48 * LDX], Qxx[48 * LDX];
+    float B[48 * LDU], PB[48 * LDU];
+    float Qux[32 * LDX], K[32 * LDX];
+    float Quu[32 * LDU];
+    float p[48], s[48], d[48], gx[48], qx[48], dxk[48], dxn[48];
+    float gu[32], qu[32], kff[32], duk[32];
+};
+
+// one 16 x 16 output tile: C[i0.., j0..] = (init ? C : 0) + op(A) op(B) over K (multiple of 4)
+//   TA: A is stored transposed (element (i, k) at A[k * lda + i]);  TB likewise for B
+template <bool TA, bool TB>
+__device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* Bm, int ldb, int K, int i0, int j0, float* Cm, int ldc,
+                                          const float* Cinit, int ldi, float alpha_diag, const double* diag)
+{
+    const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kq;
+        const float a = TA ? A[k * lda + i0 + r16] : A[(i0 + r16) * lda + k];
+        const float b = TB ? Bm[(j0 + r16) * ldb + k] : Bm[k * ldb + j0 + r16];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + 4 * kq + r, col = j0 + r16;
+        float v = acc[r];
+        if (Cinit) v += Cinit[row * ldi + col];
+        if (diag && row == col) v += alpha_diag * (float)diag[row];
+        Cm[row * ldc + col] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void riccati_kernel(RicArgs g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    RicLds& S = *reinterpret_cast<RicLds*>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const int N = g.N;
+    const double *Qd = g.w, *Rd = g.w + NX, *QNd = g.w + NX + NU;
+    const double* xb = g.x + (size_t)b * (N + 1) * NX;
+    const double* ub = g.u + (size_t)b * N * NU;
+    const double* xr = g.xref + (size_t)b * (N + 1) * NX;
+    const double* ur = g.uref + (size_t)b * N * NU;
+    // terminal cost
+    for (int i = tid; i < 48 * 48; i += 256) { const int r = i / 48, c = i % 48; S.P[r * LDX + c] = (r == c) ? (float)QNd[r] : 0.f; }
+    if (tid < 48) S.p[tid] = (float)(QNd[tid] * (xb[(size_t)N * NX + tid] - xr[(size_t)N * NX + tid]));
+    __syncthreads();
+
+    for (int k = N - 1; k >= 0; --k) {
+        const float* Ag = g.A32 + ((size_t)b * N + k) * NX * NX;
+        const float* Bg = g.B32 + ((size_t)b * N + k) * NX * NUP;
+        for (int i = tid; i < 48 * 48; i += 256) S.A[(i / 48) * LDX + (i % 48)] = Ag[i];
+        for (int i = tid; i < 48 * 32; i += 256) S.B[(i / 32) * LDU + (i % 32)] = Bg[i];
+        if (tid < 48) {
+            S.d[tid] = (float)(g.next[((size_t)b * N + k) * NX + tid] - xb[(size_t)(k + 1) * NX + tid]);
+            S.gx[tid] = (float)(Qd[tid] * (xb[(size_t)k * NX + tid] - xr[(size_t)k * NX + tid]));
+        } else if (tid >= 64 && tid < 96) {
+            const int j = tid - 64;
+            S.gu[j] = j < NU ? (float)(Rd[j] * (ub[(size_t)k * NU + j] - ur[(size_t)k * NU + j])) : 0.f;
+        }
+        __syncthreads();
+        // ---- PA = P A (9 tiles), PB = P B (6 tiles); s = P d + p
+        for (int t = wave; t < 15; t += 4) {
+            if (t < 9) mfma_tile<false, false>(S.P, LDX, S.A, LDX, 48, (t / 3) * 16, (t % 3) * 16, S.PA, LDX, nullptr, 0, 0.f, nullptr);
+            else mfma_tile<false, false>(S.P, LDX, S.B, LDU, 48, ((t - 9) / 2) * 16, ((t - 9) % 2) * 16, S.PB, LDU, nullptr, 0, 0.f, nullptr);
+        }
+        if (tid >= 192 && tid < 240) { // wave 3 has one tile less
+            const int i = tid - 192;
+            float acc = S.p[i];
+            for (int j = 0; j < 48; ++j) acc += S.P[i * LDX + j] * S.d[j];
+            S.s[i] = acc;
+        }
+        __syncthreads();
+        // ---- Qxx = Q + A' PA (9), Qux = B' PA (6), Quu = R + B' PB (4); qx = gx + A' s, qu = gu + B' s
+        for (int t = wave; t < 19; t += 4) {
+            if (t < 9) mfma_tile<true, false>(S.A, LDX, S.PA, LDX, 48, (t / 3) * 16, (t % 3) * 16, S.Qxx, LDX, nullptr, 0, 1.f, Qd);
+            else if (t < 15) mfma_tile<true, false>(S.B, LDU, S.PA, LDX, 48, ((t - 9) / 3) * 16, ((t - 9) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
+            else mfma_tile<true, false>(S.B, LDU, S.PB, LDU, 48, ((t - 15) / 2) * 16, ((t - 15) % 2) * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
+        }
+        __syncthreads();
+        if (tid < 48) {
+            float acc = S.gx[tid];
+            for (int j = 0; j < 48; ++j) acc += S.A[j * LDX + tid] * S.s[j];
+            S.qx[tid] = acc;
+        } else if (tid >= 64 && tid < 96) {
+            const int i = tid - 64;
+            float acc = S.gu[i];
+            for (int j = 0; j < 48; ++j) acc += S.B[j * LDU + i] * S.s[j];
+            S.qu[i] = acc;
+            // diagonal of Quu: + R on the 30 real inputs, identity on the 2 padding rows
+            S.Quu[i * LDU + i] += i < NU ? (float)Rd[i] : 1.f;
+        }
+        __syncthreads();
+        // ---- Cholesky of Quu (wave 0, lanes = rows; wave-synchronous)
+        if (wave == 0) {
+            const int i = tid;
+            for (int c = 0; c < 32; ++c) {
+                if (i == c) S.Quu[c * LDU + c] = sqrtf(S.Quu[c * LDU + c]);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of the wave are visible to its other lanes
+                if (i > c && i < 32) S.Quu[i * LDU + c] /= S.Quu[c * LDU + c];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (i > c && i < 32) {
+                    const float lic = S.Quu[i * LDU + c];
+                    for (int j = c + 1; j <= i; ++j) S.Quu[i * LDU + j] -= lic * S.Quu[j * LDU + c];
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            }
+        }
+        __syncthreads();
+        // ---- K = -Quu^-1 Qux (48 columns), kff = -Quu^-1 qu: one lane per right-hand side, in place
+        if (tid < 49) {
+            float* col = tid < 48 ? (S.Qux + tid) : S.qu;
+            const int cs = tid < 48 ? LDX : 1;
+            float* out = tid < 48 ? (S.K + tid) : S.kff;
+            for (int i = 0; i < 32; ++i) {
+                float acc = col[i * cs];
+                for (int j = 0; j < i; ++j) acc -= S.Quu[i * LDU + j] * out[j * cs];
+                out[i * cs] = acc / S.Quu[i * LDU + i];
+            }
+            for (int i = 31; i >= 0; --i) {
+                float acc = out[i * cs];
+                for (int j = i + 1; j < 32; ++j) acc -= S.Quu[j * LDU + i] * out[j * cs];
+                out[i * cs] = acc / S.Quu[i * LDU + i];
+            }
+            for (int i = 0; i < 32; ++i) out[i * cs] = -out[i * cs];
+        }
+        __syncthreads();
+        // feedback gains to HBM
+        {
+            float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
+            for (int i = tid; i < 32 * 48; i += 256) Kg[i] = S.K[(i / 48) * LDX + (i % 48)];
+            if (tid < 32) g.kff[((size_t)b * N + k) * 32 + tid] = S.kff[tid];
+        }
+        // ---- P <- Qxx + Qux' K (9 tiles), p <- qx + Qux' kff
+        for (int t = wave; t < 9; t += 4)
+            mfma_tile<true, false>(S.Qux, LDX, S.K, LDX, 32, (t / 3) * 16, (t % 3) * 16, S.P, LDX, S.Qxx, LDX, 0.f, nullptr);
+        if (tid >= 192 && tid < 240) {
+            const int i = tid - 192;
+            float acc = S.qx[i];
+            for (int j = 0; j < 32; ++j) acc += S.Qux[j * LDX + i] * S.kff[j];
+            S.p[i] = acc;
+        }
+        __syncthreads();
+        // symmetrise (the two triangles differ by rounding only)
+        for (int i = tid; i < 48 * 48; i += 256) {
+            const int r = i / 48, c = i % 48;
+            if (r < c) { const float m = 0.5f * (S.P[r * LDX + c] + S.P[c * LDX + r]); S.P[r * LDX + c] = m; S.P[c * LDX + r] = m; }
+        }
+        __syncthreads();
+    }
+
+    // ---- forward sweep
+    double* dxb = g.dx + (size_t)b * (N + 1) * NX;
+    double* dub = g.du + (size_t)b * N * NU;
+    if (tid < 48) { S.dxk[tid] = (float)(g.x0[(size_t)b * NX + tid] - xb[tid]); dxb[tid] = S.dxk[tid]; }
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        const float* Ag = g.A32 + ((size_t)b * N + k) * NX * NX;
+        const float* Bg = g.B32 + ((size_t)b * N + k) * NX * NUP;
+        const float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
+        if (tid < 32) {
+            float acc = g.kff[((size_t)b * N + k) * 32 + tid];
+            for (int j = 0; j < 48; ++j) acc += Kg[tid * 48 + j] * S.dxk[j];
+            S.duk[tid] = acc;
+            if (tid < NU) dub[(size_t)k * NU + tid] = acc;
+        }
+        __syncthreads();
+        if (tid < 48) {
+            float acc = (float)(g.next[((size_t)b * N + k) * NX + tid] - xb[(size_t)(k + 1) * NX + tid]);
+            for (int j = 0; j < 48; ++j) acc += Ag[tid * 48 + j] * S.dxk[j];
+            for (int j = 0; j < NU; ++j) acc += Bg[tid * NUP + j] * S.duk[j];
+            S.dxn[tid] = acc;
+            dxb[(size_t)(k + 1) * NX + tid] = acc;
+        }
+        __syncthreads();
+        if (tid < 48) S.dxk[tid] = S.dxn[tid];
+        __syncthreads();
+    }
+    if (g.apply) {
+        double* xw = g.x + (size_t)b * (N + 1) * NX;
+        double* uw = g.u + (size_t)b * N * NU;
+        for (int i = tid; i < (N + 1) * NX; i += 256) xw[i] += dxb[i];
+        for (int i = tid; i < N * NU; i += 256) {
+            double val = uw[i] + dub[i];
+            const int j = i % NU;
+            if (j < b2z1::NJ) { const double lim = b2z1::EFFORT[j]; val = val > lim ? lim : (val < -lim ? -lim : val); }
+            uw[i] = val;
+        }
+    }
+}
+
+} // namespace wb
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+struct alore_wb_solver {
+    alore_wb_config cfg{};
+    std::string err;
+    double *d_x = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_xref = nullptr, *d_uref = nullptr, *d_w = nullptr;
+    float *d_A = nullptr, *d_B = nullptr;
+    double* d_next = nullptr;
+    double *d_dx = nullptr, *d_du = nullptr;
+    float *d_K = nullptr, *d_kff = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    float ms_lin = -1.f, ms_ric = -1.f;
+    bool timed = false;
+};
+
+namespace {
+int fail(alore_wb_handle h, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (h) {
+        h->err = what;
+        if (e != hipSuccess) { h->err += ": "; h->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+#define WB_TRY(h, call)                                                        \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) return fail(h, ALORE_WB_E_HIP, #call, e_);       \
+    } while (0)
+
+template <class T>
+hipError_t zalloc(T** p, size_t n)
+{
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T));
+    return e;
+}
+
+struct Tmp { // scratch device buffers of the synchronous dynamics entry points
+    std::vector<void*> p;
+    ~Tmp() { for (void* x : p) (void)hipFree(x); }
+    template <class T>
+    T* get(size_t n)
+    {
+        T* d = nullptr;
+        if (zalloc(&d, n) != hipSuccess) return nullptr;
+        p.push_back(d);
+        return d;
+    }
+};
+} // namespace
+
+extern "C" {
+
+void alore_wb_default_config(alore_wb_config* c)
+{
+    if (!c) return;
+    c->horizon = 20; c->dt = 0.01; c->device = 0; c->max_problems = 4096;
+}
+
+int alore_wb_model_info(double* masses, double* lower, double* upper, double* effort)
+{
+    if (masses) for (int i = 0; i < b2z1::NB; ++i) masses[i] = b2z1::MASS[i];
+    for (int i = 0; i < b2z1::NJ; ++i) {
+        if (lower) lower[i] = b2z1::Q_LOWER[i];
+        if (upper) upper[i] = b2z1::Q_UPPER[i];
+        if (effort) effort[i] = b2z1::EFFORT[i];
+    }
+    return ALORE_WB_OK;
+}
+
+int alore_wb_create(const alore_wb_config* cfg, alore_wb_handle* out)
+{
+    if (!cfg || !out || cfg->horizon < 1 || cfg->horizon > 32 || cfg->max_problems < 1 || !(cfg->dt > 0)) return ALORE_WB_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= cfg->device) { (void)hipGetLastError(); return ALORE_WB_E_NO_DEVICE; }
+    if (hipSetDevice(cfg->device) != hipSuccess) return ALORE_WB_E_NO_DEVICE;
+    alore_wb_solver* h = new (std::nothrow) alore_wb_solver;
+    if (!h) return ALORE_WB_E_NOMEM;
+    h->cfg = *cfg;
+    const size_t B = cfg->max_problems, N = cfg->horizon;
+    bool ok = zalloc(&h->d_x, B * (N + 1) * wb::NX) == hipSuccess && zalloc(&h->d_u, B * N * wb::NU) == hipSuccess &&
+              zalloc(&h->d_x0, B * wb::NX) == hipSuccess && zalloc(&h->d_xref, B * (N + 1) * wb::NX) == hipSuccess &&
+              zalloc(&h->d_uref, B * N * wb::NU) == hipSuccess && zalloc(&h->d_w, (size_t)(2 * wb::NX + wb::NU)) == hipSuccess &&
+              zalloc(&h->d_A, B * N * wb::NX * wb::NX) == hipSuccess && zalloc(&h->d_B, B * N * wb::NX * wb::NUP) == hipSuccess &&
+              zalloc(&h->d_next, B * N * wb::NX) == hipSuccess && zalloc(&h->d_dx, B * (N + 1) * wb::NX) == hipSuccess &&
+              zalloc(&h->d_du, B * N * wb::NU) == hipSuccess && zalloc(&h->d_K, B * N * 32 * 48) == hipSuccess &&
+              zalloc(&h->d_kff, B * N * 32) == hipSuccess;
+    for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
+    if (!ok) { alore_wb_destroy(h); return ALORE_WB_E_NOMEM; }
+    *out = h;
+    return ALORE_WB_OK;
+}
+
+int alore_wb_destroy(alore_wb_handle h)
+{
+    if (!h) return ALORE_WB_E_INVALID;
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    delete h;
+    return ALORE_WB_OK;
+}
+
+const char* alore_wb_last_error(alore_wb_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int alore_wb_rnea(alore_wb_handle h, int n, const double* q, const double* v, const double* a, const double* f, int gravity, double* tau)
+{
+    if (!h || n <= 0 || !q || !v || !a || !tau) return fail(h, ALORE_WB_E_INVALID, "rnea: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    Tmp t;
+    double *dq = t.get<double>((size_t)n * 24), *dv = t.get<double>((size_t)n * 24), *da = t.get<double>((size_t)n * 24);
+    double *df = f ? t.get<double>((size_t)n * 12) : nullptr, *dt = t.get<double>((size_t)n * 24);
+    if (!dq || !dv || !da || !dt || (f && !df)) return fail(h, ALORE_WB_E_NOMEM, "rnea: hipMalloc");
+    WB_TRY(h, hipMemcpy(dq, q, sizeof(double) * n * 24, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(dv, v, sizeof(double) * n * 24, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(da, a, sizeof(double) * n * 24, hipMemcpyHostToDevice));
+    if (f) WB_TRY(h, hipMemcpy(df, f, sizeof(double) * n * 12, hipMemcpyHostToDevice));
+    wb::rnea_kernel<<<(n + 63) / 64, 64>>>(n, dq, dv, da, df, gravity ? b2z1::GRAVITY : 0.0, dt);
+    WB_TRY(h, hipGetLastError());
+    WB_TRY(h, hipMemcpy(tau, dt, sizeof(double) * n * 24, hipMemcpyDeviceToHost));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_forward_dynamics(alore_wb_handle h, int n, const double* q, const double* v, const double* u, double* M, double* a)
+{
+    if (!h || n <= 0 || !q || !v || !u) return fail(h, ALORE_WB_E_INVALID, "forward_dynamics: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    Tmp t;
+    // n one-stage problems: x [n][2][48] (second slot unused), u [n][1][30]
+    std::vector<double> hx((size_t)n * 2 * wb::NX, 0.0);
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(&hx[(size_t)i * 2 * wb::NX], q + (size_t)i * 24, sizeof(double) * 24);
+        std::memcpy(&hx[(size_t)i * 2 * wb::NX + 24], v + (size_t)i * 24, sizeof(double) * 24);
+    }
+    double *dx = t.get<double>(hx.size()), *du = t.get<double>((size_t)n * wb::NU), *dn = t.get<double>((size_t)n * wb::NX);
+    float *dA = t.get<float>((size_t)n * wb::NX * wb::NX), *dB = t.get<float>((size_t)n * wb::NX * wb::NUP);
+    double *dM = M ? t.get<double>((size_t)n * 576) : nullptr, *da = a ? t.get<double>((size_t)n * 24) : nullptr;
+    if (!dx || !du || !dn || !dA || !dB || (M && !dM) || (a && !da)) return fail(h, ALORE_WB_E_NOMEM, "forward_dynamics: hipMalloc");
+    WB_TRY(h, hipMemcpy(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(du, u, sizeof(double) * n * wb::NU, hipMemcpyHostToDevice));
+    wb::StageArgs g{dx, du, 1, n, h->cfg.dt, dA, dB, dn, nullptr, nullptr, dM, da};
+    wb::stage_kernel<<<n, 64>>>(g);
+    WB_TRY(h, hipGetLastError());
+    if (M) WB_TRY(h, hipMemcpy(M, dM, sizeof(double) * n * 576, hipMemcpyDeviceToHost));
+    if (a) WB_TRY(h, hipMemcpy(a, da, sizeof(double) * n * 24, hipMemcpyDeviceToHost));
+    WB_TRY(h, hipDeviceSynchronize());
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_weights(alore_wb_handle h, const double* Q, const double* R, const double* QN)
+{
+    if (!h || !Q || !R || !QN) return fail(h, ALORE_WB_E_INVALID, "set_weights: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    WB_TRY(h, hipMemcpy(h->d_w, Q, sizeof(double) * wb::NX, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(h->d_w + wb::NX, R, sizeof(double) * wb::NU, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(h->d_w + wb::NX + wb::NU, QN, sizeof(double) * wb::NX, hipMemcpyHostToDevice));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_problem(alore_wb_handle h, int B, const double* x0, const double* xref, const double* uref)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems || !x0 || !xref || !uref) return fail(h, ALORE_WB_E_INVALID, "set_problem: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = h->cfg.horizon;
+    WB_TRY(h, hipMemcpy(h->d_x0, x0, sizeof(double) * B * wb::NX, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(h->d_xref, xref, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(h->d_uref, uref, sizeof(double) * B * N * wb::NU, hipMemcpyHostToDevice));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_iterate(alore_wb_handle h, int B, const double* x, const double* u)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems || !x || !u) return fail(h, ALORE_WB_E_INVALID, "set_iterate: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = h->cfg.horizon;
+    WB_TRY(h, hipMemcpy(h->d_x, x, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(h->d_u, u, sizeof(double) * B * N * wb::NU, hipMemcpyHostToDevice));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_get_iterate(alore_wb_handle h, int B, double* x, double* u)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems) return fail(h, ALORE_WB_E_INVALID, "get_iterate: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = h->cfg.horizon;
+    WB_TRY(h, hipDeviceSynchronize());
+    if (x) WB_TRY(h, hipMemcpy(x, h->d_x, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyDeviceToHost));
+    if (u) WB_TRY(h, hipMemcpy(u, h->d_u, sizeof(double) * B * N * wb::NU, hipMemcpyDeviceToHost));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_linearize(alore_wb_handle h, int B, double* A, double* Bm, double* next)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems) return fail(h, ALORE_WB_E_INVALID, "linearize: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    const int N = h->cfg.horizon;
+    const size_t n = (size_t)B * N;
+    Tmp t;
+    double *dA = A ? t.get<double>(n * wb::NX * wb::NX) : nullptr, *dB = Bm ? t.get<double>(n * wb::NX * wb::NU) : nullptr;
+    if ((A && !dA) || (Bm && !dB)) return fail(h, ALORE_WB_E_NOMEM, "linearize: hipMalloc");
+    wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, dA, dB, nullptr, nullptr};
+    wb::stage_kernel<<<(unsigned)n, 64>>>(g);
+    WB_TRY(h, hipGetLastError());
+    if (A) WB_TRY(h, hipMemcpy(A, dA, sizeof(double) * n * wb::NX * wb::NX, hipMemcpyDeviceToHost));
+    if (Bm) WB_TRY(h, hipMemcpy(Bm, dB, sizeof(double) * n * wb::NX * wb::NU, hipMemcpyDeviceToHost));
+    if (next) WB_TRY(h, hipMemcpy(next, h->d_next, sizeof(double) * n * wb::NX, hipMemcpyDeviceToHost));
+    WB_TRY(h, hipDeviceSynchronize());
+    return ALORE_WB_OK;
+}
+
+int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems || n_iter < 1) return fail(h, ALORE_WB_E_INVALID, "rti: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const int N = h->cfg.horizon;
+    const size_t n = (size_t)B * N;
+    static bool lds_set[16] = {false};
+    if (!lds_set[h->cfg.device & 15]) {
+        WB_TRY(h, hipFuncSetAttribute((const void*)wb::riccati_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wb::RicLds)));
+        lds_set[h->cfg.device & 15] = true;
+    }
+    for (int it = 0; it < n_iter; ++it) {
+        const bool last = it == n_iter - 1;
+        if (last) WB_TRY(h, hipEventRecord(h->ev[0], s));
+        wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr};
+        wb::stage_kernel<<<(unsigned)n, 64, 0, s>>>(g);
+        if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1};
+        wb::riccati_kernel<<<B, 256, sizeof(wb::RicLds), s>>>(r);
+        if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
+    }
+    WB_TRY(h, hipGetLastError());
+    h->timed = true;
+    return ALORE_WB_OK;
+}
+
+int alore_wb_last_step(alore_wb_handle h, int B, double* dx, double* du)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems) return fail(h, ALORE_WB_E_INVALID, "last_step: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = h->cfg.horizon;
+    WB_TRY(h, hipDeviceSynchronize());
+    if (dx) WB_TRY(h, hipMemcpy(dx, h->d_dx, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyDeviceToHost));
+    if (du) WB_TRY(h, hipMemcpy(du, h->d_du, sizeof(double) * B * N * wb::NU, hipMemcpyDeviceToHost));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_last_times(alore_wb_handle h, float* linearize_ms, float* riccati_ms)
+{
+    if (!h) return ALORE_WB_E_INVALID;
+    if (h->timed) {
+        WB_TRY(h, hipEventSynchronize(h->ev[2]));
+        WB_TRY(h, hipEventElapsedTime(&h->ms_lin, h->ev[0], h->ev[1]));
+        WB_TRY(h, hipEventElapsedTime(&h->ms_ric, h->ev[1], h->ev[2]));
+        h->timed = false;
+    }
+    if (linearize_ms) *linearize_ms = h->ms_lin;
+    if (riccati_ms) *riccati_ms = h->ms_ric;
+    return ALORE_WB_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,90 @@
+/*
+ * alore_wb.h -- C ABI of the whole-body NMPC class: B2 quadruped + Z1 arm, floating base + 18 actuated joints
+ * (BASELINE.json configs[2]; SURVEY.md section 8(a) row A-RB).
+ *
+ * THE REFERENCE HAS NO IMPLEMENTATION OF THIS CLASS: no RNEA / ABA / CRBA and no whole-body OCP anywhere in the
+ * repository; its only whole-body artefact is the URDF planning_ddr_opt/utils/simulator/urdf/b2_z1/urdf/
+ * b2_plus_z1.urdf (12 leg joints :256-1416, arm joint1..6 :1527-1705, base mass :13-14), which
+ * tools/gen_b2z1_model.py turns into the number table the kernels are compiled with.  PARITY UNPINNED: the checker is
+ * oracle/wb_oracle.py (float64, 6-D spatial algebra), itself pinned by physics identities (tests/test_wb_oracle.py).
+ * What would bind here in the reference is therefore a NEW controller class next to nmpc_controller's MpcWrapper
+ * (include/nmpc_controller/mpc_wrapper.h:35-87: setReferencePose / setTrajectory / solve / update / getStates /
+ * getInputs) -- the entry points below keep that shape: weights, references, measured state in; one real-time
+ * iteration per call; predicted states and inputs out.
+ *
+ * The OCP (builder-defined, stated here because no reference text exists):
+ *   state    x = [p (3, world) | rpy (3, ZYX) | joint angles (18) | omega_base (3) | v_base (3, base frame) | joint rates (18)]   nx = 48
+ *   input    u = [joint torques (18) | foot forces (4 x 3, world frame, at the foot points FL FR RL RR)]                        nu = 30
+ *   dynamics semi-implicit Euler:  v+ = v + dt a(q, v, u),  q+ = q + dt G(q) v+,   a = M(q)^-1 ([0; tau] - RNEA(q, v, 0, f))
+ *   cost     sum_k 1/2 (x_k - xref_k)' Q (..) + 1/2 (u_k - uref_k)' R (..)  + 1/2 (x_N - xref_N)' QN (..),  Q, R, QN diagonal
+ *   bounds   |tau_i| <= effort_i of the URDF: the step is clipped to them when it is applied (the QP itself is
+ *            equality-constrained; contact consistency of the feet is the caller's job through xref / uref)
+ * One real-time iteration: linearise the dynamics about the current iterate (A_k, B_k, defects), solve the LQ problem
+ * by a Riccati sweep (float32 MFMA on the 48 x 48 / 48 x 30 blocks), apply the full step.
+ */
+#ifndef ALORE_WB_H
+#define ALORE_WB_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALORE_WB_OK 0
+#define ALORE_WB_E_INVALID (-1)
+#define ALORE_WB_E_NO_DEVICE (-2)
+#define ALORE_WB_E_HIP (-3)
+#define ALORE_WB_E_NOMEM (-4)
+
+#define ALORE_WB_NQ 24
+#define ALORE_WB_NV 24
+#define ALORE_WB_NX 48
+#define ALORE_WB_NU 30
+#define ALORE_WB_NJ 18
+
+typedef struct alore_wb_solver *alore_wb_handle;
+
+typedef struct alore_wb_config {
+    int horizon;      /* N (<= 32) */
+    double dt;
+    int device;
+    int max_problems; /* B */
+} alore_wb_config;
+
+void alore_wb_default_config(alore_wb_config *c); /* N = 20, dt = 0.01 */
+int alore_wb_create(const alore_wb_config *cfg, alore_wb_handle *out); /* fails without a GPU: there is no CPU path */
+int alore_wb_destroy(alore_wb_handle h);
+const char *alore_wb_last_error(alore_wb_handle h);
+/* the model table the library was compiled with: masses [19], joint limits lower / upper / effort [18]; any may be NULL */
+int alore_wb_model_info(double *masses, double *lower, double *upper, double *effort);
+
+/* ---- rigid-body dynamics for n independent evaluation points (HOST pointers; synchronous) ----
+ * q [n][24], v [n][24], a [n][24], f [n][12] (NULL = no foot forces), gravity 0/1 -> tau [n][24] */
+int alore_wb_rnea(alore_wb_handle h, int n, const double *q, const double *v, const double *a, const double *f, int gravity,
+                  double *tau);
+/* mass matrix M [n][24][24] (from unit accelerations) and forward dynamics a [n][24] for inputs u [n][30]; either
+ * output may be NULL */
+int alore_wb_forward_dynamics(alore_wb_handle h, int n, const double *q, const double *v, const double *u, double *M,
+                              double *a);
+
+/* ---- the OCP ---- */
+/* diagonal weights shared by the batch: Q [48], R [30], QN [48] */
+int alore_wb_set_weights(alore_wb_handle h, const double *Q, const double *R, const double *QN);
+/* measured states x0 [B][48], references xref [B][N+1][48], uref [B][N][30] (HOST pointers) */
+int alore_wb_set_problem(alore_wb_handle h, int B, const double *x0, const double *xref, const double *uref);
+/* iterate x [B][N+1][48], u [B][N][30] */
+int alore_wb_set_iterate(alore_wb_handle h, int B, const double *x, const double *u);
+int alore_wb_get_iterate(alore_wb_handle h, int B, double *x, double *u);
+/* linearisation about the current iterate, copied out for inspection: A [B][N][48][48], Bm [B][N][48][30],
+ * next [B][N][48] = f(x_k, u_k); any may be NULL */
+int alore_wb_linearize(alore_wb_handle h, int B, double *A, double *Bm, double *next);
+/* n_iter real-time iterations (linearise + Riccati + step) for B problems; asynchronous on `stream` */
+int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void *stream);
+/* the LQ step of the last iteration: dx [B][N+1][48], du [B][N][30] (before clipping), HOST pointers; synchronises */
+int alore_wb_last_step(alore_wb_handle h, int B, double *dx, double *du);
+/* kernel times of the last alore_wb_rti call in ms (linearisation, Riccati), measured with HIP events */
+int alore_wb_last_times(alore_wb_handle h, float *linearize_ms, float *riccati_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

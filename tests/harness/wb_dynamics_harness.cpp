@@ -1,0 +1,15 @@
+// Host build of csrc/wb_dynamics.h (the kernels' own RNEA source) for the CPU test suite.
+#include "../../alore_legged_manipulator_amd/csrc/wb_dynamics.h"
+
+extern "C" void wbh_rnea(const double* q, const double* v, const double* a, const double* f, double g, double* tau)
+{
+    wb::Eval e{q, v, a, f, 1.0, 1.0, 1.0, -1, -1, -1, -1, 0, 0, 0, 0, g};
+    wb::rnea(e, wb::Sink{tau, 1, 1.0, 0});
+}
+// M column j by a unit acceleration, the way the stage kernel builds the mass matrix
+extern "C" void wbh_mass_column(const double* q, int j, double* col)
+{
+    double z[24] = {0};
+    wb::Eval e{q, z, z, z, 0.0, 0.0, 0.0, -1, -1, j, -1, 0, 0, 1.0, 0, 0.0};
+    wb::rnea(e, wb::Sink{col, 1, 1.0, 0});
+}

@@ -129,3 +129,26 @@ def test_compat_library_exports_the_model_functions():
             outs.append(np.concatenate([r, d]))
         for o in outs[1:]:
             assert np.array_equal(outs[0], o)
+
+
+@pytest.mark.parametrize("hdr,prefix,minimum", [("alore_ltv_mpc.h", "alore_ltv_", 8), ("alore_wb.h", "alore_wb_", 14)])
+def test_ltv_and_whole_body_headers_are_exported(hdr, prefix, minimum):
+    from alore_legged_manipulator_amd import _lib
+    lib = _lib.load()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", hdr)).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(%s[a-z_]+)\s*\(" % prefix, src)))
+    assert len(names) >= minimum
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in {hdr} but not exported"
+
+
+def test_no_whole_body_or_ltv_solver_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from alore_legged_manipulator_amd.ltv_mpc import BatchedLtvMpc, LtvError
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody, WbError
+    with pytest.raises(WbError):
+        BatchedWholeBody(4)
+    with pytest.raises(LtvError):
+        BatchedLtvMpc(4)

@@ -1,0 +1,135 @@
+"""Whole-body class on the GPU (include/alore_wb.h) against the float64 spatial-algebra oracle (oracle/wb_oracle.py;
+no reference implementation exists: PARITY UNPINNED, the oracle is pinned by physics identities in
+tests/test_wb_oracle.py).  Tolerances: the dynamics are float64 on both sides (different formulations: 1e-10);
+derivatives are central differences on both sides (1e-6 relative to the block scale); the Riccati sweep runs on the
+float32 matrix cores and is compared with a float64 dense KKT solve of the SAME LQ problem."""
+import numpy as np
+import pytest
+
+from oracle.wb_oracle import Model, linearize, solve_lq, step
+from tests.wb_cases import make_problems, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    return Model()
+
+
+def sample(model, rng, n):
+    q = np.stack([np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-0.8, 0.8, 3), rng.uniform(model.lower, model.upper)]) for _ in range(n)])
+    return q, rng.normal(0, 0.5, (n, 24)), rng.normal(0, 1.0, (n, 24)), rng.normal(0, 60.0, (n, 12))
+
+
+def test_model_table_compiled_into_the_library(model):
+    from alore_legged_manipulator_amd.whole_body import model_info
+    info = model_info()
+    assert np.allclose(info["masses"], model.mass) and np.allclose(info["effort"], model.effort)
+    assert np.allclose(info["lower"], model.lower) and np.allclose(info["upper"], model.upper)
+
+
+def test_rnea_matches_the_oracle(model):
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    eng = BatchedWholeBody(8)
+    rng = np.random.default_rng(31)
+    q, v, a, f = sample(model, rng, 96)
+    tau = eng.rnea(q, v, a, f)
+    tau0 = eng.rnea(q, v, a, None, gravity=False)
+    for i in range(96):
+        ref = model.rnea(q[i], v[i], a[i], f[i].reshape(4, 3))
+        assert np.max(np.abs(tau[i] - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref))), i
+        assert np.max(np.abs(tau0[i] - model.rnea(q[i], v[i], a[i], None, gravity=False))) < 1e-9
+
+
+def test_mass_matrix_and_forward_dynamics(model):
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    eng = BatchedWholeBody(8)
+    rng = np.random.default_rng(32)
+    q, v, _, f = sample(model, rng, 48)
+    u = np.concatenate([rng.normal(0, 5, (48, 18)), f], axis=1)
+    M, a = eng.forward_dynamics(q, v, u)
+    for i in range(48):
+        Mo = model.crba(q[i])
+        assert np.max(np.abs(M[i] - Mo)) < 1e-10 * np.max(np.abs(Mo))
+        ao = model.aba(q[i], v[i], u[i, :18], u[i, 18:].reshape(4, 3))      # the articulated-body algorithm: a third route
+        assert np.max(np.abs(a[i] - ao)) < 1e-8 * max(1.0, np.max(np.abs(ao))), i
+
+
+def test_linearisation_of_the_discrete_dynamics(model):
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    B, N, dt = 3, 4, 0.01
+    eng = BatchedWholeBody(B, N, dt)
+    x0, xref, uref, xi, ui = make_problems(model, B, N, seed=5)
+    rng = np.random.default_rng(6)
+    xi = xi + 0.02 * rng.normal(size=xi.shape); ui = ui + rng.normal(0, 2.0, ui.shape)
+    eng.set_iterate(xi, ui)
+    A, Bm, nxt = eng.linearize()
+    for b in range(B):
+        for k in (0, N - 1):
+            Ao, Bo = linearize(model, xi[b, k], ui[b, k], dt)
+            assert np.max(np.abs(nxt[b, k] - step(model, xi[b, k], ui[b, k], dt))) < 1e-10
+            assert np.max(np.abs(A[b, k] - Ao)) < 2e-6 * max(1.0, np.max(np.abs(Ao))), (b, k, np.max(np.abs(A[b, k] - Ao)))
+            assert np.max(np.abs(Bm[b, k] - Bo)) < 2e-6 * max(1.0, np.max(np.abs(Bo))), (b, k, np.max(np.abs(Bm[b, k] - Bo)))
+
+
+def lq_reference(model, eng, x0, xref, uref, xi, ui, b, N):
+    """float64 dense KKT solve of the LQ problem the kernel solved (its own A, B; float64 defects and gradients)"""
+    Q, R, QN = weights()
+    A, Bm, nxt = eng._lin
+    d = [nxt[b, k] - xi[b, k + 1] for k in range(N)]
+    gx = [Q * (xi[b, k] - xref[b, k]) for k in range(N)]
+    gu = [R * (ui[b, k] - uref[b, k]) for k in range(N)]
+    gN = QN * (xi[b, N] - xref[b, N])
+    return solve_lq(list(A[b]), list(Bm[b]), d, np.diag(Q), np.diag(R), np.diag(QN), gx, gu, gN, x0[b] - xi[b, 0])
+
+
+def test_riccati_step_on_the_matrix_cores_matches_a_float64_kkt_solve(model):
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    B, N, dt = 6, 20, 0.01
+    eng = BatchedWholeBody(B, N, dt)
+    x0, xref, uref, xi, ui = make_problems(model, B, N, seed=9)
+    eng.set_weights(*weights())
+    eng.set_problem(x0, xref, uref)
+    eng.set_iterate(xi, ui)
+    eng._lin = eng.linearize()
+    eng.rti(1)
+    dx, du = eng.last_step()
+    worst_x = worst_u = 0.0
+    for b in range(B):
+        rx, ru = lq_reference(model, eng, x0, xref, uref, xi, ui, b, N)
+        worst_x = max(worst_x, np.max(np.abs(dx[b] - rx)) / max(1e-9, np.max(np.abs(rx))))
+        worst_u = max(worst_u, np.max(np.abs(du[b] - ru)) / max(1e-9, np.max(np.abs(ru))))
+    print(f"float32 MFMA Riccati vs float64 KKT: rel err dx {worst_x:.2e} du {worst_u:.2e}")
+    assert worst_x < 1e-4 and worst_u < 1e-4   # measured 7e-6 / 2e-5
+    x1, u1 = eng.get_iterate()
+    eff = model.effort
+    assert np.allclose(x1, xi + dx, atol=1e-12)
+    assert np.all(np.abs(u1[:, :, :18]) <= eff + 1e-12)
+
+
+def test_real_time_iterations_converge_to_the_stance(model):
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    B, N, dt = 16, 20, 0.01
+    eng = BatchedWholeBody(B, N, dt)
+    x0, xref, uref, xi, ui = make_problems(model, B, N, seed=11, spread=0.5)
+    Q, R, QN = weights()
+    eng.set_weights(Q, R, QN)
+    eng.set_problem(x0, xref, uref)
+    eng.set_iterate(xi, ui)
+
+    def cost_and_defect(x, u):
+        c = 0.5 * np.sum(Q * (x[:, :-1] - xref[:, :-1]) ** 2) + 0.5 * np.sum(R * (u - uref) ** 2) + 0.5 * np.sum(QN * (x[:, -1] - xref[:, -1]) ** 2)
+        dfc = max(np.max(np.abs(step(model, x[b, k], u[b, k], dt) - x[b, k + 1])) for b in (0, B - 1) for k in (0, N // 2, N - 1))
+        return c / B, dfc
+    steps = []
+    for it in range(6):
+        eng.rti(1)
+        dx, du = eng.last_step()
+        steps.append(float(np.max(np.abs(dx))))
+    x, u = eng.get_iterate()
+    c, dfc = cost_and_defect(x, u)
+    print("step sizes", ["%.2e" % s for s in steps], "cost/problem %.3f defect %.2e" % (c, dfc))
+    assert steps[-1] < 1e-3 * steps[0] + 1e-6     # Newton-type contraction
+    assert dfc < 1e-5                               # the trajectory is dynamically consistent
+    assert np.max(np.abs(x[:, 0] - x0)) < 1e-6

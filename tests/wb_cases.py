@@ -1,0 +1,52 @@
+"""Synthetic whole-body problems shared by the tests and bench.py (q ~ U(limits), v ~ N(0, 0.5^2); here
+around a standing pose so that the OCP is meaningful).  NumPy only."""
+import numpy as np
+
+STAND_LEG = [0.0, 0.8, -1.6]
+STAND_ARM = [0.0, 1.0, -1.2, 0.2, 0.0, 0.0]
+
+
+def stand_q(height=0.55):
+    q = np.zeros(24)
+    q[2] = height
+    q[6:18] = np.tile(STAND_LEG, 4)
+    q[18:] = STAND_ARM
+    return q
+
+
+def equilibrium_inputs(model, q):
+    """least-norm foot forces that balance the base wrench at rest, and the joint torques that go with them"""
+    cols = np.zeros((24, 12))
+    z = np.zeros(24)
+    g0 = model.rnea(q, z, z)
+    for k in range(12):
+        f = np.zeros(12); f[k] = 1.0
+        cols[:, k] = g0 - model.rnea(q, z, z, f.reshape(4, 3))      # = J_c' e_k
+    f = np.linalg.lstsq(cols[:6], g0[:6], rcond=None)[0]
+    tau = (g0 - cols @ f)[6:]
+    return np.concatenate([tau, f])
+
+
+def weights():
+    Q = np.concatenate([np.full(3, 200.0), np.full(3, 200.0), np.full(18, 20.0), np.full(6, 2.0), np.full(18, 0.5)])
+    R = np.concatenate([np.full(18, 2e-3), np.full(12, 2e-4)])
+    return Q, R, 10.0 * Q
+
+
+def make_problems(model, B, N, seed=0, spread=1.0):
+    rng = np.random.default_rng(seed)
+    qs = stand_q()
+    ueq = equilibrium_inputs(model, qs)
+    x0 = np.zeros((B, 48)); xref = np.zeros((B, N + 1, 48)); uref = np.tile(ueq, (B, N, 1))
+    for b in range(B):
+        q = qs.copy()
+        q[:3] += spread * rng.uniform(-0.03, 0.03, 3)
+        q[3:6] += spread * rng.uniform(-0.08, 0.08, 3)
+        q[6:] += spread * rng.uniform(-0.15, 0.15, 18)
+        q[6:] = np.clip(q[6:], model.lower + 0.02, model.upper - 0.02)
+        v = spread * rng.normal(0, 0.2, 24)
+        x0[b] = np.concatenate([q, v])
+        xref[b, :, :24] = qs
+    xinit = np.repeat(x0[:, None, :], N + 1, axis=1)
+    uinit = uref.copy()
+    return x0, xref, uref, xinit, uinit
