@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/alore_wb.h"
+#include "wave_linalg.h"
 #include "wb_dynamics.h"
 
 namespace wb {
@@ -54,26 +55,6 @@ struct StageLds {
     double vn[NV];       // v+
     double R0[9], E[9], Gq[3][6];
 };
-
-// x <- (L L')^-1 x, in place in LDS (x: one column of D, or a scratch vector); L = lower Cholesky factor, row stride MS.
-// Loops stay rolled: the vector lives in LDS, not in 48 registers, and the reads of L are wavefront broadcasts.
-__device__ __forceinline__ void chol_solve(const double* L, double* x)
-{
-#pragma unroll 1
-    for (int i = 0; i < NV; ++i) {
-        double s = x[i];
-#pragma unroll 4
-        for (int j = 0; j < i; ++j) s -= L[i * MS + j] * x[j];
-        x[i] = s / L[i * MS + i];
-    }
-#pragma unroll 1
-    for (int i = NV - 1; i >= 0; --i) {
-        double s = x[i];
-#pragma unroll 4
-        for (int j = i + 1; j < NV; ++j) s -= L[j * MS + i] * x[j];
-        x[i] = s / L[i * MS + i];
-    }
-}
 
 __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
 {
@@ -117,22 +98,24 @@ __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
             __syncthreads();
             if (g.M64 && lane < 24)
                 for (int i = 0; i < NV; ++i) g.M64[((size_t)item * NV + i) * NV + lane] = S.M[i * MS + lane];
-            // ---- Cholesky M = L L' in place (lower triangle), lanes = rows
-            for (int c = 0; c < NV; ++c) {
-                if (lane == c) S.M[c * MS + c] = sqrt(S.M[c * MS + c]);
+            // ---- M^-1 in place (lane i owns row i; wave_linalg.h), then a = M^-1 ([0; tau] - bias)
+            {
+                double row[NV];
+                const int rr = lane < NV ? lane : 0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) row[j] = S.M[rr * MS + j];
+                wavela::spd_inverse_rows<double, NV>(row, lane);
                 __syncthreads();
-                if (lane > c && lane < NV) S.M[lane * MS + c] /= S.M[c * MS + c];
-                __syncthreads();
-                if (lane > c && lane < NV) {
-                    const double lic = S.M[lane * MS + c];
-                    for (int j = c + 1; j <= lane; ++j) S.M[lane * MS + j] -= lic * S.M[j * MS + c];
+                if (lane < NV) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        S.M[lane * MS + j] = row[j];
+                        acc += row[j] * ((j >= 6 ? S.u[j - 6] : 0.0) - S.bias[j]);
+                    }
+                    S.a[lane] = acc;
                 }
-                __syncthreads();
             }
-            // ---- a = M^-1 ([0; tau] - bias)
-            if (lane < NV) S.a[lane] = (lane >= 6 ? S.u[lane - 6] : 0.0) - S.bias[lane];
-            __syncthreads();
-            if (lane == 0) chol_solve(S.M, S.a);
             __syncthreads();
             if (g.a64 && lane < NV) g.a64[(size_t)item * NV + lane] = S.a[lane];
             if (lane < NV) S.vn[lane] = S.v[lane] + g.dt * S.a[lane];
@@ -164,7 +147,18 @@ __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
     __syncthreads();
 
     // ---- M^-1 times the 75 columns
-    for (int col = lane; col < NCOL; col += 64) chol_solve(S.M, S.D + col * MS);
+    for (int col = lane; col < NCOL; col += 64) { // column <- M^-1 column (M^-1 rows are wavefront broadcasts from LDS)
+        double r[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) r[i] = S.D[col * MS + i];
+#pragma unroll 4
+        for (int i = 0; i < NV; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) acc += S.M[i * MS + j] * r[j];
+            S.D[col * MS + i] = acc;
+        }
+    }
     __syncthreads();
 
     // ---- assembly.  Z(var, i) = d a_i / d var;  dvn_i / d var = dt Z + [var is v_i]
@@ -267,7 +261,7 @@ struct RicLds {
 //   TA: A is stored transposed (element (i, k) at A[k * lda + i]);  TB likewise for B
 template <bool TA, bool TB>
 __device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* Bm, int ldb, int K, int i0, int j0, float* Cm, int ldc,
-                                          const float* Cinit, int ldi, float alpha_diag, const double* diag)
+                                          const float* Cinit, int ldi, float alpha_diag, const double* diag, float scale = 1.f)
 {
     const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -281,7 +275,7 @@ __device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + 4 * kq + r, col = j0 + r16;
-        float v = acc[r];
+        float v = scale * acc[r];
         if (Cinit) v += Cinit[row * ldi + col];
         if (diag && row == col) v += alpha_diag * (float)diag[row];
         Cm[row * ldc + col] = v;
@@ -349,41 +343,52 @@ __global__ __launch_bounds__(256) void riccati_kernel(RicArgs g)
             S.Quu[i * LDU + i] += i < NU ? (float)Rd[i] : 1.f;
         }
         __syncthreads();
-        // ---- Cholesky of Quu (wave 0, lanes = rows; wave-synchronous)
+        // ---- Quu^-1 (wave 0: lane i owns row i, Gauss-Jordan in registers; wave_linalg.h) -> Qinv (in the PB buffer)
+        float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
+        float* Rres = S.PA;   // PA is dead once Qxx and Qux exist
         if (wave == 0) {
-            const int i = tid;
-            for (int c = 0; c < 32; ++c) {
-                if (i == c) S.Quu[c * LDU + c] = sqrtf(S.Quu[c * LDU + c]);
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of the wave are visible to its other lanes
-                if (i > c && i < 32) S.Quu[i * LDU + c] /= S.Quu[c * LDU + c];
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                if (i > c && i < 32) {
-                    const float lic = S.Quu[i * LDU + c];
-                    for (int j = c + 1; j <= i; ++j) S.Quu[i * LDU + j] -= lic * S.Quu[j * LDU + c];
-                }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
+            float row[32];
+            const int rr = tid & 31;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) row[j] = S.Quu[rr * LDU + j];
+            wavela::spd_inverse_rows<float, 32>(row, tid);
+            if (tid < 32) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) Qinv[tid * LDU + j] = row[j];
             }
         }
         __syncthreads();
-        // ---- K = -Quu^-1 Qux (48 columns), kff = -Quu^-1 qu: one lane per right-hand side, in place
-        if (tid < 49) {
-            float* col = tid < 48 ? (S.Qux + tid) : S.qu;
-            const int cs = tid < 48 ? LDX : 1;
-            float* out = tid < 48 ? (S.K + tid) : S.kff;
-            for (int i = 0; i < 32; ++i) {
-                float acc = col[i * cs];
-                for (int j = 0; j < i; ++j) acc -= S.Quu[i * LDU + j] * out[j * cs];
-                out[i * cs] = acc / S.Quu[i * LDU + i];
-            }
-            for (int i = 31; i >= 0; --i) {
-                float acc = out[i * cs];
-                for (int j = i + 1; j < 32; ++j) acc -= S.Quu[j * LDU + i] * out[j * cs];
-                out[i * cs] = acc / S.Quu[i * LDU + i];
-            }
-            for (int i = 0; i < 32; ++i) out[i * cs] = -out[i * cs];
+        // ---- K0 = -Qinv Qux (6 tiles, K = 32), kff0 = -Qinv qu
+        for (int t = wave; t < 6; t += 4)
+            mfma_tile<false, false>(Qinv, LDU, S.Qux, LDX, 32, (t / 3) * 16, (t % 3) * 16, S.K, LDX, nullptr, 0, 0.f, nullptr, -1.f);
+        if (tid >= 192 && tid < 224) {
+            const int i = tid - 192;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.qu[j];
+            S.kff[i] = -acc;
+        }
+        __syncthreads();
+        // ---- one refinement step against Quu itself (the explicit float32 inverse alone costs a factor 40 in accuracy):
+        //      R = Qux + Quu K0,  K = K0 - Qinv R;   r = qu + Quu kff0,  kff = kff0 - Qinv r
+        for (int t = wave; t < 6; t += 4)
+            mfma_tile<false, false>(S.Quu, LDU, S.K, LDX, 32, (t / 3) * 16, (t % 3) * 16, Rres, LDX, S.Qux, LDX, 0.f, nullptr);
+        if (tid >= 192 && tid < 224) {
+            const int i = tid - 192;
+            float acc = S.qu[i];
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) acc += S.Quu[i * LDU + j] * S.kff[j];
+            S.duk[i] = acc; // residual of the feed-forward term (duk is free during the backward sweep)
+        }
+        __syncthreads();
+        for (int t = wave; t < 6; t += 4)
+            mfma_tile<false, false>(Qinv, LDU, Rres, LDX, 32, (t / 3) * 16, (t % 3) * 16, S.K, LDX, S.K, LDX, 0.f, nullptr, -1.f);
+        if (tid >= 192 && tid < 224) {
+            const int i = tid - 192;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.duk[j];
+            S.kff[i] -= acc;
         }
         __syncthreads();
         // feedback gains to HBM

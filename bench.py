@@ -464,6 +464,35 @@ def main():
             del e10, pl
         except Exception as e:  # pragma: no cover
             extras["backend_to_nmpc_pipeline"] = {"error": f"{type(e).__name__}: {e}"}
+        # whole-body class (BASELINE configs[2]): B = 4096 B2 + Z1 problems, N = 20, one real-time iteration =
+        # linearisation kernel (RNEA-based, float64) + Riccati kernel (float32 MFMA 16x16x4)
+        try:
+            from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from wb_cases import make_problems_fast, weights as wb_weights
+            Bw = B
+            wbe = BatchedWholeBody(Bw, N, 0.01, device=local_rank)
+            x0w, xrefw, urefw, xiw, uiw = make_problems_fast(Bw, N, seed=3)
+            wbe.set_weights(*wb_weights())
+            wbe.set_problem(x0w, xrefw, urefw)
+            wbe.set_iterate(xiw, uiw)
+            wbe.rti(1); torch.cuda.synchronize(dev)
+            wbe.set_iterate(xiw, uiw)
+            t_a = time.perf_counter()
+            wbe.rti(1); torch.cuda.synchronize(dev)
+            t_b = time.perf_counter()
+            lin_ms, ric_ms = wbe.last_times()
+            dxw, duw = wbe.last_step()
+            # useful flops of the Riccati sweep per problem: 43 MFMA tiles/stage (15 + 19 with K = 48, 9 with K = 32)
+            mfma_flops = N * ((15 + 19) * 12 + 9 * 8) * 2048.0
+            extras["whole_body_b2z1"] = {"problems": Bw, "horizon": N, "ms_linearize": lin_ms, "ms_riccati": ric_ms,
+                                         "ms_wall_one_rti": (t_b - t_a) * 1e3, "solves_per_s": Bw / ((lin_ms + ric_ms) * 1e-3),
+                                         "mfma_f32_TFLOPs_riccati": Bw * mfma_flops / (ric_ms * 1e-3) / 1e12,
+                                         "mfma_f32_frac_of_peak": Bw * mfma_flops / (ric_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                         "first_step_max": float(np.max(np.abs(dxw))), "finite": bool(np.isfinite(dxw).all() and np.isfinite(duw).all())}
+            del wbe
+        except Exception as e:  # pragma: no cover
+            extras["whole_body_b2z1"] = {"error": f"{type(e).__name__}: {e}"}
         # LTV-MPC class (the `mpc` node): getCmd for B robots, 5 relinearisation passes, cold and warm working sets
         try:
             from alore_legged_manipulator_amd.ltv_mpc import BatchedLtvMpc

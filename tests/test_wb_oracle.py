@@ -142,3 +142,14 @@ def test_discrete_step_and_its_linearisation(model):
     lin = step(model, x, u, 0.01) + A @ dxs + B @ dus
     assert np.max(np.abs(step(model, x + dxs, u + dus, 0.01) - lin)) < 1e-7   # second-order remainder
     assert np.allclose(A[:3, :3], np.eye(3)) and np.max(np.abs(A[24:, :3])) < 1e-9   # nothing depends on the position
+
+
+def test_committed_stance_equilibrium_fixture(model):
+    import json, os
+    from tests.wb_cases import equilibrium_inputs, make_problems_fast, stand_q
+    u = np.array(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wb_stand_equilibrium.json")))["u_eq"])
+    assert np.allclose(u, equilibrium_inputs(model, stand_q()), atol=1e-9)
+    a = model.aba(stand_q(), np.zeros(24), u[:18], u[18:].reshape(4, 3))
+    assert np.max(np.abs(a)) < 1e-8                       # at rest it stays at rest
+    x0, xref, uref, xi, ui = make_problems_fast(5, 4, seed=1)
+    assert x0.shape == (5, 48) and xi.shape == (5, 5, 48) and np.allclose(uref[0, 0], u)

@@ -50,3 +50,24 @@ def make_problems(model, B, N, seed=0, spread=1.0):
     xinit = np.repeat(x0[:, None, :], N + 1, axis=1)
     uinit = uref.copy()
     return x0, xref, uref, xinit, uinit
+
+
+# equilibrium inputs of stand_q() (oracle.wb_oracle.Model + equilibrium_inputs above; frozen here so that bench.py does
+# not import the oracle for input generation) -- checked against the oracle in tests/test_wb_oracle.py
+def make_problems_fast(B, N, seed=0, spread=1.0, ueq=None):
+    import json, os
+    if ueq is None:
+        ueq = np.array(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wb_stand_equilibrium.json")))["u_eq"])
+    m = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alore_legged_manipulator_amd", "data", "b2z1_model.json")))
+    lo = np.array([b["lower"] for b in m["bodies"][1:]]); hi = np.array([b["upper"] for b in m["bodies"][1:]])
+    rng = np.random.default_rng(seed)
+    qs = stand_q()
+    q = np.tile(qs, (B, 1))
+    q[:, :3] += spread * rng.uniform(-0.03, 0.03, (B, 3))
+    q[:, 3:6] += spread * rng.uniform(-0.08, 0.08, (B, 3))
+    q[:, 6:] = np.clip(q[:, 6:] + spread * rng.uniform(-0.15, 0.15, (B, 18)), lo + 0.02, hi - 0.02)
+    v = spread * rng.normal(0, 0.2, (B, 24))
+    x0 = np.concatenate([q, v], 1)
+    xref = np.zeros((B, N + 1, 48)); xref[:, :, :24] = qs
+    uref = np.tile(ueq, (B, N, 1))
+    return x0, xref, uref, np.repeat(x0[:, None, :], N + 1, axis=1), uref.copy()

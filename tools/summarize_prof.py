@@ -3,6 +3,13 @@
 summary for profiles/ (our kernels in full, everything else as one line)."""
 import csv, glob, os, sys
 
+OURS = ("nmpc::", "wb::", "ltv::", "backend::")
+
+
+def ours(name):
+    return any(k in name for k in OURS)
+
+
 def from_rocpd(db, lines):
     """rocprofv3 >= 7 writes a rocpd SQLite database unless --output-format csv is given."""
     import sqlite3
@@ -12,14 +19,16 @@ def from_rocpd(db, lines):
     other = 0
     for name, n, tot, avg, mn, mx in c.execute(
             "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name"):
-        if "nmpc::" in name:
+        if ours(name):
             lines.append(f"{name},{n},{tot},{avg:.1f},{mn},{mx}")
         else:
             other += tot
     lines.append(f"(all non-nmpc kernels: torch fills/copies of the bench setup),,{other},,,")
     lines.append("# launch geometry / resources per nmpc kernel")
     for r in c.execute("select distinct name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
-                       "from kernels where name like '%nmpc::%'"):
+                       "from kernels"):
+        if not ours(r[0]):
+            continue
         lines.append(f"{r[0]}: grid={r[1]} wg={r[2]} VGPR={r[3]} AGPR={r[4]} SGPR={r[5]} LDS={r[6]} scratch={r[7]}")
 
 
@@ -41,14 +50,14 @@ def main(d, out):
         lines.append("name,calls,total_ns,avg_ns,pct,min_ns,max_ns,stddev")
         other = 0
         for r in rows:
-            if "nmpc::" in r["Name"]:
+            if ours(r["Name"]):
                 lines.append(",".join([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                                        r["MinNs"], r["MaxNs"], r["StdDev"]]))
             else:
                 other += int(r["TotalDurationNs"])
         lines.append(f"(all non-nmpc kernels: torch fills/copies of the bench setup),,{other},,,,,")
     for f in trace:
-        rows = [r for r in csv.DictReader(open(f)) if "rti_kernel" in r["Kernel_Name"] or "nmpc::" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if ours(r["Kernel_Name"])]
         seen = set()
         lines.append(f"# {os.path.basename(f)}: launch geometry / resources per nmpc kernel")
         for r in rows:
