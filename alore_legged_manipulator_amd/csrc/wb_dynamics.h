@@ -89,6 +89,22 @@ struct Eval {
     int uq, uv, ua, uf; // index that receives an increment (-1: none)
     double dq, dv, da, df;
     double g;          // gravity (0 to switch it off)
+    // sin / cos of the 21 angles q[3..23] at the base point (sin at [2 t], cos at [2 t + 1], t = index - 3), or NULL;
+    // with a table, the angle that carries the increment dq is rotated by (sin dq, cos dq) = (ps, pc) instead of
+    // being recomputed: one sincos per lane instead of 21 per evaluation
+    const double* trig = nullptr;
+    double ps = 0.0, pc = 1.0;
+    WB_FN void SC(int i, double* s, double* c) const
+    {
+        if (trig) {
+            const double s0 = trig[2 * (i - 3)], c0 = trig[2 * (i - 3) + 1];
+            const bool me = i == uq;
+            *s = me ? s0 * pc + c0 * ps : s0;
+            *c = me ? c0 * pc - s0 * ps : c0;
+        } else {
+            sincos(Q(i), s, c);
+        }
+    }
     WB_FN double Q(int i) const { return q[i] + (i == uq ? dq : 0.0); }
     WB_FN double V(int i) const { return sv * v[i] + (i == uv ? dv : 0.0); }
     WB_FN double A(int i) const { return sa * a[i] + (i == ua ? da : 0.0); }
@@ -113,6 +129,7 @@ struct Sink {
 struct BaseRot {
     double cr, sr, cp, sp, cy, sy;
     WB_FN void set(double r, double p, double y) { sincos(r, &sr, &cr); sincos(p, &sp, &cp); sincos(y, &sy, &cy); }
+    WB_FN void set(const struct Eval& e);
     WB_FN V3 toBase(V3 v) const { return rotT<0>(cr, sr, rotT<1>(cp, sp, rotT<2>(cy, sy, v))); }
     WB_FN V3 toWorld(V3 v) const { return rot<2>(cy, sy, rot<1>(cp, sp, rot<0>(cr, sr, v))); }
     // d(rpy)/dt = E omega_body
@@ -122,6 +139,8 @@ struct BaseRot {
         return {w.x + sr * tp * w.y + cr * tp * w.z, cr * w.y - sr * w.z, (sr * w.y + cr * w.z) / cp};
     }
 };
+
+WB_FN void BaseRot::set(const Eval& e) { e.SC(3, &sr, &cr); e.SC(4, &sp, &cp); e.SC(5, &sy, &cy); }
 
 template <int FIRST, int D, int LEN, int FOOT>
 struct Chain {
@@ -133,7 +152,7 @@ struct Chain {
         constexpr int AX = b2z1::AXIS[I];
         const V3 p = origin<I>();
         double s, c;
-        sincos(e.Q(5 + I), &s, &c);
+        e.SC(5 + I, &s, &c);
         const double qd = e.V(5 + I), qdd = e.A(5 + I);
         const V3 ax = unit<AX>();
         const V3 wl = rotT<AX>(c, s, w);
@@ -165,7 +184,7 @@ struct Chain {
 WB_FN void rnea(const Eval& e, const Sink& tau)
 {
     BaseRot R;
-    R.set(e.Q(3), e.Q(4), e.Q(5));
+    R.set(e);
     const V3 w0 = {e.V(0), e.V(1), e.V(2)}, vl = {e.V(3), e.V(4), e.V(5)};
     const V3 wd0 = {e.A(0), e.A(1), e.A(2)};
     const V3 ac0 = V3{e.A(3), e.A(4), e.A(5)} + cross(w0, vl) + R.toBase({0.0, 0.0, e.g});

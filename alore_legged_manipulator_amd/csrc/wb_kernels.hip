@@ -11,10 +11,12 @@
 //   75 lanes (2 rounds): M^-1 times the 75 right-hand sides -> da/dq, da/dv, da/du
 //   assembly of A_k (48 x 48), B_k (48 x 30) and f(x_k, u_k) for the semi-implicit Euler step, written to HBM
 //   (float32 for the Riccati kernel, float64 on request).
-// Kernel 2, riccati_kernel: one workgroup (4 wavefronts) per problem, float32 MFMA 16x16x4 on the dense blocks.
+// Kernel 2, riccati_kernel: one workgroup (8 wavefronts) per problem, float32 MFMA 16x16x4 on the dense blocks.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -26,9 +28,17 @@
 
 namespace wb {
 
+// Diagnostic phase stamps (alore_wb_debug_stamps): workgroup 0 adds the cycles since its previous stamp to slot i.
+#define WB_STAMP(buf, i)                                                                     \
+    if ((buf) && blockIdx.x == 0 && threadIdx.x == 0) {                                      \
+        const long long now_ = (long long)__builtin_readcyclecounter();                      \
+        (buf)[i] += now_ - (buf)[31];                                                        \
+        (buf)[31] = now_;                                                                    \
+    }
+
 constexpr int NQ = 24, NV = 24, NX = 48, NU = 30, NUP = 32; // NUP: input dimension padded to the MFMA tile
 constexpr int NCOL = 75;                                     // 21 (rpy, joints) + 24 (v) + 18 (tau) + 12 (f)
-constexpr double HQ = 1e-5, HV = 1e-3;                       // central-difference steps (RNEA is quadratic in v)
+constexpr double HQ = 1e-7, HV = 1e-7;                       // forward-difference steps (float64; A, B are stored in float32)
 
 struct StageArgs {
     const double* x; // [B][N+1][48]
@@ -43,6 +53,7 @@ struct StageArgs {
     double* B64;     // optional [n][48][30]
     double* M64;     // optional [n][24][24]
     double* a64;     // optional [n][24]
+    long long* stamps; // optional [32] diagnostic
 };
 
 constexpr int MS = 25; // row stride of M / column stride of D in LDS (doubles)
@@ -53,6 +64,8 @@ struct StageLds {
     double bias[NV];
     double D[NCOL * MS]; // D[col][i]
     double vn[NV];       // v+
+    double trig[42];     // sin, cos of rpy and the joint angles at the base point
+    double tb[NV];       // RNEA at the base point (= [0; tau] up to the rounding of M^-1)
     double R0[9], E[9], Gq[3][6];
 };
 
@@ -61,19 +74,26 @@ __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
     __shared__ StageLds S;
     const int item = blockIdx.x;
     if (item >= g.n_items) return;
+    if (g.stamps && blockIdx.x == 0 && threadIdx.x == 0) g.stamps[31] = (long long)__builtin_readcyclecounter();
     const int lane = threadIdx.x;
     const int b = item / g.N, k = item % g.N;
     const double* xk = g.x + ((size_t)b * (g.N + 1) + k) * NX;
     const double* uk = g.u + ((size_t)b * g.N + k) * NU;
     if (lane < NQ) { S.q[lane] = xk[lane]; S.v[lane] = xk[NQ + lane]; S.zero[lane] = 0.0; }
     if (lane < NU) S.u[lane] = uk[lane];
+    if (lane < 21) sincos(xk[3 + lane], &S.trig[2 * lane], &S.trig[2 * lane + 1]);
     __syncthreads();
+    WB_STAMP(g.stamps, 0)
 
-    // Three passes over ONE inlined copy of the RNEA (the loop is kept rolled): pass 0 = round 1 (M columns, bias,
-    // foot-force columns), passes 1 and 2 = the +h and -h evaluations of round 2.  Outputs go straight to LDS.
+    // Two passes over ONE inlined copy of the RNEA (the loop is kept rolled): pass 0 = M columns, bias, foot-force
+    // columns; pass 1 = the 45 perturbed evaluations of d RNEA / d (rpy, joints, v) and the base point (forward
+    // differences).  Outputs go straight to LDS; sines and cosines come from the table of the base point.
+    double ph_s, ph_c;
+    sincos(HQ, &ph_s, &ph_c);
 #pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = 0; pass < 2; ++pass) {
         Eval e{S.q, S.v, S.zero, S.u + 18, 0.0, 0.0, 0.0, -1, -1, -1, -1, 0.0, 0.0, 0.0, 0.0, 0.0};
+        e.trig = S.trig; e.ps = ph_s; e.pc = ph_c;
         Sink sink{S.D + lane * MS, 1, 1.0, 0};
         bool active;
         if (pass == 0) {
@@ -82,20 +102,14 @@ __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
             else if (lane == 24) { e.sv = 1.0; e.sf = 1.0; e.g = b2z1::GRAVITY; sink.out = S.bias; }
             else { e.uf = lane - 25; e.df = 1.0; sink.out = S.D + (63 + lane - 25) * MS; sink.scale = -1.0; } // RNEA = ... - J_c' f
         } else {
-            active = lane < 45;
-            const double hh = lane < 21 ? HQ : HV, h = pass == 1 ? hh : -hh;
+            active = lane < 46;
             e.a = S.a; e.sv = 1.0; e.sa = 1.0; e.sf = 1.0; e.g = b2z1::GRAVITY;
-            if (lane < 21) { e.uq = 3 + lane; e.dq = h; } else { e.uv = lane - 21; e.dv = h; }
-            if (pass == 2) { sink.mode = 1; sink.scale = -0.5 / hh; } // D = -(tau+ - tau-) / 2h
+            if (lane < 21) { e.uq = 3 + lane; e.dq = HQ; } else if (lane < 45) { e.uv = lane - 21; e.dv = HV; } else sink.out = S.tb;
         }
         if (active) rnea(e, sink);
         if (pass == 0) {
-            if (lane >= 37 && lane < 37 + 18) { // right-hand sides of da / dtau: unit vectors on the joint rows
-                const int j = lane - 37;
-#pragma unroll
-                for (int i = 0; i < NV; ++i) S.D[(45 + j) * MS + i] = (i == 6 + j) ? 1.0 : 0.0;
-            }
             __syncthreads();
+    WB_STAMP(g.stamps, 1)
             if (g.M64 && lane < 24)
                 for (int i = 0; i < NV; ++i) g.M64[((size_t)item * NV + i) * NV + lane] = S.M[i * MS + lane];
             // ---- M^-1 in place (lane i owns row i; wave_linalg.h), then a = M^-1 ([0; tau] - bias)
@@ -117,12 +131,25 @@ __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
                 }
             }
             __syncthreads();
+            if (lane >= 24 && lane < 24 + 18) { // da / dtau_j = column 6 + j of M^-1 (= its row: symmetric)
+                const int j = lane - 24;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) S.D[(45 + j) * MS + i] = S.M[(6 + j) * MS + i];
+            }
+    WB_STAMP(g.stamps, 2)
             if (g.a64 && lane < NV) g.a64[(size_t)item * NV + lane] = S.a[lane];
             if (lane < NV) S.vn[lane] = S.v[lane] + g.dt * S.a[lane];
             __syncthreads();
+    WB_STAMP(g.stamps, 3)
         }
     }
     __syncthreads();
+    WB_STAMP(g.stamps, 4)
+    if (lane < 45) { // D <- -(RNEA(x + h e) - RNEA(x)) / h
+        const double sc = -1.0 / (lane < 21 ? HQ : HV);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) S.D[lane * MS + i] = sc * (S.D[lane * MS + i] - S.tb[i]);
+    }
     if (lane >= 45 && lane < 48) { // derivative of the kinematic map G(q) v+ with respect to rpy (v+ fixed)
         const int c = lane - 45;
         const V3 wn = {S.vn[0], S.vn[1], S.vn[2]}, vl = {S.vn[3], S.vn[4], S.vn[5]};
@@ -145,9 +172,11 @@ __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
         }
     }
     __syncthreads();
+    WB_STAMP(g.stamps, 5)
 
-    // ---- M^-1 times the 75 columns
-    for (int col = lane; col < NCOL; col += 64) { // column <- M^-1 column (M^-1 rows are wavefront broadcasts from LDS)
+    // ---- M^-1 times the 57 columns that need it (45 derivative columns, 12 foot-force columns)
+    if (lane < 57) {
+        const int col = lane < 45 ? lane : 63 + (lane - 45);
         double r[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) r[i] = S.D[col * MS + i];
@@ -160,33 +189,39 @@ __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
         }
     }
     __syncthreads();
+    WB_STAMP(g.stamps, 6)
 
-    // ---- assembly.  Z(var, i) = d a_i / d var;  dvn_i / d var = dt Z + [var is v_i]
+    // ---- assembly: lane = column c of [A | B] (78 + 2 padding columns, two rounds); its da / d(var) column is read
+    //      once, all 48 rows come from registers; for a fixed row the lanes store consecutive floats.
+    //      dvn_i / d var = dt Z_i + [var is v_i];  q rows: [row == var] + dt (G dvn + dG/drpy v+)
     const double dt = g.dt;
-    auto zcol = [](int c) -> int { return c < 3 ? -1 : (c < 24 ? c - 3 : (c < 48 ? 21 + c - 24 : 45 + c - 48)); }; // c: 0..77
-    auto dvn = [&](int i, int c, int zc) -> double { return (zc >= 0 ? dt * S.D[zc * MS + i] : 0.0) + ((c == 24 + i) ? 1.0 : 0.0); };
     float* A32 = g.A32 + (size_t)item * NX * NX;
     float* B32 = g.B32 + (size_t)item * NX * NUP;
-    for (int idx = lane; idx < NX * (NX + NUP); idx += 64) {
-        const int r = idx / (NX + NUP), cc = idx % (NX + NUP);
-        if (cc >= NX + NU) { B32[r * NUP + (cc - NX)] = 0.0f; continue; }
-        const int c = cc, zc = zcol(c);
-        double val;
-        if (r >= 24) val = dvn(r - 24, c, zc);
-        else if (r >= 6) val = ((r == c) ? 1.0 : 0.0) + dt * dvn(r, c, zc);
-        else {
-            const double* Gm = (r < 3) ? (S.R0 + 3 * r) : (S.E + 3 * (r - 3));
-            const int off = (r < 3) ? 3 : 0; // p rows use v_lin (3..5), rpy rows use omega (0..2)
-            double acc = Gm[0] * dvn(off, c, zc) + Gm[1] * dvn(off + 1, c, zc) + Gm[2] * dvn(off + 2, c, zc);
-            if (c >= 3 && c < 6) acc += S.Gq[c - 3][r];
-            val = ((r == c) ? 1.0 : 0.0) + dt * acc;
-        }
-        if (c < NX) {
-            A32[r * NX + c] = (float)val;
-            if (g.A64) g.A64[((size_t)item * NX + r) * NX + c] = val;
-        } else {
-            B32[r * NUP + (c - NX)] = (float)val;
-            if (g.B64) g.B64[((size_t)item * NX + r) * NU + (c - NX)] = val;
+    for (int c = lane; c < NX + NUP; c += 64) {
+        const int zc = c < 3 ? -1 : (c < 24 ? c - 3 : (c < 48 ? 21 + c - 24 : (c < NX + NU ? 45 + c - 48 : -1)));
+        double z[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) z[i] = (zc >= 0 ? dt * S.D[zc * MS + i] : 0.0) + ((c == 24 + i) ? 1.0 : 0.0);
+        const bool pad = c >= NX + NU;
+        float* out = c < NX ? (A32 + c) : (B32 + (c - NX));
+        const int ld = c < NX ? NX : NUP;
+        double* out64 = c < NX ? (g.A64 ? g.A64 + (size_t)item * NX * NX + c : nullptr) : ((g.B64 && !pad) ? g.B64 + (size_t)item * NX * NU + (c - NX) : nullptr);
+        const int ld64 = c < NX ? NX : NU;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            double val;
+            if (r >= 24) val = z[r - 24];
+            else if (r >= 6) val = ((r == c) ? 1.0 : 0.0) + dt * z[r];
+            else {
+                const double* Gm = (r < 3) ? (S.R0 + 3 * r) : (S.E + 3 * (r - 3));
+                const int off = (r < 3) ? 3 : 0; // p rows use v_lin (3..5), rpy rows use omega (0..2)
+                double acc = Gm[0] * z[off] + Gm[1] * z[off + 1] + Gm[2] * z[off + 2];
+                if (c >= 3 && c < 6) acc += S.Gq[c - 3][r];
+                val = ((r == c) ? 1.0 : 0.0) + dt * acc;
+            }
+            if (pad) val = 0.0;
+            out[r * ld] = (float)val;
+            if (out64) out64[(size_t)r * ld64] = val;
         }
     }
     if (lane < NX) { // f(x_k, u_k)
@@ -201,6 +236,7 @@ __global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
         }
         g.next[(size_t)item * NX + r] = val;
     }
+    WB_STAMP(g.stamps, 7)
 }
 
 // one lane per evaluation point (alore_wb_rnea)
@@ -215,7 +251,7 @@ __global__ __launch_bounds__(64) void rnea_kernel(int n, const double* q, const 
 
 
 // =====================================================================================================================
-// Kernel 2: Riccati sweep of the LQ problem of one real-time iteration.  One workgroup (4 wavefronts) per problem, all
+// Kernel 2: Riccati sweep of the LQ problem of one real-time iteration.  One workgroup (8 wavefronts) per problem, all
 // matrices of the current stage in LDS (float32), the dense products on the matrix cores:
 //   v_mfma_f32_16x16x4_f32:  lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives
 //   C[4 (l >> 4) + r][l & 15], r = 0..3  (cdna_hip_programming.md, "A/B operands ... 16x16x4").
@@ -246,47 +282,60 @@ struct RicArgs {
     double* du;          // [B][N][30]
     int N;
     int apply;           // 1: x += dx, u += du (clipped)
+    long long* stamps;   // optional [32] diagnostic
 };
 
+// 53.6 KB: three workgroups per CU.  Buffers are reused inside a stage: Qxx is written over P (dead after P A, P B, P d),
+// Quu^-1 lives in PB and the refinement residual in PA (both dead once Qxx, Qux, Quu exist), K lives in B (dead after
+// qu = gu + B' s), and the next cost-to-go accumulates in place over Qxx.
 struct RicLds {
-    float P[48 * LDX], A[48 * LDX], PA[48 * LDX], Qxx[48 * LDX];
+    float P[48 * LDX], A[48 * LDX], PA[48 * LDX];
     float B[48 * LDU], PB[48 * LDU];
-    float Qux[32 * LDX], K[32 * LDX];
+    float Qux[32 * LDX];
     float Quu[32 * LDU];
+    float wq[48], wr[32];
     float p[48], s[48], d[48], gx[48], qx[48], dxk[48], dxn[48];
     float gu[32], qu[32], kff[32], duk[32];
 };
 
-// one 16 x 16 output tile: C[i0.., j0..] = (init ? C : 0) + op(A) op(B) over K (multiple of 4)
+// one 16 x 16 output tile: C[i0.., j0..] = scale * op(A) op(B) (+ Cinit) (+ alpha_diag * diag on the diagonal), K a
+// multiple of 4 known at compile time: all operands of the tile are fetched from LDS first (2 K / 4 independent
+// reads in flight), then the K / 4 matrix instructions run back to back.
 //   TA: A is stored transposed (element (i, k) at A[k * lda + i]);  TB likewise for B
-template <bool TA, bool TB>
-__device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* Bm, int ldb, int K, int i0, int j0, float* Cm, int ldc,
-                                          const float* Cinit, int ldi, float alpha_diag, const double* diag, float scale = 1.f)
+template <bool TA, bool TB, int K>
+__device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* Bm, int ldb, int i0, int j0, float* Cm, int ldc,
+                                          const float* Cinit, int ldi, float alpha_diag, const float* diag, float scale = 1.f)
 {
     const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + kq;
-        const float a = TA ? A[k * lda + i0 + r16] : A[(i0 + r16) * lda + k];
-        const float b = TB ? Bm[(j0 + r16) * ldb + k] : Bm[k * ldb + j0 + r16];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    float a[K / 4], b[K / 4];
+#pragma unroll
+    for (int s = 0; s < K / 4; ++s) {
+        const int k = 4 * s + kq;
+        a[s] = TA ? A[k * lda + i0 + r16] : A[(i0 + r16) * lda + k];
+        b[s] = TB ? Bm[(j0 + r16) * ldb + k] : Bm[k * ldb + j0 + r16];
     }
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < K / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + 4 * kq + r, col = j0 + r16;
         float v = scale * acc[r];
         if (Cinit) v += Cinit[row * ldi + col];
-        if (diag && row == col) v += alpha_diag * (float)diag[row];
+        if (diag && row == col) v += alpha_diag * diag[row];
         Cm[row * ldc + col] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void riccati_kernel(RicArgs g)
+constexpr int RIC_WAVES = 4, RIC_THREADS = 64 * RIC_WAVES, RIC_LAST = 64 * (RIC_WAVES - 1); // RIC_LAST: first thread of the last wave
+
+__global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     RicLds& S = *reinterpret_cast<RicLds*>(smem);
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    if (g.stamps && blockIdx.x == 0 && threadIdx.x == 0) g.stamps[31] = (long long)__builtin_readcyclecounter();
     const int N = g.N;
     const double *Qd = g.w, *Rd = g.w + NX, *QNd = g.w + NX + NU;
     const double* xb = g.x + (size_t)b * (N + 1) * NX;
@@ -294,42 +343,52 @@ __global__ __launch_bounds__(256) void riccati_kernel(RicArgs g)
     const double* xr = g.xref + (size_t)b * (N + 1) * NX;
     const double* ur = g.uref + (size_t)b * N * NU;
     // terminal cost
-    for (int i = tid; i < 48 * 48; i += 256) { const int r = i / 48, c = i % 48; S.P[r * LDX + c] = (r == c) ? (float)QNd[r] : 0.f; }
-    if (tid < 48) S.p[tid] = (float)(QNd[tid] * (xb[(size_t)N * NX + tid] - xr[(size_t)N * NX + tid]));
+    for (int i = tid; i < 48 * 48; i += RIC_THREADS) { const int r = i / 48, c = i % 48; S.P[r * LDX + c] = (r == c) ? (float)QNd[r] : 0.f; }
+    if (tid < 48) { S.p[tid] = (float)(QNd[tid] * (xb[(size_t)N * NX + tid] - xr[(size_t)N * NX + tid])); S.wq[tid] = (float)Qd[tid]; }
+    else if (tid >= 64 && tid < 96) S.wr[tid - 64] = (tid - 64) < NU ? (float)Rd[tid - 64] : 1.f; // identity on the 2 padding inputs
+    float* const SK = S.B;   // feedback gain of the stage (32 x 48, stride LDX fits: 32 * 49 <= 48 * 33)
     __syncthreads();
 
     for (int k = N - 1; k >= 0; --k) {
         const float* Ag = g.A32 + ((size_t)b * N + k) * NX * NX;
         const float* Bg = g.B32 + ((size_t)b * N + k) * NX * NUP;
-        for (int i = tid; i < 48 * 48; i += 256) S.A[(i / 48) * LDX + (i % 48)] = Ag[i];
-        for (int i = tid; i < 48 * 32; i += 256) S.B[(i / 32) * LDU + (i % 32)] = Bg[i];
+        for (int i = tid; i < 48 * 12 + 48 * 8; i += RIC_THREADS) { // 16-byte loads: 12 per row of A, 8 per row of B
+            const bool isA = i < 48 * 12;
+            const int q4 = isA ? i : i - 48 * 12, r = isA ? q4 / 12 : q4 / 8, c4 = isA ? q4 % 12 : q4 % 8;
+            const float4 v4 = reinterpret_cast<const float4*>(isA ? Ag : Bg)[q4];
+            float* dst = isA ? (S.A + r * LDX + 4 * c4) : (S.B + r * LDU + 4 * c4);
+            dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
+        }
         if (tid < 48) {
             S.d[tid] = (float)(g.next[((size_t)b * N + k) * NX + tid] - xb[(size_t)(k + 1) * NX + tid]);
-            S.gx[tid] = (float)(Qd[tid] * (xb[(size_t)k * NX + tid] - xr[(size_t)k * NX + tid]));
+            S.gx[tid] = S.wq[tid] * (float)(xb[(size_t)k * NX + tid] - xr[(size_t)k * NX + tid]);
         } else if (tid >= 64 && tid < 96) {
             const int j = tid - 64;
-            S.gu[j] = j < NU ? (float)(Rd[j] * (ub[(size_t)k * NU + j] - ur[(size_t)k * NU + j])) : 0.f;
+            S.gu[j] = j < NU ? S.wr[j] * (float)(ub[(size_t)k * NU + j] - ur[(size_t)k * NU + j]) : 0.f;
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 0)
         // ---- PA = P A (9 tiles), PB = P B (6 tiles); s = P d + p
-        for (int t = wave; t < 15; t += 4) {
-            if (t < 9) mfma_tile<false, false>(S.P, LDX, S.A, LDX, 48, (t / 3) * 16, (t % 3) * 16, S.PA, LDX, nullptr, 0, 0.f, nullptr);
-            else mfma_tile<false, false>(S.P, LDX, S.B, LDU, 48, ((t - 9) / 2) * 16, ((t - 9) % 2) * 16, S.PB, LDU, nullptr, 0, 0.f, nullptr);
+        for (int t = wave; t < 15; t += RIC_WAVES) {
+            if (t < 9) mfma_tile<false, false, 48>(S.P, LDX, S.A, LDX, (t / 3) * 16, (t % 3) * 16, S.PA, LDX, nullptr, 0, 0.f, nullptr);
+            else mfma_tile<false, false, 48>(S.P, LDX, S.B, LDU, ((t - 9) / 2) * 16, ((t - 9) % 2) * 16, S.PB, LDU, nullptr, 0, 0.f, nullptr);
         }
-        if (tid >= 192 && tid < 240) { // wave 3 has one tile less
-            const int i = tid - 192;
+        if (tid >= RIC_LAST && tid < RIC_LAST + 48) { // the last wave has one tile less
+            const int i = tid - RIC_LAST;
             float acc = S.p[i];
             for (int j = 0; j < 48; ++j) acc += S.P[i * LDX + j] * S.d[j];
             S.s[i] = acc;
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 1)
         // ---- Qxx = Q + A' PA (9), Qux = B' PA (6), Quu = R + B' PB (4); qx = gx + A' s, qu = gu + B' s
-        for (int t = wave; t < 19; t += 4) {
-            if (t < 9) mfma_tile<true, false>(S.A, LDX, S.PA, LDX, 48, (t / 3) * 16, (t % 3) * 16, S.Qxx, LDX, nullptr, 0, 1.f, Qd);
-            else if (t < 15) mfma_tile<true, false>(S.B, LDU, S.PA, LDX, 48, ((t - 9) / 3) * 16, ((t - 9) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
-            else mfma_tile<true, false>(S.B, LDU, S.PB, LDU, 48, ((t - 15) / 2) * 16, ((t - 15) % 2) * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
+        for (int t = wave; t < 19; t += RIC_WAVES) {
+            if (t < 9) mfma_tile<true, false, 48>(S.A, LDX, S.PA, LDX, (t / 3) * 16, (t % 3) * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
+            else if (t < 15) mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, ((t - 9) / 3) * 16, ((t - 9) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
+            else mfma_tile<true, false, 48>(S.B, LDU, S.PB, LDU, ((t - 15) / 2) * 16, ((t - 15) % 2) * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 2)
         if (tid < 48) {
             float acc = S.gx[tid];
             for (int j = 0; j < 48; ++j) acc += S.A[j * LDX + tid] * S.s[j];
@@ -340,79 +399,90 @@ __global__ __launch_bounds__(256) void riccati_kernel(RicArgs g)
             for (int j = 0; j < 48; ++j) acc += S.B[j * LDU + i] * S.s[j];
             S.qu[i] = acc;
             // diagonal of Quu: + R on the 30 real inputs, identity on the 2 padding rows
-            S.Quu[i * LDU + i] += i < NU ? (float)Rd[i] : 1.f;
+            S.Quu[i * LDU + i] += S.wr[i];
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 3)
         // ---- Quu^-1 (wave 0: lane i owns row i, Gauss-Jordan in registers; wave_linalg.h) -> Qinv (in the PB buffer)
         float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
         float* Rres = S.PA;   // PA is dead once Qxx and Qux exist
         if (wave == 0) {
-            float row[32];
-            const int rr = tid & 31;
+            float row[NU]; // the 2 padding inputs are an identity block
+            const int rr = tid < NU ? tid : 0;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) row[j] = S.Quu[rr * LDU + j];
-            wavela::spd_inverse_rows<float, 32>(row, tid);
-            if (tid < 32) {
+            for (int j = 0; j < NU; ++j) row[j] = S.Quu[rr * LDU + j];
+            wavela::spd_inverse_rows<float, NU>(row, tid);
+            if (tid < NU) {
 #pragma unroll
-                for (int j = 0; j < 32; ++j) Qinv[tid * LDU + j] = row[j];
+                for (int j = 0; j < NU; ++j) Qinv[tid * LDU + j] = row[j];
+                Qinv[tid * LDU + 30] = 0.f; Qinv[tid * LDU + 31] = 0.f;
+            } else if (tid < 32) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) Qinv[tid * LDU + j] = (j == tid) ? 1.f : 0.f;
             }
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 4)
         // ---- K0 = -Qinv Qux (6 tiles, K = 32), kff0 = -Qinv qu
-        for (int t = wave; t < 6; t += 4)
-            mfma_tile<false, false>(Qinv, LDU, S.Qux, LDX, 32, (t / 3) * 16, (t % 3) * 16, S.K, LDX, nullptr, 0, 0.f, nullptr, -1.f);
-        if (tid >= 192 && tid < 224) {
-            const int i = tid - 192;
+        for (int t = wave; t < 6; t += RIC_WAVES)
+            mfma_tile<false, false, 32>(Qinv, LDU, S.Qux, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, nullptr, 0, 0.f, nullptr, -1.f);
+        if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
+            const int i = tid - RIC_LAST;
             float acc = 0.f;
 #pragma unroll 8
             for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.qu[j];
             S.kff[i] = -acc;
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 5)
         // ---- one refinement step against Quu itself (the explicit float32 inverse alone costs a factor 40 in accuracy):
         //      R = Qux + Quu K0,  K = K0 - Qinv R;   r = qu + Quu kff0,  kff = kff0 - Qinv r
-        for (int t = wave; t < 6; t += 4)
-            mfma_tile<false, false>(S.Quu, LDU, S.K, LDX, 32, (t / 3) * 16, (t % 3) * 16, Rres, LDX, S.Qux, LDX, 0.f, nullptr);
-        if (tid >= 192 && tid < 224) {
-            const int i = tid - 192;
+        for (int t = wave; t < 6; t += RIC_WAVES)
+            mfma_tile<false, false, 32>(S.Quu, LDU, SK, LDX, (t / 3) * 16, (t % 3) * 16, Rres, LDX, S.Qux, LDX, 0.f, nullptr);
+        if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
+            const int i = tid - RIC_LAST;
             float acc = S.qu[i];
 #pragma unroll 8
             for (int j = 0; j < 32; ++j) acc += S.Quu[i * LDU + j] * S.kff[j];
             S.duk[i] = acc; // residual of the feed-forward term (duk is free during the backward sweep)
         }
         __syncthreads();
-        for (int t = wave; t < 6; t += 4)
-            mfma_tile<false, false>(Qinv, LDU, Rres, LDX, 32, (t / 3) * 16, (t % 3) * 16, S.K, LDX, S.K, LDX, 0.f, nullptr, -1.f);
-        if (tid >= 192 && tid < 224) {
-            const int i = tid - 192;
+        WB_STAMP(g.stamps, 6)
+        for (int t = wave; t < 6; t += RIC_WAVES)
+            mfma_tile<false, false, 32>(Qinv, LDU, Rres, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, SK, LDX, 0.f, nullptr, -1.f);
+        if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
+            const int i = tid - RIC_LAST;
             float acc = 0.f;
 #pragma unroll 8
             for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.duk[j];
             S.kff[i] -= acc;
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 7)
         // feedback gains to HBM
         {
             float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
-            for (int i = tid; i < 32 * 48; i += 256) Kg[i] = S.K[(i / 48) * LDX + (i % 48)];
+            for (int i = tid; i < 32 * 48; i += RIC_THREADS) Kg[i] = SK[(i / 48) * LDX + (i % 48)];
             if (tid < 32) g.kff[((size_t)b * N + k) * 32 + tid] = S.kff[tid];
         }
         // ---- P <- Qxx + Qux' K (9 tiles), p <- qx + Qux' kff
-        for (int t = wave; t < 9; t += 4)
-            mfma_tile<true, false>(S.Qux, LDX, S.K, LDX, 32, (t / 3) * 16, (t % 3) * 16, S.P, LDX, S.Qxx, LDX, 0.f, nullptr);
-        if (tid >= 192 && tid < 240) {
-            const int i = tid - 192;
+        for (int t = wave; t < 9; t += RIC_WAVES)
+            mfma_tile<true, false, 32>(S.Qux, LDX, SK, LDX, (t / 3) * 16, (t % 3) * 16, S.P, LDX, S.P, LDX, 0.f, nullptr);
+        if (tid >= RIC_LAST && tid < RIC_LAST + 48) {
+            const int i = tid - RIC_LAST;
             float acc = S.qx[i];
             for (int j = 0; j < 32; ++j) acc += S.Qux[j * LDX + i] * S.kff[j];
             S.p[i] = acc;
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 8)
         // symmetrise (the two triangles differ by rounding only)
-        for (int i = tid; i < 48 * 48; i += 256) {
+        for (int i = tid; i < 48 * 48; i += RIC_THREADS) {
             const int r = i / 48, c = i % 48;
             if (r < c) { const float m = 0.5f * (S.P[r * LDX + c] + S.P[c * LDX + r]); S.P[r * LDX + c] = m; S.P[c * LDX + r] = m; }
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 9)
     }
 
     // ---- forward sweep
@@ -442,11 +512,12 @@ __global__ __launch_bounds__(256) void riccati_kernel(RicArgs g)
         if (tid < 48) S.dxk[tid] = S.dxn[tid];
         __syncthreads();
     }
+    WB_STAMP(g.stamps, 10)
     if (g.apply) {
         double* xw = g.x + (size_t)b * (N + 1) * NX;
         double* uw = g.u + (size_t)b * N * NU;
-        for (int i = tid; i < (N + 1) * NX; i += 256) xw[i] += dxb[i];
-        for (int i = tid; i < N * NU; i += 256) {
+        for (int i = tid; i < (N + 1) * NX; i += RIC_THREADS) xw[i] += dxb[i];
+        for (int i = tid; i < N * NU; i += RIC_THREADS) {
             double val = uw[i] + dub[i];
             const int j = i % NU;
             if (j < b2z1::NJ) { const double lim = b2z1::EFFORT[j]; val = val > lim ? lim : (val < -lim ? -lim : val); }
@@ -468,6 +539,7 @@ struct alore_wb_solver {
     double* d_next = nullptr;
     double *d_dx = nullptr, *d_du = nullptr;
     float *d_K = nullptr, *d_kff = nullptr;
+    long long* d_stamps = nullptr; // [64] when ALORE_WB_STAMPS=1
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_lin = -1.f, ms_ric = -1.f;
     bool timed = false;
@@ -548,6 +620,7 @@ int alore_wb_create(const alore_wb_config* cfg, alore_wb_handle* out)
               zalloc(&h->d_du, B * N * wb::NU) == hipSuccess && zalloc(&h->d_K, B * N * 32 * 48) == hipSuccess &&
               zalloc(&h->d_kff, B * N * 32) == hipSuccess;
     for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
+    if (ok && std::getenv("ALORE_WB_STAMPS")) ok = zalloc(&h->d_stamps, (size_t)64) == hipSuccess;
     if (!ok) { alore_wb_destroy(h); return ALORE_WB_E_NOMEM; }
     *out = h;
     return ALORE_WB_OK;
@@ -556,7 +629,17 @@ int alore_wb_create(const alore_wb_config* cfg, alore_wb_handle* out)
 int alore_wb_destroy(alore_wb_handle h)
 {
     if (!h) return ALORE_WB_E_INVALID;
-    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff};
+    if (h->d_stamps) { // diagnostic: cycles of workgroup 0 per phase, summed over all launches
+        long long st[64];
+        if (hipMemcpy(st, h->d_stamps, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::fprintf(stderr, "[alore_wb stamps] stage kernel, workgroup 0, cycles per phase:");
+            for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %lld", st[i]);
+            std::fprintf(stderr, "\n[alore_wb stamps] riccati kernel, workgroup 0, cycles per phase (all stages):");
+            for (int i = 0; i < 12; ++i) std::fprintf(stderr, " %lld", st[32 + i]);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -600,7 +683,7 @@ int alore_wb_forward_dynamics(alore_wb_handle h, int n, const double* q, const d
     if (!dx || !du || !dn || !dA || !dB || (M && !dM) || (a && !da)) return fail(h, ALORE_WB_E_NOMEM, "forward_dynamics: hipMalloc");
     WB_TRY(h, hipMemcpy(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
     WB_TRY(h, hipMemcpy(du, u, sizeof(double) * n * wb::NU, hipMemcpyHostToDevice));
-    wb::StageArgs g{dx, du, 1, n, h->cfg.dt, dA, dB, dn, nullptr, nullptr, dM, da};
+    wb::StageArgs g{dx, du, 1, n, h->cfg.dt, dA, dB, dn, nullptr, nullptr, dM, da, nullptr};
     wb::stage_kernel<<<n, 64>>>(g);
     WB_TRY(h, hipGetLastError());
     if (M) WB_TRY(h, hipMemcpy(M, dM, sizeof(double) * n * 576, hipMemcpyDeviceToHost));
@@ -660,7 +743,7 @@ int alore_wb_linearize(alore_wb_handle h, int B, double* A, double* Bm, double* 
     Tmp t;
     double *dA = A ? t.get<double>(n * wb::NX * wb::NX) : nullptr, *dB = Bm ? t.get<double>(n * wb::NX * wb::NU) : nullptr;
     if ((A && !dA) || (Bm && !dB)) return fail(h, ALORE_WB_E_NOMEM, "linearize: hipMalloc");
-    wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, dA, dB, nullptr, nullptr};
+    wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, dA, dB, nullptr, nullptr, nullptr};
     wb::stage_kernel<<<(unsigned)n, 64>>>(g);
     WB_TRY(h, hipGetLastError());
     if (A) WB_TRY(h, hipMemcpy(A, dA, sizeof(double) * n * wb::NX * wb::NX, hipMemcpyDeviceToHost));
@@ -685,11 +768,11 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
     for (int it = 0; it < n_iter; ++it) {
         const bool last = it == n_iter - 1;
         if (last) WB_TRY(h, hipEventRecord(h->ev[0], s));
-        wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr};
+        wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps};
         wb::stage_kernel<<<(unsigned)n, 64, 0, s>>>(g);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
-        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1};
-        wb::riccati_kernel<<<B, 256, sizeof(wb::RicLds), s>>>(r);
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_stamps ? h->d_stamps + 32 : nullptr};
+        wb::riccati_kernel<<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
     }
     WB_TRY(h, hipGetLastError());
