@@ -69,7 +69,7 @@ struct StageLds {
     double R0[9], E[9], Gq[3][6];
 };
 
-__global__ __launch_bounds__(64) void stage_kernel(StageArgs g)
+__global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
 {
     __shared__ StageLds S;
     const int item = blockIdx.x;
