@@ -61,6 +61,7 @@ struct Params {
     double* cost_out; // [B]
     double* err_out;  // [B][2]
     int* ret_out;     // [B][3]: ret, iterations, evaluations
+    long long* stamps; // diagnostic (ALORE_BE_STAMPS=1): [64] cycles per phase of workgroup 0, [63] = last stamp
 };
 
 size_t lds_bytes(int P);

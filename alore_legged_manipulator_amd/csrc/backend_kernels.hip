@@ -26,20 +26,51 @@ namespace backend {
 
 namespace {
 
+// diagnostic phase stamps: workgroup 0 adds the cycles since its previous stamp to slot i
+#define BE_STAMP(i)                                                                              \
+    if (gp->stamps && blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+        const long long now_ = (long long)__builtin_readcyclecounter();                          \
+        gp->stamps[i] += now_ - gp->stamps[63];                                                  \
+        gp->stamps[63] = now_;                                                                   \
+    }
+
 constexpr int NS = 17; // Simpson nodes per piece (sparseResolution 8)
 constexpr int RES = 8;
 
+// Wavefront reductions on the DPP data path (no LDS crossbar): inclusive scan inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8), row totals passed on with row_bcast15 / row_bcast31, result read from lane 63 and returned
+// wave-uniform.  A double moves as two 32-bit halves.  The summation order is fixed, so results are reproducible.
+// Callers are in wave-uniform control flow (all 64 lanes active).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    v += dpp_f64<0x111, 0xF>(0.0, v); // row_shr:1   (lanes without a source keep `old` = 0)
+    v += dpp_f64<0x112, 0xF>(0.0, v); // row_shr:2
+    v += dpp_f64<0x114, 0xF>(0.0, v); // row_shr:4
+    v += dpp_f64<0x118, 0xF>(0.0, v); // row_shr:8
+    v += dpp_f64<0x142, 0xA>(0.0, v); // row_bcast15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xC>(0.0, v); // row_bcast31 into rows 2 and 3
+    return lane63(v);
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
+    v = fmax(v, dpp_f64<0x111, 0xF>(v, v)); // lanes without a source keep `old` = their own value
+    v = fmax(v, dpp_f64<0x112, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x114, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x118, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x142, 0xA>(v, v));
+    v = fmax(v, dpp_f64<0x143, 0xC>(v, v));
+    return lane63(v);
 }
 __device__ __forceinline__ double uni(double v) // value known to be wave-uniform -> SGPR pair
 {
@@ -135,6 +166,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     const int lane = threadIdx.x, M = uni(e.M), n = uni(e.n), NN = M * NS;
     const double xvI = c.standard_diff ? 0.0 : c.icr_xv;
     __syncthreads();
+    BE_STAMP(0)
     if (lane == 0) ++e.evals;
     // ---- norm guard (optimizer.cpp:635-636: `inf` is the macro 1 >> 30 = 0)
     double part = 0.0;
@@ -161,6 +193,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
             if (k == M) { L.kv[d][M] = e.tail[d][1]; L.ka[d][M] = e.tail[d][2]; }
         }
     __syncthreads();
+    BE_STAMP(1)
     // ---- knot system: right-hand sides (lane = (knot, dim)), factorisation + solves (lanes 0, 1)
     for (int t = lane; t < 2 * (M - 1); t += 64) {
         const int k = 1 + (t >> 1), d = t & 1;
@@ -181,13 +214,16 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         L.y[d][k - 1][1] = rr[1];
     }
     __syncthreads();
+    BE_STAMP(2)
     if (lane == 0) minco::knot_factor(M, L.T, L.sinv);
     __syncthreads();
+    BE_STAMP(3)
     if (lane < 2) {
         minco::knot_solve(M, L.T, L.sinv, &L.y[lane][0][0]);
         for (int k = 1; k < M; ++k) { L.kv[lane][k] = L.y[lane][k - 1][0]; L.ka[lane][k] = L.y[lane][k - 1][1]; }
     }
     __syncthreads();
+    BE_STAMP(4)
     // ---- coefficients, energy and its partial gradients: lane = (piece, dim)
     double epart = 0.0;
     for (int t = lane; t < 2 * M; t += 64) {
@@ -212,6 +248,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     }
     double cost_part = epart;
     __syncthreads();
+    BE_STAMP(5)
 
     // ---- pass A over the nodes: flat state, Simpson integrands, pose-independent penalties
     const double w_mom = e.stage == 1 ? c.p_moment : c.w_moment, w_acc = e.stage == 1 ? c.p_acc : c.w_acc,
@@ -273,6 +310,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         L.nodeT[node] = gT;
     }
     __syncthreads();
+    BE_STAMP(6)
 
     // ---- Simpson panels and the running pose: prefix scan over the 8 M panels
     {
@@ -300,6 +338,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         }
     }
     __syncthreads();
+    BE_STAMP(7)
     if (lane == 0) {
         e.xy_err[0] = L.posx[RES * M] - e.final_xy[0];
         e.xy_err[1] = L.posy[RES * M] - e.final_xy[1];
@@ -307,6 +346,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     __syncthreads(); // fx / fy are consumed; they now carry the position gradients of the chain rule
     for (int node = lane; node < NN; node += 64) { L.fx[node] = 0.0; L.fy[node] = 0.0; }
     __syncthreads();
+    BE_STAMP(8)
 
     // ---- pose-dependent terms
     if (e.stage == 2) { // obstacle clearance at the even nodes
@@ -348,6 +388,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         }
     }
     __syncthreads();
+    BE_STAMP(9)
     // ---- chain coefficients: inclusive suffix sums over the nodes (+ the ALM terminal term)
     {
         double add_x = 0.0, add_y = 0.0;
@@ -373,6 +414,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         }
     }
     __syncthreads();
+    BE_STAMP(10)
     // ---- pass C: chain rule through the Simpson sums into the node terms
     for (int node = lane; node < NN; node += 64) {
         const int i = node / NS, j = node - i * NS;
@@ -398,6 +440,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         L.nodeT[node] += XT * cx + YT * cyy;
     }
     __syncthreads();
+    BE_STAMP(11)
     // ---- node terms -> coefficient gradient: lane = (piece, power, dim); time gradient: lane = piece
     for (int t = lane; t < 12 * M; t += 64) {
         const int i = t / 12, r = t - i * 12, q = r >> 1, d = r & 1;
@@ -406,9 +449,17 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         for (int j = 0; j < NS; ++j) {
             const double* E = L.E + (i * NS + j) * 6;
             const double tt = j * half;
-            double p0 = 1.0, p1 = 0.0, p2 = 0.0; // t^q, q t^(q-1), q (q-1) t^(q-2)
-            if (q >= 1) { double pw = 1.0; for (int s = 1; s < q; ++s) pw *= tt; p1 = q * pw; p0 = pw * tt; }
-            if (q >= 2) { double pw = 1.0; for (int s = 2; s < q; ++s) pw *= tt; p2 = q * (q - 1) * pw; }
+            // t^(q-2), t^(q-1), t^q from the running powers 1, t, t^2, ... (same products in the same order as a
+            // power loop per exponent, without its data-dependent trip count)
+            double pw = 1.0, pm2 = 0.0, pm1 = 0.0, pq = 1.0;
+#pragma unroll
+            for (int k = 0; k <= 5; ++k) {
+                if (k == q - 2) pm2 = pw;
+                if (k == q - 1) pm1 = pw;
+                if (k == q) pq = pw;
+                pw *= tt;
+            }
+            const double p0 = pq, p1 = q >= 1 ? q * pm1 : 0.0, p2 = q >= 2 ? q * (q - 1) * pm2 : 0.0;
             acc += p0 * E[d] + p1 * E[2 + d] + p2 * E[4 + d];
         }
         L.gdC[t] += acc; // gdC index (6 i + q) * 2 + d = 12 i + r
@@ -419,6 +470,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         L.gdT[i] += acc;
     }
     __syncthreads();
+    BE_STAMP(12)
     // ---- adjoint of the spline: coefficient gradient -> knot-state gradient -> knot system -> variables
     // phase 1: every (piece, dim) lane turns its coefficient gradient into the gradients of its two knot states;
     // the start knot is written directly, the end knot goes through a staging slot (E is free by now)
@@ -432,19 +484,23 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         if (i == M - 1) for (int k = 0; k < 3; ++k) L.gk[d][M][k] = 0.0;
     }
     __syncthreads();
+    BE_STAMP(13)
     for (int t = lane; t < 2 * M; t += 64) {
         const int i = t >> 1, d = t & 1;
         for (int k = 0; k < 3; ++k) L.gk[d][i + 1][k] += L.E[t * 3 + k];
     }
     __syncthreads();
+    BE_STAMP(14)
     for (int t = lane; t < 2 * (M - 1); t += 64) {
         const int k = 1 + (t >> 1), d = t & 1;
         L.y[d][k - 1][0] = L.gk[d][k][1];
         L.y[d][k - 1][1] = L.gk[d][k][2];
     }
     __syncthreads();
+    BE_STAMP(15)
     if (lane < 2) minco::knot_solve(M, L.T, L.sinv, &L.y[lane][0][0]); // K is symmetric: the same sweep
     __syncthreads();
+    BE_STAMP(16)
     // way-point and tail gradients: lane = (knot 1..M, dim)
     for (int t = lane; t < 2 * M; t += 64) {
         const int k = 1 + (t >> 1), d = t & 1;
@@ -484,6 +540,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         }
     }
     __syncthreads();
+    BE_STAMP(17)
     double cost = uni(wave_sum(cost_part));
     cost += (e.stage == 1 ? c.p_time : e.time_weight) * sumT;
     return cost;
@@ -610,30 +667,78 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* __restrict__ gp, co
                 ++bound;
                 if (bound > m) bound = m;
                 end = (end + 1) % m;
+                // Two-loop recursion (lbfgs.hpp:704-735).  d stays in registers (NVL values per lane); the (s, y)
+                // pairs come from HBM in chunks of CH pairs whose 2 * CH * NVL loads are all in flight together --
+                // one memory latency per chunk instead of two per pair.  Same operations in the same order as the
+                // pair-at-a-time form: results are bit-identical.
+                constexpr int NVL = (3 * P + 63) / 64, CH = 8;
+                double dreg[NVL];
+#pragma unroll
+                for (int r = 0; r < NVL; ++r) dreg[r] = (lane + 64 * r < n) ? L.d[lane + 64 * r] : 0.0;
                 int j = end;
-                for (int i = 0; i < bound; ++i) {
-                    j = (j + m - 1) % m;
-                    const double* sj = hist + (size_t)j * 2 * nstride;
-                    const double* yj = sj + nstride;
-                    double p = 0.0;
-                    for (int v = lane; v < n; v += 64) p += sj[v] * L.d[v];
-                    const double a = uni(wave_sum(p)) / L.ys[j];
-                    if (lane == 0) L.alpha[j] = a;
-                    for (int v = lane; v < n; v += 64) L.d[v] += (-a) * yj[v];
+                for (int i0 = 0; i0 < bound; i0 += CH) {
+                    const int cnt = min(CH, bound - i0);
+                    double sv[CH][NVL], yv[CH][NVL];
+#pragma unroll
+                    for (int cidx = 0; cidx < CH; ++cidx) {
+                        const int jj = (j + 2 * m - 1 - cidx) % m;
+                        const double* sj = hist + (size_t)jj * 2 * nstride;
+#pragma unroll
+                        for (int r = 0; r < NVL; ++r) {
+                            const bool in = cidx < cnt && lane + 64 * r < n;
+                            sv[cidx][r] = in ? sj[lane + 64 * r] : 0.0;
+                            yv[cidx][r] = in ? sj[nstride + lane + 64 * r] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int cidx = 0; cidx < CH; ++cidx) {
+                        if (cidx < cnt) {
+                            j = (j + m - 1) % m;
+                            double p = 0.0;
+#pragma unroll
+                            for (int r = 0; r < NVL; ++r) p += sv[cidx][r] * dreg[r];
+                            const double a = uni(wave_sum(p)) / L.ys[j];
+                            if (lane == 0) L.alpha[j] = a;
+#pragma unroll
+                            for (int r = 0; r < NVL; ++r) dreg[r] += (-a) * yv[cidx][r];
+                        }
+                    }
                 }
                 const double sc = ys / yy;
-                for (int v = lane; v < n; v += 64) L.d[v] *= sc;
-                __syncthreads();
-                for (int i = 0; i < bound; ++i) {
-                    const double* sj = hist + (size_t)j * 2 * nstride;
-                    const double* yj = sj + nstride;
-                    double p = 0.0;
-                    for (int v = lane; v < n; v += 64) p += yj[v] * L.d[v];
-                    const double beta = uni(wave_sum(p)) / L.ys[j];
-                    const double a = L.alpha[j];
-                    for (int v = lane; v < n; v += 64) L.d[v] += (a - beta) * sj[v];
-                    j = (j + 1) % m;
+#pragma unroll
+                for (int r = 0; r < NVL; ++r) dreg[r] *= sc;
+                __syncthreads(); // alpha[] written by lane 0 is read back below
+                for (int i0 = 0; i0 < bound; i0 += CH) {
+                    const int cnt = min(CH, bound - i0);
+                    double sv[CH][NVL], yv[CH][NVL];
+#pragma unroll
+                    for (int cidx = 0; cidx < CH; ++cidx) {
+                        const int jj = (j + cidx) % m;
+                        const double* sj = hist + (size_t)jj * 2 * nstride;
+#pragma unroll
+                        for (int r = 0; r < NVL; ++r) {
+                            const bool in = cidx < cnt && lane + 64 * r < n;
+                            sv[cidx][r] = in ? sj[lane + 64 * r] : 0.0;
+                            yv[cidx][r] = in ? sj[nstride + lane + 64 * r] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int cidx = 0; cidx < CH; ++cidx) {
+                        if (cidx < cnt) {
+                            double p = 0.0;
+#pragma unroll
+                            for (int r = 0; r < NVL; ++r) p += yv[cidx][r] * dreg[r];
+                            const double beta = uni(wave_sum(p)) / L.ys[j];
+                            const double a = L.alpha[j];
+#pragma unroll
+                            for (int r = 0; r < NVL; ++r) dreg[r] += (a - beta) * sv[cidx][r];
+                            j = (j + 1) % m;
+                        }
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < NVL; ++r)
+                    if (lane + 64 * r < n) L.d[lane + 64 * r] = dreg[r];
             }
             __syncthreads();
             step = 1.0;
@@ -731,6 +836,7 @@ __device__ void load_problem(const Params& prm, int b)
 template <int P>
 __global__ __launch_bounds__(64) void backend_kernel(const Params* __restrict__ gp)
 {
+    if (gp->stamps && blockIdx.x == 0 && threadIdx.x == 0) gp->stamps[63] = (long long)__builtin_readcyclecounter();
     const Params& prm = *gp;
     Lds<P>& L = lds<P>();
     EvalCtx& e = L.e;

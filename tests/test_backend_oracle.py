@@ -323,3 +323,23 @@ def test_optimiser_is_sensitive_to_the_last_digits(orc):
     assert same < len(dev)          # some runs end on a different iteration
     assert dev.max() > 1e-4         # ... with a visibly different final cost
     assert dev.max() < 0.2          # ... that is still the same valley
+
+
+def test_optimiser_outcomes_are_multimodal():
+    """The reference's stopping rule (relative decrease < 5e-4 over 3 iterations) is loose enough that the SAME problem,
+    perturbed in the 14th digit, ends on clearly separated costs: problem 33 of the Monte-Carlo seed used by the GPU
+    whole-plan test lands on ~310 or ~342 (10 % apart).  This is why whole plans are compared statistically."""
+    import copy
+    from alore_legged_manipulator_amd.flat_traj import monte_carlo_goals
+    from oracle.backend_driver import BackendOracle, EsdfGrid
+    orc = BackendOracle()
+    grid = EsdfGrid.free(half=20.0)
+    ft = monte_carlo_goals(96, seed=20260206)[33]
+    rng = np.random.default_rng(1)
+    costs = []
+    for _ in range(16):
+        f2 = copy.deepcopy(ft)
+        f2.traj_pts = ft.traj_pts * (1 + 1e-14 * rng.standard_normal(ft.traj_pts.shape))
+        costs.append(orc.minco_plan(grid, f2)["cost"])
+    costs = np.sort(costs)
+    assert (costs[-1] - costs[0]) / costs[0] > 0.05, costs
