@@ -71,6 +71,11 @@ SYMBOLS = (
     ("alore_nmpc_batch_free", C.c_int, [C.c_void_p, C.POINTER(Batch)]),
     ("alore_nmpc_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     ("alore_nmpc_host_free", C.c_int, [C.c_void_p]),
+    ("alore_nmpc_comm_unique_id", C.c_int, [C.c_char_p]),
+    ("alore_nmpc_comm_create", C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    ("alore_nmpc_comm_destroy", C.c_int, [C.c_void_p]),
+    ("alore_nmpc_comm_all_gather", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.POINTER(Batch), C.c_void_p]),
+    ("alore_nmpc_comm_last_error", C.c_char_p, []),
     ("alore_nmpc_batch_upload", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(Batch), C.c_int, C.c_void_p]),
     ("alore_nmpc_batch_download", C.c_int, [C.c_void_p, C.POINTER(Batch), C.POINTER(Batch), C.c_int, C.c_void_p]),
     ("alore_nmpc_batch_default_bounds", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p]),

@@ -273,6 +273,22 @@ int alore_nmpc_get_launch_info(alore_nmpc_handle h, alore_nmpc_launch_info *out)
  * alore_nmpc_get_launch_info then synchronises on the stop event. */
 int alore_nmpc_set_timing(alore_nmpc_handle h, int enable);
 
+/* ---- multi-GPU result exchange for C / C++ callers (RCCL over xGMI) -------------------------------------------
+ * One process per GPU; rank r owns problems [r B, (r + 1) B) -- the solves need no communication.  What the north star
+ * asks for is the converged trajectories on every rank: alore_nmpc_comm_all_gather does that with one grouped RCCL call
+ * (x, u, status, kkt; any member NULL on either side is skipped) on the caller's stream.  `all` holds DEVICE pointers
+ * sized n_ranks x the per-rank member.  Rank 0 obtains the 128-byte id and hands it to the other ranks by whatever
+ * means the launcher has (MPI broadcast, a file, an environment variable).  RCCL is loaded on first use; the functions
+ * return ALORE_NMPC_E_HIP with a text in alore_nmpc_comm_last_error() when it is missing.  (The Python layer's
+ * shard.ResultGatherer does the same through torch.distributed; bench.py uses that one.) */
+typedef struct alore_nmpc_comm *alore_nmpc_comm_handle;
+int alore_nmpc_comm_unique_id(char id[128]);
+int alore_nmpc_comm_create(int n_ranks, int rank, const char id[128], int device, alore_nmpc_comm_handle *out);
+int alore_nmpc_comm_destroy(alore_nmpc_comm_handle c);
+int alore_nmpc_comm_all_gather(alore_nmpc_comm_handle c, const alore_nmpc_batch *local, int B, int N,
+                               const alore_nmpc_batch *all, void *stream);
+const char *alore_nmpc_comm_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

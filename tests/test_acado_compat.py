@@ -110,8 +110,8 @@ def test_wrapper_call_sequence_matches_reference_semantics():
             for t, (g, e) in enumerate(zip(got, exp)):
                 assert g[0] == e[0] == 0, (name, b, t)
                 # tick 0 uses the stale linearisation (prepared before the reset): must agree as well
-                assert relerr(g[1], e[1]) < 2e-4, (name, b, t, "x")
-                assert relerr(g[2], e[2]) < 2e-4, (name, b, t, "u")
+                assert relerr(g[1], e[1]) < 1e-4, (name, b, t, "x")
+                assert relerr(g[2], e[2]) < 1e-4, (name, b, t, "u")
     # the preparation-side workspace members are kept up to date
     orc.preparation_step()
     comp.preparation_step()

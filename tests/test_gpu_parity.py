@@ -438,3 +438,36 @@ def test_without_diagnostics_same_solution(nmpc_mod, N, B):
     for k in ("x", "u", "dual", "status", "n_iter"):
         assert np.array_equal(oa[k], ob[k]), k
     assert (ob["kkt"] == -7.0).all() and (ob["obj"] == -7.0).all()      # untouched
+
+
+@pytest.mark.gpu
+def test_c_abi_result_exchange_over_rccl_single_rank():
+    """alore_nmpc_comm_* (the C / C++ caller's multi-GPU path): with one rank the all-gather must reproduce the local
+    results on the gathered buffers -- exercises the lazy RCCL load, communicator creation and the grouped call on a
+    real device.  (More ranks need more GPUs; the Python twin of this path is covered by tests/test_shard_gloo.py.)"""
+    import ctypes as C
+    import torch
+    from alore_legged_manipulator_amd import _lib
+    from alore_legged_manipulator_amd.nmpc import BatchedNmpc
+    from alore_legged_manipulator_amd.scenarios import make_batch
+    lib = _lib.load()
+    B, N = 64, 20
+    eng = BatchedNmpc(B, N)
+    eng.load(make_batch(B, N, seed=5))
+    eng.rti(1)
+    uid = C.create_string_buffer(128)
+    assert lib.alore_nmpc_comm_unique_id(uid) == 0, lib.alore_nmpc_comm_last_error()
+    comm = C.c_void_p()
+    assert lib.alore_nmpc_comm_create(1, 0, uid, 0, C.byref(comm)) == 0, lib.alore_nmpc_comm_last_error()
+    local, allb = _lib.Batch(), _lib.Batch()
+    out = {"x": torch.zeros(B * 3 * (N + 1), dtype=torch.float32, device="cuda"), "u": torch.zeros(B * 2 * N, dtype=torch.float32, device="cuda"),
+           "status": torch.full((B,), -7, dtype=torch.int32, device="cuda"), "kkt": torch.zeros(B, dtype=torch.float32, device="cuda")}
+    for k in ("x", "u", "status", "kkt"):
+        setattr(local, k, eng.t[k].data_ptr())
+        setattr(allb, k, out[k].data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.alore_nmpc_comm_all_gather(comm, C.byref(local), B, N, C.byref(allb), stream) == 0, lib.alore_nmpc_comm_last_error()
+    torch.cuda.synchronize()
+    for k in ("x", "u", "status", "kkt"):
+        assert torch.equal(out[k].reshape(-1), eng.t[k].reshape(-1)), k
+    assert lib.alore_nmpc_comm_destroy(comm) == 0
