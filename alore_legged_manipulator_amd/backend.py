@@ -75,6 +75,8 @@ def _bind(L):
     L.alore_backend_last_error.argtypes = [C.c_void_p]
     L.alore_backend_last_error.restype = C.c_char_p
     L.alore_backend_set_map.argtypes = [C.c_void_p, DP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.alore_backend_build_esdf.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, C.c_double, DP]
     L.alore_backend_set_problems.argtypes = [C.c_void_p, C.c_int, C.POINTER(FlatTrajC), C.c_void_p]
     L.alore_backend_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.alore_backend_results.argtypes = [C.c_void_p, C.c_int, C.POINTER(StatusC), DP, DP, DP, C.c_void_p]
@@ -137,6 +139,15 @@ class BatchedMSPlanner:
     def set_map(self, dist: np.ndarray, x_lo: float, y_lo: float, res: float):
         dist = np.ascontiguousarray(dist, dtype=np.float64)
         self._check(self.L.alore_backend_set_map(self.h, _dp(dist), dist.shape[0], dist.shape[1], x_lo, y_lo, res))
+
+    def build_esdf(self, grid: np.ndarray, x_lo: float, y_lo: float, res: float, odom=(0.0, 0.0), detection_range: float = 1e3) -> np.ndarray:
+        """SDFmap::updateESDF2d on the device from a uint8 state grid (0 unknown, 1 free, 2 occupied); the result becomes
+        the planner's map and is returned."""
+        g = np.ascontiguousarray(grid, dtype=np.uint8)
+        dist = np.zeros(g.shape)
+        self._check(self.L.alore_backend_build_esdf(self.h, g.ctypes.data_as(C.POINTER(C.c_ubyte)), g.shape[0], g.shape[1], x_lo, y_lo, res,
+                                                    float(odom[0]), float(odom[1]), float(detection_range), _dp(dist)))
+        return dist
 
     def set_free_map(self, half: float = 40.0, res: float = 0.1, value: float = 100.0):
         n = int(round(2 * half / res))

@@ -198,6 +198,31 @@ int alore_backend_set_map(alore_backend_handle h, const double* dist, int nx, in
     return ALORE_BE_OK;
 }
 
+int alore_backend_build_esdf(alore_backend_handle h, const unsigned char* grid, int nx, int ny, double x_lo, double y_lo, double res,
+                             double odom_x, double odom_y, double detection_range, double* dist_out)
+{
+    if (!h || !grid || nx < 2 || ny < 2 || !(res > 0.0) || !(detection_range > 0.0)) return fail(h, ALORE_BE_E_INVALID, "build_esdf: bad argument");
+    BE_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)nx * ny;
+    const bool same = h->d_map && h->map.nx == nx && h->map.ny == ny && h->map.x_lo == x_lo && h->map.y_lo == y_lo && h->map.res == res;
+    if (!same) {
+        if (h->d_map) { (void)hipFree(h->d_map); h->d_map = nullptr; }
+        BE_TRY(h, hipMalloc((void**)&h->d_map, sizeof(double) * n));
+        BE_TRY(h, backend::esdf_fill_max(h->d_map, n, nullptr));
+        h->map = backend::MapView{h->d_map, nx, ny, x_lo, y_lo, x_lo + nx * res, y_lo + ny * res, res};
+    }
+    unsigned char* d_grid = nullptr;
+    BE_TRY(h, hipMalloc((void**)&d_grid, n));
+    hipError_t e = hipMemcpy(d_grid, grid, n, hipMemcpyHostToDevice);
+    int empty = 0;
+    if (e == hipSuccess) e = backend::esdf_update(d_grid, nx, ny, res, x_lo, y_lo, odom_x, odom_y, detection_range, h->d_map, nullptr, &empty);
+    (void)hipFree(d_grid);
+    if (e != hipSuccess) return fail(h, ALORE_BE_E_HIP, "build_esdf", e);
+    if (empty) return fail(h, ALORE_BE_E_INVALID, "build_esdf: the window around the odometry does not intersect the map");
+    if (dist_out) BE_TRY(h, hipMemcpy(dist_out, h->d_map, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return ALORE_BE_OK;
+}
+
 int alore_backend_set_problems(alore_backend_handle h, int count, const alore_flat_traj* pr, void* stream)
 {
     if (!h || count < 1 || count > h->B || !pr) return fail(h, ALORE_BE_E_INVALID, "set_problems: bad argument");

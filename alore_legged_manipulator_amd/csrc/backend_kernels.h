@@ -69,4 +69,9 @@ size_t lds_bytes(int P);
 // `p` must stay alive until the copy has been issued from pinned memory or has completed (callers keep it in the handle)
 hipError_t launch(const Params& p, const Params* d_params, int P, hipStream_t s);
 
+// esdf_build.hip: SDFmap::updateESDF2d on the device
+hipError_t esdf_fill_max(double* p, size_t n, hipStream_t s);
+hipError_t esdf_update(const unsigned char* d_grid, int GLX, int GLY, double res, double x_lo, double y_lo, double odom_x, double odom_y,
+                       double range, double* d_dist, hipStream_t s, int* empty_window);
+
 } // namespace backend

@@ -1,0 +1,159 @@
+// esdf_build.hip -- SDFmap::updateESDF2d (P/utils/plan_env/src/sdf_map.cpp:618-681) on the GPU: the Euclidean signed
+// distance field the back_end queries, built from the occupancy grid inside the window odom +- detection_range.
+//
+// The reference runs Felzenszwalb's lower-envelope distance transform (fillESDF, :683-714) along y for every row, then
+// along x for every column, once for the occupied cells (distance outside obstacles) and once for the rest (distance
+// inside), and combines them.  One line is a sequential envelope walk; lines are independent: ONE THREAD PER LINE,
+// consecutive threads = consecutive columns in the column passes (coalesced), envelope stacks in a global workspace.
+// The reference indexes its (X+1) x (Y+1) scratch with stride Y, so the last element of a row is the first of the next
+// and the last column's results land on the next row's first column; executed sequentially that is well defined, and
+// the same final contents are produced here by letting exactly the thread that would have written last do the write
+// (see `keep` below).  All values are sums of squared integers until the final sqrt: results are bit-identical to the
+// reference's arithmetic (checked against oracle/backend_oracle.c: be_update_esdf2d, which matches SciPy's exact EDT).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "backend_kernels.h"
+
+namespace backend {
+
+namespace {
+
+struct EsdfArgs {
+    const unsigned char* grid; // [GLX][GLY] 0 unknown, 1 unoccupied, 2 occupied (sdf_map.h:98)
+    int GLY, min_x, min_y, X, Y;
+    double res;
+    double* tmp;   // (X+1)(Y+1), stride Y
+    double* out;   // pos or neg, same indexing
+    int* v;        // [lines][D + 2]
+    double* z;     // [lines][D + 3]
+    int D;         // max(X, Y) + 1
+    int negative;  // 0: seeds = occupied cells; 1: seeds = everything else
+};
+
+// fillESDF for line `line`; get(q) reads the input of the line, put(q, val) receives (q - v)^2 + get(v)
+template <class Get, class Put>
+__device__ __forceinline__ void fill_line(int end, int* v, double* z, Get get, Put put)
+{
+    int k = 0;
+    v[0] = 0;
+    z[0] = -DBL_MAX;
+    z[1] = DBL_MAX;
+    for (int q = 1; q <= end; q++) {
+        double s;
+        k++;
+        const double fq = get(q) + q * q;
+        do {
+            k--;
+            const int vk = v[k];
+            s = (fq - (get(vk) + vk * vk)) / (2 * q - 2 * vk);
+        } while (s <= z[k]);
+        k++;
+        v[k] = q;
+        z[k] = s;
+        z[k + 1] = DBL_MAX;
+    }
+    k = 0;
+    for (int q = 0; q <= end; q++) {
+        while (z[k + 1] < q) k++;
+        const int vk = v[k];
+        put(q, (double)((q - vk) * (q - vk)) + get(vk));
+    }
+}
+
+__global__ void esdf_rows(EsdfArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x > a.X) return;
+    const unsigned char* g = a.grid + (size_t)(x + a.min_x) * a.GLY + a.min_y;
+    const int neg = a.negative;
+    auto get = [&](int y) -> double {
+        const int st = g[y];
+        const bool seed = neg ? (st == 1 || st == 0) : (st == 2);
+        return seed ? 0.0 : DBL_MAX;
+    };
+    double* row = a.tmp + (size_t)x * a.Y;
+    const bool last_row = x == a.X;
+    const int Y = a.Y;
+    // element y = Y of row x is element 0 of row x + 1, which row x + 1 (running later in the reference) overwrites
+    auto put = [&](int y, double val) { if (y < Y || last_row) row[y] = val; };
+    fill_line(a.Y, a.v + (size_t)x * (a.D + 2), a.z + (size_t)x * (a.D + 3), get, put);
+}
+
+__global__ void esdf_cols(EsdfArgs a)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y > a.Y) return;
+    const double* in = a.tmp + y;
+    double* out = a.out + y;
+    const int Y = a.Y;
+    const double res = a.res;
+    auto get = [&](int x) -> double { return in[(size_t)x * Y]; };
+    // column Y (processed last by the reference) writes over rows 1.. of column 0: column 0 keeps only its first entry
+    auto put = [&](int x, double val) { if (y != 0 || x == 0) out[(size_t)x * Y] = res * sqrt(val); };
+    fill_line(a.X, a.v + (size_t)y * (a.D + 2), a.z + (size_t)y * (a.D + 3), get, put);
+}
+
+__global__ void esdf_combine(const double* pos, const double* neg, double* dist_all, int GLY, int min_x, int min_y, int X, int Y, double res)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)X * Y) return;
+    const int x = (int)(t / Y), y = (int)(t % Y);
+    const size_t i = (size_t)x * Y + y;
+    double d = pos[i];
+    if (neg[i] > 0.0) d += (-neg[i] + res);
+    dist_all[(size_t)(x + min_x) * GLY + y + min_y] = d;
+}
+
+__global__ void fill_max(double* p, size_t n)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) p[t] = DBL_MAX;
+}
+
+} // namespace
+
+hipError_t esdf_fill_max(double* p, size_t n, hipStream_t s)
+{
+    fill_max<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, n);
+    return hipGetLastError();
+}
+
+// d_grid: device copy of the state grid; d_dist: the map the optimiser reads (updated in the window)
+hipError_t esdf_update(const unsigned char* d_grid, int GLX, int GLY, double res, double x_lo, double y_lo, double odom_x, double odom_y,
+                       double range, double* d_dist, hipStream_t s, int* empty_window)
+{
+    const double inv = 1.0 / res, gx = GLX * res, gy = GLY * res;
+    const int min_x = (int)floor(fmax(0.0, odom_x - range - x_lo) * inv), min_y = (int)floor(fmax(0.0, odom_y - range - y_lo) * inv);
+    const int max_x = (int)ceil(fmin(gx, odom_x + range - x_lo) * inv) - 1, max_y = (int)ceil(fmin(gy, odom_y + range - y_lo) * inv) - 1;
+    const int X = max_x - min_x, Y = max_y - min_y;
+    *empty_window = (X < 1 || Y < 1) ? 1 : 0;
+    if (*empty_window) return hipSuccess;
+    const size_t total = (size_t)(X + 1) * (Y + 1);
+    const int D = (X > Y ? X : Y) + 1, lines = D;
+    double *tmp = nullptr, *pos = nullptr, *neg = nullptr, *z = nullptr;
+    int* v = nullptr;
+    hipError_t e = hipMalloc((void**)&tmp, sizeof(double) * total);
+    if (e == hipSuccess) e = hipMalloc((void**)&pos, sizeof(double) * total);
+    if (e == hipSuccess) e = hipMalloc((void**)&neg, sizeof(double) * total);
+    if (e == hipSuccess) e = hipMalloc((void**)&v, sizeof(int) * (size_t)lines * (D + 2));
+    if (e == hipSuccess) e = hipMalloc((void**)&z, sizeof(double) * (size_t)lines * (D + 3));
+    if (e == hipSuccess) e = hipMemsetAsync(pos, 0, sizeof(double) * total, s);
+    if (e == hipSuccess) e = hipMemsetAsync(neg, 0, sizeof(double) * total, s);
+    if (e == hipSuccess) {
+        for (int pass = 0; pass < 2; ++pass) {
+            EsdfArgs a{d_grid, GLY, min_x, min_y, X, Y, res, tmp, pass == 0 ? pos : neg, v, z, D, pass};
+            esdf_rows<<<(X + 64) / 64, 64, 0, s>>>(a);
+            esdf_cols<<<(Y + 64) / 64, 64, 0, s>>>(a);
+        }
+        esdf_combine<<<(unsigned)(((size_t)X * Y + 255) / 256), 256, 0, s>>>(pos, neg, d_dist, GLY, min_x, min_y, X, Y, res);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(tmp); (void)hipFree(pos); (void)hipFree(neg); (void)hipFree(v); (void)hipFree(z);
+    return e;
+}
+
+} // namespace backend

@@ -97,6 +97,12 @@ const char *alore_backend_last_error(alore_backend_handle h);
 /* plan_env::SDFmap as the optimiser queries it (sdf_map.cpp:760-863): double grid, dist[ix * ny + iy], cell
  * centres at ((i + 0.5) res + lo); copied to the device and kept until replaced */
 int alore_backend_set_map(alore_backend_handle h, const double *dist, int nx, int ny, double x_lo, double y_lo, double res);
+/* The same map built on the device from the occupancy grid: SDFmap::updateESDF2d (sdf_map.cpp:618-681, fillESDF
+ * :683-714).  grid [nx][ny] holds the reference's cell states (0 unknown, 1 unoccupied, 2 occupied; sdf_map.h:98); the
+ * field is recomputed inside the window (odom_x, odom_y) +- detection_range, cells outside it keep their values
+ * (DBL_MAX after the first call with a new geometry, as in sdf_map.h:160).  dist_out (HOST, [nx][ny]) may be NULL. */
+int alore_backend_build_esdf(alore_backend_handle h, const unsigned char *grid, int nx, int ny, double x_lo, double y_lo, double res,
+                             double odom_x, double odom_y, double detection_range, double *dist_out);
 
 /* upload `count` problems (<= max_problems) into the handle's device slots 0..count-1 */
 int alore_backend_set_problems(alore_backend_handle h, int count, const alore_flat_traj *problems, void *stream);

@@ -88,6 +88,20 @@ class EsdfGrid:
         X, Y = np.meshgrid(c, c, indexing="ij")
         return EsdfGrid(fn(X, Y), -half, -half, res)
 
+    @staticmethod
+    def from_occupancy(grid: np.ndarray, x_lo: float, y_lo: float, res: float, odom=(0.0, 0.0), detection_range: float = 1e3) -> "EsdfGrid":
+        """SDFmap::updateESDF2d on a uint8 state grid (0 unknown, 1 free, 2 occupied), starting from DBL_MAX everywhere"""
+        if not os.path.exists(SO):
+            build()
+        L = C.CDLL(SO)
+        g = np.ascontiguousarray(grid, dtype=np.uint8)
+        dist = np.full(g.shape, np.finfo(np.float64).max)
+        L.be_update_esdf2d.restype = C.c_int
+        L.be_update_esdf2d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        rc = L.be_update_esdf2d(g.ctypes.data, g.shape[0], g.shape[1], res, x_lo, y_lo, odom[0], odom[1], detection_range, dist.ctypes.data)
+        assert rc == 0
+        return EsdfGrid(dist, x_lo, y_lo, res)
+
     def c_map(self) -> Map:
         return Map(_ptr(self.dist), self.nx, self.ny, self.x_lo, self.y_lo, self.x_hi, self.y_hi, self.res)
 

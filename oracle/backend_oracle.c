@@ -790,3 +790,86 @@ int be_minco_plan(const be_config *c, const be_map *map, const be_problem *p, be
     r->evals = evals;
     return r->collision ? -1 : 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* ESDF construction: SDFmap::updateESDF2d + fillESDF (P/utils/plan_env/src/sdf_map.cpp:618-714).                      */
+/* Two-pass Felzenszwalb distance transform (rows, then columns) of the occupied cells (positive part) and of the      */
+/* non-occupied cells (negative part) inside the window odom +- detection_range, combined as pos - neg + res inside     */
+/* obstacles.  The reference indexes its (X+1) x (Y+1) scratch buffers with stride Y: the last element of a row is the   */
+/* first of the next.  Executed sequentially that has a defined outcome, restated here statement by statement (the     */
+/* combine step leaves the last row and column of the window untouched, :671-679).                                     */
+/* grid states: 0 Unknown, 1 Unoccupied, 2 Occupied (sdf_map.h:98)                                                     */
+/* ------------------------------------------------------------------------------------------------------------------ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+
+static void fill_esdf(const double *in, int in_stride, double *out, int out_stride, int end, double scale_sqrt, int *v, double *z)
+{
+    /* f_get_val(q) = in[q * in_stride];  f_set_val(q, val): out[q * out_stride] = scale_sqrt > 0 ? scale_sqrt * sqrt(val) : val */
+    int k = 0, q;
+    v[0] = 0;
+    z[0] = -DBL_MAX;
+    z[1] = DBL_MAX;
+    for (q = 1; q <= end; q++) {
+        double s;
+        k++;
+        do {
+            k--;
+            s = ((in[q * in_stride] + q * q) - (in[v[k] * in_stride] + v[k] * v[k])) / (2 * q - 2 * v[k]);
+        } while (s <= z[k]);
+        k++;
+        v[k] = q;
+        z[k] = s;
+        z[k + 1] = DBL_MAX;
+    }
+    k = 0;
+    for (q = 0; q <= end; q++) {
+        double val;
+        while (z[k + 1] < q) k++;
+        val = (q - v[k]) * (q - v[k]) + in[v[k] * in_stride];
+        out[q * out_stride] = scale_sqrt > 0.0 ? scale_sqrt * sqrt(val) : val;
+    }
+}
+
+/* dist_all [GLX][GLY] is updated in place inside the window (cells outside keep their values; the reference starts from
+ * DBL_MAX everywhere, sdf_map.h:160).  Returns 0, or -1 when the window is empty. */
+int be_update_esdf2d(const unsigned char *grid, int GLX, int GLY, double res, double x_lo, double y_lo, double odom_x, double odom_y,
+                     double range, double *dist_all)
+{
+    const double inv = 1.0 / res, gx_hi = x_lo + GLX * res, gy_hi = y_lo + GLY * res;
+    const int min_x = (int)floor(fmax(0.0, odom_x - range - x_lo) * inv), min_y = (int)floor(fmax(0.0, odom_y - range - y_lo) * inv);
+    const int max_x = (int)ceil(fmin(gx_hi - x_lo, odom_x + range - x_lo) * inv) - 1;
+    const int max_y = (int)ceil(fmin(gy_hi - y_lo, odom_y + range - y_lo) * inv) - 1;
+    const int X = max_x - min_x, Y = max_y - min_y;
+    int x, y, pass;
+    size_t total;
+    double *tmp, *pos, *neg, *line_in, *z;
+    int *v;
+    if (X < 1 || Y < 1) return -1;
+    total = (size_t)(X + 1) * (Y + 1);
+    tmp = calloc(total, sizeof(double)); pos = calloc(total, sizeof(double)); neg = calloc(total, sizeof(double));
+    line_in = malloc(sizeof(double) * (size_t)((X > Y ? X : Y) + 2));
+    z = malloc(sizeof(double) * (size_t)((X > Y ? X : Y) + 3));
+    v = malloc(sizeof(int) * (size_t)((X > Y ? X : Y) + 2));
+    for (pass = 0; pass < 2; ++pass) {
+        double *dst = pass == 0 ? pos : neg;
+        for (x = 0; x <= X; x++) {
+            for (y = 0; y <= Y; y++) {
+                const int st = grid[(size_t)(x + min_x) * GLY + (y + min_y)];
+                const int seed = pass == 0 ? (st == 2) : (st == 1 || st == 0);
+                line_in[y] = seed ? 0.0 : DBL_MAX;
+            }
+            fill_esdf(line_in, 1, tmp + (size_t)x * Y, 1, Y, 0.0, v, z);
+        }
+        for (y = 0; y <= Y; y++) fill_esdf(tmp + y, Y, dst + y, Y, X, res, v, z);
+    }
+    for (x = 0; x < X; x++)
+        for (y = 0; y < Y; y++) {
+            const size_t g = (size_t)(x + min_x) * GLY + y + min_y, i = (size_t)x * Y + y;
+            dist_all[g] = pos[i];
+            if (neg[i] > 0.0) dist_all[g] += (-neg[i] + res);
+        }
+    free(tmp); free(pos); free(neg); free(line_in); free(z); free(v);
+    return 0;
+}

@@ -94,6 +94,9 @@ double be_energy(int M, const double *T, const double *coef, const double w[2], 
 void be_spline_adjoint(int M, const double *T, const double *coef, const double *gdC, const double *gdT,
                        double *grad_pts, double *grad_T, double grad_tail[2]);
 double be_esdf(const be_map *m, double x, double y, double grad[2], int mode, double mindis);
+/* SDFmap::updateESDF2d (sdf_map.cpp:618-681): grid states 0 unknown / 1 free / 2 occupied, dist_all updated in the window */
+int be_update_esdf2d(const unsigned char *grid, int GLX, int GLY, double res, double x_lo, double y_lo, double odom_x, double odom_y,
+                     double range, double *dist_all);
 
 /* one cost-callback evaluation.  stage 1 = costFunctionCallbackPath, 2 = costFunctionCallback.
  * x, g: 3M-1 (inner points, tail s, virtual times).  lam/rho: ALM state (stage 2).  xy_err out. */

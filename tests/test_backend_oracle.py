@@ -343,3 +343,27 @@ def test_optimiser_outcomes_are_multimodal():
         costs.append(orc.minco_plan(grid, f2)["cost"])
     costs = np.sort(costs)
     assert (costs[-1] - costs[0]) / costs[0] > 0.05, costs
+
+
+def test_esdf_construction_equals_the_exact_euclidean_transform():
+    """be_update_esdf2d (SDFmap::updateESDF2d + fillESDF restated, with the reference's stride-Y scratch indexing) against
+    SciPy's exact Euclidean distance transform: positive part outside obstacles, -(inside distance) + res inside."""
+    from scipy import ndimage
+    from oracle.backend_driver import EsdfGrid
+    rng = np.random.default_rng(0)
+    n, res = 120, 0.1
+    g = np.ones((n, n), np.uint8)
+    for _ in range(12):
+        x, y = rng.integers(5, n - 15, 2)
+        w, h = rng.integers(2, 10, 2)
+        g[x:x + w, y:y + h] = 2
+    g[40:44, 60:63] = 0                                      # unknown cells count as free for the inside distance
+    E = EsdfGrid.from_occupancy(g, -6.0, -6.0, res)
+    occ = g == 2
+    exp = np.where(occ, -ndimage.distance_transform_edt(occ) * res + res, ndimage.distance_transform_edt(~occ) * res)
+    inner = (slice(0, n - 2), slice(0, n - 2))               # the combine step leaves the last row / column untouched
+    assert np.max(np.abs(E.dist[inner] - exp[inner])) < 1e-12
+    assert np.all(E.dist[n - 1, :] > 1e300) and np.all(E.dist[:, n - 1] > 1e300)
+    # a window around the robot only: cells outside keep the initial DBL_MAX
+    W = EsdfGrid.from_occupancy(g, -6.0, -6.0, res, odom=(0.0, 0.0), detection_range=3.0)
+    assert W.dist[0, 0] > 1e300 and W.dist[60, 60] < 1e3
