@@ -77,6 +77,7 @@ def _bind(L):
     L.alore_backend_set_map.argtypes = [C.c_void_p, DP, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     L.alore_backend_build_esdf.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                            C.c_double, C.c_double, C.c_double, DP]
+    L.alore_backend_predicted_state.argtypes = [C.c_void_p, C.c_int, C.c_double, DP, DP, DP, DP, DP, DP, C.POINTER(C.c_int)]
     L.alore_backend_set_problems.argtypes = [C.c_void_p, C.c_int, C.POINTER(FlatTrajC), C.c_void_p]
     L.alore_backend_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.alore_backend_results.argtypes = [C.c_void_p, C.c_int, C.POINTER(StatusC), DP, DP, DP, C.c_void_p]
@@ -148,6 +149,17 @@ class BatchedMSPlanner:
         self._check(self.L.alore_backend_build_esdf(self.h, g.ctypes.data_as(C.POINTER(C.c_ubyte)), g.shape[0], g.shape[1], x_lo, y_lo, res,
                                                     float(odom[0]), float(odom[1]), float(detection_range), _dp(dist)))
         return dist
+
+    def predicted_state(self, times, resolution: float = 0.01, start_times=None, start_xytheta=None):
+        """MSPlanner::get_the_predicted_state[_and_path] for the plans of the last launch"""
+        t = np.ascontiguousarray(times, np.float64)
+        n = t.shape[0]
+        st = None if start_times is None else np.ascontiguousarray(start_times, np.float64)
+        sx = None if start_xytheta is None else np.ascontiguousarray(start_xytheta, np.float64)
+        xyt, vaj, oaj, fwd = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n, np.int32)
+        self._check(self.L.alore_backend_predicted_state(self.h, n, float(resolution), _dp(st), _dp(t), _dp(sx), _dp(xyt), _dp(vaj), _dp(oaj),
+                                                         fwd.ctypes.data_as(C.POINTER(C.c_int))))
+        return {"xytheta": xyt, "vaj": vaj, "oaj": oaj, "forward": fwd.astype(bool)}
 
     def set_free_map(self, half: float = 40.0, res: float = 0.1, value: float = 100.0):
         n = int(round(2 * half / res))

@@ -223,6 +223,36 @@ int alore_backend_build_esdf(alore_backend_handle h, const unsigned char* grid, 
     return ALORE_BE_OK;
 }
 
+int alore_backend_predicted_state(alore_backend_handle h, int count, double resolution, const double* start_time, const double* time,
+                                  const double* start_xytheta, double* xytheta, double* vaj, double* oaj, int* forward)
+{
+    if (!h || count < 1 || count > h->B || !time || !(resolution > 0.0)) return fail(h, ALORE_BE_E_INVALID, "predicted_state: bad argument");
+    BE_TRY(h, hipSetDevice(h->device));
+    const size_t n = count;
+    double *d_in = nullptr, *d_out = nullptr;
+    int* d_fwd = nullptr;
+    BE_TRY(h, hipMalloc((void**)&d_in, sizeof(double) * n * 5));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(double) * n * 9);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_fwd, sizeof(int) * n);
+    if (e == hipSuccess) e = hipMemcpy(d_in, time, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && start_time) e = hipMemcpy(d_in + n, start_time, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && start_xytheta) e = hipMemcpy(d_in + 2 * n, start_xytheta, sizeof(double) * n * 3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        backend::PredictArgs g{count, h->P, h->d_M, h->r_T, h->r_coef, h->d_sxyt, start_time ? d_in + n : nullptr, d_in,
+                               start_xytheta ? d_in + 2 * n : nullptr, resolution, h->cfg.icr_xv, h->cfg.standard_diff != 0,
+                               d_out, d_out + 3 * n, d_out + 6 * n, d_fwd};
+        e = backend::predicted_state(g, nullptr);
+    }
+    if (e == hipSuccess && xytheta) e = hipMemcpy(xytheta, d_out, sizeof(double) * n * 3, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && vaj) e = hipMemcpy(vaj, d_out + 3 * n, sizeof(double) * n * 3, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && oaj) e = hipMemcpy(oaj, d_out + 6 * n, sizeof(double) * n * 3, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && forward) e = hipMemcpy(forward, d_fwd, sizeof(int) * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_fwd);
+    if (e != hipSuccess) return fail(h, ALORE_BE_E_HIP, "predicted_state", e);
+    return ALORE_BE_OK;
+}
+
 int alore_backend_set_problems(alore_backend_handle h, int count, const alore_flat_traj* pr, void* stream)
 {
     if (!h || count < 1 || count > h->B || !pr) return fail(h, ALORE_BE_E_INVALID, "set_problems: bad argument");

@@ -69,6 +69,21 @@ size_t lds_bytes(int P);
 // `p` must stay alive until the copy has been issued from pinned memory or has completed (callers keep it in the handle)
 hipError_t launch(const Params& p, const Params* d_params, int P, hipStream_t s);
 
+// MSPlanner::get_the_predicted_state[_and_path] on the plans of the last launch (esdf_build.hip)
+struct PredictArgs {
+    int count, P;
+    const int* n_pieces;
+    const double *T, *coef;          // ResultStore
+    const double* plan_start_xyt;    // [B][3] start pose of the plan (final_initStateXYTheta_)
+    const double *start_time, *time; // [B] (start_time may be null = 0)
+    const double* start_xyt;         // [B][3] or null (= plan start pose)
+    double step, xv;
+    bool standard_diff;
+    double *xyt_out, *vaj_out, *oaj_out;
+    int* forward_out;
+};
+hipError_t predicted_state(const PredictArgs& g, hipStream_t s);
+
 // esdf_build.hip: SDFmap::updateESDF2d on the device
 hipError_t esdf_fill_max(double* p, size_t n, hipStream_t s);
 hipError_t esdf_update(const unsigned char* d_grid, int GLX, int GLY, double res, double x_lo, double y_lo, double odom_x, double odom_y,

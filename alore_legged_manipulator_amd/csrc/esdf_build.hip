@@ -156,4 +156,82 @@ hipError_t esdf_update(const unsigned char* d_grid, int GLX, int GLY, double res
     return e;
 }
 
+// ---- MSPlanner::get_the_predicted_state / get_the_predicted_state_and_path (optimizer.cpp:1108-1262) -----------------
+// One thread per plan walks the Simpson steps in the reference's order (the sum is sequential by definition).
+namespace {
+__device__ __forceinline__ void plan_eval(const double* T, const double* coef, int M, double t, double* p, double* v, double* a, double* j)
+{
+    int idx;
+    double d = 0.0;
+    for (idx = 0; idx < M && t > (d = T[idx]); ++idx) t -= d; // Trajectory::locatePieceIdx (trajectory.hpp:472-490)
+    if (idx == M) { --idx; t += T[idx]; }
+#pragma unroll
+    for (int dm = 0; dm < 2; ++dm) {
+        const double* c = coef + 12 * idx + dm;
+        const double c0 = c[0], c1 = c[2], c2 = c[4], c3 = c[6], c4 = c[8], c5 = c[10];
+        if (p) p[dm] = ((((c5 * t + c4) * t + c3) * t + c2) * t + c1) * t + c0;
+        if (v) v[dm] = (((5.0 * c5 * t + 4.0 * c4) * t + 3.0 * c3) * t + 2.0 * c2) * t + c1;
+        if (a) a[dm] = ((20.0 * c5 * t + 12.0 * c4) * t + 6.0 * c3) * t + 2.0 * c2;
+        if (j) j[dm] = (60.0 * c5 * t + 24.0 * c4) * t + 6.0 * c3;
+    }
+}
+__device__ __forceinline__ void simpson_add(bool standard, double xv, double w6, const double* p1, const double* v1, const double* p2,
+                                            const double* v2, const double* p3, const double* v3, double* xyt)
+{
+    double s1, c1, s2, c2, s3, c3;
+    sincos(p1[0], &s1, &c1); sincos(p2[0], &s2, &c2); sincos(p3[0], &s3, &c3);
+    if (standard) {
+        xyt[0] += w6 * (v1[1] * c1 + 4.0 * v2[1] * c2 + v3[1] * c3);
+        xyt[1] += w6 * (v1[1] * s1 + 4.0 * v2[1] * s2 + v3[1] * s3);
+    } else {
+        const double x1 = v1[1] * c1 + v1[0] * xv * s1, x2 = v2[1] * c2 + v2[0] * xv * s2, x3 = v3[1] * c3 + v3[0] * xv * s3;
+        const double y1 = v1[1] * s1 - v1[0] * xv * c1, y2 = v2[1] * s2 - v2[0] * xv * c2, y3 = v3[1] * s3 - v3[0] * xv * c3;
+        xyt[0] += w6 * (x1 + 4.0 * x2 + x3);
+        xyt[1] += w6 * (y1 + 4.0 * y2 + y3);
+    }
+    xyt[2] = p3[0];
+}
+__global__ void predicted_state_kernel(PredictArgs g)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.count) return;
+    const int M = g.n_pieces[b];
+    const double* T = g.T + (size_t)b * g.P;
+    const double* coef = g.coef + (size_t)b * g.P * 12;
+    const double start_time = g.start_time ? g.start_time[b] : 0.0, time = g.time[b], step = g.step;
+    double xyt[3];
+    for (int k = 0; k < 3; ++k) xyt[k] = g.start_xyt ? g.start_xyt[(size_t)b * 3 + k] : g.plan_start_xyt[(size_t)b * 3 + k];
+    double total = 0.0;
+    for (int i = 0; i < M; ++i) total += T[i];
+    const double check = time > total ? total : time;
+    const int n = (int)floor((check - start_time) / step);
+    const double left = check - n * step - start_time;
+    double p1[2], v1[2], p2[2], v2[2], p3[2], v3[2], a3[2], j3[2];
+    plan_eval(T, coef, M, start_time, p3, v3, nullptr, nullptr);
+    for (int i = 0; i < n; ++i) {
+        p1[0] = p3[0]; p1[1] = p3[1]; v1[0] = v3[0]; v1[1] = v3[1];
+        plan_eval(T, coef, M, start_time + i * step + step / 2.0, p2, v2, nullptr, nullptr);
+        plan_eval(T, coef, M, start_time + i * step + step, p3, v3, nullptr, nullptr);
+        simpson_add(g.standard_diff, g.xv, step / 6.0, p1, v1, p2, v2, p3, v3, xyt);
+    }
+    p1[0] = p3[0]; p1[1] = p3[1]; v1[0] = v3[0]; v1[1] = v3[1];
+    plan_eval(T, coef, M, check - left / 2.0, p2, v2, nullptr, nullptr);
+    plan_eval(T, coef, M, check, p3, v3, a3, j3);
+    simpson_add(g.standard_diff, g.xv, left / 6.0, p1, v1, p2, v2, p3, v3, xyt);
+    for (int k = 0; k < 3; ++k) g.xyt_out[(size_t)b * 3 + k] = xyt[k];
+    g.oaj_out[(size_t)b * 3] = v3[0]; g.oaj_out[(size_t)b * 3 + 1] = a3[0]; g.oaj_out[(size_t)b * 3 + 2] = j3[0];
+    g.vaj_out[(size_t)b * 3] = v3[1]; g.vaj_out[(size_t)b * 3 + 1] = a3[1]; g.vaj_out[(size_t)b * 3 + 2] = j3[1];
+    double pe[2], ps[2];
+    plan_eval(T, coef, M, time, pe, nullptr, nullptr, nullptr);
+    plan_eval(T, coef, M, start_time, ps, nullptr, nullptr, nullptr);
+    g.forward_out[b] = pe[1] - ps[1] > 0.0 ? 1 : 0;
+}
+} // namespace
+
+hipError_t predicted_state(const PredictArgs& g, hipStream_t s)
+{
+    predicted_state_kernel<<<(g.count + 63) / 64, 64, 0, s>>>(g);
+    return hipGetLastError();
+}
+
 } // namespace backend

@@ -144,6 +144,14 @@ int alore_backend_lbfgs(alore_backend_handle h, int count, int stage, double *x,
 /* duration of the last alore_backend_plan launch in ms (HIP events on its stream; synchronises) */
 int alore_backend_last_plan_ms(alore_backend_handle h, float *ms);
 
+/* MSPlanner::get_the_predicted_state (optimizer.cpp:1108-1188) and get_the_predicted_state_and_path (:1190-1262) on the
+ * plans of the last alore_backend_plan: the pose reached at time[b] by Simpson integration in steps of `resolution`
+ * (trajPredictResolution) from start_time[b] (NULL: 0) and start_xytheta[b] (NULL: the plan's start pose), the flat
+ * derivatives there (vaj = v, a, j of the arc length; oaj = omega, alpha, jerk of the yaw) and the reference's
+ * if_forward flag.  HOST pointers, [count] / [count][3]; outputs may be NULL. */
+int alore_backend_predicted_state(alore_backend_handle h, int count, double resolution, const double *start_time, const double *time,
+                                  const double *start_xytheta, double *xytheta, double *vaj, double *oaj, int *forward);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,20 @@ class EsdfGrid:
         return Map(_ptr(self.dist), self.nx, self.ny, self.x_lo, self.y_lo, self.x_hi, self.y_hi, self.res)
 
 
+def predicted_state(T, coef, step, time, start_time=0.0, start_xytheta=(0.0, 0.0, 0.0), standard_diff=True, xv=0.0):
+    """MSPlanner::get_the_predicted_state[_and_path] on a plan (T [M], coef [(6 i + k) * 2 + d])"""
+    if not os.path.exists(SO):
+        build()
+    L = C.CDLL(SO)
+    L.be_predicted_state.restype = C.c_int
+    L.be_predicted_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    T = np.ascontiguousarray(T, np.float64); coef = np.ascontiguousarray(coef, np.float64)
+    xyt = np.array(start_xytheta, np.float64); vaj = np.zeros(3); oaj = np.zeros(3)
+    fwd = L.be_predicted_state(T.ctypes.data, coef.ctypes.data, len(T), 1 if standard_diff else 0, xv, step, start_time, time,
+                               xyt.ctypes.data, vaj.ctypes.data, oaj.ctypes.data)
+    return xyt, vaj, oaj, bool(fwd)
+
+
 class BackendOracle:
     def __init__(self):
         if not os.path.exists(SO):

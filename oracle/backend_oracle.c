@@ -873,3 +873,75 @@ int be_update_esdf2d(const unsigned char *grid, int GLX, int GLY, double res, do
     free(tmp); free(pos); free(neg); free(line_in); free(z); free(v);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* MSPlanner::get_the_predicted_state / get_the_predicted_state_and_path (optimizer.cpp:1108-1188, 1190-1262): the pose   */
+/* reached at `time` by Simpson integration of the flat trajectory in steps of trajPredictResolution from start_time,   */
+/* and the flat derivatives there.  coef [(6 i + k) * 2 + d] (ascending powers), T [M].                                 */
+/* ------------------------------------------------------------------------------------------------------------------ */
+static int traj_locate(const double *T, int M, double *t)
+{ /* Trajectory::locatePieceIdx (trajectory.hpp:472-490) */
+    int idx;
+    double d = 0.0;
+    for (idx = 0; idx < M && *t > (d = T[idx]); ++idx) *t -= d;
+    if (idx == M) { --idx; *t += T[idx]; }
+    return idx;
+}
+static void traj_eval(const double *T, const double *coef, int M, double t, double p[2], double v[2], double a[2], double j[2])
+{
+    double tl = t;
+    const int i = traj_locate(T, M, &tl);
+    int d;
+    for (d = 0; d < 2; ++d) {
+        const double c0 = coef[(6 * i + 0) * 2 + d], c1 = coef[(6 * i + 1) * 2 + d], c2 = coef[(6 * i + 2) * 2 + d];
+        const double c3 = coef[(6 * i + 3) * 2 + d], c4 = coef[(6 * i + 4) * 2 + d], c5 = coef[(6 * i + 5) * 2 + d];
+        if (p) p[d] = ((((c5 * tl + c4) * tl + c3) * tl + c2) * tl + c1) * tl + c0;
+        if (v) v[d] = (((5.0 * c5 * tl + 4.0 * c4) * tl + 3.0 * c3) * tl + 2.0 * c2) * tl + c1;
+        if (a) a[d] = ((20.0 * c5 * tl + 12.0 * c4) * tl + 6.0 * c3) * tl + 2.0 * c2;
+        if (j) j[d] = (60.0 * c5 * tl + 24.0 * c4) * tl + 6.0 * c3;
+    }
+}
+static void simpson_add(int standard_diff, double xv, double w6, const double p1[2], const double v1[2], const double p2[2], const double v2[2],
+                        const double p3[2], const double v3[2], double xyt[3])
+{
+    if (standard_diff) {
+        xyt[0] += w6 * (v1[1] * cos(p1[0]) + 4.0 * v2[1] * cos(p2[0]) + v3[1] * cos(p3[0]));
+        xyt[1] += w6 * (v1[1] * sin(p1[0]) + 4.0 * v2[1] * sin(p2[0]) + v3[1] * sin(p3[0]));
+    } else {
+        const double x1 = v1[1] * cos(p1[0]) + v1[0] * xv * sin(p1[0]), x2 = v2[1] * cos(p2[0]) + v2[0] * xv * sin(p2[0]),
+                     x3 = v3[1] * cos(p3[0]) + v3[0] * xv * sin(p3[0]);
+        const double y1 = v1[1] * sin(p1[0]) - v1[0] * xv * cos(p1[0]), y2 = v2[1] * sin(p2[0]) - v2[0] * xv * cos(p2[0]),
+                     y3 = v3[1] * sin(p3[0]) - v3[0] * xv * cos(p3[0]);
+        xyt[0] += w6 * (x1 + 4.0 * x2 + x3);
+        xyt[1] += w6 * (y1 + 4.0 * y2 + y3);
+    }
+    xyt[2] = p3[0];
+}
+/* returns if_forward of the _and_path variant; xyt in: start pose, out: predicted pose */
+int be_predicted_state(const double *T, const double *coef, int M, int standard_diff, double xv, double step, double start_time, double time,
+                       double xyt[3], double vaj[3], double oaj[3])
+{
+    double total = 0.0, check = time, p1[2], v1[2], p2[2], v2[2], p3[2], v3[2], a3[2], j3[2], pe[2], ps[2];
+    int i, n;
+    double left;
+    for (i = 0; i < M; ++i) total += T[i];
+    if (time > total) check = total;
+    n = (int)floor((check - start_time) / step);
+    left = check - n * step - start_time;
+    traj_eval(T, coef, M, start_time, p3, v3, 0, 0);
+    for (i = 0; i < n; ++i) {
+        p1[0] = p3[0]; p1[1] = p3[1]; v1[0] = v3[0]; v1[1] = v3[1];
+        traj_eval(T, coef, M, start_time + i * step + step / 2.0, p2, v2, 0, 0);
+        traj_eval(T, coef, M, start_time + i * step + step, p3, v3, 0, 0);
+        simpson_add(standard_diff, xv, step / 6.0, p1, v1, p2, v2, p3, v3, xyt);
+    }
+    p1[0] = p3[0]; p1[1] = p3[1]; v1[0] = v3[0]; v1[1] = v3[1];
+    traj_eval(T, coef, M, check - left / 2.0, p2, v2, 0, 0);
+    traj_eval(T, coef, M, check, p3, v3, a3, j3);
+    simpson_add(standard_diff, xv, left / 6.0, p1, v1, p2, v2, p3, v3, xyt);
+    oaj[0] = v3[0]; oaj[1] = a3[0]; oaj[2] = j3[0];
+    vaj[0] = v3[1]; vaj[1] = a3[1]; vaj[2] = j3[1];
+    traj_eval(T, coef, M, time, pe, 0, 0, 0);
+    traj_eval(T, coef, M, start_time, ps, 0, 0, 0);
+    return pe[1] - ps[1] > 0.0 ? 1 : 0;
+}

@@ -94,6 +94,9 @@ double be_energy(int M, const double *T, const double *coef, const double w[2], 
 void be_spline_adjoint(int M, const double *T, const double *coef, const double *gdC, const double *gdT,
                        double *grad_pts, double *grad_T, double grad_tail[2]);
 double be_esdf(const be_map *m, double x, double y, double grad[2], int mode, double mindis);
+/* MSPlanner::get_the_predicted_state[_and_path] (optimizer.cpp:1108-1262); xyt: start pose in, predicted pose out */
+int be_predicted_state(const double *T, const double *coef, int M, int standard_diff, double xv, double step, double start_time, double time,
+                       double xyt[3], double vaj[3], double oaj[3]);
 /* SDFmap::updateESDF2d (sdf_map.cpp:618-681): grid states 0 unknown / 1 free / 2 occupied, dist_all updated in the window */
 int be_update_esdf2d(const unsigned char *grid, int GLX, int GLY, double res, double x_lo, double y_lo, double odom_x, double odom_y,
                      double range, double *dist_all);

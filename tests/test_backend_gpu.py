@@ -248,3 +248,31 @@ def test_esdf_built_on_the_device_is_bit_identical_to_the_oracle(orc):
     ft = waypoint_path([[0.0, 0.0], [6.0, 0.5]], 0.1, 0.4)
     res2 = pl2.minco_plan([ft])
     assert res2["ok"][0] == 1 and res2["min_dist"][0] > orc.cfg.final_min_safe_dis
+
+
+def test_predicted_state_matches_the_oracle(orc):
+    """alore_backend_predicted_state (MSPlanner::get_the_predicted_state / _and_path) on the GPU's own plans against the
+    oracle's restatement fed with the same coefficients: same Simpson steps in the same order, 1e-10."""
+    from oracle.backend_driver import predicted_state
+    fts = monte_carlo_goals(24, seed=8)
+    pl = planner_for(free_grid(), len(fts))
+    res = pl.minco_plan(fts)
+    rng = np.random.default_rng(2)
+    total = np.array([res["T"][b, :res["n_pieces"][b]].sum() for b in range(len(fts))])
+    times = total * rng.uniform(0.05, 1.3, len(fts))           # some beyond the end of the plan (clamped)
+    out = pl.predicted_state(times, resolution=0.01)
+    st = total * rng.uniform(0.0, 0.4, len(fts))
+    sx = rng.uniform(-1, 1, (len(fts), 3))
+    out2 = pl.predicted_state(np.maximum(times, st + 0.05), resolution=0.02, start_times=st, start_xytheta=sx)
+    for b, ft in enumerate(fts):
+        M = res["n_pieces"][b]
+        T, coef = res["T"][b, :M], res["coef"][b, :6 * M].reshape(-1)
+        xyt, vaj, oaj, fwd = predicted_state(T, coef, 0.01, times[b], start_xytheta=ft.start_xytheta)
+        assert np.max(np.abs(out["xytheta"][b] - xyt)) < 1e-10 and np.max(np.abs(out["vaj"][b] - vaj)) < 1e-9
+        assert np.max(np.abs(out["oaj"][b] - oaj)) < 1e-9 and bool(out["forward"][b]) == fwd
+        xyt, vaj, oaj, fwd = predicted_state(T, coef, 0.02, max(times[b], st[b] + 0.05), start_time=st[b], start_xytheta=sx[b])
+        assert np.max(np.abs(out2["xytheta"][b] - xyt)) < 1e-10 and bool(out2["forward"][b]) == fwd
+    # at the end of the plan the predicted pose is the goal the optimiser was asked to reach (terminal error < tol)
+    end = pl.predicted_state(total + 1.0)
+    goal = np.array([ft.final_xytheta for ft in fts])
+    assert np.max(np.hypot(end["xytheta"][:, 0] - goal[:, 0], end["xytheta"][:, 1] - goal[:, 1])) < 0.05
