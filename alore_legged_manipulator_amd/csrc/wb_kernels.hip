@@ -24,6 +24,7 @@
 
 #include "../../include/alore_wb.h"
 #include "wave_linalg.h"
+#include "wb_aba.h"
 #include "wb_dynamics.h"
 
 namespace wb {
@@ -526,6 +527,15 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     }
 }
 
+// one lane per evaluation point (alore_wb_aba): the articulated-body algorithm of wb_aba.h
+__global__ __launch_bounds__(64) void aba_kernel(int n, const double* q, const double* v, const double* u, double grav, double* acc)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Eval e{q + (size_t)t * NQ, v + (size_t)t * NV, v + (size_t)t * NV, u + (size_t)t * NU + 18, 1.0, 0.0, 1.0, -1, -1, -1, -1, 0.0, 0.0, 0.0, 0.0, grav};
+    aba(e, u + (size_t)t * NU, Sink{acc + (size_t)t * NV, 1, 1.0, 0});
+}
+
 } // namespace wb
 
 // =====================================================================================================================
@@ -663,6 +673,22 @@ int alore_wb_rnea(alore_wb_handle h, int n, const double* q, const double* v, co
     wb::rnea_kernel<<<(n + 63) / 64, 64>>>(n, dq, dv, da, df, gravity ? b2z1::GRAVITY : 0.0, dt);
     WB_TRY(h, hipGetLastError());
     WB_TRY(h, hipMemcpy(tau, dt, sizeof(double) * n * 24, hipMemcpyDeviceToHost));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_aba(alore_wb_handle h, int n, const double* q, const double* v, const double* u, double* a)
+{
+    if (!h || n <= 0 || !q || !v || !u || !a) return fail(h, ALORE_WB_E_INVALID, "aba: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    Tmp t;
+    double *dq = t.get<double>((size_t)n * 24), *dv = t.get<double>((size_t)n * 24), *du = t.get<double>((size_t)n * wb::NU), *da = t.get<double>((size_t)n * 24);
+    if (!dq || !dv || !du || !da) return fail(h, ALORE_WB_E_NOMEM, "aba: hipMalloc");
+    WB_TRY(h, hipMemcpy(dq, q, sizeof(double) * n * 24, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(dv, v, sizeof(double) * n * 24, hipMemcpyHostToDevice));
+    WB_TRY(h, hipMemcpy(du, u, sizeof(double) * n * wb::NU, hipMemcpyHostToDevice));
+    wb::aba_kernel<<<(n + 63) / 64, 64>>>(n, dq, dv, du, b2z1::GRAVITY, da);
+    WB_TRY(h, hipGetLastError());
+    WB_TRY(h, hipMemcpy(a, da, sizeof(double) * n * 24, hipMemcpyDeviceToHost));
     return ALORE_WB_OK;
 }
 

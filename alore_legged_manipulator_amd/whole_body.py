@@ -32,6 +32,7 @@ def _bind(L):
         "alore_wb_model_info": (C.c_int, [DP, DP, DP, DP]),
         "alore_wb_rnea": (C.c_int, [H, C.c_int, DP, DP, DP, DP, C.c_int, DP]),
         "alore_wb_forward_dynamics": (C.c_int, [H, C.c_int, DP, DP, DP, DP, DP]),
+        "alore_wb_aba": (C.c_int, [H, C.c_int, DP, DP, DP, DP]),
         "alore_wb_set_weights": (C.c_int, [H, DP, DP, DP]),
         "alore_wb_set_problem": (C.c_int, [H, C.c_int, DP, DP, DP]),
         "alore_wb_set_iterate": (C.c_int, [H, C.c_int, DP, DP]),
@@ -105,6 +106,13 @@ class BatchedWholeBody:
         M, a = np.zeros((n, NV, NV)), np.zeros((n, NV))
         self._check(self.L.alore_wb_forward_dynamics(self.h, n, _dp(q), _dp(v), _dp(u), _dp(M), _dp(a)))
         return M, a
+
+    def aba(self, q, v, u):
+        """forward dynamics by the articulated-body algorithm (no mass matrix)"""
+        q, v, u = _f64(q, (-1, NQ)), _f64(v, (-1, NV)), _f64(u, (-1, NU))
+        a = np.zeros((q.shape[0], NV))
+        self._check(self.L.alore_wb_aba(self.h, q.shape[0], _dp(q), _dp(v), _dp(u), _dp(a)))
+        return a
 
     # ---- OCP ------------------------------------------------------------------------------------------------------
     def set_weights(self, Q, R, QN):

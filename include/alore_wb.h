@@ -66,6 +66,9 @@ int alore_wb_rnea(alore_wb_handle h, int n, const double *q, const double *v, co
 int alore_wb_forward_dynamics(alore_wb_handle h, int n, const double *q, const double *v, const double *u, double *M,
                               double *a);
 
+/* the same accelerations by the articulated-body algorithm (O(n), no mass matrix): u [n][30] -> a [n][24] */
+int alore_wb_aba(alore_wb_handle h, int n, const double *q, const double *v, const double *u, double *a);
+
 /* ---- the OCP ---- */
 /* diagonal weights shared by the batch: Q [48], R [30], QN [48] */
 int alore_wb_set_weights(alore_wb_handle h, const double *Q, const double *R, const double *QN);

@@ -13,3 +13,11 @@ extern "C" void wbh_mass_column(const double* q, int j, double* col)
     wb::Eval e{q, z, z, z, 0.0, 0.0, 0.0, -1, -1, j, -1, 0, 0, 1.0, 0, 0.0};
     wb::rnea(e, wb::Sink{col, 1, 1.0, 0});
 }
+
+#include "../../alore_legged_manipulator_amd/csrc/wb_aba.h"
+extern "C" void wbh_aba(const double* q, const double* v, const double* tau, const double* f, double g, double* acc)
+{
+    double z[24] = {0};
+    wb::Eval e{q, v, z, f, 1.0, 0.0, 1.0, -1, -1, -1, -1, 0, 0, 0, 0, g};
+    wb::aba(e, tau, wb::Sink{acc, 1, 1.0, 0});
+}

@@ -48,3 +48,18 @@ def test_mass_matrix_columns(H):
         col = np.zeros(24)
         H.wbh_mass_column(dp(q), j, dp(col))
         assert np.max(np.abs(col - M[:, j])) < 1e-11
+
+
+def test_aba_matches_the_spatial_oracle(H):
+    """csrc/wb_aba.h (the GPU's articulated-body algorithm, 3 x 3 block form) against the oracle's 6-D ABA and against
+    M^-1 (tau - bias): three routes to the same accelerations."""
+    m = Model()
+    rng = np.random.default_rng(10)
+    for _ in range(20):
+        q = np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-0.8, 0.8, 3), rng.uniform(m.lower, m.upper)])
+        v, tau, f = rng.normal(0, 1, 24), rng.normal(0, 8, 18), rng.normal(0, 80, 12)
+        acc = np.zeros(24)
+        H.wbh_aba(dp(q), dp(v), dp(tau), dp(f), C.c_double(m.g), dp(acc))
+        ref = m.aba(q, v, tau, f.reshape(4, 3))
+        assert np.max(np.abs(acc - ref)) < 1e-9 * max(1.0, np.max(np.abs(ref))), np.max(np.abs(acc - ref))
+        assert np.max(np.abs(acc - m.forward_dynamics(q, v, tau, f.reshape(4, 3)))) < 1e-8 * max(1.0, np.max(np.abs(ref)))
