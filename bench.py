@@ -416,7 +416,7 @@ def main():
             t_a = time.perf_counter()
             nt = 30
             for i in range(nt):
-                ctl.tick(0.07 + 0.01 * i)
+                ctl.tick_full(0.07 + 0.01 * i)   # the C entry point (alore_host_controller_tick); no Python unpacking of the B commands
             t_b = time.perf_counter()
             extras["controller_tick"] = {"robots": B, "ms_per_tick": (t_b - t_a) / nt * 1e3,
                                          "robot_ticks_per_s": B * nt / (t_b - t_a),
