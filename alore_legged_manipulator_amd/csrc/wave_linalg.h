@@ -31,12 +31,50 @@ __device__ __forceinline__ void spd_inverse_rows(T (&a)[N], int lane)
         const T pk = T(1) / rowk[k];
         const bool me = lane == k;
         const T g = a[k] * pk;
+        // two operations per element and lane: every other row subtracts g x (pivot row); the pivot row itself (g_eff = 0
+        // leaves it untouched) is scaled by 1 / pivot
+        const T g_eff = me ? T(0) : g, sc = me ? pk : T(1);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             if (j == k) continue;
-            a[j] = me ? rowk[j] * pk : a[j] - g * rowk[j];
+            a[j] = (a[j] - g_eff * rowk[j]) * sc;
         }
         a[k] = me ? pk : -g;
+    }
+}
+
+// The same elimination with a row spread over TWO lanes: lane r (< N) holds columns 0 .. N/2 - 1 of row r, lane r + 32
+// columns N/2 .. N - 1 (N even, N <= 32).  A step moves N/2 pivot-row entries per lane through the cross-lane permute
+// (each half fetches its own half of the pivot row) plus the lane's pivot-column entry, and updates N/2 elements: less
+// than half the instructions of the one-lane-per-row form, which spends its time issuing N broadcasts and 2 N
+// arithmetic instructions per step on one wavefront.
+__device__ __forceinline__ float fetch(float x, int src) { return __shfl(x, src, 64); }
+__device__ __forceinline__ double fetch(double x, int src) { return __shfl(x, src, 64); }
+
+template <class T, int N>
+__device__ __forceinline__ void spd_inverse_rows_split(T (&a)[N / 2], int lane)
+{
+    static_assert(N % 2 == 0 && N <= 32, "row halves on lanes r and r + 32");
+    constexpr int H = N / 2;
+    const int r = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        constexpr int dummy = 0; (void)dummy;
+        const int hk = k / H, kk = k % H;                 // compile-time after unrolling
+        T rowk[H];
+#pragma unroll
+        for (int j = 0; j < H; ++j) rowk[j] = fetch(a[j], k + 32 * half);   // my half of pivot row k
+        const T piv = bcast(a[kk], k + 32 * hk);          // A[k][k], wave-uniform
+        const T pk = T(1) / piv;
+        const T f = fetch(a[kk], r + 32 * hk);            // A[r][k] of my row (held by the half that owns column k)
+        const bool me = r == k;
+        const T g = f * pk;
+        const T g_eff = me ? T(0) : g, sc = me ? pk : T(1);
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const T upd = (a[j] - g_eff * rowk[j]) * sc;
+            a[j] = (j == kk && half == hk) ? (me ? pk : -g) : upd;
+        }
     }
 }
 

@@ -114,6 +114,8 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
             if (g.M64 && lane < 24)
                 for (int i = 0; i < NV; ++i) g.M64[((size_t)item * NV + i) * NV + lane] = S.M[i * MS + lane];
             // ---- M^-1 in place (lane i owns row i; wave_linalg.h), then a = M^-1 ([0; tau] - bias)
+            // (the two-lanes-per-row variant used by the Riccati kernel does not pay here: a float64 element costs two
+            //  cross-lane permutes, measured equal)
             {
                 double row[NV];
                 const int rr = lane < NV ? lane : 0;
@@ -258,9 +260,9 @@ __global__ __launch_bounds__(64) void rnea_kernel(int n, const double* q, const 
 //   C[4 (l >> 4) + r][l & 15], r = 0..3  (cdna_hip_programming.md, "A/B operands ... 16x16x4").
 // Backward, stage k = N-1 .. 0 (P, p: cost-to-go 1/2 dx' P dx + p' dx of stage k + 1):
 //   PA = P A, PB = P B, s = P d + p                              (15 output tiles)
-//   Qxx = Q + A' PA, Qux = B' PA, Quu = R + B' PB, qx, qu        (19 tiles)
+//   Qxx = Q + A' PA, Qux = B' PA, Quu = R + B' PB, qx, qu        (15 tiles: the symmetric ones upper-triangular)
 //   Quu = L L' (Cholesky, 30 x 30), K = -Quu^-1 Qux, kff = -Quu^-1 qu   -> HBM (used by the forward sweep)
-//   P <- Qxx + Qux' K, p <- qx + Qux' kff                        (9 tiles)
+//   P <- Qxx + Qux' K, p <- qx + Qux' kff                        (6 tiles)
 // Forward: dx_0 = x0 - x_0, du_k = K_k dx_k + kff_k, dx_{k+1} = A_k dx_k + B_k du_k + d_k; then x += dx, u += du with
 // the joint torques clipped to the URDF effort limits.
 // =====================================================================================================================
@@ -303,7 +305,7 @@ struct RicLds {
 // multiple of 4 known at compile time: all operands of the tile are fetched from LDS first (2 K / 4 independent
 // reads in flight), then the K / 4 matrix instructions run back to back.
 //   TA: A is stored transposed (element (i, k) at A[k * lda + i]);  TB likewise for B
-template <bool TA, bool TB, int K>
+template <bool TA, bool TB, int K, bool MIRROR = false>
 __device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* Bm, int ldb, int i0, int j0, float* Cm, int ldc,
                                           const float* Cinit, int ldi, float alpha_diag, const float* diag, float scale = 1.f)
 {
@@ -316,18 +318,28 @@ __device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* 
         a[s] = TA ? A[k * lda + i0 + r16] : A[(i0 + r16) * lda + k];
         b[s] = TB ? Bm[(j0 + r16) * ldb + k] : Bm[k * ldb + j0 + r16];
     }
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    // two accumulation chains (even / odd K steps): a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles for its predecessor
+    f4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < K / 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+    for (int s = 0; s < K / 4; s += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
+    }
+    acc += acc1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + 4 * kq + r, col = j0 + r16;
+        if (MIRROR && row > col) continue; // symmetric result: the upper triangle is computed once and written twice
         float v = scale * acc[r];
         if (Cinit) v += Cinit[row * ldi + col];
         if (diag && row == col) v += alpha_diag * diag[row];
         Cm[row * ldc + col] = v;
+        if (MIRROR && row < col) Cm[col * ldc + row] = v;
     }
 }
+
+// upper-triangular 16 x 16 tiles of a symmetric 48 x 48 / 32 x 32 result
+__device__ constexpr int SYM3_I[6] = {0, 0, 0, 1, 1, 2}, SYM3_J[6] = {0, 1, 2, 1, 2, 2}, SYM2_I[3] = {0, 0, 1}, SYM2_J[3] = {0, 1, 1};
 
 constexpr int RIC_WAVES = 4, RIC_THREADS = 64 * RIC_WAVES, RIC_LAST = 64 * (RIC_WAVES - 1); // RIC_LAST: first thread of the last wave
 
@@ -383,10 +395,10 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         __syncthreads();
         WB_STAMP(g.stamps, 1)
         // ---- Qxx = Q + A' PA (9), Qux = B' PA (6), Quu = R + B' PB (4); qx = gx + A' s, qu = gu + B' s
-        for (int t = wave; t < 19; t += RIC_WAVES) {
-            if (t < 9) mfma_tile<true, false, 48>(S.A, LDX, S.PA, LDX, (t / 3) * 16, (t % 3) * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
-            else if (t < 15) mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, ((t - 9) / 3) * 16, ((t - 9) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
-            else mfma_tile<true, false, 48>(S.B, LDU, S.PB, LDU, ((t - 15) / 2) * 16, ((t - 15) % 2) * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
+        for (int t = wave; t < 15; t += RIC_WAVES) { // Qxx and Quu are symmetric: upper-triangular tiles, mirrored on store
+            if (t < 6) mfma_tile<true, false, 48, true>(S.A, LDX, S.PA, LDX, SYM3_I[t] * 16, SYM3_J[t] * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
+            else if (t < 12) mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, ((t - 6) / 3) * 16, ((t - 6) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
+            else mfma_tile<true, false, 48, true>(S.B, LDU, S.PB, LDU, SYM2_I[t - 12] * 16, SYM2_J[t - 12] * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
         }
         __syncthreads();
         WB_STAMP(g.stamps, 2)
@@ -408,18 +420,19 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
         float* Rres = S.PA;   // PA is dead once Qxx and Qux exist
         if (wave == 0) {
-            float row[NU]; // the 2 padding inputs are an identity block
-            const int rr = tid < NU ? tid : 0;
+            // row r of Quu on lanes r and r + 32 (15 columns each); the 2 padding inputs are an identity block
+            float rowh[NU / 2];
+            const int r5 = tid & 31, rr = r5 < NU ? r5 : 0, hh = tid >> 5;
 #pragma unroll
-            for (int j = 0; j < NU; ++j) row[j] = S.Quu[rr * LDU + j];
-            wavela::spd_inverse_rows<float, NU>(row, tid);
-            if (tid < NU) {
+            for (int j = 0; j < NU / 2; ++j) rowh[j] = S.Quu[rr * LDU + hh * (NU / 2) + j];
+            wavela::spd_inverse_rows_split<float, NU>(rowh, tid);
+            if (r5 < NU) {
 #pragma unroll
-                for (int j = 0; j < NU; ++j) Qinv[tid * LDU + j] = row[j];
-                Qinv[tid * LDU + 30] = 0.f; Qinv[tid * LDU + 31] = 0.f;
-            } else if (tid < 32) {
+                for (int j = 0; j < NU / 2; ++j) Qinv[r5 * LDU + hh * (NU / 2) + j] = rowh[j];
+                if (hh == 1) { Qinv[r5 * LDU + 30] = 0.f; Qinv[r5 * LDU + 31] = 0.f; }
+            } else if (hh == 0) {
 #pragma unroll
-                for (int j = 0; j < 32; ++j) Qinv[tid * LDU + j] = (j == tid) ? 1.f : 0.f;
+                for (int j = 0; j < 32; ++j) Qinv[r5 * LDU + j] = (j == r5) ? 1.f : 0.f;
             }
         }
         __syncthreads();
@@ -467,8 +480,8 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             if (tid < 32) g.kff[((size_t)b * N + k) * 32 + tid] = S.kff[tid];
         }
         // ---- P <- Qxx + Qux' K (9 tiles), p <- qx + Qux' kff
-        for (int t = wave; t < 9; t += RIC_WAVES)
-            mfma_tile<true, false, 32>(S.Qux, LDX, SK, LDX, (t / 3) * 16, (t % 3) * 16, S.P, LDX, S.P, LDX, 0.f, nullptr);
+        for (int t = wave; t < 6; t += RIC_WAVES) // symmetric: 6 tiles, mirrored (no separate symmetrisation pass)
+            mfma_tile<true, false, 32, true>(S.Qux, LDX, SK, LDX, SYM3_I[t] * 16, SYM3_J[t] * 16, S.P, LDX, S.P, LDX, 0.f, nullptr);
         if (tid >= RIC_LAST && tid < RIC_LAST + 48) {
             const int i = tid - RIC_LAST;
             float acc = S.qx[i];
@@ -477,12 +490,6 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         }
         __syncthreads();
         WB_STAMP(g.stamps, 8)
-        // symmetrise (the two triangles differ by rounding only)
-        for (int i = tid; i < 48 * 48; i += RIC_THREADS) {
-            const int r = i / 48, c = i % 48;
-            if (r < c) { const float m = 0.5f * (S.P[r * LDX + c] + S.P[c * LDX + r]); S.P[r * LDX + c] = m; S.P[c * LDX + r] = m; }
-        }
-        __syncthreads();
         WB_STAMP(g.stamps, 9)
     }
 

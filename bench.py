@@ -483,9 +483,10 @@ def main():
             t_b = time.perf_counter()
             lin_ms, ric_ms = wbe.last_times()
             dxw, duw = wbe.last_step()
-            # matrix-core flops of the Riccati sweep per problem: per stage 34 tiles with K = 48 (12 MFMAs each) and
-            # 27 tiles with K = 32 (8 each) = 624 v_mfma_f32_16x16x4_f32 of 2048 flops (SQ_INSTS_MFMA agrees: profiles/)
-            mfma_flops = N * ((15 + 19) * 12 + (6 * 3 + 9) * 8) * 2048.0
+            # matrix-core flops of the Riccati sweep per problem: per stage 30 tiles with K = 48 (12 MFMAs each; the
+            # symmetric products only their upper-triangular tiles) and 24 tiles with K = 32 (8 each) = 552
+            # v_mfma_f32_16x16x4_f32 of 2048 flops (SQ_INSTS_MFMA agrees: profiles/)
+            mfma_flops = N * ((15 + 15) * 12 + (6 * 3 + 6) * 8) * 2048.0
             extras["whole_body_b2z1"] = {"problems": Bw, "horizon": N, "ms_linearize": lin_ms, "ms_riccati": ric_ms,
                                          "ms_wall_one_rti": (t_b - t_a) * 1e3, "solves_per_s": Bw / ((lin_ms + ric_ms) * 1e-3),
                                          "mfma_f32_TFLOPs_riccati": Bw * mfma_flops / (ric_ms * 1e-3) / 1e12,
