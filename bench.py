@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
+    ap.add_argument("--workload", choices=("planar", "whole_body"), default="planar",
+                    help="planar = BASELINE configs[1] (the headline); whole_body = configs[2] (B2+Z1, one line with an MFMA roofline block)")
     return ap.parse_args()
 
 
@@ -139,6 +141,70 @@ def cpu_baseline(N: int, batch: dict, seconds: float) -> dict:
     return out
 
 
+def whole_body_main(a, rank, world, local_rank, torch, dist):
+    """BASELINE configs[2]: B = 4096 B2 + Z1 whole-body problems per GPU, N = 20; a step = one real-time iteration
+    (linearisation kernel + Riccati kernel) of every problem from the same iterate.  Independent problems: ranks are
+    replicas of the same shard size (weak scaling), no collective."""
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from wb_cases import make_problems_fast, weights as wb_weights
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    B, N = a.batch, a.horizon
+    eng = BatchedWholeBody(B, N, 0.01, device=local_rank)
+    x0, xref, uref, xi, ui = make_problems_fast(B, N, seed=3 + rank)
+    eng.set_weights(*wb_weights())
+    eng.set_problem(x0, xref, uref)
+    steps, warm = min(a.steps, 50), min(a.warmup, 5)
+    lin = ric = 0.0
+    for i in range(warm):
+        eng.set_iterate(xi, ui); eng.rti(1)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    t_host = 0.0
+    for i in range(steps):
+        th = time.perf_counter()
+        eng.set_iterate(xi, ui)          # every step starts from the same cold iterate (host upload, not part of the step)
+        torch.cuda.synchronize(dev)
+        t_host += time.perf_counter() - th
+        eng.rti(1)
+        l, r_ = eng.last_times()         # HIP events around the two kernels; synchronises
+        lin += l; ric += r_
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0 - t_host
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0].item())
+    dx, du = eng.last_step()
+    if rank == 0:
+        lin /= steps; ric /= steps
+        mfma_flops = N * ((15 + 15) * 12 + (6 * 3 + 6) * 8) * 2048.0 * B
+        tf = mfma_flops / (ric * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "whole_body_rti_solves_per_s", "value": B * world * steps / elapsed, "unit": "solves/s", "n_gpus": world,
+            "steps": steps, "warmup": warm, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 dynamics / f32 MFMA Riccati", "data": "synthetic",
+            "config": {"workload": f"B={B} per GPU B2+Z1 whole-body NMPC (floating base + 18 joints, nx 48, nu 30), N={N}, one "
+                                   "real-time iteration (linearise + Riccati + step) per problem", "batch_per_gpu": B, "horizon": N,
+                       "parallelism": f"independent replicas x{world}"},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
+                         "traffic": None, "kernel": "wb::riccati_kernel", "kernel_ms_avg": ric,
+                         "mfma_instructions_per_problem_stage": 552},
+            "kernels_ms": {"wb::stage_kernel": lin, "wb::riccati_kernel": ric},
+            "finite": bool(np.isfinite(dx).all() and np.isfinite(du).all())}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -151,6 +217,9 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    if a.workload == "whole_body":
+        return whole_body_main(a, rank, world, local_rank, torch, dist)
 
     from alore_legged_manipulator_amd.nmpc import BatchedNmpc
     from alore_legged_manipulator_amd.scenarios import make_batch
