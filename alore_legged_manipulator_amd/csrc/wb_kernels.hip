@@ -365,7 +365,8 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     for (int k = N - 1; k >= 0; --k) {
         const float* Ag = g.A32 + ((size_t)b * N + k) * NX * NX;
         const float* Bg = g.B32 + ((size_t)b * N + k) * NX * NUP;
-        for (int i = tid; i < 48 * 12 + 48 * 8; i += RIC_THREADS) { // 16-byte loads: 12 per row of A, 8 per row of B
+        // A_k was fetched by the idle wavefronts during the previous stage's Quu inversion (except for the first stage)
+        for (int i = tid + (k == N - 1 ? 0 : 48 * 12); i < 48 * 12 + 48 * 8; i += RIC_THREADS) { // 16-byte loads: 12 per row of A, 8 per row of B
             const bool isA = i < 48 * 12;
             const int q4 = isA ? i : i - 48 * 12, r = isA ? q4 / 12 : q4 / 8, c4 = isA ? q4 % 12 : q4 % 8;
             const float4 v4 = reinterpret_cast<const float4*>(isA ? Ag : Bg)[q4];
@@ -419,6 +420,14 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         // ---- Quu^-1 (wave 0: lane i owns row i, Gauss-Jordan in registers; wave_linalg.h) -> Qinv (in the PB buffer)
         float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
         float* Rres = S.PA;   // PA is dead once Qxx and Qux exist
+        if (wave != 0 && k > 0) { // S.A is dead from here to the end of the stage: fetch A_{k-1} while wavefront 0 inverts
+            const float4* An = reinterpret_cast<const float4*>(g.A32 + ((size_t)b * N + k - 1) * NX * NX);
+            for (int i = tid - 64; i < 48 * 12; i += RIC_THREADS - 64) {
+                const float4 v4 = An[i];
+                float* dst = S.A + (i / 12) * LDX + 4 * (i % 12);
+                dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
+            }
+        }
         if (wave == 0) {
             // row r of Quu on lanes r and r + 32 (15 columns each); the 2 padding inputs are an identity block
             float rowh[NU / 2];
@@ -498,23 +507,62 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     double* dub = g.du + (size_t)b * N * NU;
     if (tid < 48) { S.dxk[tid] = (float)(g.x0[(size_t)b * NX + tid] - xb[tid]); dxb[tid] = S.dxk[tid]; }
     __syncthreads();
+    // row r of a product on the four lanes of quad r (thread 4 r + part): each lane reads a contiguous quarter of the
+    // matrix row with 16-byte loads and the quad adds up over DPP -- 4 x fewer dependent loads per lane than one lane
+    // per row, and the four lanes of a quad read one 192-byte run
+    const int qrow = tid >> 2, part = tid & 3;
+    auto quad_total = [](float v) {
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+        return v;
+    };
     for (int k = 0; k < N; ++k) {
         const float* Ag = g.A32 + ((size_t)b * N + k) * NX * NX;
         const float* Bg = g.B32 + ((size_t)b * N + k) * NX * NUP;
         const float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
-        if (tid < 32) {
-            float acc = g.kff[((size_t)b * N + k) * 32 + tid];
-            for (int j = 0; j < 48; ++j) acc += Kg[tid * 48 + j] * S.dxk[j];
-            S.duk[tid] = acc;
-            if (tid < NU) dub[(size_t)k * NU + tid] = acc;
+        {   // du_k = K dx + kff: rows 0..31 on threads 0..127
+            float acc = 0.f;
+            if (qrow < 32) {
+                const float4* kr = reinterpret_cast<const float4*>(Kg + qrow * 48 + part * 12);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 kv = kr[q];
+                    const float* dxp = S.dxk + part * 12 + 4 * q;
+                    acc += kv.x * dxp[0] + kv.y * dxp[1] + kv.z * dxp[2] + kv.w * dxp[3];
+                }
+            }
+            acc = quad_total(acc);
+            if (qrow < 32 && part == 0) {
+                acc += g.kff[((size_t)b * N + k) * 32 + qrow];
+                S.duk[qrow] = acc;
+                if (qrow < NU) dub[(size_t)k * NU + qrow] = acc;
+            }
         }
         __syncthreads();
-        if (tid < 48) {
-            float acc = (float)(g.next[((size_t)b * N + k) * NX + tid] - xb[(size_t)(k + 1) * NX + tid]);
-            for (int j = 0; j < 48; ++j) acc += Ag[tid * 48 + j] * S.dxk[j];
-            for (int j = 0; j < NU; ++j) acc += Bg[tid * NUP + j] * S.duk[j];
-            S.dxn[tid] = acc;
-            dxb[(size_t)(k + 1) * NX + tid] = acc;
+        {   // dx_{k+1} = A dx + B du + d: rows 0..47 on threads 0..191
+            float acc = 0.f;
+            if (qrow < 48) {
+                const float4* ar = reinterpret_cast<const float4*>(Ag + qrow * 48 + part * 12);
+                const float4* br = reinterpret_cast<const float4*>(Bg + qrow * NUP + part * 8);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 av = ar[q];
+                    const float* dxp = S.dxk + part * 12 + 4 * q;
+                    acc += av.x * dxp[0] + av.y * dxp[1] + av.z * dxp[2] + av.w * dxp[3];
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { // the two padding columns of B are zero and duk[30..31] = 0
+                    const float4 bv = br[q];
+                    const float* dup = S.duk + part * 8 + 4 * q;
+                    acc += bv.x * dup[0] + bv.y * dup[1] + bv.z * dup[2] + bv.w * dup[3];
+                }
+            }
+            acc = quad_total(acc);
+            if (qrow < 48 && part == 0) {
+                acc += (float)(g.next[((size_t)b * N + k) * NX + qrow] - xb[(size_t)(k + 1) * NX + qrow]);
+                S.dxn[qrow] = acc;
+                dxb[(size_t)(k + 1) * NX + qrow] = acc;
+            }
         }
         __syncthreads();
         if (tid < 48) S.dxk[tid] = S.dxn[tid];
