@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
     {
         double* xo = d.xopt + (size_t)b * (T + 1) * 3;
         // the rollout xbar of the last pass is not stored: redo stateTrans to get xbar[i-1] for the linear model
-        double bx = x0, by = y0, bth = th0, bv = 0.0; // xbar[i - 1]
+        double bth = th0, bv = 0.0; // heading and speed of xbar[i - 1] (its position does not enter the linear model)
         double tx = x0, ty = y0, tth = th0;          // temp (linear prediction)
         xo[0] = tx; xo[1] = ty; xo[2] = tth;
         // NOTE: the reference's xbar at this point is the rollout of the output BEFORE the last solve (predictMotion
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
             tth = tth + dt * u1; tx = nx; ty = ny;
             xo[3 * i] = tx; xo[3 * i + 1] = ty; xo[3 * i + 2] = tth;
             double yd = fmin(fmax(u1, -c.max_omega), c.max_omega);
-            bx += u0 * cos(bth) * dt; by += u0 * sin(bth) * dt; bth += yd * dt; bv = u0;
+            bth += yd * dt; bv = u0;
         }
     }
     if (dl > 0) { // output_buff: drop the oldest, append the command just computed
