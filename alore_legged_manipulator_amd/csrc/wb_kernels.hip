@@ -417,71 +417,117 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         }
         __syncthreads();
         WB_STAMP(g.stamps, 3)
-        // ---- Quu^-1 (wave 0: lane i owns row i, Gauss-Jordan in registers; wave_linalg.h) -> Qinv (in the PB buffer)
         float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
         float* Rres = S.PA;   // PA is dead once Qxx and Qux exist
-        if (wave != 0 && k > 0) { // S.A is dead from here to the end of the stage: fetch A_{k-1} while wavefront 0 inverts
-            const float4* An = reinterpret_cast<const float4*>(g.A32 + ((size_t)b * N + k - 1) * NX * NX);
-            for (int i = tid - 64; i < 48 * 12; i += RIC_THREADS - 64) {
-                const float4 v4 = An[i];
-                float* dst = S.A + (i / 12) * LDX + 4 * (i % 12);
-                dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
+        // clamp flags / values of the control limits live in gx / d (dead after qx, qu): the LDS block must not grow --
+        // 53.6 KB is the last size of which three fit a CU at the hardware's allocation granularity (one more 256 B and
+        // only two workgroups are resident: measured 2.8 -> 4.2 ms)
+        float* clampm = S.gx;
+        float* clampv = S.d;
+        if (tid < 32) clampm[tid] = 0.f;
+        // Round 0 solves the unconstrained stage problem.  If its feed-forward step drives a joint torque past the URDF
+        // effort limit, those inputs are clamped to the limit and the free ones are re-solved against them
+        // (control-limited DDP, Tassa et al. 2014, one projection): in Quu the clamped rows / columns become an
+        // identity block, their right-hand side the clamped value, and their gain rows are zeroed afterwards.  P' and p'
+        // keep their form (Qxx + Qux' K, qx + Qux' kff) because (qu + Quu kff) and (Qux + Quu K) vanish on the free rows.
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) { // kept rolled: the inversion is ~2000 unrolled instructions
+            // ---- Quu^-1 (wave 0: lane i owns row i, Gauss-Jordan in registers; wave_linalg.h) -> Qinv (in the PB buffer)
+            if (wave != 0 && k > 0 && round == 0) { // S.A is dead from here to the end of the stage: fetch A_{k-1} while wavefront 0 inverts
+                const float4* An = reinterpret_cast<const float4*>(g.A32 + ((size_t)b * N + k - 1) * NX * NX);
+                for (int i = tid - 64; i < 48 * 12; i += RIC_THREADS - 64) {
+                    const float4 v4 = An[i];
+                    float* dst = S.A + (i / 12) * LDX + 4 * (i % 12);
+                    dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
+                }
             }
-        }
-        if (wave == 0) {
-            // row r of Quu on lanes r and r + 32 (15 columns each); the 2 padding inputs are an identity block
-            float rowh[NU / 2];
-            const int r5 = tid & 31, rr = r5 < NU ? r5 : 0, hh = tid >> 5;
+            if (wave == 0) {
+                // row r of Quu on lanes r and r + 32 (15 columns each); the 2 padding inputs are an identity block
+                float rowh[NU / 2];
+                const int r5 = tid & 31, rr = r5 < NU ? r5 : 0, hh = tid >> 5;
 #pragma unroll
-            for (int j = 0; j < NU / 2; ++j) rowh[j] = S.Quu[rr * LDU + hh * (NU / 2) + j];
-            wavela::spd_inverse_rows_split<float, NU>(rowh, tid);
-            if (r5 < NU) {
+                for (int j = 0; j < NU / 2; ++j) rowh[j] = S.Quu[rr * LDU + hh * (NU / 2) + j];
+                wavela::spd_inverse_rows_split<float, NU>(rowh, tid);
+                if (r5 < NU) {
 #pragma unroll
-                for (int j = 0; j < NU / 2; ++j) Qinv[r5 * LDU + hh * (NU / 2) + j] = rowh[j];
-                if (hh == 1) { Qinv[r5 * LDU + 30] = 0.f; Qinv[r5 * LDU + 31] = 0.f; }
-            } else if (hh == 0) {
+                    for (int j = 0; j < NU / 2; ++j) Qinv[r5 * LDU + hh * (NU / 2) + j] = rowh[j];
+                    if (hh == 1) { Qinv[r5 * LDU + 30] = 0.f; Qinv[r5 * LDU + 31] = 0.f; }
+                } else if (hh == 0) {
 #pragma unroll
-                for (int j = 0; j < 32; ++j) Qinv[r5 * LDU + j] = (j == r5) ? 1.f : 0.f;
+                    for (int j = 0; j < 32; ++j) Qinv[r5 * LDU + j] = (j == r5) ? 1.f : 0.f;
+                }
             }
-        }
-        __syncthreads();
-        WB_STAMP(g.stamps, 4)
-        // ---- K0 = -Qinv Qux (6 tiles, K = 32), kff0 = -Qinv qu
-        for (int t = wave; t < 6; t += RIC_WAVES)
-            mfma_tile<false, false, 32>(Qinv, LDU, S.Qux, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, nullptr, 0, 0.f, nullptr, -1.f);
-        if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
-            const int i = tid - RIC_LAST;
-            float acc = 0.f;
+            __syncthreads();
+            WB_STAMP(g.stamps, 4)
+            // ---- K0 = -Qinv Qux (6 tiles, K = 32), kff0 = -Qinv qu
+            for (int t = wave; t < 6; t += RIC_WAVES)
+                mfma_tile<false, false, 32>(Qinv, LDU, S.Qux, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, nullptr, 0, 0.f, nullptr, -1.f);
+            if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
+                const int i = tid - RIC_LAST;
+                float acc = 0.f;
 #pragma unroll 8
-            for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.qu[j];
-            S.kff[i] = -acc;
-        }
-        __syncthreads();
-        WB_STAMP(g.stamps, 5)
-        // ---- one refinement step against Quu itself (the explicit float32 inverse alone costs a factor 40 in accuracy):
-        //      R = Qux + Quu K0,  K = K0 - Qinv R;   r = qu + Quu kff0,  kff = kff0 - Qinv r
-        for (int t = wave; t < 6; t += RIC_WAVES)
-            mfma_tile<false, false, 32>(S.Quu, LDU, SK, LDX, (t / 3) * 16, (t % 3) * 16, Rres, LDX, S.Qux, LDX, 0.f, nullptr);
-        if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
-            const int i = tid - RIC_LAST;
-            float acc = S.qu[i];
+                for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.qu[j];
+                S.kff[i] = -acc;
+            }
+            __syncthreads();
+            WB_STAMP(g.stamps, 5)
+            // ---- one refinement step against Quu itself (the explicit float32 inverse alone costs a factor 40 in accuracy):
+            //      R = Qux + Quu K0,  K = K0 - Qinv R;   r = qu + Quu kff0,  kff = kff0 - Qinv r
+            for (int t = wave; t < 6; t += RIC_WAVES)
+                mfma_tile<false, false, 32>(S.Quu, LDU, SK, LDX, (t / 3) * 16, (t % 3) * 16, Rres, LDX, S.Qux, LDX, 0.f, nullptr);
+            if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
+                const int i = tid - RIC_LAST;
+                float acc = S.qu[i];
 #pragma unroll 8
-            for (int j = 0; j < 32; ++j) acc += S.Quu[i * LDU + j] * S.kff[j];
-            S.duk[i] = acc; // residual of the feed-forward term (duk is free during the backward sweep)
-        }
-        __syncthreads();
-        WB_STAMP(g.stamps, 6)
-        for (int t = wave; t < 6; t += RIC_WAVES)
-            mfma_tile<false, false, 32>(Qinv, LDU, Rres, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, SK, LDX, 0.f, nullptr, -1.f);
-        if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
-            const int i = tid - RIC_LAST;
-            float acc = 0.f;
+                for (int j = 0; j < 32; ++j) acc += S.Quu[i * LDU + j] * S.kff[j];
+                S.duk[i] = acc; // residual of the feed-forward term (duk is free during the backward sweep)
+            }
+            __syncthreads();
+            WB_STAMP(g.stamps, 6)
+            for (int t = wave; t < 6; t += RIC_WAVES)
+                mfma_tile<false, false, 32>(Qinv, LDU, Rres, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, SK, LDX, 0.f, nullptr, -1.f);
+            if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
+                const int i = tid - RIC_LAST;
+                float acc = 0.f;
 #pragma unroll 8
-            for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.duk[j];
-            S.kff[i] -= acc;
+                for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.duk[j];
+                S.kff[i] -= acc;
+            }
+            __syncthreads();
+            WB_STAMP(g.stamps, 7)
+            if (round == 1) break;
+            // ---- torque limits on the feed-forward step of this stage
+            int hit = 0;
+            if (tid < b2z1::NJ) {
+                const float ucur = (float)ub[(size_t)k * NU + tid], eff = (float)b2z1::EFFORT[tid];
+                const float lo = -eff - ucur, hi = eff - ucur, kf = S.kff[tid];
+                if (kf < lo - 1e-4f * eff) { clampm[tid] = 1.f; clampv[tid] = lo; hit = 1; }
+                else if (kf > hi + 1e-4f * eff) { clampm[tid] = 1.f; clampv[tid] = hi; hit = 1; }
+            }
+            // "any input clamped?" without __syncthreads_or (its LDS temporary pushes the block past the size of which
+            // three fit a CU): every wavefront ballots the 18 flags itself
+            (void)hit;
+            __syncthreads();
+            if (!__any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f) || g.apply == 2) break;
+            // masked system, in place: qu first (it needs the unmasked rows of Quu), then Quu
+            if (tid < 32) {
+                float acc = S.qu[tid];
+                for (int j = 0; j < b2z1::NJ; ++j) acc += clampm[j] != 0.f ? S.Quu[tid * LDU + j] * clampv[j] : 0.f;
+                S.duk[tid] = clampm[tid] != 0.f ? -clampv[tid] : acc;
+            }
+            __syncthreads();
+            if (tid < 32) S.qu[tid] = S.duk[tid];
+            for (int i = tid; i < 32 * 32; i += RIC_THREADS) {
+                const int r = i >> 5, c = i & 31;
+                if (clampm[r] != 0.f || clampm[c] != 0.f) S.Quu[r * LDU + c] = (r == c) ? 1.f : 0.f;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        WB_STAMP(g.stamps, 7)
+        if (__any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f)) { // clamped inputs do not react to dx
+            for (int i = tid; i < 32 * 48; i += RIC_THREADS)
+                if (clampm[i / 48] != 0.f) SK[(i / 48) * LDX + (i % 48)] = 0.f;
+            __syncthreads();
+        }
         // feedback gains to HBM
         {
             float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
@@ -852,7 +898,7 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
         wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps};
         wb::stage_kernel<<<(unsigned)n, 64, 0, s>>>(g);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
-        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_stamps ? h->d_stamps + 32 : nullptr};
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, std::getenv("ALORE_WB_NOCLAMP") ? 2 : 1, h->d_stamps ? h->d_stamps + 32 : nullptr};
         wb::riccati_kernel<<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
     }

@@ -545,6 +545,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from wb_cases import make_problems_fast, weights as wb_weights
             Bw = B
+            from alore_legged_manipulator_amd.whole_body import model_info
+            wbe_effort = model_info()["effort"]
             wbe = BatchedWholeBody(Bw, N, 0.01, device=local_rank)
             x0w, xrefw, urefw, xiw, uiw = make_problems_fast(Bw, N, seed=3)
             wbe.set_weights(*wb_weights())
@@ -557,6 +559,10 @@ def main():
             t_b = time.perf_counter()
             lin_ms, ric_ms = wbe.last_times()
             dxw, duw = wbe.last_step()
+            x1w, u1w = wbe.get_iterate()
+            sat = float(np.mean(np.any(np.abs(u1w[:, :, :18]) >= wbe_effort - 1e-9, axis=2)))   # stages with a torque on its limit
+            wbe.rti(1); torch.cuda.synchronize(dev)     # the next iteration from the updated iterate (closed-loop regime)
+            lin2_ms, ric2_ms = wbe.last_times()
             # matrix-core flops of the Riccati sweep per problem: per stage 30 tiles with K = 48 (12 MFMAs each; the
             # symmetric products only their upper-triangular tiles) and 24 tiles with K = 32 (8 each) = 552
             # v_mfma_f32_16x16x4_f32 of 2048 flops (SQ_INSTS_MFMA agrees: profiles/)
@@ -565,6 +571,9 @@ def main():
                                          "ms_wall_one_rti": (t_b - t_a) * 1e3, "solves_per_s": Bw / ((lin_ms + ric_ms) * 1e-3),
                                          "mfma_f32_TFLOPs_riccati": Bw * mfma_flops / (ric_ms * 1e-3) / 1e12,
                                          "mfma_f32_frac_of_peak": Bw * mfma_flops / (ric_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                         "stages_with_a_saturated_torque_frac": sat,
+                                         "second_iteration": {"ms_linearize": lin2_ms, "ms_riccati": ric2_ms,
+                                                              "solves_per_s": Bw / ((lin2_ms + ric2_ms) * 1e-3)},
                                          "first_step_max": float(np.max(np.abs(dxw))), "finite": bool(np.isfinite(dxw).all() and np.isfinite(duw).all())}
             del wbe
         except Exception as e:  # pragma: no cover

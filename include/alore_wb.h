@@ -17,8 +17,10 @@
  *   input    u = [joint torques (18) | foot forces (4 x 3, world frame, at the foot points FL FR RL RR)]                        nu = 30
  *   dynamics semi-implicit Euler:  v+ = v + dt a(q, v, u),  q+ = q + dt G(q) v+,   a = M(q)^-1 ([0; tau] - RNEA(q, v, 0, f))
  *   cost     sum_k 1/2 (x_k - xref_k)' Q (..) + 1/2 (u_k - uref_k)' R (..)  + 1/2 (x_N - xref_N)' QN (..),  Q, R, QN diagonal
- *   bounds   |tau_i| <= effort_i of the URDF: the step is clipped to them when it is applied (the QP itself is
- *            equality-constrained; contact consistency of the feet is the caller's job through xref / uref)
+ *   bounds   |tau_i| <= effort_i of the URDF, handled in the Riccati sweep as in control-limited DDP (Tassa et al. 2014,
+ *            one projection per stage): where the feed-forward step of a stage would leave the limit, that input is
+ *            clamped, the others are re-solved against it and its feedback row is zero; the applied inputs are clipped
+ *            as well.  Contact consistency of the feet is the caller's job through xref / uref.
  * One real-time iteration: linearise the dynamics about the current iterate (A_k, B_k, defects), solve the LQ problem
  * by a Riccati sweep (float32 MFMA on the 48 x 48 / 48 x 30 blocks), apply the full step.
  */

@@ -301,3 +301,42 @@ def solve_lq(A, B, d, Q, R, QN, gx, gu, gN, dx0):
     dx = np.array([z[ox(k):ox(k) + nx] for k in range(N + 1)])
     du = np.array([z[ou(k):ou(k) + nu] for k in range(N)])
     return dx, du
+
+
+def solve_lq_clamped(A, B, d, Q, R, QN, gx, gu, gN, dx0, u_cur, effort, tol=1e-4):
+    """The stage-wise (Riccati) solution of the same LQ problem with the kernels' treatment of the torque limits
+    (control-limited DDP, one projection per stage): the unconstrained feed-forward step of a stage is computed first;
+    inputs i < 18 whose step leaves [-effort_i - u_i, effort_i - u_i] are clamped to the limit, the others re-solved
+    against them, the gain rows of the clamped inputs are zero.  Returns dx, du and the number of clamped inputs per stage.
+    float64; with no clamp anywhere it equals solve_lq."""
+    N = len(A); nx, nu = B[0].shape
+    P, p = QN.copy(), gN.copy()
+    Ks, ks, nclamp = [None] * N, [None] * N, [0] * N
+    for k in range(N - 1, -1, -1):
+        PA, PB, s = P @ A[k], P @ B[k], P @ d[k] + p
+        Qxx, Qux, Quu = Q + A[k].T @ PA, B[k].T @ PA, R + B[k].T @ PB
+        qx, qu = gx[k] + A[k].T @ s, gu[k] + B[k].T @ s
+        kff = -np.linalg.solve(Quu, qu)
+        lo, hi = -effort - u_cur[k][:18], effort - u_cur[k][:18]
+        cl = np.zeros(nu, bool); kc = np.zeros(nu)
+        low, high = kff[:18] < lo - tol * effort, kff[:18] > hi + tol * effort
+        cl[:18] = low | high
+        kc[:18] = np.where(low, lo, np.where(high, hi, 0.0))
+        if cl.any():
+            f = ~cl
+            kff = kc.copy()
+            kff[f] = -np.linalg.solve(Quu[np.ix_(f, f)], qu[f] + Quu[np.ix_(f, cl)] @ kc[cl])
+            K = np.zeros((nu, nx))
+            K[f] = -np.linalg.solve(Quu[np.ix_(f, f)], Qux[f])
+        else:
+            K = -np.linalg.solve(Quu, Qux)
+        Ks[k], ks[k], nclamp[k] = K, kff, int(cl.sum())
+        P = Qxx + Qux.T @ K
+        P = 0.5 * (P + P.T)
+        p = qx + Qux.T @ kff
+    dx = np.zeros((N + 1, nx)); du = np.zeros((N, nu))
+    dx[0] = dx0
+    for k in range(N):
+        du[k] = Ks[k] @ dx[k] + ks[k]
+        dx[k + 1] = A[k] @ dx[k] + B[k] @ du[k] + d[k]
+    return dx, du, nclamp

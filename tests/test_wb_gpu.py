@@ -186,3 +186,40 @@ def test_receding_horizon_loop_holds_the_stance(model):
     print(f"closed loop: pose error {err0:.3f} -> {err:.4f}, max |v| {vel:.4f}")
     # the 0.2 s horizon with these weights pulls gently: the error halves in about 1.5 s and never grows past its start
     assert err < 0.5 * err0 and vel < 0.5 and max(hist) <= 1.2 * err0, hist
+
+
+def test_torque_limits_in_the_riccati_sweep(model):
+    """A posture reference far from the start with stiff weights asks for more joint torque than the URDF allows: the
+    Riccati kernel clamps the feed-forward step of those inputs stage by stage and re-solves the free ones (one
+    projection, control-limited DDP).  Compared with the float64 restatement of the same rule fed with the kernel's own
+    A, B; the applied inputs respect the limits."""
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    from oracle.wb_oracle import solve_lq_clamped
+    B, N, dt = 4, 20, 0.01
+    eng = BatchedWholeBody(B, N, dt)
+    x0, xref, uref, xi, ui = make_problems(model, B, N, seed=31, spread=0.3)
+    xref = xref.copy()
+    xref[:, :, 18:24] += np.array([0.9, -0.8, 0.9, -0.7, 0.8, -0.9])          # arm posture far away
+    Q, R, QN = weights()
+    Q = Q.copy(); Q[18:24] = 4000.0; QN = 10 * Q
+    eng.set_weights(Q, R, QN)
+    eng.set_problem(x0, xref, uref)
+    eng.set_iterate(xi, ui)
+    A, Bm, nxt = eng.linearize()
+    eng.rti(1)
+    dx, du = eng.last_step()
+    x1, u1 = eng.get_iterate()
+    total_clamps, worst = 0, 0.0
+    for b in range(B):
+        d = [nxt[b, k] - xi[b, k + 1] for k in range(N)]
+        gx = [Q * (xi[b, k] - xref[b, k]) for k in range(N)]
+        gu = [R * (ui[b, k] - uref[b, k]) for k in range(N)]
+        gN = QN * (xi[b, N] - xref[b, N])
+        rx, ru, nc = solve_lq_clamped(list(A[b]), list(Bm[b]), d, np.diag(Q), np.diag(R), np.diag(QN), gx, gu, gN, x0[b] - xi[b, 0],
+                                      list(ui[b]), model.effort)
+        total_clamps += sum(nc)
+        worst = max(worst, np.max(np.abs(dx[b] - rx)) / np.max(np.abs(rx)), np.max(np.abs(du[b] - ru)) / np.max(np.abs(ru)))
+    print(f"clamped inputs over {B} problems x {N} stages: {total_clamps}; worst rel dev from the float64 restatement {worst:.2e}")
+    assert total_clamps > 0
+    assert worst < 2e-3
+    assert np.all(np.abs(u1[:, :, :18]) <= model.effort + 1e-9)

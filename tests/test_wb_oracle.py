@@ -153,3 +153,25 @@ def test_committed_stance_equilibrium_fixture(model):
     assert np.max(np.abs(a)) < 1e-8                       # at rest it stays at rest
     x0, xref, uref, xi, ui = make_problems_fast(5, 4, seed=1)
     assert x0.shape == (5, 48) and xi.shape == (5, 5, 48) and np.allclose(uref[0, 0], u)
+
+
+def test_clamped_riccati_equals_the_kkt_solve_without_clamps_and_respects_limits(model):
+    from oracle.wb_oracle import solve_lq_clamped
+    rng = np.random.default_rng(7)
+    N, nx, nu = 5, 48, 30
+    A = [np.eye(nx) + 0.02 * rng.normal(size=(nx, nx)) for _ in range(N)]
+    B = [0.3 * rng.normal(size=(nx, nu)) for _ in range(N)]
+    d = [0.01 * rng.normal(size=nx) for _ in range(N)]
+    Q, R = np.diag(rng.uniform(1, 3, nx)), np.diag(rng.uniform(0.05, 0.2, nu))
+    gx = [0.1 * rng.normal(size=nx) for _ in range(N)]; gu = [0.1 * rng.normal(size=nu) for _ in range(N)]; gN = 0.1 * rng.normal(size=nx)
+    dx0 = 0.05 * rng.normal(size=nx)
+    u_cur = [np.zeros(nu) for _ in range(N)]
+    dx, du = solve_lq(A, B, d, Q, R, Q, gx, gu, gN, dx0)
+    big = np.full(18, 1e6)
+    dx2, du2, nc = solve_lq_clamped(A, B, d, Q, R, Q, gx, gu, gN, dx0, u_cur, big)
+    assert sum(nc) == 0 and np.max(np.abs(dx2 - dx)) < 1e-9 and np.max(np.abs(du2 - du)) < 1e-9
+    lim = np.full(18, 0.5 * np.max(np.abs(du[:, :18])))                       # limits that bite
+    dx3, du3, nc3 = solve_lq_clamped(A, B, d, Q, R, Q, gx, gu, gN, np.zeros(nx), u_cur, lim)
+    assert sum(nc3) > 0
+    # with dx0 = 0 the feed-forward steps are the steps of stage 0: inside the limits there
+    assert np.all(np.abs(du3[0, :18]) <= lim + 1e-9)
