@@ -38,7 +38,7 @@ namespace wb {
     }
 
 constexpr int NQ = 24, NV = 24, NX = 48, NU = 30, NUP = 32; // NUP: input dimension padded to the MFMA tile
-constexpr int NCOL = 75;                                     // 21 (rpy, joints) + 24 (v) + 18 (tau) + 12 (f)
+constexpr int NCOL = 57;                                     // columns kept in LDS: 21 (rpy, joints) + 24 (v) + 12 (f); da/dtau is M^-1 itself
 constexpr double HQ = 1e-7, HV = 1e-7;                       // forward-difference steps (float64; A, B are stored in float32)
 
 struct StageArgs {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
             active = lane < 37;
             if (lane < 24) { e.ua = lane; e.da = 1.0; sink.out = S.M + lane; sink.stride = MS; }
             else if (lane == 24) { e.sv = 1.0; e.sf = 1.0; e.g = b2z1::GRAVITY; sink.out = S.bias; }
-            else { e.uf = lane - 25; e.df = 1.0; sink.out = S.D + (63 + lane - 25) * MS; sink.scale = -1.0; } // RNEA = ... - J_c' f
+            else { e.uf = lane - 25; e.df = 1.0; sink.out = S.D + (45 + lane - 25) * MS; sink.scale = -1.0; } // RNEA = ... - J_c' f
         } else {
             active = lane < 46;
             e.a = S.a; e.sv = 1.0; e.sa = 1.0; e.sf = 1.0; e.g = b2z1::GRAVITY;
@@ -134,11 +134,6 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
                 }
             }
             __syncthreads();
-            if (lane >= 24 && lane < 24 + 18) { // da / dtau_j = column 6 + j of M^-1 (= its row: symmetric)
-                const int j = lane - 24;
-#pragma unroll
-                for (int i = 0; i < NV; ++i) S.D[(45 + j) * MS + i] = S.M[(6 + j) * MS + i];
-            }
     WB_STAMP(g.stamps, 2)
             if (g.a64 && lane < NV) g.a64[(size_t)item * NV + lane] = S.a[lane];
             if (lane < NV) S.vn[lane] = S.v[lane] + g.dt * S.a[lane];
@@ -179,7 +174,7 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
 
     // ---- M^-1 times the 57 columns that need it (45 derivative columns, 12 foot-force columns)
     if (lane < 57) {
-        const int col = lane < 45 ? lane : 63 + (lane - 45);
+        const int col = lane; // 45 derivative columns, then the 12 foot-force columns
         double r[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) r[i] = S.D[col * MS + i];
@@ -201,10 +196,15 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
     float* A32 = g.A32 + (size_t)item * NX * NX;
     float* B32 = g.B32 + (size_t)item * NX * NUP;
     for (int c = lane; c < NX + NUP; c += 64) {
-        const int zc = c < 3 ? -1 : (c < 24 ? c - 3 : (c < 48 ? 21 + c - 24 : (c < NX + NU ? 45 + c - 48 : -1)));
+        // source of this column's da / d(var): a derivative column of D, a row of M^-1 (torque j: column 6 + j of the
+        // symmetric inverse), a foot-force column of D, or nothing (base position, padding)
+        const double* zsrc = c < 3 ? nullptr
+                             : (c < 24 ? S.D + (c - 3) * MS
+                                : (c < 48 ? S.D + (21 + c - 24) * MS
+                                   : (c < 48 + 18 ? S.M + (6 + c - 48) * MS : (c < NX + NU ? S.D + (45 + c - 66) * MS : nullptr))));
         double z[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) z[i] = (zc >= 0 ? dt * S.D[zc * MS + i] : 0.0) + ((c == 24 + i) ? 1.0 : 0.0);
+        for (int i = 0; i < NV; ++i) z[i] = (zsrc ? dt * zsrc[i] : 0.0) + ((c == 24 + i) ? 1.0 : 0.0);
         const bool pad = c >= NX + NU;
         float* out = c < NX ? (A32 + c) : (B32 + (c - NX));
         const int ld = c < NX ? NX : NUP;
