@@ -378,7 +378,9 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             S.gx[tid] = S.wq[tid] * (float)(xb[(size_t)k * NX + tid] - xr[(size_t)k * NX + tid]);
         } else if (tid >= 64 && tid < 96) {
             const int j = tid - 64;
-            S.gu[j] = j < NU ? S.wr[j] * (float)(ub[(size_t)k * NU + j] - ur[(size_t)k * NU + j]) : 0.f;
+            const float ucur = j < NU ? (float)ub[(size_t)k * NU + j] : 0.f;
+            S.dxn[j] = ucur; // current input of the stage, for the torque limits below (dxn is free during the backward sweep)
+            S.gu[j] = j < NU ? S.wr[j] * (ucur - (float)ur[(size_t)k * NU + j]) : 0.f;
         }
         __syncthreads();
         WB_STAMP(g.stamps, 0)
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             // ---- torque limits on the feed-forward step of this stage
             int hit = 0;
             if (tid < b2z1::NJ) {
-                const float ucur = (float)ub[(size_t)k * NU + tid], eff = (float)b2z1::EFFORT[tid];
+                const float ucur = S.dxn[tid], eff = (float)b2z1::EFFORT[tid];
                 const float lo = -eff - ucur, hi = eff - ucur, kf = S.kff[tid];
                 if (kf < lo - 1e-4f * eff) { clampm[tid] = 1.f; clampv[tid] = lo; hit = 1; }
                 else if (kf > hi + 1e-4f * eff) { clampm[tid] = 1.f; clampv[tid] = hi; hit = 1; }
