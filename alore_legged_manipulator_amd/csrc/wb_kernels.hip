@@ -285,6 +285,7 @@ struct RicArgs {
     double* du;          // [B][N][30]
     int N;
     int apply;           // 1: x += dx, u += du (clipped)
+    int limits;          // 1: torque limits inside the sweep (control-limited DDP); 0: only the applied inputs are clipped
     long long* stamps;   // optional [32] diagnostic
 };
 
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             // three fit a CU): every wavefront ballots the 18 flags itself
             (void)hit;
             __syncthreads();
-            if (!__any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f) || g.apply == 2) break;
+            if (!g.limits || !__any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f)) break;
             // masked system, in place: qu first (it needs the unmasked rows of Quu), then Quu
             if (tid < 32) {
                 float acc = S.qu[tid];
@@ -653,6 +654,7 @@ struct alore_wb_solver {
     double *d_dx = nullptr, *d_du = nullptr;
     float *d_K = nullptr, *d_kff = nullptr;
     long long* d_stamps = nullptr; // [64] when ALORE_WB_STAMPS=1
+    int limits = 1;                // alore_wb_set_torque_limits
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_lin = -1.f, ms_ric = -1.f;
     bool timed = false;
@@ -831,6 +833,13 @@ int alore_wb_set_weights(alore_wb_handle h, const double* Q, const double* R, co
     return ALORE_WB_OK;
 }
 
+int alore_wb_set_torque_limits(alore_wb_handle h, int enable)
+{
+    if (!h) return ALORE_WB_E_INVALID;
+    h->limits = enable ? 1 : 0;
+    return ALORE_WB_OK;
+}
+
 int alore_wb_set_problem(alore_wb_handle h, int B, const double* x0, const double* xref, const double* uref)
 {
     if (!h || B <= 0 || B > h->cfg.max_problems || !x0 || !xref || !uref) return fail(h, ALORE_WB_E_INVALID, "set_problem: bad argument");
@@ -900,7 +909,7 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
         wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps};
         wb::stage_kernel<<<(unsigned)n, 64, 0, s>>>(g);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
-        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, std::getenv("ALORE_WB_NOCLAMP") ? 2 : 1, h->d_stamps ? h->d_stamps + 32 : nullptr};
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr};
         wb::riccati_kernel<<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
     }

@@ -34,6 +34,7 @@ def _bind(L):
         "alore_wb_forward_dynamics": (C.c_int, [H, C.c_int, DP, DP, DP, DP, DP]),
         "alore_wb_aba": (C.c_int, [H, C.c_int, DP, DP, DP, DP]),
         "alore_wb_set_weights": (C.c_int, [H, DP, DP, DP]),
+        "alore_wb_set_torque_limits": (C.c_int, [H, C.c_int]),
         "alore_wb_set_problem": (C.c_int, [H, C.c_int, DP, DP, DP]),
         "alore_wb_set_iterate": (C.c_int, [H, C.c_int, DP, DP]),
         "alore_wb_get_iterate": (C.c_int, [H, C.c_int, DP, DP]),
@@ -118,6 +119,9 @@ class BatchedWholeBody:
     def set_weights(self, Q, R, QN):
         Q, R, QN = _f64(Q, (NX,)), _f64(R, (NU,)), _f64(QN, (NX,))
         self._check(self.L.alore_wb_set_weights(self.h, _dp(Q), _dp(R), _dp(QN)))
+
+    def set_torque_limits(self, enable: bool):
+        self._check(self.L.alore_wb_set_torque_limits(self.h, 1 if enable else 0))
 
     def set_problem(self, x0, xref, uref):
         x0, xref, uref = _f64(x0, (-1, NX)), _f64(xref, (-1, self.N + 1, NX)), _f64(uref, (-1, self.N, NU))

@@ -74,6 +74,8 @@ int alore_wb_aba(alore_wb_handle h, int n, const double *q, const double *v, con
 /* ---- the OCP ---- */
 /* diagonal weights shared by the batch: Q [48], R [30], QN [48] */
 int alore_wb_set_weights(alore_wb_handle h, const double *Q, const double *R, const double *QN);
+/* torque limits inside the Riccati sweep (default 1); 0: the sweep is unconstrained and only the applied inputs are clipped */
+int alore_wb_set_torque_limits(alore_wb_handle h, int enable);
 /* measured states x0 [B][48], references xref [B][N+1][48], uref [B][N][30] (HOST pointers) */
 int alore_wb_set_problem(alore_wb_handle h, int B, const double *x0, const double *xref, const double *uref);
 /* iterate x [B][N+1][48], u [B][N][30] */

@@ -223,3 +223,9 @@ def test_torque_limits_in_the_riccati_sweep(model):
     assert total_clamps > 0
     assert worst < 2e-3
     assert np.all(np.abs(u1[:, :, :18]) <= model.effort + 1e-9)
+    # switched off, the sweep is the unconstrained one again (and differs from the limited one on this problem)
+    eng.set_torque_limits(False)
+    eng.set_iterate(xi, ui)
+    eng.rti(1)
+    dx_u, du_u = eng.last_step()
+    assert np.max(np.abs(du_u - du)) > 1.0
