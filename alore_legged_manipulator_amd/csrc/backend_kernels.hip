@@ -7,7 +7,7 @@
 //   final collision check on a dense Simpson resample                       :474-571
 // in float64.  Inside a cost evaluation the 64 lanes work on
 //   - the knot system of the minimum-jerk spline (csrc/minco_spline.h: SPD 2 x 2 block-tridiagonal instead
-//     of the reference's 6M x 6M band LU; lanes 0/1 = the two flat dimensions),
+//     of the reference's 6M x 6M band LU), solved by parallel cyclic reduction, lane = knot (knot_pcr below),
 //   - (piece, dimension) for the Hermite coefficients, the energy and the adjoint,
 //   - the M x 17 Simpson nodes for everything in attachPenaltyFunctional (lane = node, 64 per round),
 //   - wave prefix / suffix scans for the pose integration (every pose depends on all earlier Simpson panels)
@@ -154,6 +154,69 @@ extern __shared__ __align__(16) unsigned char lds_raw[];
 template <int P>
 __device__ __forceinline__ Lds<P>& lds() { return *reinterpret_cast<Lds<P>*>(lds_raw); }
 
+// Knot system by parallel cyclic reduction: equation k (interior knot k = lane + 1) is
+//   L_k y_{k-1} + D_k y_k + U_k y_{k+1} = r_k,   L_k = U_{k-1}',   2 x 2 blocks (csrc/minco_spline.h: knot_diag, knot_upper).
+// One lane per knot, both flat dimensions as two right-hand sides.  A step with stride s eliminates the neighbours at
+// distance s (alpha = -L D_{k-s}^-1, gamma = -U D_{k+s}^-1); after ceil(log2 nk) steps every equation stands alone.
+// The sequential block Thomas sweeps this replaces kept one or two lanes busy for ~18 k cycles per solve; here the
+// dependent chain is 4 - 5 steps.  The matrix is symmetric, so the adjoint system of the gradient is the same call.
+struct B2 { double a, b, c, d; }; // [[a, b], [c, d]]
+__device__ __forceinline__ B2 mul(const B2& x, const B2& y) { return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; }
+__device__ __forceinline__ B2 inv2(const B2& m)
+{
+    const double id = 1.0 / (m.a * m.d - m.b * m.c);
+    return {m.d * id, -m.b * id, -m.c * id, m.a * id};
+}
+__device__ __forceinline__ B2 shfl_up(const B2& m, int s) { return {__shfl_up(m.a, s), __shfl_up(m.b, s), __shfl_up(m.c, s), __shfl_up(m.d, s)}; }
+__device__ __forceinline__ B2 shfl_down(const B2& m, int s) { return {__shfl_down(m.a, s), __shfl_down(m.b, s), __shfl_down(m.c, s), __shfl_down(m.d, s)}; }
+
+// rhs / solution: y[d][lane][0..1] in LDS for d = 0, 1 (the caller's layout); all 64 lanes must call
+__device__ __forceinline__ void knot_pcr(int M, const double* T, double (*y0)[2], double (*y1)[2])
+{
+    const int e = threadIdx.x, nk = M - 1;
+    const bool act = e < nk;
+    B2 Lk{0, 0, 0, 0}, Dk{1, 0, 0, 1}, Uk{0, 0, 0, 0};
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+    if (act) {
+        const int k = e + 1;
+        const minco::InvT l(T[k - 1]), r(T[k]);
+        const minco::Sym2 dg = minco::knot_diag(l, r);
+        Dk = {dg.a, dg.b, dg.b, dg.c};
+        if (k > 1) { const minco::Mat2 u = minco::knot_upper(l); Lk = {u.a, u.c, u.b, u.d}; } // U_{k-1}'
+        if (k < M - 1) { const minco::Mat2 u = minco::knot_upper(r); Uk = {u.a, u.b, u.c, u.d}; }
+        r0 = y0[e][0]; r1 = y0[e][1]; r2 = y1[e][0]; r3 = y1[e][1];
+    }
+    for (int s = 1; s < nk; s <<= 1) {
+        const B2 Lm = shfl_up(Lk, s), Dm = shfl_up(Dk, s), Um = shfl_up(Uk, s);
+        const double m0 = __shfl_up(r0, s), m1 = __shfl_up(r1, s), m2 = __shfl_up(r2, s), m3 = __shfl_up(r3, s);
+        const B2 Lp = shfl_down(Lk, s), Dp = shfl_down(Dk, s), Up = shfl_down(Uk, s);
+        const double p0 = __shfl_down(r0, s), p1 = __shfl_down(r1, s), p2 = __shfl_down(r2, s), p3 = __shfl_down(r3, s);
+        const bool hm = act && e - s >= 0, hp = act && e + s < nk;
+        B2 al{0, 0, 0, 0}, ga{0, 0, 0, 0};
+        if (hm) { const B2 t = mul(Lk, inv2(Dm)); al = {-t.a, -t.b, -t.c, -t.d}; }
+        if (hp) { const B2 t = mul(Uk, inv2(Dp)); ga = {-t.a, -t.b, -t.c, -t.d}; }
+        if (hm) {
+            const B2 t = mul(al, Um);
+            Dk = {Dk.a + t.a, Dk.b + t.b, Dk.c + t.c, Dk.d + t.d};
+            r0 += al.a * m0 + al.b * m1; r1 += al.c * m0 + al.d * m1;
+            r2 += al.a * m2 + al.b * m3; r3 += al.c * m2 + al.d * m3;
+            Lk = mul(al, Lm);
+        } else Lk = {0, 0, 0, 0};
+        if (hp) {
+            const B2 t = mul(ga, Lp);
+            Dk = {Dk.a + t.a, Dk.b + t.b, Dk.c + t.c, Dk.d + t.d};
+            r0 += ga.a * p0 + ga.b * p1; r1 += ga.c * p0 + ga.d * p1;
+            r2 += ga.a * p2 + ga.b * p3; r3 += ga.c * p2 + ga.d * p3;
+            Uk = mul(ga, Up);
+        } else Uk = {0, 0, 0, 0};
+    }
+    if (act) {
+        const B2 di = inv2(Dk);
+        y0[e][0] = di.a * r0 + di.b * r1; y0[e][1] = di.c * r0 + di.d * r1;
+        y1[e][0] = di.a * r2 + di.b * r3; y1[e][1] = di.c * r2 + di.d * r3;
+    }
+}
+
 // One cost callback.  x in L.x, gradient to L.g.  Returns the cost (wave-uniform).  *skipped is set when the
 // reference's norm guard fires (cost 0, gradient untouched).
 template <int P>
@@ -215,15 +278,11 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     }
     __syncthreads();
     BE_STAMP(2)
-    if (lane == 0) minco::knot_factor(M, L.T, L.sinv);
+    knot_pcr(M, L.T, L.y[0], L.y[1]);
     __syncthreads();
-    BE_STAMP(3)
-    if (lane < 2) {
-        minco::knot_solve(M, L.T, L.sinv, &L.y[lane][0][0]);
+    if (lane < 2)
         for (int k = 1; k < M; ++k) { L.kv[lane][k] = L.y[lane][k - 1][0]; L.ka[lane][k] = L.y[lane][k - 1][1]; }
-    }
     __syncthreads();
-    BE_STAMP(4)
     // ---- coefficients, energy and its partial gradients: lane = (piece, dim)
     double epart = 0.0;
     for (int t = lane; t < 2 * M; t += 64) {
@@ -498,7 +557,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     }
     __syncthreads();
     BE_STAMP(15)
-    if (lane < 2) minco::knot_solve(M, L.T, L.sinv, &L.y[lane][0][0]); // K is symmetric: the same sweep
+    knot_pcr(M, L.T, L.y[0], L.y[1]); // K is symmetric: the same system
     __syncthreads();
     BE_STAMP(16)
     // way-point and tail gradients: lane = (knot 1..M, dim)
