@@ -135,7 +135,6 @@ struct Lds {
     EvalCtx e;
     double T[P];
     double kp[2][P + 1], kv[2][P + 1], ka[2][P + 1]; // knot states per flat dimension
-    minco::Sym2 sinv[P];
     double y[2][P][2];                                // knot system right-hand side / solution per dimension
     double coef[P * 12];                              // (6 i + q) * 2 + d
     double gdC[P * 12];
