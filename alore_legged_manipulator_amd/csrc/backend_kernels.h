@@ -61,6 +61,7 @@ struct Params {
     double* cost_out; // [B]
     double* err_out;  // [B][2]
     int* ret_out;     // [B][3]: ret, iterations, evaluations
+    const int* order;  // optional: workgroup w works on problem order[w] (longest problems first: a launch ends with its slowest wavefront)
     long long* stamps; // diagnostic (ALORE_BE_STAMPS=1): [64] cycles per phase of workgroup 0, [63] = last stamp
 };
 

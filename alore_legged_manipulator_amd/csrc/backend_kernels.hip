@@ -898,8 +898,9 @@ __global__ __launch_bounds__(64) void backend_kernel(const Params* __restrict__ 
     const Params& prm = *gp;
     Lds<P>& L = lds<P>();
     EvalCtx& e = L.e;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= prm.count) return;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= prm.count) return;
+    const int b = prm.order ? prm.order[blockIdx.x] : (int)blockIdx.x;
     const Config& c = prm.cfg;
     load_problem<P>(prm, b);
     const int M = uni(e.M), n = uni(e.n), nstride = 3 * prm.prob.P;
