@@ -3,15 +3,16 @@
 // No reference code exists for this class (SURVEY.md 8(a) row A-RB); the OCP is stated in include/alore_wb.h.
 //
 // Kernel 1, stage_kernel: ONE WAVEFRONT PER (problem, stage).  Lanes are independent RNEA evaluations
-// (wb_dynamics.h) that differ by a unit vector or a perturbation:
-//   round 1   24 lanes: columns of M(q) (unit accelerations, no gravity) | 1 lane: bias RNEA(q, v, 0, f) |
+// (wb_dynamics.h) that differ by a unit vector or a perturbation; sines / cosines come from one table per stage:
+//   pass 0    24 lanes: columns of M(q) (unit accelerations, no gravity) | 1 lane: bias RNEA(q, v, 0, f) |
 //             12 lanes: columns of -J_c' (unit foot forces)
-//   Cholesky of M in LDS, a = M^-1 ([0; tau] - bias)
-//   round 2   45 lanes: d RNEA(q, v, a, f) / d (rpy, joints, v) by central differences (2 evaluations each)
-//   75 lanes (2 rounds): M^-1 times the 75 right-hand sides -> da/dq, da/dv, da/du
-//   assembly of A_k (48 x 48), B_k (48 x 30) and f(x_k, u_k) for the semi-implicit Euler step, written to HBM
-//   (float32 for the Riccati kernel, float64 on request).
-// Kernel 2, riccati_kernel: one workgroup (8 wavefronts) per problem, float32 MFMA 16x16x4 on the dense blocks.
+//   M^-1 by an in-register Gauss-Jordan (wave_linalg.h: lane = row, pivot rows by v_readlane), a = M^-1 ([0; tau] - bias)
+//   pass 1    45 lanes: d RNEA(q, v, a, f) / d (rpy, joints, v) by forward differences against the base point (lane 45)
+//   57 lanes: M^-1 times the derivative and foot-force columns -> da/dq, da/dv, da/df;  da/dtau = M^-1 itself
+//   assembly, lane = column of [A_k | B_k] (48 x 48, 48 x 30), and f(x_k, u_k) for the semi-implicit Euler step, to HBM
+//   (float32 for the Riccati kernel, float64 on request).  18.4 KB of LDS, 8 wavefronts per CU.
+// Kernel 2, riccati_kernel: one workgroup (4 wavefronts) per problem, float32 MFMA 16x16x4 on the dense blocks, torque
+// limits inside the sweep; 53.6 KB of LDS, 3 workgroups per CU.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
