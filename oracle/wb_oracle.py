@@ -5,7 +5,7 @@ THE REFERENCE HAS NO IMPLEMENTATION OF THIS CLASS (no RNEA / ABA / CRBA, no whol
 here either): PARITY UNPINNED.  The only reference artefact is the URDF, turned into numbers by
 tools/gen_b2z1_model.py.  This oracle is written in 6-D spatial algebra (Featherstone, "Rigid Body Dynamics
 Algorithms", 2008: RNEA table 5.1, CRBA table 6.2, ABA table 7.1 with a floating base as in section 9.4) -- a
-different formulation from the kernels (3-D Newton-Euler vectors, mass matrix from unit accelerations, Cholesky) --
+different formulation from the kernels (3-D Newton-Euler vectors, mass matrix from unit accelerations, Gauss-Jordan) --
 and is pinned by the physics identities of SURVEY.md 8(c) (tests/test_wb_oracle.py): gravity torques against the
 gradient of the potential energy, CRBA against RNEA columns, symmetry / positive definiteness, ABA o RNEA = identity,
 energy and momentum conservation of passive rollouts.
