@@ -255,14 +255,16 @@ __global__ __launch_bounds__(64) void rnea_kernel(int n, const double* q, const 
 
 
 // =====================================================================================================================
-// Kernel 2: Riccati sweep of the LQ problem of one real-time iteration.  One workgroup (8 wavefronts) per problem, all
+// Kernel 2: Riccati sweep of the LQ problem of one real-time iteration.  One workgroup (4 wavefronts) per problem, all
 // matrices of the current stage in LDS (float32), the dense products on the matrix cores:
 //   v_mfma_f32_16x16x4_f32:  lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives
 //   C[4 (l >> 4) + r][l & 15], r = 0..3  (cdna_hip_programming.md, "A/B operands ... 16x16x4").
 // Backward, stage k = N-1 .. 0 (P, p: cost-to-go 1/2 dx' P dx + p' dx of stage k + 1):
 //   PA = P A, PB = P B, s = P d + p                              (15 output tiles)
 //   Qxx = Q + A' PA, Qux = B' PA, Quu = R + B' PB, qx, qu        (15 tiles: the symmetric ones upper-triangular)
-//   Quu = L L' (Cholesky, 30 x 30), K = -Quu^-1 Qux, kff = -Quu^-1 qu   -> HBM (used by the forward sweep)
+//   Quu^-1 (30 x 30, in-register Gauss-Jordan on one wavefront, a row on two lanes), K = -Quu^-1 Qux, kff = -Quu^-1 qu
+//   with one refinement step on the matrix cores (18 tiles); torque limits: clamp + re-solve of the free inputs;
+//   K, kff -> HBM (used by the forward sweep)
 //   P <- Qxx + Qux' K, p <- qx + Qux' kff                        (6 tiles)
 // Forward: dx_0 = x0 - x_0, du_k = K_k dx_k + kff_k, dx_{k+1} = A_k dx_k + B_k du_k + d_k; then x += dx, u += du with
 // the joint torques clipped to the URDF effort limits.
