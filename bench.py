@@ -141,6 +141,27 @@ def cpu_baseline(N: int, batch: dict, seconds: float) -> dict:
     return out
 
 
+def wb_cpu_baseline(N, xi, ui, x0, xref, uref):
+    """The float64 NumPy oracle (kind "port": there is no reference implementation of this class) on ONE problem: the
+    linearisation of 4 of its N stages (scaled to N) and the dense KKT solve of its LQ problem, one thread."""
+    from oracle.wb_oracle import Model, linearize, solve_lq
+    from wb_cases import weights as wb_weights
+    m = Model()
+    Q, R, QN = wb_weights()
+    t0 = time.perf_counter()
+    AB = [linearize(m, xi[0, k], ui[0, k], 0.01) for k in range(4)]
+    t_lin = (time.perf_counter() - t0) * N / 4
+    A = [AB[k % 4][0] for k in range(N)]; Bm = [AB[k % 4][1] for k in range(N)]
+    d = [np.zeros(48) for _ in range(N)]
+    gx = [Q * (xi[0, k] - xref[0, k]) for k in range(N)]; gu = [R * (ui[0, k] - uref[0, k]) for k in range(N)]
+    t0 = time.perf_counter()
+    solve_lq(A, Bm, d, np.diag(Q), np.diag(R), np.diag(QN), gx, gu, QN * (xi[0, N] - xref[0, N]), x0[0] - xi[0, 0])
+    t_qp = time.perf_counter() - t0
+    return {"value": 1.0 / (t_lin + t_qp), "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"one problem: oracle/wb_oracle.py linearize (central differences of the spatial-algebra step) on 4 of {N} "
+                      f"stages, scaled ({t_lin:.1f} s), + dense KKT solve ({t_qp:.2f} s); NumPy float64, one thread"}
+
+
 def whole_body_main(a, rank, world, local_rank, torch, dist):
     """BASELINE configs[2]: B = 4096 B2 + Z1 whole-body problems per GPU, N = 20; a step = one real-time iteration
     (linearisation kernel + Riccati kernel) of every problem from the same iterate.  Independent problems: ranks are
@@ -199,7 +220,8 @@ def whole_body_main(a, rank, world, local_rank, torch, dist):
                          "traffic": None, "kernel": "wb::riccati_kernel", "kernel_ms_avg": ric,
                          "mfma_instructions_per_problem_stage": 552},
             "kernels_ms": {"wb::stage_kernel": lin, "wb::riccati_kernel": ric},
-            "finite": bool(np.isfinite(dx).all() and np.isfinite(du).all())}))
+            "finite": bool(np.isfinite(dx).all() and np.isfinite(du).all()),
+            "cpu_baseline": None if a.no_cpu_baseline else wb_cpu_baseline(N, xi, ui, x0, xref, uref)}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
