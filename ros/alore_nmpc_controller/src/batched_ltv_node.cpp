@@ -167,8 +167,12 @@ int main(int argc, char** argv)
     f.stopped.assign(f.B, 0); f.fresh.assign(f.B, 0); f.at_goal.assign(f.B, 0);
     f.output.assign((size_t)f.B * f.cfg.predict_steps * 2, 0.0);
     ros::NodeHandle root;
+    // robot_ns = "" with one robot: the reference node's own private topic names (~traj, ~odom, ~cmd, ...), so that the
+    // remaps of planner_sim.launch apply unchanged (launch/planner_sim_dropin.launch)
+    const bool dropin = ns.empty() && f.B == 1;
+    if (dropin) root = nh;
     for (int b = 0; b < f.B; ++b) {
-        const std::string pre = ns + std::to_string(b) + "/";
+        const std::string pre = dropin ? std::string() : ns + std::to_string(b) + "/";
         f.subs.push_back(root.subscribe<nav_msgs::Odometry>(pre + "odom", 1, boost::bind(&Fleet::odom, &f, b, _1)));
         f.subs.push_back(root.subscribe<carstatemsgs::Polynome>(pre + "traj", 1, boost::bind(&Fleet::traj, &f, b, _1)));
         f.cmd_pub.push_back(root.advertise<carstatemsgs::CarState>(pre + "cmd", 1));

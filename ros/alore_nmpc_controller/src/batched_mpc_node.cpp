@@ -121,8 +121,12 @@ int main(int argc, char** argv)
     }
     f.cmds.resize(f.B);
     ros::NodeHandle root;
+    // robot_ns = "" with one robot: the reference node's own private topic names (~traj, ~odom, ~cmd, ...), so that the
+    // remaps of planner_sim.launch apply unchanged (launch/planner_sim_dropin.launch)
+    const bool dropin = ns.empty() && f.B == 1;
+    if (dropin) root = nh;
     for (int b = 0; b < f.B; ++b) {
-        const std::string pre = ns + std::to_string(b) + "/";
+        const std::string pre = dropin ? std::string() : ns + std::to_string(b) + "/";
         f.subs.push_back(root.subscribe<nav_msgs::Odometry>(pre + "odom", 1, boost::bind(&Fleet::odom, &f, b, _1)));
         f.subs.push_back(root.subscribe<geometry_msgs::PointStamped>(pre + "EKF_ICR", 1, boost::bind(&Fleet::icr, &f, b, _1)));
         f.subs.push_back(root.subscribe<carstatemsgs::Polynome>(pre + "traj", 1, boost::bind(&Fleet::traj, &f, b, _1)));
