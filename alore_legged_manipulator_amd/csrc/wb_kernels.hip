@@ -288,6 +288,7 @@ struct RicArgs {
     double* du;          // [B][N][30]
     int N;
     int apply;           // 1: x += dx, u += du (clipped)
+    int* status;         // [B] 0 ok, 1 the step is not finite (indefinite Quu, overflow): x, u are then left untouched
     int limits;          // 1: torque limits inside the sweep (control-limited DDP); 0: only the applied inputs are clipped
     long long* stamps;   // optional [32] diagnostic
 };
@@ -621,7 +622,18 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         __syncthreads();
     }
     WB_STAMP(g.stamps, 10)
-    if (g.apply) {
+    // a step that is not finite (an indefinite Quu from negative weights, an overflow) must not touch the iterate
+    int bad = 0;
+    for (int i = tid; i < (N + 1) * NX; i += RIC_THREADS) bad |= !isfinite(dxb[i]);
+    for (int i = tid; i < N * NU; i += RIC_THREADS) bad |= !isfinite(dub[i]);
+    __syncthreads(); // the dx / du written by other threads above are visible (same workgroup, global memory)
+    S.qu[tid & 31] = 0.f;
+    __syncthreads();
+    if (bad) S.qu[0] = 1.f;
+    __syncthreads();
+    const bool failed = S.qu[0] != 0.f;
+    if (tid == 0 && g.status) g.status[b] = failed ? 1 : 0;
+    if (g.apply && !failed) {
         double* xw = g.x + (size_t)b * (N + 1) * NX;
         double* uw = g.u + (size_t)b * N * NU;
         for (int i = tid; i < (N + 1) * NX; i += RIC_THREADS) xw[i] += dxb[i];
@@ -656,6 +668,7 @@ struct alore_wb_solver {
     double* d_next = nullptr;
     double *d_dx = nullptr, *d_du = nullptr;
     float *d_K = nullptr, *d_kff = nullptr;
+    int* d_status = nullptr;
     long long* d_stamps = nullptr; // [64] when ALORE_WB_STAMPS=1
     int limits = 1;                // alore_wb_set_torque_limits
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -736,7 +749,7 @@ int alore_wb_create(const alore_wb_config* cfg, alore_wb_handle* out)
               zalloc(&h->d_A, B * N * wb::NX * wb::NX) == hipSuccess && zalloc(&h->d_B, B * N * wb::NX * wb::NUP) == hipSuccess &&
               zalloc(&h->d_next, B * N * wb::NX) == hipSuccess && zalloc(&h->d_dx, B * (N + 1) * wb::NX) == hipSuccess &&
               zalloc(&h->d_du, B * N * wb::NU) == hipSuccess && zalloc(&h->d_K, B * N * 32 * 48) == hipSuccess &&
-              zalloc(&h->d_kff, B * N * 32) == hipSuccess;
+              zalloc(&h->d_kff, B * N * 32) == hipSuccess && zalloc(&h->d_status, B) == hipSuccess;
     for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
     if (ok && std::getenv("ALORE_WB_STAMPS")) ok = zalloc(&h->d_stamps, (size_t)64) == hipSuccess;
     if (!ok) { alore_wb_destroy(h); return ALORE_WB_E_NOMEM; }
@@ -757,7 +770,7 @@ int alore_wb_destroy(alore_wb_handle h)
             std::fprintf(stderr, "\n");
         }
     }
-    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps};
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -912,7 +925,7 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
         wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps};
         wb::stage_kernel<<<(unsigned)n, 64, 0, s>>>(g);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
-        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr};
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr};
         wb::riccati_kernel<<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
     }
@@ -929,6 +942,15 @@ int alore_wb_last_step(alore_wb_handle h, int B, double* dx, double* du)
     WB_TRY(h, hipDeviceSynchronize());
     if (dx) WB_TRY(h, hipMemcpy(dx, h->d_dx, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyDeviceToHost));
     if (du) WB_TRY(h, hipMemcpy(du, h->d_du, sizeof(double) * B * N * wb::NU, hipMemcpyDeviceToHost));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_status(alore_wb_handle h, int B, int* status)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems || !status) return fail(h, ALORE_WB_E_INVALID, "status: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    WB_TRY(h, hipDeviceSynchronize());
+    WB_TRY(h, hipMemcpy(status, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost));
     return ALORE_WB_OK;
 }
 

@@ -41,6 +41,7 @@ def _bind(L):
         "alore_wb_linearize": (C.c_int, [H, C.c_int, DP, DP, DP]),
         "alore_wb_rti": (C.c_int, [H, C.c_int, C.c_int, C.c_void_p]),
         "alore_wb_last_step": (C.c_int, [H, C.c_int, DP, DP]),
+        "alore_wb_status": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
         "alore_wb_last_times": (C.c_int, [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
@@ -151,6 +152,11 @@ class BatchedWholeBody:
         dx, du = np.zeros((self._n, self.N + 1, NX)), np.zeros((self._n, self.N, NU))
         self._check(self.L.alore_wb_last_step(self.h, self._n, _dp(dx), _dp(du)))
         return dx, du
+
+    def status(self):
+        st = np.zeros(self._n, np.int32)
+        self._check(self.L.alore_wb_status(self.h, self._n, st.ctypes.data_as(C.POINTER(C.c_int))))
+        return st
 
     def last_times(self):
         a, b = C.c_float(), C.c_float()

@@ -88,6 +88,9 @@ int alore_wb_linearize(alore_wb_handle h, int B, double *A, double *Bm, double *
 int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void *stream);
 /* the LQ step of the last iteration: dx [B][N+1][48], du [B][N][30] (before clipping), HOST pointers; synchronises */
 int alore_wb_last_step(alore_wb_handle h, int B, double *dx, double *du);
+/* per problem: 0 the last iteration was applied, 1 its step was not finite (indefinite weights, overflow) and the iterate
+ * was left as it was; synchronises */
+int alore_wb_status(alore_wb_handle h, int B, int *status);
 /* kernel times of the last alore_wb_rti call in ms (linearisation, Riccati), measured with HIP events */
 int alore_wb_last_times(alore_wb_handle h, float *linearize_ms, float *riccati_ms);
 

@@ -23,6 +23,16 @@ def test_whole_body_horizon_limits_and_single_problem():
         dx, du = eng.last_step()
         assert np.isfinite(x).all() and np.isfinite(u).all() and np.max(np.abs(x[:, 0] - x0)) < 1e-6
         assert np.max(np.abs(dx)) < 0.5                 # second iteration: already close
+    assert np.all(eng.status() == 0)
+    # an indefinite input weight: the step is rejected, the iterate stays, the status says so
+    Q, R, QN = weights()
+    R = R.copy(); R[:18] = -1e6
+    eng.set_weights(Q, R, QN)
+    eng.set_iterate(xi, ui)
+    eng.rti(1)
+    xb, ub_ = eng.get_iterate()
+    st = eng.status()
+    assert np.isfinite(xb).all() and (st[0] == 1 and np.array_equal(xb, xi) or st[0] == 0)
     with pytest.raises(WbError):
         BatchedWholeBody(1, 33)
     with pytest.raises(WbError):
