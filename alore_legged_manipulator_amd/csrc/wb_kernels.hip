@@ -721,6 +721,13 @@ void alore_wb_default_config(alore_wb_config* c)
     c->horizon = 20; c->dt = 0.01; c->device = 0; c->max_problems = 4096;
 }
 
+int alore_wb_kernel_info(int* stage_lds_bytes, int* riccati_lds_bytes)
+{
+    if (stage_lds_bytes) *stage_lds_bytes = (int)sizeof(wb::StageLds);
+    if (riccati_lds_bytes) *riccati_lds_bytes = (int)sizeof(wb::RicLds);
+    return ALORE_WB_OK;
+}
+
 int alore_wb_model_info(double* masses, double* lower, double* upper, double* effort)
 {
     if (masses) for (int i = 0; i < b2z1::NB; ++i) masses[i] = b2z1::MASS[i];

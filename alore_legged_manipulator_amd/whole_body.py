@@ -30,6 +30,7 @@ def _bind(L):
         "alore_wb_destroy": (C.c_int, [H]),
         "alore_wb_last_error": (C.c_char_p, [H]),
         "alore_wb_model_info": (C.c_int, [DP, DP, DP, DP]),
+        "alore_wb_kernel_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "alore_wb_rnea": (C.c_int, [H, C.c_int, DP, DP, DP, DP, C.c_int, DP]),
         "alore_wb_forward_dynamics": (C.c_int, [H, C.c_int, DP, DP, DP, DP, DP]),
         "alore_wb_aba": (C.c_int, [H, C.c_int, DP, DP, DP, DP]),

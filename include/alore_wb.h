@@ -59,6 +59,10 @@ const char *alore_wb_last_error(alore_wb_handle h);
 /* the model table the library was compiled with: masses [19], joint limits lower / upper / effort [18]; any may be NULL */
 int alore_wb_model_info(double *masses, double *lower, double *upper, double *effort);
 
+/* LDS bytes per workgroup of the two kernels (residency: 8 stage wavefronts / 3 Riccati workgroups per CU need
+ * <= 20480 / <= 53760 bytes; a test guards both) */
+int alore_wb_kernel_info(int *stage_lds_bytes, int *riccati_lds_bytes);
+
 /* ---- rigid-body dynamics for n independent evaluation points (HOST pointers; synchronous) ----
  * q [n][24], v [n][24], a [n][24], f [n][12] (NULL = no foot forces), gravity 0/1 -> tau [n][24] */
 int alore_wb_rnea(alore_wb_handle h, int n, const double *q, const double *v, const double *a, const double *f, int gravity,

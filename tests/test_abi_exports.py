@@ -152,3 +152,16 @@ def test_no_whole_body_or_ltv_solver_without_a_gpu():
         BatchedWholeBody(4)
     with pytest.raises(LtvError):
         BatchedLtvMpc(4)
+
+
+def test_whole_body_kernels_stay_below_their_residency_cliffs():
+    """LDS per workgroup decides how many workgroups a CU holds: one more 256-byte block in the Riccati kernel (or a
+    __syncthreads_or, which owns an LDS temporary) costs a third of its throughput (measured: 2.8 -> 4.2 ms)."""
+    from alore_legged_manipulator_amd import _lib
+    from alore_legged_manipulator_amd.whole_body import _bind
+    lib = _lib.load()
+    _bind(lib)
+    a, b = C.c_int(), C.c_int()
+    assert lib.alore_wb_kernel_info(C.byref(a), C.byref(b)) == 0
+    assert a.value <= 20480, a.value       # 8 wavefronts of the stage kernel per CU
+    assert b.value <= 53760, b.value       # 3 workgroups of the Riccati kernel per CU
