@@ -134,40 +134,39 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
                 double s[5];
 #pragma unroll
                 for (int r = 0; r < 5; ++r) s[r] = P[r][0] * C0 + P[r][1] * C1 + p[r];
-                // columns of Fw (5 x 7): col0 = e0, col1 = e1, col2 = (A02, A12, 1, 0, 0), col3 = col4 = 0,
-                //                        col5 = (B00, B10, 0, 1, 0), col6 = (0, 0, dt, 0, 1)
-                double Fc[7][5];
-#pragma unroll
-                for (int k = 0; k < 7; ++k)
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) Fc[k][r] = 0.0;
-                Fc[0][0] = 1.0; Fc[1][1] = 1.0; Fc[2][0] = A02; Fc[2][1] = A12; Fc[2][2] = 1.0;
-                Fc[5][0] = B00; Fc[5][1] = B10; Fc[5][3] = 1.0; Fc[6][2] = dt; Fc[6][4] = 1.0;
+                // Pull-back H = Fw' P Fw, h = Fw' s through the columns of Fw (5 x 7):
+                //   c0 = e0, c1 = e1, c2 = (A02, A12, 1, 0, 0), c3 = c4 = 0, c5 = (B00, B10, 0, 1, 0), c6 = (0, 0, dt, 0, 1)
+                // written out term by term (the columns are mostly unit vectors: 50 products instead of the 420 of the
+                // dense triple loop, whose multiplications by literal zeros IEEE arithmetic does not let the compiler drop)
                 Quad7 q;
-                double PF[7][5]; // P Fc[k]
+                double PF[7][5]; // P c_k
 #pragma unroll
-                for (int k = 0; k < 7; ++k)
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int t = 0; t < 5; ++t) acc += P[r][t] * Fc[k][t];
-                        PF[k][r] = acc;
-                    }
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    double hk = 0.0;
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) hk += Fc[k][r] * s[r];
-                    q.h[k] = hk;
-#pragma unroll
-                    for (int m = 0; m < 7; ++m) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int r = 0; r < 5; ++r) acc += Fc[m][r] * PF[k][r];
-                        q.H[m][k] = acc;
-                    }
+                for (int r = 0; r < 5; ++r) {
+                    PF[0][r] = P[r][0];
+                    PF[1][r] = P[r][1];
+                    PF[2][r] = A02 * P[r][0] + A12 * P[r][1] + P[r][2];
+                    PF[3][r] = 0.0;
+                    PF[4][r] = 0.0;
+                    PF[5][r] = B00 * P[r][0] + B10 * P[r][1] + P[r][3];
+                    PF[6][r] = dt * P[r][2] + P[r][4];
                 }
+#pragma unroll
+                for (int k = 0; k < 7; ++k) { // row m of H: c_m' (P c_k)
+                    q.H[0][k] = PF[k][0];
+                    q.H[1][k] = PF[k][1];
+                    q.H[2][k] = A02 * PF[k][0] + A12 * PF[k][1] + PF[k][2];
+                    q.H[3][k] = 0.0;
+                    q.H[4][k] = 0.0;
+                    q.H[5][k] = B00 * PF[k][0] + B10 * PF[k][1] + PF[k][3];
+                    q.H[6][k] = dt * PF[k][2] + PF[k][4];
+                }
+                q.h[0] = s[0];
+                q.h[1] = s[1];
+                q.h[2] = A02 * s[0] + A12 * s[1] + s[2];
+                q.h[3] = 0.0;
+                q.h[4] = 0.0;
+                q.h[5] = B00 * s[0] + B10 * s[1] + s[3];
+                q.h[6] = dt * s[2] + s[4];
                 q.H[5][5] += Ruu0[0]; q.H[6][6] += Ruu0[1];
                 q.h[5] += -2.0 * c.matrix_q[2] * dr[(dl + j) * 2];
                 if (j >= 1) {
