@@ -125,11 +125,15 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
             for (int j = K - 1; j >= 0; --j) {
                 const double A02 = W(d, j, 0, b), A12 = W(d, j, 1, b), B00 = W(d, j, 2, b), B10 = W(d, j, 3, b);
                 const double C0 = W(d, j, 4, b), C1 = W(d, j, 5, b);
+                // every load of the stage before its first store (a load behind a possibly aliasing store waits for its own
+                // round trip): references, working-set status
+                const double xr0 = xr[(dl + j) * 3], xr1 = xr[(dl + j) * 3 + 1], xr2 = xr[(dl + j) * 3 + 2], dr0 = dr[(dl + j) * 2];
+                const int st1 = d.st[((size_t)j * 2 + 1) * d.stride + b], st0 = d.st[((size_t)j * 2) * d.stride + b];
                 W(d, j, 34, b) = lo_eff[0]; W(d, j, 35, b) = hi_eff[0]; W(d, j, 36, b) = lo_eff[1]; W(d, j, 37, b) = hi_eff[1];
                 // tracking on the next position, then pull back through xi' = Fw w + c:
                 //   x' = x + A02 th + B00 u0 + C0 ; y' = y + A12 th + B10 u0 + C1 ; th' = th + dt u1 ; v' = u0 ; om' = u1
 #pragma unroll
-                for (int r = 0; r < 3; ++r) { P[r][r] += Qp2[r]; p[r] -= Qp2[r] * xr[(dl + j) * 3 + r]; }
+                for (int r = 0; r < 3; ++r) { P[r][r] += Qp2[r]; p[r] -= Qp2[r] * (r == 0 ? xr0 : (r == 1 ? xr1 : xr2)); }
                 // s = P c + p
                 double s[5];
 #pragma unroll
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
                 q.h[5] = B00 * s[0] + B10 * s[1] + s[3];
                 q.h[6] = dt * s[2] + s[4];
                 q.H[5][5] += Ruu0[0]; q.H[6][6] += Ruu0[1];
-                q.h[5] += -2.0 * c.matrix_q[2] * dr[(dl + j) * 2];
+                q.h[5] += -2.0 * c.matrix_q[2] * dr0;
                 if (j >= 1) {
 #pragma unroll
                     for (int cc = 0; cc < 2; ++cc) {
@@ -176,7 +180,6 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
                         q.H[5 + cc][3 + cc] -= Rd2[cc]; q.H[3 + cc][5 + cc] -= Rd2[cc];
                     }
                 }
-                const int st1 = d.st[((size_t)j * 2 + 1) * d.stride + b], st0 = d.st[((size_t)j * 2) * d.stride + b];
                 // ---- eliminate u1 (index 6): u1 = a1 . w[0..5] + f1
                 {
                     double a1[6], f1;
@@ -247,29 +250,35 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
             double best_sev = -1.0;
             int best_j = 0, best_c = 0, best_ns = 0;
             for (int j = 0; j < K; ++j) {
+                // the whole stage record in one burst (38 independent loads in flight): read one by one between the
+                // stores to out[] / st[] below, every load would wait out its own round trip to L2
+                double R[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) R[f] = W(d, j, f, b);
+                const int st_j[2] = {d.st[((size_t)j * 2) * d.stride + b], d.st[((size_t)j * 2 + 1) * d.stride + b]};
                 double w7[7];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) w7[k] = xi[k];
-                double u0 = W(d, j, 26, b);
+                double u0 = R[26];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) u0 += W(d, j, 21 + k, b) * xi[k];
+                for (int k = 0; k < 5; ++k) u0 += R[21 + k] * xi[k];
                 w7[5] = u0;
-                double u1 = W(d, j, 12, b);
+                double u1 = R[12];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) u1 += W(d, j, 6 + k, b) * w7[k];
+                for (int k = 0; k < 6; ++k) u1 += R[6 + k] * w7[k];
                 w7[6] = u1;
-                double g1 = W(d, j, 20, b), g0 = W(d, j, 33, b);
+                double g1 = R[20], g0 = R[33];
 #pragma unroll
-                for (int k = 0; k < 7; ++k) g1 += W(d, j, 13 + k, b) * w7[k];
+                for (int k = 0; k < 7; ++k) g1 += R[13 + k] * w7[k];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) g0 += W(d, j, 27 + k, b) * w7[k];
+                for (int k = 0; k < 6; ++k) g0 += R[27 + k] * w7[k];
                 const double uu[2] = {u0, u1}, gg[2] = {g0, g1};
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
                     int* sp = d.st + ((size_t)j * 2 + cc) * d.stride + b;
-                    const int s = *sp;
+                    const int s = st_j[cc];
                     const double val = uu[cc], prev = xi[3 + cc], grad = gg[cc];
-                    const double lo = W(d, j, 34 + 2 * cc, b), hi = W(d, j, 35 + 2 * cc, b);
+                    const double lo = R[34 + 2 * cc], hi = R[35 + 2 * cc];
                     int ns = s;
                     double sev = 0.0;
                     if (s == FREE) {
@@ -304,8 +313,8 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
                 }
                 out[2 * (dl + j)] = u0;
                 out[2 * (dl + j) + 1] = u1;
-                const double A02 = W(d, j, 0, b), A12 = W(d, j, 1, b), B00 = W(d, j, 2, b), B10 = W(d, j, 3, b);
-                const double nx = xi[0] + A02 * xi[2] + B00 * u0 + W(d, j, 4, b), ny = xi[1] + A12 * xi[2] + B10 * u0 + W(d, j, 5, b);
+                const double A02 = R[0], A12 = R[1], B00 = R[2], B10 = R[3];
+                const double nx = xi[0] + A02 * xi[2] + B00 * u0 + R[4], ny = xi[1] + A12 * xi[2] + B10 * u0 + R[5];
                 xi[2] = xi[2] + dt * u1; xi[0] = nx; xi[1] = ny; xi[3] = u0; xi[4] = u1;
             }
             if (single && changes > 0) d.st[((size_t)best_j * 2 + best_c) * d.stride + b] = best_ns;
