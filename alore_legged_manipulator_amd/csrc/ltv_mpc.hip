@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -36,6 +38,12 @@ namespace ltv {
 constexpr int MAXT = 64;
 enum : int { FREE = 0, BOX_LO = 1, BOX_HI = 2, RATE_LO = 3, RATE_HI = 4 };
 constexpr int NF = 38; // doubles per stage record
+#define LTV_STAMP(i)                                                                         \
+    if (d.stamps && b == 0) {                                                                \
+        const long long now_ = (long long)__builtin_readcyclecounter();                      \
+        d.stamps[i] += now_ - d.stamps[7];                                                   \
+        d.stamps[7] = now_;                                                                  \
+    }
 constexpr int SINGLE_AFTER = 24; // from this sweep on only the most severe change is applied (breaks cycles)
 
 struct Dev {
@@ -53,6 +61,7 @@ struct Dev {
     int* sweeps;         // [B]
     int* status;         // [B]
     int n_relin, reset;
+    long long* stamps;   // diagnostic (ALORE_LTV_STAMPS=1): cycles of robot 0 in rollout / backward / forward / rest
 };
 
 struct Quad7 { // symmetric 7 x 7 form H and vector h in w = (xi0..4, u0, u1); only the entries that can be non-zero are kept dense
@@ -86,30 +95,46 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
     const double x0 = d.now[(size_t)b * 3], y0 = d.now[(size_t)b * 3 + 1], th0 = d.now[(size_t)b * 3 + 2];
     int sweeps = 0, status = 0;
 
+    if (d.stamps && b == 0) d.stamps[7] = (long long)__builtin_readcyclecounter();
     for (int relin = 0; relin < d.n_relin; ++relin) {
         // ---- predictMotion: rollout of the last output; the linear model about xbar[dl + j] goes to the records
         double px = x0, py = y0, pth = th0, pv = 0.0; // now_state.v = 0 (odometry callback)
         double pos0[3] = {x0, y0, th0};
-        for (int i = 0; i <= T; ++i) {
-            if (i >= dl && i < T) {
-                const int j = i - dl;
-                const double B00 = cos(pth) * dt, B10 = sin(pth) * dt;
-                const double A02 = -B10 * pv, A12 = B00 * pv;
-                W(d, j, 0, b) = A02; W(d, j, 1, b) = A12; W(d, j, 2, b) = B00; W(d, j, 3, b) = B10;
-                W(d, j, 4, b) = -A02 * pth; W(d, j, 5, b) = -A12 * pth;
-                if (j == 0) { pos0[0] = px; pos0[1] = py; pos0[2] = pth; }
+        // the previous output is read eight steps at a time (16 loads in flight; a load issued behind the record stores of
+        // the step before would wait out its own round trip), one sincos per step serves the model and the rollout
+        for (int i0 = 0; i0 <= T; i0 += 8) {
+            double oa[8], oy[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = i0 + q;
+                oa[q] = i < T ? out[2 * i] : 0.0;
+                oy[q] = i < T ? out[2 * i + 1] : 0.0;
             }
-            if (i == T) break;
-            // stateTrans(temp, a = output(0, i), yaw_dot = output(1, i))
-            const double a = out[2 * i];
-            double yd = out[2 * i + 1];
-            yd = fmin(fmax(yd, -c.max_omega), c.max_omega);
-            px += a * cos(pth) * dt;
-            py += a * sin(pth) * dt;
-            pth += yd * dt;
-            pv = a;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = i0 + q;
+                if (i > T) break;
+                double sn, cs;
+                sincos(pth, &sn, &cs);
+                if (i >= dl && i < T) {
+                    const int j = i - dl;
+                    const double B00 = cs * dt, B10 = sn * dt;
+                    const double A02 = -B10 * pv, A12 = B00 * pv;
+                    W(d, j, 0, b) = A02; W(d, j, 1, b) = A12; W(d, j, 2, b) = B00; W(d, j, 3, b) = B10;
+                    W(d, j, 4, b) = -A02 * pth; W(d, j, 5, b) = -A12 * pth;
+                    if (j == 0) { pos0[0] = px; pos0[1] = py; pos0[2] = pth; }
+                }
+                if (i == T) break;
+                // stateTrans(temp, a = output(0, i), yaw_dot = output(1, i))
+                const double a = oa[q];
+                const double yd = fmin(fmax(oy[q], -c.max_omega), c.max_omega);
+                px += a * cs * dt;
+                py += a * sn * dt;
+                pth += yd * dt;
+                pv = a;
+            }
         }
-
+        LTV_STAMP(0)
         // ---- working-set iterations
         bool settled = false;
         for (sweeps = 0; sweeps < c.max_sweeps && !settled; ++sweeps) {
@@ -239,6 +264,7 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
                     hi_eff[1] = (st1 == RATE_HI) ? fmin(umax[1], h1 - rmax[1]) : umax[1];
                 }
             }
+            LTV_STAMP(1)
             // forward sweep: inputs, multipliers, violations -> next working set
             double xi[5] = {pos0[0], pos0[1], pos0[2], 0.0, 0.0};
             int changes = 0;
@@ -319,6 +345,7 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
             }
             if (single && changes > 0) d.st[((size_t)best_j * 2 + best_c) * d.stride + b] = best_ns;
             settled = (changes == 0);
+            LTV_STAMP(2)
         }
         status = settled ? 0 : 1;
         for (int i = 0; i < dl; ++i) { out[2 * i] = bf[2 * i]; out[2 * i + 1] = bf[2 * i + 1]; } // solveMPCV: the delayed inputs
@@ -347,6 +374,7 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
         for (int i = 0; i + 1 < dl; ++i) { bf[2 * i] = bf[2 * (i + 1)]; bf[2 * i + 1] = bf[2 * (i + 1) + 1]; }
         bf[2 * (dl - 1)] = out[2 * dl]; bf[2 * (dl - 1) + 1] = out[2 * dl + 1];
     }
+    LTV_STAMP(3)
     d.sweeps[b] = sweeps;
     d.status[b] = status;
 }
@@ -415,6 +443,7 @@ struct alore_ltv_solver {
     double *d_now = nullptr, *d_xref = nullptr, *d_dref = nullptr, *d_out = nullptr, *d_buff = nullptr, *d_xopt = nullptr, *d_ws = nullptr,
            *d_est = nullptr;
     int *d_st = nullptr, *d_sweeps = nullptr, *d_status = nullptr, *d_goal = nullptr;
+    long long* d_stamps = nullptr;
     char* h_stage = nullptr; // pinned
     size_t stage_bytes = 0;
 };
@@ -480,6 +509,7 @@ int alore_ltv_create(const alore_ltv_config* cfg, int device, int max_robots, al
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(zalloc(&h->d_now, B * 3)); A(zalloc(&h->d_xref, B * T * 3)); A(zalloc(&h->d_dref, B * T * 2)); A(zalloc(&h->d_out, B * T * 2));
     A(zalloc(&h->d_buff, B * dl * 2)); A(zalloc(&h->d_xopt, B * (T + 1) * 3)); A(zalloc(&h->d_ws, T * ltv::NF * B)); A(zalloc(&h->d_est, B * 3));
+    if (std::getenv("ALORE_LTV_STAMPS")) A(zalloc(&h->d_stamps, (size_t)8));
     A(zalloc(&h->d_st, T * 2 * B)); A(zalloc(&h->d_sweeps, B)); A(zalloc(&h->d_status, B)); A(zalloc(&h->d_goal, B));
     h->stage_bytes = sizeof(double) * B * ((T + 1) * 3 + T * 5 + 8) + sizeof(int) * B * 4 + 1024;
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault);
@@ -492,6 +522,12 @@ int alore_ltv_destroy(alore_ltv_handle h)
 {
     if (!h) return ALORE_LTV_E_INVALID;
     (void)hipSetDevice(h->device);
+    if (h->d_stamps) {
+        long long st[8];
+        if (hipMemcpy(st, h->d_stamps, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
+            std::fprintf(stderr, "[alore_ltv stamps] robot 0, cycles: rollout %lld, backward %lld, forward %lld, rest %lld\n", st[0], st[1], st[2], st[3]);
+        (void)hipFree(h->d_stamps);
+    }
     lfree(h);
     delete h;
     return ALORE_LTV_OK;
@@ -550,6 +586,7 @@ int alore_ltv_get_cmd(alore_ltv_handle h, int B, const double* now_state, int n_
     d.now = h->d_now; d.xref = h->d_xref; d.dref = h->d_dref; d.output = h->d_out; d.buff = h->d_buff; d.xopt = h->d_xopt;
     d.ws = h->d_ws; d.st = h->d_st; d.sweeps = h->d_sweeps; d.status = h->d_status;
     d.n_relin = n_relin; d.reset = reset;
+    d.stamps = h->d_stamps;
     hipLaunchKernelGGL(ltv::get_cmd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d);
     LTV_TRY(h, hipGetLastError());
     LTV_TRY(h, hipStreamSynchronize(s)); // `hn` is reused by the next call
