@@ -599,11 +599,39 @@ int alore_ltv_results(alore_ltv_handle h, int B, double* output, double* xopt, i
     LTV_TRY(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const size_t T = h->cfg.predict_steps;
-    if (output) LTV_TRY(h, hipMemcpyAsync(output, h->d_out, sizeof(double) * B * T * 2, hipMemcpyDeviceToHost, s));
-    if (xopt) LTV_TRY(h, hipMemcpyAsync(xopt, h->d_xopt, sizeof(double) * B * (T + 1) * 3, hipMemcpyDeviceToHost, s));
-    if (sweeps) LTV_TRY(h, hipMemcpyAsync(sweeps, h->d_sweeps, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    if (status) LTV_TRY(h, hipMemcpyAsync(status, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    // through the pinned slab of the handle (a device-to-pageable copy is staged by the runtime in small pieces with a host
+    // wait per piece): layout  output | xopt | sweeps | status
+    char* base = h->h_stage;
+    double* so = (double*)base;
+    double* sx = so + (size_t)B * T * 2;
+    int* ss = (int*)(sx + (size_t)B * (T + 1) * 3);
+    int* st = ss + B;
+    if (output) LTV_TRY(h, hipMemcpyAsync(so, h->d_out, sizeof(double) * B * T * 2, hipMemcpyDeviceToHost, s));
+    if (xopt) LTV_TRY(h, hipMemcpyAsync(sx, h->d_xopt, sizeof(double) * B * (T + 1) * 3, hipMemcpyDeviceToHost, s));
+    if (sweeps) LTV_TRY(h, hipMemcpyAsync(ss, h->d_sweeps, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    if (status) LTV_TRY(h, hipMemcpyAsync(st, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
     LTV_TRY(h, hipStreamSynchronize(s));
+    if (output) std::memcpy(output, so, sizeof(double) * B * T * 2);
+    if (xopt) std::memcpy(xopt, sx, sizeof(double) * B * (T + 1) * 3);
+    if (sweeps) std::memcpy(sweeps, ss, sizeof(int) * B);
+    if (status) std::memcpy(status, st, sizeof(int) * B);
+    return ALORE_LTV_OK;
+}
+
+int alore_ltv_commands(alore_ltv_handle h, int B, double* cmd, int* status, void* stream)
+{
+    if (!h || B < 1 || B > h->B || !cmd) return lfail(h, ALORE_LTV_E_INVALID, "commands: bad argument");
+    LTV_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t T = h->cfg.predict_steps, dl = h->cfg.delay_num;
+    double* sc = (double*)h->h_stage;
+    int* st = (int*)(sc + (size_t)B * 2);
+    // column delay_num of every robot's output: a strided copy, 16 bytes per robot
+    LTV_TRY(h, hipMemcpy2DAsync(sc, sizeof(double) * 2, h->d_out + dl * 2, sizeof(double) * T * 2, sizeof(double) * 2, B, hipMemcpyDeviceToHost, s));
+    if (status) LTV_TRY(h, hipMemcpyAsync(st, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    LTV_TRY(h, hipStreamSynchronize(s));
+    std::memcpy(cmd, sc, sizeof(double) * B * 2);
+    if (status) std::memcpy(status, st, sizeof(int) * B);
     return ALORE_LTV_OK;
 }
 

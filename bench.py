@@ -616,8 +616,9 @@ def main():
             t_a = time.perf_counter(); g0 = lt.get_cmd(st0, n_relin=5, reset=True); t_cold = time.perf_counter() - t_a
             t_a = time.perf_counter()
             for i in range(10):
-                g1 = lt.get_cmd(st0, n_relin=5)
+                c1, s1 = lt.tick(st0, n_relin=5)     # commands + status only (16 B per robot over the bus)
             t_warm = (time.perf_counter() - t_a) / 10
+            g1 = lt.get_cmd(st0, n_relin=5)
             extras["ltv_mpc"] = {"robots": B, "relinearisations": 5, "cold_ms": t_cold * 1e3, "warm_ms": t_warm * 1e3,
                                  "robot_ticks_per_s_warm": B / t_warm, "sweeps_last_qp_cold_mean": float(g0["sweeps"].mean()),
                                  "sweeps_last_qp_warm_mean": float(g1["sweeps"].mean()), "unsettled": int((g1["status"] != 0).sum())}

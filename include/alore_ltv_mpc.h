@@ -65,6 +65,9 @@ int alore_ltv_get_cmd(alore_ltv_handle h, int B, const double *now_state, int n_
  * :271-302), sweeps [B] (working-set sweeps of the last QP), status [B] (0 ok, 1 sweep cap reached); any may be NULL.
  * Synchronises the stream. */
 int alore_ltv_results(alore_ltv_handle h, int B, double *output, double *xopt, int *sweeps, int *status, void *stream);
+/* what a control tick needs: cmd [B][2] = output(:, delay_num) per robot (mpc.cpp:169-172) and the status; 16 bytes per robot
+ * cross the bus instead of the whole prediction.  Synchronises the stream. */
+int alore_ltv_commands(alore_ltv_handle h, int B, double *cmd, int *status, void *stream);
 /* overwrite the stored previous output / delay buffer (tests): output [B][T][2], buff [B][d][2] */
 int alore_ltv_set_state(alore_ltv_handle h, int B, const double *output, const double *buff, void *stream);
 

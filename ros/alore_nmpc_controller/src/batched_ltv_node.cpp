@@ -43,7 +43,7 @@ struct Fleet {
     std::vector<double> est;          // [B][3]
     std::vector<char> has_odom, receive_traj, stopped, fresh;
     std::vector<int> at_goal;
-    std::vector<double> output;       // [B][T][2]
+    std::vector<double> output;       // [B][2] the commands of the tick
     std::vector<ros::Subscriber> subs;
     std::vector<ros::Publisher> cmd_pub;
 
@@ -107,16 +107,15 @@ struct Fleet {
         }
         if (alore_ltv_refs_from_store(ltv, store, B, now.toSec(), est.data(), at_goal.data(), nullptr) != 0 ||
             alore_ltv_get_cmd(ltv, B, est.data(), n_relin, 0, nullptr) != 0 ||
-            alore_ltv_results(ltv, B, output.data(), nullptr, nullptr, nullptr, nullptr) != 0) {
+            alore_ltv_commands(ltv, B, output.data(), nullptr, nullptr) != 0) {
             ROS_ERROR_THROTTLE(1.0, "alore_ltv tick failed: %s", alore_ltv_last_error(ltv));
             return;
         }
-        const int T = cfg.predict_steps, d = cfg.delay_num;
         for (int b = 0; b < B; ++b) {
             if (stopped[b]) { publish(b, now, 0.0, 0.0); continue; }         // emergency stop: zero command
             if (!has_odom[b] || !receive_traj[b]) continue;                   // mpc.cpp:132-133
             if (at_goal[b]) { publish(b, now, 0.0, 0.0); receive_traj[b] = 0; continue; }   // :142-156
-            publish(b, now, output[((size_t)b * T + d) * 2], output[((size_t)b * T + d) * 2 + 1]);
+            publish(b, now, output[(size_t)b * 2], output[(size_t)b * 2 + 1]);
         }
     }
 };
@@ -165,7 +164,7 @@ int main(int argc, char** argv)
     }
     f.pending.resize(f.B); f.est.assign(3 * f.B, 0.0); f.has_odom.assign(f.B, 0); f.receive_traj.assign(f.B, 0);
     f.stopped.assign(f.B, 0); f.fresh.assign(f.B, 0); f.at_goal.assign(f.B, 0);
-    f.output.assign((size_t)f.B * f.cfg.predict_steps * 2, 0.0);
+    f.output.assign((size_t)f.B * 2, 0.0);
     ros::NodeHandle root;
     // robot_ns = "" with one robot: the reference node's own private topic names (~traj, ~odom, ~cmd, ...), so that the
     // remaps of planner_sim.launch apply unchanged (launch/planner_sim_dropin.launch)

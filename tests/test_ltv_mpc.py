@@ -156,6 +156,10 @@ def test_gpu_get_cmd_tracks_the_oracle_over_relinearisations_and_ticks():
         eng.set_refs(np.stack(xr), np.stack(dr))
         got = eng.get_cmd(state, n_relin=n_relin, reset=(tick == 0))
         assert np.all(got["status"] == 0)
+        cmd_only = np.zeros((B, 2)); st_only = np.zeros(B, np.int32)
+        import ctypes as C
+        eng._check(eng.L.alore_ltv_commands(eng.h, B, cmd_only.ctypes.data_as(C.POINTER(C.c_double)), st_only.ctypes.data_as(C.POINTER(C.c_int)), None))
+        assert np.array_equal(cmd_only, got["cmd"]) and np.all(st_only == 0)     # the strided commands-only download
         for b in range(B):
             out_o[b], buff_o[b], infos = get_cmd(list(state[b]) + [0.0], out_o[b], buff_o[b], xr[b].T, dr[b].T, p, n_relin)
             assert np.max(np.abs(got["output"][b] - out_o[b].T)) < 1e-6, (tick, b)
