@@ -655,6 +655,19 @@ __global__ __launch_bounds__(64) void aba_kernel(int n, const double* q, const d
     aba(e, u + (size_t)t * NU, Sink{acc + (size_t)t * NV, 1, 1.0, 0});
 }
 
+// receding horizon: stage k <- stage k + 1 for the iterate (the last stage is repeated), as MpcWrapper::update's shift
+__global__ void shift_kernel(int B, int N, double* x, double* u)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    double* xb = x + (size_t)b * (N + 1) * NX;
+    double* ub = u + (size_t)b * N * NU;
+    for (int k = 0; k < N; ++k) { // sequential in k, parallel inside a stage: reads of stage k + 1 precede its overwrite
+        if (t < NX) xb[(size_t)k * NX + t] = xb[(size_t)(k + 1) * NX + t];
+        if (t < NU && k + 1 < N) ub[(size_t)k * NU + t] = ub[(size_t)(k + 1) * NU + t];
+        __syncthreads();
+    }
+}
+
 } // namespace wb
 
 // =====================================================================================================================
@@ -871,6 +884,32 @@ int alore_wb_set_problem(alore_wb_handle h, int B, const double* x0, const doubl
     WB_TRY(h, hipMemcpy(h->d_x0, x0, sizeof(double) * B * wb::NX, hipMemcpyHostToDevice));
     WB_TRY(h, hipMemcpy(h->d_xref, xref, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyHostToDevice));
     WB_TRY(h, hipMemcpy(h->d_uref, uref, sizeof(double) * B * N * wb::NU, hipMemcpyHostToDevice));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_x0(alore_wb_handle h, int B, const double* x0)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems || !x0) return fail(h, ALORE_WB_E_INVALID, "set_x0: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    WB_TRY(h, hipMemcpy(h->d_x0, x0, sizeof(double) * B * wb::NX, hipMemcpyHostToDevice));
+    return ALORE_WB_OK;
+}
+
+int alore_wb_shift_iterate(alore_wb_handle h, int B, void* stream)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems) return fail(h, ALORE_WB_E_INVALID, "shift_iterate: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    wb::shift_kernel<<<B, 64, 0, (hipStream_t)stream>>>(B, h->cfg.horizon, h->d_x, h->d_u);
+    WB_TRY(h, hipGetLastError());
+    return ALORE_WB_OK;
+}
+
+int alore_wb_get_first_input(alore_wb_handle h, int B, double* u0)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems || !u0) return fail(h, ALORE_WB_E_INVALID, "get_first_input: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t N = h->cfg.horizon;
+    WB_TRY(h, hipMemcpy2D(u0, sizeof(double) * wb::NU, h->d_u, sizeof(double) * N * wb::NU, sizeof(double) * wb::NU, B, hipMemcpyDeviceToHost));
     return ALORE_WB_OK;
 }
 

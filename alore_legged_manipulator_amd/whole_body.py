@@ -37,6 +37,9 @@ def _bind(L):
         "alore_wb_set_weights": (C.c_int, [H, DP, DP, DP]),
         "alore_wb_set_torque_limits": (C.c_int, [H, C.c_int]),
         "alore_wb_set_problem": (C.c_int, [H, C.c_int, DP, DP, DP]),
+        "alore_wb_set_x0": (C.c_int, [H, C.c_int, DP]),
+        "alore_wb_shift_iterate": (C.c_int, [H, C.c_int, C.c_void_p]),
+        "alore_wb_get_first_input": (C.c_int, [H, C.c_int, DP]),
         "alore_wb_set_iterate": (C.c_int, [H, C.c_int, DP, DP]),
         "alore_wb_get_iterate": (C.c_int, [H, C.c_int, DP, DP]),
         "alore_wb_linearize": (C.c_int, [H, C.c_int, DP, DP, DP]),
@@ -129,6 +132,18 @@ class BatchedWholeBody:
         x0, xref, uref = _f64(x0, (-1, NX)), _f64(xref, (-1, self.N + 1, NX)), _f64(uref, (-1, self.N, NU))
         self._n = x0.shape[0]
         self._check(self.L.alore_wb_set_problem(self.h, self._n, _dp(x0), _dp(xref), _dp(uref)))
+
+    def set_x0(self, x0):
+        x0 = _f64(x0, (-1, NX))
+        self._check(self.L.alore_wb_set_x0(self.h, x0.shape[0], _dp(x0)))
+
+    def shift_iterate(self):
+        self._check(self.L.alore_wb_shift_iterate(self.h, self._n, None))
+
+    def first_input(self):
+        u0 = np.zeros((self._n, NU))
+        self._check(self.L.alore_wb_get_first_input(self.h, self._n, _dp(u0)))
+        return u0
 
     def set_iterate(self, x, u):
         x, u = _f64(x, (-1, self.N + 1, NX)), _f64(u, (-1, self.N, NU))

@@ -82,6 +82,11 @@ int alore_wb_set_weights(alore_wb_handle h, const double *Q, const double *R, co
 int alore_wb_set_torque_limits(alore_wb_handle h, int enable);
 /* measured states x0 [B][48], references xref [B][N+1][48], uref [B][N][30] (HOST pointers) */
 int alore_wb_set_problem(alore_wb_handle h, int B, const double *x0, const double *xref, const double *uref);
+/* what one control tick moves: the measured states in (x0 [B][48]), the iterate shifted by one stage on the device (the
+ * last stage repeated, asynchronous on `stream`), the first inputs out (u0 [B][30]) */
+int alore_wb_set_x0(alore_wb_handle h, int B, const double *x0);
+int alore_wb_shift_iterate(alore_wb_handle h, int B, void *stream);
+int alore_wb_get_first_input(alore_wb_handle h, int B, double *u0);
 /* iterate x [B][N+1][48], u [B][N][30] */
 int alore_wb_set_iterate(alore_wb_handle h, int B, const double *x, const double *u);
 int alore_wb_get_iterate(alore_wb_handle h, int B, double *x, double *u);

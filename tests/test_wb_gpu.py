@@ -166,17 +166,24 @@ def test_receding_horizon_loop_holds_the_stance(model):
     x_now = x0.copy()
     err0 = np.max(np.abs(x_now[:, :24] - xref[:, 0, :24]))
     hist = []
+    eng.set_problem(x_now, xref, uref)
     for tick in range(200):
-        eng.set_problem(x_now, xref, uref)
+        eng.set_x0(x_now)                                   # per tick: 48 doubles per robot in, 30 out
         eng.rti(2 if tick == 0 else 1)
-        x, u = eng.get_iterate()
-        u0 = u[:, 0]
+        u0 = eng.first_input()
+        if tick == 0:                                       # the tick interface moves the same data as the full one
+            x, u = eng.get_iterate()
+            assert np.array_equal(u0, u[:, 0])
         a = eng.aba(x_now[:, :24], x_now[:, 24:], u0)
         v_next = x_now[:, 24:] + dt * a
         q_next = np.stack([x_now[b, :24] + dt * model.qdot(x_now[b, :24], v_next[b]) for b in range(B)])
         x_now = np.concatenate([q_next, v_next], 1)
-        # shift: drop stage 0, repeat the last stage
-        eng.set_iterate(np.concatenate([x[:, 1:], x[:, -1:]], 1), np.concatenate([u[:, 1:], u[:, -1:]], 1))
+        if tick == 0:                                       # device shift = drop stage 0, repeat the last stage
+            eng.shift_iterate()
+            xs, us = eng.get_iterate()
+            assert np.array_equal(xs, np.concatenate([x[:, 1:], x[:, -1:]], 1)) and np.array_equal(us, np.concatenate([u[:, 1:], u[:, -1:]], 1))
+        else:
+            eng.shift_iterate()
         assert np.isfinite(x_now).all()
         if tick % 40 == 39:
             hist.append(round(float(np.max(np.abs(x_now[:, :24] - xref[:, 0, :24]))), 4))
