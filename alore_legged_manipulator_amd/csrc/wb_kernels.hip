@@ -408,21 +408,22 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             else if (t < 12) mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, ((t - 6) / 3) * 16, ((t - 6) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
             else mfma_tile<true, false, 48, true>(S.B, LDU, S.PB, LDU, SYM2_I[t - 12] * 16, SYM2_J[t - 12] * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
         }
-        __syncthreads();
-        WB_STAMP(g.stamps, 2)
-        if (tid < 48) {
-            float acc = S.gx[tid];
-            for (int j = 0; j < 48; ++j) acc += S.A[j * LDX + tid] * S.s[j];
-            S.qx[tid] = acc;
-        } else if (tid >= 64 && tid < 96) {
-            const int i = tid - 64;
-            float acc = S.gu[i];
-            for (int j = 0; j < 48; ++j) acc += S.B[j * LDU + i] * S.s[j];
-            S.qu[i] = acc;
-            // diagonal of Quu: + R on the 30 real inputs, identity on the 2 padding rows
-            S.Quu[i * LDU + i] += S.wr[i];
+        // qx = gx + A' s and qu = gu + B' s on the wavefront that has one tile less in this phase
+        if (wave == RIC_WAVES - 1) {
+            const int l = tid - RIC_LAST;
+            if (l < 48) {
+                float acc = S.gx[l];
+                for (int j = 0; j < 48; ++j) acc += S.A[j * LDX + l] * S.s[j];
+                S.qx[l] = acc;
+            }
+            if (l < 32) {
+                float acc = S.gu[l];
+                for (int j = 0; j < 48; ++j) acc += S.B[j * LDU + l] * S.s[j];
+                S.qu[l] = acc;
+            }
         }
         __syncthreads();
+        WB_STAMP(g.stamps, 2)
         WB_STAMP(g.stamps, 3)
         float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
         float* Rres = S.PA;   // PA is dead once Qxx and Qux exist
@@ -449,6 +450,10 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
                 }
             }
             if (wave == 0) {
+                // diagonal of Quu: + R on the 30 real inputs, identity on the 2 padding rows (the tiles above wrote B' P B);
+                // LDS operations of one wavefront complete in order, so the row loads below see it
+                if (round == 0 && tid < 32) S.Quu[tid * LDU + tid] += S.wr[tid];
+                __builtin_amdgcn_wave_barrier();
                 // row r of Quu on lanes r and r + 32 (15 columns each); the 2 padding inputs are an identity block
                 float rowh[NU / 2];
                 const int r5 = tid & 31, rr = r5 < NU ? r5 : 0, hh = tid >> 5;
