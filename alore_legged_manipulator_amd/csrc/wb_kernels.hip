@@ -56,8 +56,12 @@ struct StageArgs {
     double* M64;     // optional [n][24][24]
     double* a64;     // optional [n][24]
     long long* stamps; // optional [32] diagnostic
+    const double* xref = nullptr; // [B][N+1][48]  with uref and vec: the stage's right-hand sides for the Riccati kernel
+    const double* uref = nullptr; // [B][N][30]
+    float* vec = nullptr;         // [n][160]: defect f(x_k, u_k) - x_{k+1} | x_k - xref_k | u_k (32) | u_k - uref_k (32), float32
 };
 
+constexpr int VEC = 160; // floats per stage in StageArgs::vec
 constexpr int MS = 25; // row stride of M / column stride of D in LDS (doubles)
 
 struct StageLds {
@@ -69,6 +73,7 @@ struct StageLds {
     double trig[42];     // sin, cos of rpy and the joint angles at the base point
     double tb[NV];       // RNEA at the base point (= [0; tau] up to the rounding of M^-1)
     double R0[9], E[9], Gq[3][6];
+    double xn[NX], xr[NX], ur[32]; // x_{k+1}, xref_k, uref_k: fetched with the stage's inputs, used for StageArgs::vec at the end
 };
 
 __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
@@ -83,6 +88,10 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
     const double* uk = g.u + ((size_t)b * g.N + k) * NU;
     if (lane < NQ) { S.q[lane] = xk[lane]; S.v[lane] = xk[NQ + lane]; S.zero[lane] = 0.0; }
     if (lane < NU) S.u[lane] = uk[lane];
+    if (g.vec) {
+        if (lane < NX) { S.xn[lane] = xk[NX + lane]; S.xr[lane] = g.xref[((size_t)b * (g.N + 1) + k) * NX + lane]; }
+        if (lane < NU) S.ur[lane] = g.uref[((size_t)b * g.N + k) * NU + lane];
+    }
     if (lane < 21) sincos(xk[3 + lane], &S.trig[2 * lane], &S.trig[2 * lane + 1]);
     __syncthreads();
     WB_STAMP(g.stamps, 0)
@@ -239,6 +248,18 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
             val = S.q[r] + dt * (Gm[0] * S.vn[off] + Gm[1] * S.vn[off + 1] + Gm[2] * S.vn[off + 2]);
         }
         g.next[(size_t)item * NX + r] = val;
+        if (g.vec) {
+            float* vo = g.vec + (size_t)item * VEC;
+            vo[r] = (float)(val - S.xn[r]);
+            vo[48 + r] = (float)((r < NQ ? S.q[r] : S.v[r - NQ]) - S.xr[r]);
+        }
+    }
+    if (g.vec && lane < 32) {
+        const int j = lane;
+        float* vo = g.vec + (size_t)item * VEC;
+        const float ucur = j < NU ? (float)S.u[j] : 0.f;
+        vo[96 + j] = ucur;
+        vo[128 + j] = j < NU ? ucur - (float)S.ur[j] : 0.f;
     }
     WB_STAMP(g.stamps, 7)
 }
@@ -291,6 +312,7 @@ struct RicArgs {
     int* status;         // [B] 0 ok, 1 the step is not finite (indefinite Quu, overflow): x, u are then left untouched
     int limits;          // 1: torque limits inside the sweep (control-limited DDP); 0: only the applied inputs are clipped
     long long* stamps;   // optional [32] diagnostic
+    const float* vec;    // [B][N][160] right-hand sides written by the stage kernel
 };
 
 // 53.6 KB: three workgroups per CU.  Buffers are reused inside a stage: Qxx is written over P (dead after P A, P B, P d),
@@ -364,30 +386,53 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     for (int i = tid; i < 48 * 48; i += RIC_THREADS) { const int r = i / 48, c = i % 48; S.P[r * LDX + c] = (r == c) ? (float)QNd[r] : 0.f; }
     if (tid < 48) { S.p[tid] = (float)(QNd[tid] * (xb[(size_t)N * NX + tid] - xr[(size_t)N * NX + tid])); S.wq[tid] = (float)Qd[tid]; }
     else if (tid >= 64 && tid < 96) S.wr[tid - 64] = (tid - 64) < NU ? (float)Rd[tid - 64] : 1.f; // identity on the 2 padding inputs
-    float* const SK = S.B;   // feedback gain of the stage (32 x 48, stride LDX fits: 32 * 49 <= 48 * 33)
+    float* const SK = S.PA;  // feedback gain of the stage (32 x 48): PA is dead once Qxx and Qux exist
+    __syncthreads();
+
+    // A stage's A, B (16-byte pieces) and right-hand sides travel global -> registers -> LDS and are requested AHEAD of
+    // their use: A_{k-1} while Quu of stage k is inverted (S.A is dead when the inversion ends), B_{k-1} and the vectors
+    // under the gain computation (S.B holds the refinement residual until the gains exist), so that no HBM round trip
+    // stands in front of a stage.  Every thread loads with clamped indices (no divergent register state).
+    const int vi = tid < VEC ? tid : VEC - 1;
+    const int ia0 = tid, ia1 = tid + RIC_THREADS, ia2 = (tid + 2 * RIC_THREADS) < 48 * 12 ? tid + 2 * RIC_THREADS : 48 * 12 - 1;
+    const int ib0 = tid, ib1 = (tid + RIC_THREADS) < 48 * 8 ? tid + RIC_THREADS : 48 * 8 - 1;
+    float4 pa0, pa1, pa2, pb0, pb1;
+    float pvec;
+#define RIC_REQUEST_A(kk)                                                                                    \
+    {                                                                                                        \
+        const float4* Ag_ = reinterpret_cast<const float4*>(g.A32 + ((size_t)b * N + (kk)) * NX * NX);       \
+        pa0 = Ag_[ia0]; pa1 = Ag_[ia1]; pa2 = Ag_[ia2];                                                      \
+    }
+#define RIC_REQUEST_B(kk)                                                                                    \
+    {                                                                                                        \
+        const float4* Bg_ = reinterpret_cast<const float4*>(g.B32 + ((size_t)b * N + (kk)) * NX * NUP);      \
+        pb0 = Bg_[ib0]; pb1 = Bg_[ib1];                                                                      \
+        pvec = g.vec[((size_t)b * N + (kk)) * VEC + vi];                                                     \
+    }
+#define RIC_PUT4(base, ld, per_row, idx, v)                                                                  \
+    { float* dst_ = (base) + ((idx) / (per_row)) * (ld) + 4 * ((idx) % (per_row)); dst_[0] = (v).x; dst_[1] = (v).y; dst_[2] = (v).z; dst_[3] = (v).w; }
+#define RIC_DEPOSIT_A()                                                                                      \
+    {                                                                                                        \
+        RIC_PUT4(S.A, LDX, 12, ia0, pa0) RIC_PUT4(S.A, LDX, 12, ia1, pa1)                                    \
+        if (tid + 2 * RIC_THREADS < 48 * 12) RIC_PUT4(S.A, LDX, 12, ia2, pa2)                                \
+    }
+#define RIC_DEPOSIT_B()                                                                                      \
+    {                                                                                                        \
+        RIC_PUT4(S.B, LDU, 8, ib0, pb0)                                                                      \
+        if (tid + RIC_THREADS < 48 * 8) RIC_PUT4(S.B, LDU, 8, ib1, pb1)                                      \
+        /* d | gx = Q (x - xref) | current input (for the torque limits; dxn is free during the backward sweep) | gu = R (u - uref) */ \
+        if (tid < 48) S.d[tid] = pvec;                                                                       \
+        else if (tid < 96) S.gx[tid - 48] = S.wq[tid - 48] * pvec;                                           \
+        else if (tid < 128) S.dxn[tid - 96] = pvec;                                                          \
+        else if (tid < 160) S.gu[tid - 128] = S.wr[tid - 128] * pvec;                                        \
+    }
+    RIC_REQUEST_A(N - 1)
+    RIC_REQUEST_B(N - 1)
+    RIC_DEPOSIT_A()
+    RIC_DEPOSIT_B()
     __syncthreads();
 
     for (int k = N - 1; k >= 0; --k) {
-        const float* Ag = g.A32 + ((size_t)b * N + k) * NX * NX;
-        const float* Bg = g.B32 + ((size_t)b * N + k) * NX * NUP;
-        // A_k was fetched by the idle wavefronts during the previous stage's Quu inversion (except for the first stage)
-        for (int i = tid + (k == N - 1 ? 0 : 48 * 12); i < 48 * 12 + 48 * 8; i += RIC_THREADS) { // 16-byte loads: 12 per row of A, 8 per row of B
-            const bool isA = i < 48 * 12;
-            const int q4 = isA ? i : i - 48 * 12, r = isA ? q4 / 12 : q4 / 8, c4 = isA ? q4 % 12 : q4 % 8;
-            const float4 v4 = reinterpret_cast<const float4*>(isA ? Ag : Bg)[q4];
-            float* dst = isA ? (S.A + r * LDX + 4 * c4) : (S.B + r * LDU + 4 * c4);
-            dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
-        }
-        if (tid < 48) {
-            S.d[tid] = (float)(g.next[((size_t)b * N + k) * NX + tid] - xb[(size_t)(k + 1) * NX + tid]);
-            S.gx[tid] = S.wq[tid] * (float)(xb[(size_t)k * NX + tid] - xr[(size_t)k * NX + tid]);
-        } else if (tid >= 64 && tid < 96) {
-            const int j = tid - 64;
-            const float ucur = j < NU ? (float)ub[(size_t)k * NU + j] : 0.f;
-            S.dxn[j] = ucur; // current input of the stage, for the torque limits below (dxn is free during the backward sweep)
-            S.gu[j] = j < NU ? S.wr[j] * (ucur - (float)ur[(size_t)k * NU + j]) : 0.f;
-        }
-        __syncthreads();
         WB_STAMP(g.stamps, 0)
         // ---- PA = P A (9 tiles), PB = P B (6 tiles); s = P d + p
         for (int t = wave; t < 15; t += RIC_WAVES) {
@@ -402,37 +447,37 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         }
         __syncthreads();
         WB_STAMP(g.stamps, 1)
-        // ---- Qxx = Q + A' PA (9), Qux = B' PA (6), Quu = R + B' PB (4); qx = gx + A' s, qu = gu + B' s
-        for (int t = wave; t < 15; t += RIC_WAVES) { // Qxx and Quu are symmetric: upper-triangular tiles, mirrored on store
-            if (t < 6) mfma_tile<true, false, 48, true>(S.A, LDX, S.PA, LDX, SYM3_I[t] * 16, SYM3_J[t] * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
-            else if (t < 12) mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, ((t - 6) / 3) * 16, ((t - 6) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
-            else mfma_tile<true, false, 48, true>(S.B, LDU, S.PB, LDU, SYM2_I[t - 12] * 16, SYM2_J[t - 12] * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
-        }
-        // qx = gx + A' s and qu = gu + B' s on the wavefront that has one tile less in this phase
-        if (wave == RIC_WAVES - 1) {
-            const int l = tid - RIC_LAST;
-            if (l < 48) {
+        // ---- Qxx = Q + A' PA (6 upper-triangular tiles, mirrored), Qux = B' PA (6), qx = gx + A' s, qu = gu + B' s on
+        //      wavefronts 1 .. 3, WHILE wavefront 0 forms Quu = R + B' PB (3 tiles) and inverts it (the first pass of the
+        //      loop below): the inversion is one wavefront's dependent chain and the longest phase of a stage
+        if (wave != 0) {
+            for (int t = wave - 1; t < 12; t += RIC_WAVES - 1) {
+                if (t < 6) mfma_tile<true, false, 48, true>(S.A, LDX, S.PA, LDX, SYM3_I[t] * 16, SYM3_J[t] * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
+                else mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, ((t - 6) / 3) * 16, ((t - 6) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
+            }
+            const int l = tid & 63;
+            if (wave == 1 && l < 48) {
                 float acc = S.gx[l];
                 for (int j = 0; j < 48; ++j) acc += S.A[j * LDX + l] * S.s[j];
                 S.qx[l] = acc;
             }
-            if (l < 32) {
+            if (wave == 2 && l < 32) {
                 float acc = S.gu[l];
                 for (int j = 0; j < 48; ++j) acc += S.B[j * LDU + l] * S.s[j];
                 S.qu[l] = acc;
             }
+        } else {
+            for (int t = 0; t < 3; ++t)
+                mfma_tile<true, false, 48, true>(S.B, LDU, S.PB, LDU, SYM2_I[t] * 16, SYM2_J[t] * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
         }
-        __syncthreads();
-        WB_STAMP(g.stamps, 2)
-        WB_STAMP(g.stamps, 3)
+        if (k > 0) RIC_REQUEST_A(k - 1) // lands while Quu is inverted
         float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
-        float* Rres = S.PA;   // PA is dead once Qxx and Qux exist
-        // clamp flags / values of the control limits live in gx / d (dead after qx, qu): the LDS block must not grow --
-        // 53.6 KB is the last size of which three fit a CU at the hardware's allocation granularity (one more 256 B and
-        // only two workgroups are resident: measured 2.8 -> 4.2 ms)
-        float* clampm = S.gx;
-        float* clampv = S.d;
-        if (tid < 32) clampm[tid] = 0.f;
+        float* Rres = S.B;    // B is dead once Qux, Quu and qu exist (32 rows of stride LDX fit: 32 * 49 <= 48 * 33)
+        // clamp flags / values of the control limits live in dxk / s (free during the backward sweep / dead after qx, qu):
+        // the LDS block must not grow -- 53.6 KB is the last size of which three fit a CU at the hardware's allocation
+        // granularity (one more 256 B and only two workgroups are resident: measured 2.8 -> 4.2 ms)
+        float* clampm = S.dxk;
+        float* clampv = S.s;
         // Round 0 solves the unconstrained stage problem.  If its feed-forward step drives a joint torque past the URDF
         // effort limit, those inputs are clamped to the limit and the free ones are re-solved against them
         // (control-limited DDP, Tassa et al. 2014, one projection): in Quu the clamped rows / columns become an
@@ -441,14 +486,6 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) { // kept rolled: the inversion is ~2000 unrolled instructions
             // ---- Quu^-1 (wave 0: lane i owns row i, Gauss-Jordan in registers; wave_linalg.h) -> Qinv (in the PB buffer)
-            if (wave != 0 && k > 0 && round == 0) { // S.A is dead from here to the end of the stage: fetch A_{k-1} while wavefront 0 inverts
-                const float4* An = reinterpret_cast<const float4*>(g.A32 + ((size_t)b * N + k - 1) * NX * NX);
-                for (int i = tid - 64; i < 48 * 12; i += RIC_THREADS - 64) {
-                    const float4 v4 = An[i];
-                    float* dst = S.A + (i / 12) * LDX + 4 * (i % 12);
-                    dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
-                }
-            }
             if (wave == 0) {
                 // diagonal of Quu: + R on the 30 real inputs, identity on the 2 padding rows (the tiles above wrote B' P B);
                 // LDS operations of one wavefront complete in order, so the row loads below see it
@@ -471,6 +508,10 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             }
             __syncthreads();
             WB_STAMP(g.stamps, 4)
+            if (round == 0) {
+                if (tid < 32) clampm[tid] = 0.f;
+                if (k > 0) { RIC_DEPOSIT_A() RIC_REQUEST_B(k - 1) } // S.A is dead; B_{k-1} and the vectors land under the gain computation
+            }
             // ---- K0 = -Qinv Qux (6 tiles, K = 32), kff0 = -Qinv qu
             for (int t = wave; t < 6; t += RIC_WAVES)
                 mfma_tile<false, false, 32>(Qinv, LDU, S.Qux, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, nullptr, 0, 0.f, nullptr, -1.f);
@@ -540,6 +581,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
                 if (clampm[i / 48] != 0.f) SK[(i / 48) * LDX + (i % 48)] = 0.f;
             __syncthreads();
         }
+        if (k > 0) RIC_DEPOSIT_B() // S.B (refinement residual) and the stage's vectors are dead; read again after the barrier below
         // feedback gains to HBM
         {
             float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
@@ -574,24 +616,41 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
         return v;
     };
+    // The rows of K_k, A_k, B_k, kff_k and the defect of a stage are requested one stage ahead (registers), so that the HBM /
+    // L2 round trip of stage k + 1 runs under the two products of stage k; dx alternates between two LDS vectors.
+    const int krow = qrow < 32 ? qrow : 31, arow = qrow < 48 ? qrow : 47;
+    float4 kn[3], an[3], bn[2];
+    float kffn = 0.f;
+    double nxn = 0.0, xnn = 0.0;
+#define RIC_FWD_REQUEST(kk)                                                                                  \
+    {                                                                                                        \
+        const float4* kr_ = reinterpret_cast<const float4*>(g.K + ((size_t)b * N + (kk)) * 32 * 48 + krow * 48 + part * 12);     \
+        const float4* ar_ = reinterpret_cast<const float4*>(g.A32 + ((size_t)b * N + (kk)) * NX * NX + arow * 48 + part * 12);   \
+        const float4* br_ = reinterpret_cast<const float4*>(g.B32 + ((size_t)b * N + (kk)) * NX * NUP + arow * NUP + part * 8);  \
+        kn[0] = kr_[0]; kn[1] = kr_[1]; kn[2] = kr_[2];                                                      \
+        an[0] = ar_[0]; an[1] = ar_[1]; an[2] = ar_[2];                                                      \
+        bn[0] = br_[0]; bn[1] = br_[1];                                                                      \
+        kffn = g.kff[((size_t)b * N + (kk)) * 32 + krow];                                                    \
+        nxn = g.next[((size_t)b * N + (kk)) * NX + arow]; xnn = xb[(size_t)((kk) + 1) * NX + arow];          \
+    }
+    RIC_FWD_REQUEST(0)
+    float* dxc = S.dxk;  // dx_k
+    float* dxw = S.dxn;  // dx_{k+1}
     for (int k = 0; k < N; ++k) {
-        const float* Ag = g.A32 + ((size_t)b * N + k) * NX * NX;
-        const float* Bg = g.B32 + ((size_t)b * N + k) * NX * NUP;
-        const float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
+        float4 kc[3] = {kn[0], kn[1], kn[2]}, ac[3] = {an[0], an[1], an[2]}, bc[2] = {bn[0], bn[1]};
+        const float kffc = kffn;
+        const double nxc = nxn, xnc = xnn;
+        if (k + 1 < N) RIC_FWD_REQUEST(k + 1)
         {   // du_k = K dx + kff: rows 0..31 on threads 0..127
             float acc = 0.f;
-            if (qrow < 32) {
-                const float4* kr = reinterpret_cast<const float4*>(Kg + qrow * 48 + part * 12);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const float4 kv = kr[q];
-                    const float* dxp = S.dxk + part * 12 + 4 * q;
-                    acc += kv.x * dxp[0] + kv.y * dxp[1] + kv.z * dxp[2] + kv.w * dxp[3];
-                }
+            for (int q = 0; q < 3; ++q) {
+                const float* dxp = dxc + part * 12 + 4 * q;
+                acc += kc[q].x * dxp[0] + kc[q].y * dxp[1] + kc[q].z * dxp[2] + kc[q].w * dxp[3];
             }
             acc = quad_total(acc);
             if (qrow < 32 && part == 0) {
-                acc += g.kff[((size_t)b * N + k) * 32 + qrow];
+                acc += kffc;
                 S.duk[qrow] = acc;
                 if (qrow < NU) dub[(size_t)k * NU + qrow] = acc;
             }
@@ -599,32 +658,25 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         __syncthreads();
         {   // dx_{k+1} = A dx + B du + d: rows 0..47 on threads 0..191
             float acc = 0.f;
-            if (qrow < 48) {
-                const float4* ar = reinterpret_cast<const float4*>(Ag + qrow * 48 + part * 12);
-                const float4* br = reinterpret_cast<const float4*>(Bg + qrow * NUP + part * 8);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const float4 av = ar[q];
-                    const float* dxp = S.dxk + part * 12 + 4 * q;
-                    acc += av.x * dxp[0] + av.y * dxp[1] + av.z * dxp[2] + av.w * dxp[3];
-                }
+            for (int q = 0; q < 3; ++q) {
+                const float* dxp = dxc + part * 12 + 4 * q;
+                acc += ac[q].x * dxp[0] + ac[q].y * dxp[1] + ac[q].z * dxp[2] + ac[q].w * dxp[3];
+            }
 #pragma unroll
-                for (int q = 0; q < 2; ++q) { // the two padding columns of B are zero and duk[30..31] = 0
-                    const float4 bv = br[q];
-                    const float* dup = S.duk + part * 8 + 4 * q;
-                    acc += bv.x * dup[0] + bv.y * dup[1] + bv.z * dup[2] + bv.w * dup[3];
-                }
+            for (int q = 0; q < 2; ++q) { // the two padding columns of B are zero and duk[30..31] = 0
+                const float* dup = S.duk + part * 8 + 4 * q;
+                acc += bc[q].x * dup[0] + bc[q].y * dup[1] + bc[q].z * dup[2] + bc[q].w * dup[3];
             }
             acc = quad_total(acc);
             if (qrow < 48 && part == 0) {
-                acc += (float)(g.next[((size_t)b * N + k) * NX + qrow] - xb[(size_t)(k + 1) * NX + qrow]);
-                S.dxn[qrow] = acc;
+                acc += (float)(nxc - xnc);
+                dxw[qrow] = acc;
                 dxb[(size_t)(k + 1) * NX + qrow] = acc;
             }
         }
         __syncthreads();
-        if (tid < 48) S.dxk[tid] = S.dxn[tid];
-        __syncthreads();
+        float* t_ = dxc; dxc = dxw; dxw = t_;
     }
     WB_STAMP(g.stamps, 10)
     // a step that is not finite (an indefinite Quu from negative weights, an overflow) must not touch the iterate
@@ -684,6 +736,7 @@ struct alore_wb_solver {
     double *d_x = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_xref = nullptr, *d_uref = nullptr, *d_w = nullptr;
     float *d_A = nullptr, *d_B = nullptr;
     double* d_next = nullptr;
+    float* d_vec = nullptr; // [B][N][160]
     double *d_dx = nullptr, *d_du = nullptr;
     float *d_K = nullptr, *d_kff = nullptr;
     int* d_status = nullptr;
@@ -774,7 +827,8 @@ int alore_wb_create(const alore_wb_config* cfg, alore_wb_handle* out)
               zalloc(&h->d_A, B * N * wb::NX * wb::NX) == hipSuccess && zalloc(&h->d_B, B * N * wb::NX * wb::NUP) == hipSuccess &&
               zalloc(&h->d_next, B * N * wb::NX) == hipSuccess && zalloc(&h->d_dx, B * (N + 1) * wb::NX) == hipSuccess &&
               zalloc(&h->d_du, B * N * wb::NU) == hipSuccess && zalloc(&h->d_K, B * N * 32 * 48) == hipSuccess &&
-              zalloc(&h->d_kff, B * N * 32) == hipSuccess && zalloc(&h->d_status, B) == hipSuccess;
+              zalloc(&h->d_kff, B * N * 32) == hipSuccess && zalloc(&h->d_status, B) == hipSuccess &&
+              zalloc(&h->d_vec, B * N * wb::VEC) == hipSuccess;
     for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
     if (ok && std::getenv("ALORE_WB_STAMPS")) ok = zalloc(&h->d_stamps, (size_t)64) == hipSuccess;
     if (!ok) { alore_wb_destroy(h); return ALORE_WB_E_NOMEM; }
@@ -795,7 +849,7 @@ int alore_wb_destroy(alore_wb_handle h)
             std::fprintf(stderr, "\n");
         }
     }
-    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status};
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -973,10 +1027,10 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
     for (int it = 0; it < n_iter; ++it) {
         const bool last = it == n_iter - 1;
         if (last) WB_TRY(h, hipEventRecord(h->ev[0], s));
-        wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps};
+        wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps, h->d_xref, h->d_uref, h->d_vec};
         wb::stage_kernel<<<(unsigned)n, 64, 0, s>>>(g);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
-        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr};
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec};
         wb::riccati_kernel<<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
     }
