@@ -336,7 +336,10 @@ template <bool TA, bool TB, int K, bool MIRROR = false>
 __device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* Bm, int ldb, int i0, int j0, float* Cm, int ldc,
                                           const float* Cinit, int ldi, float alpha_diag, const float* diag, float scale = 1.f)
 {
-    const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l)); // opaque: the addresses of a tile are recomputed per call instead of being kept in registers
+                                  // across the whole stage loop (hoisted, they cost ~100 VGPRs and spill)
+    const int r16 = l & 15, kq = l >> 4;
     typedef float f4 __attribute__((ext_vector_type(4)));
     float a[K / 4], b[K / 4];
 #pragma unroll
@@ -450,18 +453,20 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         // ---- Qxx = Q + A' PA (6 upper-triangular tiles, mirrored), Qux = B' PA (6), qx = gx + A' s, qu = gu + B' s on
         //      wavefronts 1 .. 3, WHILE wavefront 0 forms Quu = R + B' PB (3 tiles) and inverts it (the first pass of the
         //      loop below): the inversion is one wavefront's dependent chain and the longest phase of a stage
-        if (wave != 0) {
-            for (int t = wave - 1; t < 12; t += RIC_WAVES - 1) {
+        const int role = wave; // 0 inverts, 1 .. 3 multiply (rotating the role over the wavefronts / SIMDs was measured: no effect)
+        const int wl = tid & 63;
+        if (role != 0) {
+            for (int t = role - 1; t < 12; t += RIC_WAVES - 1) {
                 if (t < 6) mfma_tile<true, false, 48, true>(S.A, LDX, S.PA, LDX, SYM3_I[t] * 16, SYM3_J[t] * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
                 else mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, ((t - 6) / 3) * 16, ((t - 6) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
             }
             const int l = tid & 63;
-            if (wave == 1 && l < 48) {
+            if (role == 1 && l < 48) {
                 float acc = S.gx[l];
                 for (int j = 0; j < 48; ++j) acc += S.A[j * LDX + l] * S.s[j];
                 S.qx[l] = acc;
             }
-            if (wave == 2 && l < 32) {
+            if (role == 2 && l < 32) {
                 float acc = S.gu[l];
                 for (int j = 0; j < 48; ++j) acc += S.B[j * LDU + l] * S.s[j];
                 S.qu[l] = acc;
@@ -486,26 +491,31 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) { // kept rolled: the inversion is ~2000 unrolled instructions
             // ---- Quu^-1 (wave 0: lane i owns row i, Gauss-Jordan in registers; wave_linalg.h) -> Qinv (in the PB buffer)
-            if (wave == 0) {
+            if (role == 0) {
                 // diagonal of Quu: + R on the 30 real inputs, identity on the 2 padding rows (the tiles above wrote B' P B);
                 // LDS operations of one wavefront complete in order, so the row loads below see it
-                if (round == 0 && tid < 32) S.Quu[tid * LDU + tid] += S.wr[tid];
+                WB_STAMP(g.stamps, 2)
+                if (round == 0 && wl < 32) S.Quu[wl * LDU + wl] += S.wr[wl];
                 __builtin_amdgcn_wave_barrier();
-                // row r of Quu on lanes r and r + 32 (15 columns each); the 2 padding inputs are an identity block
-                float rowh[NU / 2];
-                const int r5 = tid & 31, rr = r5 < NU ? r5 : 0, hh = tid >> 5;
+                // row r of Quu on lane r (30 columns): pivot rows travel through v_readlane (scalar registers).  The form
+                // with a row on two lanes halves the arithmetic but needs a cross-lane permute per moved element, and a
+                // ds_bpermute costs ~34 cycles next to the LDS traffic of the other wavefronts (480 of them: 16 k cycles,
+                // whether in 30 steps or in 15 steps with 2 x 2 pivots); the 2 padding inputs are an identity block
+                float rowf[NU];
+                const int rr = wl < NU ? wl : 0;
 #pragma unroll
-                for (int j = 0; j < NU / 2; ++j) rowh[j] = S.Quu[rr * LDU + hh * (NU / 2) + j];
-                wavela::spd_inverse_rows_split<float, NU>(rowh, tid);
-                if (r5 < NU) {
+                for (int j = 0; j < NU; ++j) rowf[j] = S.Quu[rr * LDU + j];
+                wavela::spd_inverse_rows<float, NU>(rowf, wl);
+                if (wl < NU) {
 #pragma unroll
-                    for (int j = 0; j < NU / 2; ++j) Qinv[r5 * LDU + hh * (NU / 2) + j] = rowh[j];
-                    if (hh == 1) { Qinv[r5 * LDU + 30] = 0.f; Qinv[r5 * LDU + 31] = 0.f; }
-                } else if (hh == 0) {
+                    for (int j = 0; j < NU; ++j) Qinv[wl * LDU + j] = rowf[j];
+                    Qinv[wl * LDU + 30] = 0.f; Qinv[wl * LDU + 31] = 0.f;
+                } else if (wl < 32) {
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) Qinv[r5 * LDU + j] = (j == r5) ? 1.f : 0.f;
+                    for (int j = 0; j < 32; ++j) Qinv[wl * LDU + j] = (j == wl) ? 1.f : 0.f;
                 }
             }
+            WB_STAMP(g.stamps, 3)
             __syncthreads();
             WB_STAMP(g.stamps, 4)
             if (round == 0) {
