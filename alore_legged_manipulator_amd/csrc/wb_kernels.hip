@@ -332,15 +332,15 @@ struct RicLds {
 // multiple of 4 known at compile time: all operands of the tile are fetched from LDS first (2 K / 4 independent
 // reads in flight), then the K / 4 matrix instructions run back to back.
 //   TA: A is stored transposed (element (i, k) at A[k * lda + i]);  TB likewise for B
-template <bool TA, bool TB, int K, bool MIRROR = false>
-__device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* Bm, int ldb, int i0, int j0, float* Cm, int ldc,
-                                          const float* Cinit, int ldi, float alpha_diag, const float* diag, float scale = 1.f)
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <bool TA, bool TB, int K>
+__device__ __forceinline__ f4 mfma_acc(const float* A, int lda, const float* Bm, int ldb, int i0, int j0)
 {
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l)); // opaque: the addresses of a tile are recomputed per call instead of being kept in registers
                                   // across the whole stage loop (hoisted, they cost ~100 VGPRs and spill)
     const int r16 = l & 15, kq = l >> 4;
-    typedef float f4 __attribute__((ext_vector_type(4)));
     float a[K / 4], b[K / 4];
 #pragma unroll
     for (int s = 0; s < K / 4; ++s) {
@@ -355,7 +355,16 @@ __device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* 
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s + 1], b[s + 1], acc1, 0, 0, 0);
     }
-    acc += acc1;
+    return acc + acc1;
+}
+
+template <bool MIRROR>
+__device__ __forceinline__ void tile_store(f4 acc, int i0, int j0, float* Cm, int ldc, const float* Cinit, int ldi, float alpha_diag,
+                                           const float* diag, float scale = 1.f)
+{
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int r16 = l & 15, kq = l >> 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + 4 * kq + r, col = j0 + r16;
@@ -366,6 +375,13 @@ __device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* 
         Cm[row * ldc + col] = v;
         if (MIRROR && row < col) Cm[col * ldc + row] = v;
     }
+}
+
+template <bool TA, bool TB, int K, bool MIRROR = false>
+__device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* Bm, int ldb, int i0, int j0, float* Cm, int ldc,
+                                          const float* Cinit, int ldi, float alpha_diag, const float* diag, float scale = 1.f)
+{
+    tile_store<MIRROR>(mfma_acc<TA, TB, K>(A, lda, Bm, ldb, i0, j0), i0, j0, Cm, ldc, Cinit, ldi, alpha_diag, diag, scale);
 }
 
 // upper-triangular 16 x 16 tiles of a symmetric 48 x 48 / 32 x 32 result
@@ -437,12 +453,10 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 
     for (int k = N - 1; k >= 0; --k) {
         WB_STAMP(g.stamps, 0)
-        // ---- PA = P A (9 tiles), PB = P B (6 tiles); s = P d + p
-        for (int t = wave; t < 15; t += RIC_WAVES) {
-            if (t < 9) mfma_tile<false, false, 48>(S.P, LDX, S.A, LDX, (t / 3) * 16, (t % 3) * 16, S.PA, LDX, nullptr, 0, 0.f, nullptr);
-            else mfma_tile<false, false, 48>(S.P, LDX, S.B, LDU, ((t - 9) / 2) * 16, ((t - 9) % 2) * 16, S.PB, LDU, nullptr, 0, 0.f, nullptr);
-        }
-        if (tid >= RIC_LAST && tid < RIC_LAST + 48) { // the last wave has one tile less
+        // ---- PB = P B (6 tiles), s = P d + p
+        for (int t = wave; t < 6; t += RIC_WAVES)
+            mfma_tile<false, false, 48>(S.P, LDX, S.B, LDU, (t / 2) * 16, (t % 2) * 16, S.PB, LDU, nullptr, 0, 0.f, nullptr);
+        if (tid >= RIC_LAST && tid < RIC_LAST + 48) { // the last wave has one tile only
             const int i = tid - RIC_LAST;
             float acc = S.p[i];
             for (int j = 0; j < 48; ++j) acc += S.P[i * LDX + j] * S.d[j];
@@ -450,30 +464,42 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         }
         __syncthreads();
         WB_STAMP(g.stamps, 1)
-        // ---- Qxx = Q + A' PA (6 upper-triangular tiles, mirrored), Qux = B' PA (6), qx = gx + A' s, qu = gu + B' s on
-        //      wavefronts 1 .. 3, WHILE wavefront 0 forms Quu = R + B' PB (3 tiles) and inverts it (the first pass of the
-        //      loop below): the inversion is one wavefront's dependent chain and the longest phase of a stage
+        // ---- Quu = B' PB (3 upper-triangular tiles, mirrored; R is added by the inverting wavefront)
+        if (wave != 0)
+            mfma_tile<true, false, 48, true>(S.B, LDU, S.PB, LDU, SYM2_I[wave - 1] * 16, SYM2_J[wave - 1] * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
+        __syncthreads();
+        WB_STAMP(g.stamps, 2)
+        // ---- Wavefront 0 inverts Quu (the first pass of the loop below: one wavefront's dependent chain, the longest
+        //      phase of a stage) WHILE wavefronts 1 .. 3 do everything that hangs on A: wavefront w owns COLUMN BLOCK
+        //      j = w - 1 -- PA(:, j) = P A(:, j) (3 tiles), Qux(:, j) = B' PA(:, j) (2), Qxx(i <= j, j) = A(:, i)' PA(:, j)
+        //      (j + 1 upper-triangular tiles) all read only the wavefront's own block of PA, so no barrier separates
+        //      them.  Qxx overwrites P, which the other wavefronts still read for their PA: its tiles wait in registers
+        //      until the barrier that ends the inversion.  qx = gx + A' s, qu = gu + B' s on the wavefront with fewest tiles.
         const int role = wave; // 0 inverts, 1 .. 3 multiply (rotating the role over the wavefronts / SIMDs was measured: no effect)
         const int wl = tid & 63;
+        f4 qxx[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (role != 0) {
-            for (int t = role - 1; t < 12; t += RIC_WAVES - 1) {
-                if (t < 6) mfma_tile<true, false, 48, true>(S.A, LDX, S.PA, LDX, SYM3_I[t] * 16, SYM3_J[t] * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
-                else mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, ((t - 6) / 3) * 16, ((t - 6) % 3) * 16, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
-            }
-            const int l = tid & 63;
+            const int j0 = (role - 1) * 16;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                mfma_tile<false, false, 48>(S.P, LDX, S.A, LDX, i * 16, j0, S.PA, LDX, nullptr, 0, 0.f, nullptr);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, i * 16, j0, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < role) qxx[i] = mfma_acc<true, false, 48>(S.A, LDX, S.PA, LDX, i * 16, j0);
+            const int l = wl;
             if (role == 1 && l < 48) {
                 float acc = S.gx[l];
                 for (int j = 0; j < 48; ++j) acc += S.A[j * LDX + l] * S.s[j];
                 S.qx[l] = acc;
             }
-            if (role == 2 && l < 32) {
+            if (role == 1 && l < 32) {
                 float acc = S.gu[l];
                 for (int j = 0; j < 48; ++j) acc += S.B[j * LDU + l] * S.s[j];
                 S.qu[l] = acc;
             }
-        } else {
-            for (int t = 0; t < 3; ++t)
-                mfma_tile<true, false, 48, true>(S.B, LDU, S.PB, LDU, SYM2_I[t] * 16, SYM2_J[t] * 16, S.Quu, LDU, nullptr, 0, 0.f, nullptr);
         }
         if (k > 0) RIC_REQUEST_A(k - 1) // lands while Quu is inverted
         float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
@@ -494,7 +520,6 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             if (role == 0) {
                 // diagonal of Quu: + R on the 30 real inputs, identity on the 2 padding rows (the tiles above wrote B' P B);
                 // LDS operations of one wavefront complete in order, so the row loads below see it
-                WB_STAMP(g.stamps, 2)
                 if (round == 0 && wl < 32) S.Quu[wl * LDU + wl] += S.wr[wl];
                 __builtin_amdgcn_wave_barrier();
                 // row r of Quu on lane r (30 columns): pivot rows travel through v_readlane (scalar registers).  The form
@@ -519,41 +544,46 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             __syncthreads();
             WB_STAMP(g.stamps, 4)
             if (round == 0) {
+                if (role != 0) { // Qxx = Q + A' PA over P: every wavefront is through with P now
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (i < role) tile_store<true>(qxx[i], i * 16, (role - 1) * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
+                }
                 if (tid < 32) clampm[tid] = 0.f;
                 if (k > 0) { RIC_DEPOSIT_A() RIC_REQUEST_B(k - 1) } // S.A is dead; B_{k-1} and the vectors land under the gain computation
             }
-            // ---- K0 = -Qinv Qux (6 tiles, K = 32), kff0 = -Qinv qu
-            for (int t = wave; t < 6; t += RIC_WAVES)
-                mfma_tile<false, false, 32>(Qinv, LDU, S.Qux, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, nullptr, 0, 0.f, nullptr, -1.f);
-            if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
-                const int i = tid - RIC_LAST;
+            // ---- K0 = -Qinv Qux, then one refinement step against Quu itself (the explicit float32 inverse alone costs a
+            //      factor 40 in accuracy): R = Qux + Quu K0, K = K0 - Qinv R.  A COLUMN BLOCK of K needs only the same
+            //      column block of K0 and R, so wavefront w < 3 runs the three products for columns 16 w .. 16 w + 15
+            //      (2 tiles each) back to back without a barrier; the last wavefront does the same for the vector:
+            //      kff0 = -Qinv qu, r = qu + Quu kff0, kff = kff0 - Qinv r
+            if (wave < 3) {
+                const int j0 = wave * 16;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    mfma_tile<false, false, 32>(Qinv, LDU, S.Qux, LDX, i * 16, j0, SK, LDX, nullptr, 0, 0.f, nullptr, -1.f);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    mfma_tile<false, false, 32>(S.Quu, LDU, SK, LDX, i * 16, j0, Rres, LDX, S.Qux, LDX, 0.f, nullptr);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    mfma_tile<false, false, 32>(Qinv, LDU, Rres, LDX, i * 16, j0, SK, LDX, SK, LDX, 0.f, nullptr, -1.f);
+            } else if (wl < 32) {
+                const int i = wl;
                 float acc = 0.f;
 #pragma unroll 8
                 for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.qu[j];
                 S.kff[i] = -acc;
-            }
-            __syncthreads();
-            WB_STAMP(g.stamps, 5)
-            // ---- one refinement step against Quu itself (the explicit float32 inverse alone costs a factor 40 in accuracy):
-            //      R = Qux + Quu K0,  K = K0 - Qinv R;   r = qu + Quu kff0,  kff = kff0 - Qinv r
-            for (int t = wave; t < 6; t += RIC_WAVES)
-                mfma_tile<false, false, 32>(S.Quu, LDU, SK, LDX, (t / 3) * 16, (t % 3) * 16, Rres, LDX, S.Qux, LDX, 0.f, nullptr);
-            if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
-                const int i = tid - RIC_LAST;
-                float acc = S.qu[i];
+                __builtin_amdgcn_wave_barrier(); // one wavefront: its LDS operations complete in order
+                acc = S.qu[i];
 #pragma unroll 8
                 for (int j = 0; j < 32; ++j) acc += S.Quu[i * LDU + j] * S.kff[j];
                 S.duk[i] = acc; // residual of the feed-forward term (duk is free during the backward sweep)
-            }
-            __syncthreads();
-            WB_STAMP(g.stamps, 6)
-            for (int t = wave; t < 6; t += RIC_WAVES)
-                mfma_tile<false, false, 32>(Qinv, LDU, Rres, LDX, (t / 3) * 16, (t % 3) * 16, SK, LDX, SK, LDX, 0.f, nullptr, -1.f);
-            if (tid >= RIC_LAST && tid < RIC_LAST + 32) {
-                const int i = tid - RIC_LAST;
-                float acc = 0.f;
+                __builtin_amdgcn_wave_barrier();
+                acc = 0.f;
 #pragma unroll 8
                 for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.duk[j];
+                __builtin_amdgcn_wave_barrier();
                 S.kff[i] -= acc;
             }
             __syncthreads();
