@@ -54,75 +54,12 @@ __device__ __forceinline__ void spd_inverse_rows(T (&a)[N], int lane)
     for (int j = 0; j < N; ++j) a[j] *= mine;
 }
 
-// The same elimination with a row spread over TWO lanes: lane r (< N) holds columns 0 .. N/2 - 1 of row r, lane r + 32
-// columns N/2 .. N - 1 (N even, N <= 32).  A step moves N/2 pivot-row entries per lane through the cross-lane permute
-// (each half fetches its own half of the pivot row) plus the lane's pivot-column entry, and updates N/2 elements: less
-// than half the instructions of the one-lane-per-row form, which spends its time issuing N broadcasts and 2 N
-// arithmetic instructions per step on one wavefront.
-__device__ __forceinline__ float fetch(float x, int src) { return __shfl(x, src, 64); }
-__device__ __forceinline__ double fetch(double x, int src) { return __shfl(x, src, 64); }
-
-template <class T, int N>
-__device__ __forceinline__ void spd_inverse_rows_split(T (&a)[N / 2], int lane)
-{
-    static_assert(N % 2 == 0 && N <= 32, "row halves on lanes r and r + 32");
-    constexpr int H = N / 2;
-    const int r = lane & 31, half = lane >> 5;
-    T mine = T(1); // 1 / pivot of my row, applied once at the end (see spd_inverse_rows)
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int hk = k / H, kk = k % H;                 // compile-time after unrolling
-        T rowk[H];
-#pragma unroll
-        for (int j = 0; j < H; ++j) rowk[j] = fetch(a[j], k + 32 * half);   // my half of pivot row k
-        const T piv = bcast(a[kk], k + 32 * hk);          // A[k][k], wave-uniform
-        const T pk = pivot_rcp(piv);
-        const T f = fetch(a[kk], r + 32 * hk);            // A[r][k] of my row (held by the half that owns column k)
-        const bool me = r == k;
-        const T g = me ? T(0) : f * pk;
-        if (me) mine = pk;
-#pragma unroll
-        for (int j = 0; j < H; ++j) {
-            const T upd = a[j] - g * rowk[j];
-            a[j] = (j == kk && half == hk) ? (me ? T(1) : -g) : upd;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < H; ++j) a[j] *= mine;
-}
-
-// The two-lanes-per-row elimination with 2 x 2 PIVOT BLOCKS: N / 2 steps instead of N.  A step of the scalar form is one
-// dependent chain (cross-lane permute of the pivot row -> reciprocal -> update -> next permute, ~600 cycles next to the
-// LDS traffic of the other wavefronts) whatever the amount of arithmetic in it; two pivots per step halve the number of
-// chains.  The 2 x 2 diagonal block of a Schur complement of an SPD matrix is SPD (determinant > 0, no pivoting).  Pivot
-// rows take the same update with their accumulator cleared: row <- D^-1 [row_a; row_b].
-template <class T, int N>
-__device__ __forceinline__ void spd_inverse_rows_split2(T (&a)[N / 2], int lane)
-{
-    static_assert(N % 2 == 0 && N <= 32, "row halves on lanes r and r + 32, pivots in pairs");
-    constexpr int H = N / 2;
-    const int r = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int m = 0; m < N / 2; ++m) {
-        const int ca = 2 * m, cb = 2 * m + 1;             // compile-time after unrolling
-        const int ha = ca / H, ka = ca % H, hb = cb / H, kb = cb % H;
-        T rowa[H], rowb[H];
-#pragma unroll
-        for (int j = 0; j < H; ++j) { rowa[j] = fetch(a[j], ca + 32 * half); rowb[j] = fetch(a[j], cb + 32 * half); }
-        const T daa = bcast(a[ka], ca + 32 * ha), dab = bcast(a[kb], ca + 32 * hb), dbb = bcast(a[kb], cb + 32 * hb);
-        const T idet = pivot_rcp(daa * dbb - dab * dab);
-        const T i00 = dbb * idet, i01 = -dab * idet, i11 = daa * idet;
-        const T fa = fetch(a[ka], r + 32 * ha), fb = fetch(a[kb], r + 32 * hb); // my row's entries in the two pivot columns
-        const bool mea = r == ca, meb = r == cb;
-        const T ga = mea ? -i00 : (meb ? -i01 : fa * i00 + fb * i01);
-        const T gb = mea ? -i01 : (meb ? -i11 : fa * i01 + fb * i11);
-#pragma unroll
-        for (int j = 0; j < H; ++j) {
-            const T base = (mea || meb) ? T(0) : a[j];
-            const T upd = base - ga * rowa[j] - gb * rowb[j];
-            a[j] = (j == ka && half == ha) ? -ga : ((j == kb && half == hb) ? -gb : upd);
-        }
-    }
-}
-
+// Measured alternatives for the 30 x 30 float32 case inside the Riccati kernel (three workgroups per CU, the other
+// wavefronts busy with LDS-fed matrix tiles), all dropped:
+//   * a row on two lanes (15 columns each), pivot row by ds_bpermute: half the arithmetic, but 16 permutes per step at
+//     ~34 cycles each next to the tile traffic -- 16 k cycles against 14 k for this form; the same with 2 x 2 pivot
+//     blocks (15 steps): the same 480 permutes, the same 16 k cycles;
+//   * the pivot row through LDS memory (16-byte stores by the owner, broadcast loads): an LDS round trip per step in the
+//     dependent chain, 27 k cycles;
+//   * s_setprio around the elimination: 1.5 k cycles faster itself, the other phases of the three workgroups lose more.
 } // namespace wavela
