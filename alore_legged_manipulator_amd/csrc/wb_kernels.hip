@@ -473,8 +473,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         //      phase of a stage) WHILE wavefronts 1 .. 3 do everything that hangs on A: wavefront w owns COLUMN BLOCK
         //      j = w - 1 -- PA(:, j) = P A(:, j) (3 tiles), Qux(:, j) = B' PA(:, j) (2), Qxx(i <= j, j) = A(:, i)' PA(:, j)
         //      (j + 1 upper-triangular tiles) all read only the wavefront's own block of PA, so no barrier separates
-        //      them.  Qxx overwrites P, which the other wavefronts still read for their PA: its tiles wait in registers
-        //      until the barrier that ends the inversion.  qx = gx + A' s, qu = gu + B' s on the wavefront with fewest tiles.
+        //      them.  The Qxx tiles stay in registers until the end of the stage, where the same wavefront adds Qux' K.  qx = gx + A' s, qu = gu + B' s on the wavefront with fewest tiles.
         const int role = wave; // 0 inverts, 1 .. 3 multiply (rotating the role over the wavefronts / SIMDs was measured: no effect)
         const int wl = tid & 63;
         f4 qxx[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -544,12 +543,6 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             __syncthreads();
             WB_STAMP(g.stamps, 4)
             if (round == 0) {
-                if (role != 0) { // Qxx = Q + A' PA over P: every wavefront is through with P now
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        if (i < role) tile_store<true>(qxx[i], i * 16, (role - 1) * 16, S.P, LDX, nullptr, 0, 1.f, S.wq);
-                }
-                if (tid < 32) clampm[tid] = 0.f;
                 if (k > 0) { RIC_DEPOSIT_A() RIC_REQUEST_B(k - 1) } // S.A is dead; B_{k-1} and the vectors land under the gain computation
             }
             // ---- K0 = -Qinv Qux, then one refinement step against Quu itself (the explicit float32 inverse alone costs a
@@ -584,23 +577,24 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 #pragma unroll 8
                 for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.duk[j];
                 __builtin_amdgcn_wave_barrier();
-                S.kff[i] -= acc;
+                const float kf = S.kff[i] - acc;
+                S.kff[i] = kf;
+                if (round == 0) { // torque limits on the feed-forward step of this stage: flags / values for the pass below
+                    float m = 0.f;
+                    if (g.limits && i < b2z1::NJ) {
+                        const float ucur = S.dxn[i], eff = (float)b2z1::EFFORT[i];
+                        const float lo = -eff - ucur, hi = eff - ucur;
+                        if (kf < lo - 1e-4f * eff) { m = 1.f; clampv[i] = lo; }
+                        else if (kf > hi + 1e-4f * eff) { m = 1.f; clampv[i] = hi; }
+                    }
+                    clampm[i] = m;
+                }
             }
             __syncthreads();
             WB_STAMP(g.stamps, 7)
             if (round == 1) break;
-            // ---- torque limits on the feed-forward step of this stage
-            int hit = 0;
-            if (tid < b2z1::NJ) {
-                const float ucur = S.dxn[tid], eff = (float)b2z1::EFFORT[tid];
-                const float lo = -eff - ucur, hi = eff - ucur, kf = S.kff[tid];
-                if (kf < lo - 1e-4f * eff) { clampm[tid] = 1.f; clampv[tid] = lo; hit = 1; }
-                else if (kf > hi + 1e-4f * eff) { clampm[tid] = 1.f; clampv[tid] = hi; hit = 1; }
-            }
             // "any input clamped?" without __syncthreads_or (its LDS temporary pushes the block past the size of which
             // three fit a CU): every wavefront ballots the 18 flags itself
-            (void)hit;
-            __syncthreads();
             if (!g.limits || !__any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f)) break;
             // masked system, in place: qu first (it needs the unmasked rows of Quu), then Quu
             if (tid < 32) {
@@ -628,11 +622,16 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             for (int i = tid; i < 32 * 48; i += RIC_THREADS) Kg[i] = SK[(i / 48) * LDX + (i % 48)];
             if (tid < 32) g.kff[((size_t)b * N + k) * 32 + tid] = S.kff[tid];
         }
-        // ---- P <- Qxx + Qux' K (9 tiles), p <- qx + Qux' kff
-        for (int t = wave; t < 6; t += RIC_WAVES) // symmetric: 6 tiles, mirrored (no separate symmetrisation pass)
-            mfma_tile<true, false, 32, true>(S.Qux, LDX, SK, LDX, SYM3_I[t] * 16, SYM3_J[t] * 16, S.P, LDX, S.P, LDX, 0.f, nullptr);
-        if (tid >= RIC_LAST && tid < RIC_LAST + 48) {
-            const int i = tid - RIC_LAST;
+        // ---- P <- Q + Qxx + Qux' K: the 6 upper-triangular tiles, each on the wavefront that still holds its Qxx tile in
+        //      registers (Qxx never goes through LDS), mirrored on store; p <- qx + Qux' kff on wavefront 0
+        if (role != 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < role)
+                    tile_store<true>(mfma_acc<true, false, 32>(S.Qux, LDX, SK, LDX, i * 16, (role - 1) * 16) + qxx[i], i * 16, (role - 1) * 16, S.P, LDX,
+                                     nullptr, 0, 1.f, S.wq);
+        } else if (wl < 48) {
+            const int i = wl;
             float acc = S.qx[i];
             for (int j = 0; j < 32; ++j) acc += S.Qux[j * LDX + i] * S.kff[j];
             S.p[i] = acc;
