@@ -60,6 +60,7 @@ struct Dev {
     int* st;             // [T][2][stride] working set (kept between calls: warm start)
     int* sweeps;         // [B]
     int* status;         // [B]
+    double* cmd;         // [B][2] the command a tick publishes: column delay_num of the output
     int n_relin, reset;
     long long* stamps;   // diagnostic (ALORE_LTV_STAMPS=1): cycles of robot 0 in rollout / backward / forward / rest
 };
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
     LTV_STAMP(3)
     d.sweeps[b] = sweeps;
     d.status[b] = status;
+    d.cmd[2 * b] = out[2 * dl]; d.cmd[2 * b + 1] = out[2 * dl + 1];
 }
 
 // getRefPoints of the `mpc` node on the trajectory store: thread = (robot, i), then smooth_yaw per robot
@@ -441,7 +443,7 @@ struct alore_ltv_solver {
     int device = 0, B = 0;
     std::string err;
     double *d_now = nullptr, *d_xref = nullptr, *d_dref = nullptr, *d_out = nullptr, *d_buff = nullptr, *d_xopt = nullptr, *d_ws = nullptr,
-           *d_est = nullptr;
+           *d_est = nullptr, *d_cmd = nullptr;
     int *d_st = nullptr, *d_sweeps = nullptr, *d_status = nullptr, *d_goal = nullptr;
     long long* d_stamps = nullptr;
     char* h_stage = nullptr; // pinned
@@ -468,7 +470,7 @@ hipError_t zalloc(T** p, size_t n)
 }
 void lfree(alore_ltv_handle h)
 {
-    void* ptrs[] = {h->d_now, h->d_xref, h->d_dref, h->d_out, h->d_buff, h->d_xopt, h->d_ws, h->d_est, h->d_st, h->d_sweeps, h->d_status, h->d_goal};
+    void* ptrs[] = {h->d_now, h->d_xref, h->d_dref, h->d_out, h->d_buff, h->d_xopt, h->d_ws, h->d_est, h->d_st, h->d_sweeps, h->d_status, h->d_goal, h->d_cmd};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
 }
@@ -510,7 +512,7 @@ int alore_ltv_create(const alore_ltv_config* cfg, int device, int max_robots, al
     A(zalloc(&h->d_now, B * 3)); A(zalloc(&h->d_xref, B * T * 3)); A(zalloc(&h->d_dref, B * T * 2)); A(zalloc(&h->d_out, B * T * 2));
     A(zalloc(&h->d_buff, B * dl * 2)); A(zalloc(&h->d_xopt, B * (T + 1) * 3)); A(zalloc(&h->d_ws, T * ltv::NF * B)); A(zalloc(&h->d_est, B * 3));
     if (std::getenv("ALORE_LTV_STAMPS")) A(zalloc(&h->d_stamps, (size_t)8));
-    A(zalloc(&h->d_st, T * 2 * B)); A(zalloc(&h->d_sweeps, B)); A(zalloc(&h->d_status, B)); A(zalloc(&h->d_goal, B));
+    A(zalloc(&h->d_st, T * 2 * B)); A(zalloc(&h->d_sweeps, B)); A(zalloc(&h->d_status, B)); A(zalloc(&h->d_goal, B)); A(zalloc(&h->d_cmd, B * 2));
     h->stage_bytes = sizeof(double) * B * ((T + 1) * 3 + T * 5 + 8) + sizeof(int) * B * 4 + 1024;
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault);
     if (e != hipSuccess) { lfree(h); delete h; return e == hipErrorOutOfMemory ? ALORE_LTV_E_NOMEM : ALORE_LTV_E_HIP; }
@@ -573,23 +575,48 @@ int alore_ltv_refs_from_store(alore_ltv_handle h, void* nmpc, int B, double now,
     return ALORE_LTV_OK;
 }
 
-int alore_ltv_get_cmd(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, void* stream)
+static int ltv_enqueue(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, hipStream_t s)
 {
-    if (!h || B < 1 || B > h->B || !now_state || n_relin < 1) return lfail(h, ALORE_LTV_E_INVALID, "get_cmd: bad argument");
-    LTV_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
     double* hn = (double*)h->h_stage;
     std::memcpy(hn, now_state, sizeof(double) * B * 3);
     LTV_TRY(h, hipMemcpyAsync(h->d_now, hn, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
     ltv::Dev d{};
     d.c = h->cfg; d.B = B; d.stride = h->B;
     d.now = h->d_now; d.xref = h->d_xref; d.dref = h->d_dref; d.output = h->d_out; d.buff = h->d_buff; d.xopt = h->d_xopt;
-    d.ws = h->d_ws; d.st = h->d_st; d.sweeps = h->d_sweeps; d.status = h->d_status;
+    d.ws = h->d_ws; d.st = h->d_st; d.sweeps = h->d_sweeps; d.status = h->d_status; d.cmd = h->d_cmd;
     d.n_relin = n_relin; d.reset = reset;
     d.stamps = h->d_stamps;
     hipLaunchKernelGGL(ltv::get_cmd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d);
     LTV_TRY(h, hipGetLastError());
-    LTV_TRY(h, hipStreamSynchronize(s)); // `hn` is reused by the next call
+    return ALORE_LTV_OK;
+}
+
+int alore_ltv_get_cmd(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, void* stream)
+{
+    if (!h || B < 1 || B > h->B || !now_state || n_relin < 1) return lfail(h, ALORE_LTV_E_INVALID, "get_cmd: bad argument");
+    LTV_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = ltv_enqueue(h, B, now_state, n_relin, reset, s);
+    if (rc != ALORE_LTV_OK) return rc;
+    LTV_TRY(h, hipStreamSynchronize(s)); // the staging slab is reused by the next call
+    return ALORE_LTV_OK;
+}
+
+// one control tick: states in, getCmd, commands (and status) out -- one upload, one launch, one download, one wait
+int alore_ltv_tick(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, double* cmd, int* status, void* stream)
+{
+    if (!h || B < 1 || B > h->B || !now_state || n_relin < 1 || !cmd) return lfail(h, ALORE_LTV_E_INVALID, "tick: bad argument");
+    LTV_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = ltv_enqueue(h, B, now_state, n_relin, reset, s);
+    if (rc != ALORE_LTV_OK) return rc;
+    double* sc = (double*)h->h_stage + (size_t)B * 3;
+    int* st = (int*)(sc + (size_t)B * 2);
+    LTV_TRY(h, hipMemcpyAsync(sc, h->d_cmd, sizeof(double) * B * 2, hipMemcpyDeviceToHost, s));
+    if (status) LTV_TRY(h, hipMemcpyAsync(st, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    LTV_TRY(h, hipStreamSynchronize(s));
+    std::memcpy(cmd, sc, sizeof(double) * B * 2);
+    if (status) std::memcpy(status, st, sizeof(int) * B);
     return ALORE_LTV_OK;
 }
 
@@ -626,8 +653,8 @@ int alore_ltv_commands(alore_ltv_handle h, int B, double* cmd, int* status, void
     const size_t T = h->cfg.predict_steps, dl = h->cfg.delay_num;
     double* sc = (double*)h->h_stage;
     int* st = (int*)(sc + (size_t)B * 2);
-    // column delay_num of every robot's output: a strided copy, 16 bytes per robot
-    LTV_TRY(h, hipMemcpy2DAsync(sc, sizeof(double) * 2, h->d_out + dl * 2, sizeof(double) * T * 2, sizeof(double) * 2, B, hipMemcpyDeviceToHost, s));
+    // column delay_num of every robot's output, packed by the kernel (16 bytes per robot)
+    LTV_TRY(h, hipMemcpyAsync(sc, h->d_cmd, sizeof(double) * B * 2, hipMemcpyDeviceToHost, s));
     if (status) LTV_TRY(h, hipMemcpyAsync(st, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
     LTV_TRY(h, hipStreamSynchronize(s));
     std::memcpy(cmd, sc, sizeof(double) * B * 2);

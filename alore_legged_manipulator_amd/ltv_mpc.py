@@ -32,6 +32,7 @@ def _bind(L):
     L.alore_ltv_get_cmd.argtypes = [C.c_void_p, C.c_int, DP, C.c_int, C.c_int, C.c_void_p]
     L.alore_ltv_results.argtypes = [C.c_void_p, C.c_int, DP, DP, IP, IP, C.c_void_p]
     L.alore_ltv_commands.argtypes = [C.c_void_p, C.c_int, DP, IP, C.c_void_p]
+    L.alore_ltv_tick.argtypes = [C.c_void_p, C.c_int, DP, C.c_int, C.c_int, DP, IP, C.c_void_p]
     L.alore_ltv_set_state.argtypes = [C.c_void_p, C.c_int, DP, DP, C.c_void_p]
     L._ltv_bound = True
 
@@ -107,9 +108,8 @@ class BatchedLtvMpc:
         """getCmd for all robots, returning only what a control tick publishes: cmd (n, 2) and the status"""
         now_state = np.ascontiguousarray(now_state, np.float64)
         n = now_state.shape[0]
-        self._check(self.L.alore_ltv_get_cmd(self.h, n, _dp(now_state), int(n_relin), 1 if reset else 0, None))
         cmd = np.zeros((n, 2)); st = np.zeros(n, np.int32)
-        self._check(self.L.alore_ltv_commands(self.h, n, _dp(cmd), st.ctypes.data_as(IP), None))
+        self._check(self.L.alore_ltv_tick(self.h, n, _dp(now_state), int(n_relin), 1 if reset else 0, _dp(cmd), st.ctypes.data_as(IP), None))
         return cmd, st
 
     def get_cmd(self, now_state, n_relin=5, reset=False):

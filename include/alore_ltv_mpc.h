@@ -68,6 +68,10 @@ int alore_ltv_results(alore_ltv_handle h, int B, double *output, double *xopt, i
 /* what a control tick needs: cmd [B][2] = output(:, delay_num) per robot (mpc.cpp:169-172) and the status; 16 bytes per robot
  * cross the bus instead of the whole prediction.  Synchronises the stream. */
 int alore_ltv_commands(alore_ltv_handle h, int B, double *cmd, int *status, void *stream);
+/* one control tick in one call (CmdCallback, mpc.cpp:142-175): states in, getCmd, cmd [B][2] and status [B] (may be NULL)
+ * out -- one upload, one launch, one download, one wait on the stream */
+int alore_ltv_tick(alore_ltv_handle h, int B, const double *now_state, int n_relin, int reset, double *cmd, int *status,
+                   void *stream);
 /* overwrite the stored previous output / delay buffer (tests): output [B][T][2], buff [B][d][2] */
 int alore_ltv_set_state(alore_ltv_handle h, int B, const double *output, const double *buff, void *stream);
 

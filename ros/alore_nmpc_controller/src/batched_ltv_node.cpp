@@ -106,8 +106,7 @@ struct Fleet {
             for (int b : robots) { pending[b].valid = false; receive_traj[b] = 1; stopped[b] = 0; fresh[b] = 1; }
         }
         if (alore_ltv_refs_from_store(ltv, store, B, now.toSec(), est.data(), at_goal.data(), nullptr) != 0 ||
-            alore_ltv_get_cmd(ltv, B, est.data(), n_relin, 0, nullptr) != 0 ||
-            alore_ltv_commands(ltv, B, output.data(), nullptr, nullptr) != 0) {
+            alore_ltv_tick(ltv, B, est.data(), n_relin, 0, output.data(), nullptr, nullptr) != 0) {
             ROS_ERROR_THROTTLE(1.0, "alore_ltv tick failed: %s", alore_ltv_last_error(ltv));
             return;
         }

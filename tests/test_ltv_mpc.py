@@ -143,6 +143,7 @@ def test_gpu_get_cmd_tracks_the_oracle_over_relinearisations_and_ticks():
     B, n_relin = 12, 4
     rng = np.random.default_rng(77)
     eng = BatchedLtvMpc(B)
+    eng_tick = BatchedLtvMpc(B)   # the same ticks through the one-call entry point (alore_ltv_tick)
     specs = [(rng.uniform(0.5, 2.5), rng.uniform(-1.5, 1.5)) for _ in range(B)]
     state = np.array([[rng.uniform(-.1, .1), rng.uniform(-.1, .1), rng.uniform(-.2, .2)] for _ in range(B)])
     out_o = [np.zeros((2, p.T)) for _ in range(B)]
@@ -159,7 +160,10 @@ def test_gpu_get_cmd_tracks_the_oracle_over_relinearisations_and_ticks():
         cmd_only = np.zeros((B, 2)); st_only = np.zeros(B, np.int32)
         import ctypes as C
         eng._check(eng.L.alore_ltv_commands(eng.h, B, cmd_only.ctypes.data_as(C.POINTER(C.c_double)), st_only.ctypes.data_as(C.POINTER(C.c_int)), None))
-        assert np.array_equal(cmd_only, got["cmd"]) and np.all(st_only == 0)     # the strided commands-only download
+        assert np.array_equal(cmd_only, got["cmd"]) and np.all(st_only == 0)     # the commands-only download
+        eng_tick.set_refs(np.stack(xr), np.stack(dr))
+        cmd_t, st_t = eng_tick.tick(state, n_relin=n_relin, reset=(tick == 0))
+        assert np.array_equal(cmd_t, got["cmd"]) and np.all(st_t == 0)
         for b in range(B):
             out_o[b], buff_o[b], infos = get_cmd(list(state[b]) + [0.0], out_o[b], buff_o[b], xr[b].T, dr[b].T, p, n_relin)
             assert np.max(np.abs(got["output"][b] - out_o[b].T)) < 1e-6, (tick, b)
