@@ -280,13 +280,17 @@ __global__ __launch_bounds__(64) void rnea_kernel(int n, const double* q, const 
 // matrices of the current stage in LDS (float32), the dense products on the matrix cores:
 //   v_mfma_f32_16x16x4_f32:  lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives
 //   C[4 (l >> 4) + r][l & 15], r = 0..3  (cdna_hip_programming.md, "A/B operands ... 16x16x4").
-// Backward, stage k = N-1 .. 0 (P, p: cost-to-go 1/2 dx' P dx + p' dx of stage k + 1):
-//   PA = P A, PB = P B, s = P d + p                              (15 output tiles)
-//   Qxx = Q + A' PA, Qux = B' PA, Quu = R + B' PB, qx, qu        (15 tiles: the symmetric ones upper-triangular)
-//   Quu^-1 (30 x 30, in-register Gauss-Jordan on one wavefront, a row on two lanes), K = -Quu^-1 Qux, kff = -Quu^-1 qu
-//   with one refinement step on the matrix cores (18 tiles); torque limits: clamp + re-solve of the free inputs;
-//   K, kff -> HBM (used by the forward sweep)
-//   P <- Qxx + Qux' K, p <- qx + Qux' kff                        (6 tiles)
+// Backward, stage k = N-1 .. 0 (P, p: cost-to-go 1/2 dx' P dx + p' dx of stage k + 1), arranged around the inversion of Quu,
+// which is ONE wavefront's dependent chain and the longest phase of a stage:
+//   1. PB = P B (6 tiles), s = P d + p                                                    | barrier
+//   2. Quu = B' PB (3 upper-triangular tiles, mirrored)                                   | barrier
+//   3. wavefront 0: Quu + R, Quu^-1 (30 x 30, in-register Gauss-Jordan, wave_linalg.h)
+//      wavefront w = 1..3 owns column block j = w - 1: PA(:, j) = P A(:, j), Qux(:, j) = B' PA(:, j), the upper-triangular
+//      tiles of Qxx(., j) = A' PA(:, j) (kept in registers), qx, qu -- no barrier inside a column block   | barrier
+//   4. wavefront w = 0..2, column block w: K0 = -Quu^-1 Qux, R = Qux + Quu K0, K = K0 - Quu^-1 R (one refinement step),
+//      wavefront 3 the same for kff, and the torque-limit test (clamp + re-solve of the free inputs: back to 3.)  | barrier
+//   5. K, kff -> HBM (forward sweep); P <- Q + Qxx + Qux' K on the wavefronts that hold the Qxx tiles, p <- qx + Qux' kff  | barrier
+// The next stage's A, B and right-hand sides are requested into registers during 4. and deposited when their buffers die.
 // Forward: dx_0 = x0 - x_0, du_k = K_k dx_k + kff_k, dx_{k+1} = A_k dx_k + B_k du_k + d_k; then x += dx, u += du with
 // the joint torques clipped to the URDF effort limits.
 // =====================================================================================================================
