@@ -162,15 +162,23 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
         const int c = lane - 45;
         const V3 wn = {S.vn[0], S.vn[1], S.vn[2]}, vl = {S.vn[3], S.vn[4], S.vn[5]};
         const double h = 1e-6;
-        const double h0 = c == 0 ? h : 0.0, h1 = c == 1 ? h : 0.0, h2 = c == 2 ? h : 0.0;
+        // sines / cosines of rpy from the stage's table; the perturbed angle by the addition theorem (sin h, cos h of h = 1e-6)
+        constexpr double sh = 9.99999999999833333e-07, ch = 0.9999999999995;
         BaseRot Rp, Rm;
-        Rp.set(S.q[3] + h0, S.q[4] + h1, S.q[5] + h2);
-        Rm.set(S.q[3] - h0, S.q[4] - h1, S.q[5] - h2);
+        Rp.sr = Rm.sr = S.trig[0]; Rp.cr = Rm.cr = S.trig[1]; Rp.sp = Rm.sp = S.trig[2]; Rp.cp = Rm.cp = S.trig[3];
+        Rp.sy = Rm.sy = S.trig[4]; Rp.cy = Rm.cy = S.trig[5];
+        {
+            const double s0 = S.trig[2 * c], c0 = S.trig[2 * c + 1];
+            const double sp_ = s0 * ch + c0 * sh, cp_ = c0 * ch - s0 * sh, sm_ = s0 * ch - c0 * sh, cm_ = c0 * ch + s0 * sh;
+            if (c == 0) { Rp.sr = sp_; Rp.cr = cp_; Rm.sr = sm_; Rm.cr = cm_; }
+            else if (c == 1) { Rp.sp = sp_; Rp.cp = cp_; Rm.sp = sm_; Rm.cp = cm_; }
+            else { Rp.sy = sp_; Rp.cy = cp_; Rm.sy = sm_; Rm.cy = cm_; }
+        }
         const V3 dp = (0.5 / h) * (Rp.toWorld(vl) - Rm.toWorld(vl)), dr = (0.5 / h) * (Rp.rates(wn) - Rm.rates(wn));
         S.Gq[c][0] = dp.x; S.Gq[c][1] = dp.y; S.Gq[c][2] = dp.z; S.Gq[c][3] = dr.x; S.Gq[c][4] = dr.y; S.Gq[c][5] = dr.z;
     } else if (lane == 48) {
         BaseRot R;
-        R.set(S.q[3], S.q[4], S.q[5]);
+        R.sr = S.trig[0]; R.cr = S.trig[1]; R.sp = S.trig[2]; R.cp = S.trig[3]; R.sy = S.trig[4]; R.cy = S.trig[5];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             const V3 em = {m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0};
@@ -205,7 +213,8 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
     const double dt = g.dt;
     float* A32 = g.A32 + (size_t)item * NX * NX;
     float* B32 = g.B32 + (size_t)item * NX * NUP;
-    for (int c = lane; c < NX + NUP; c += 64) {
+    {
+        const int c = lane; // the first 64 columns: the 48 of A and the first 16 of B
         // source of this column's da / d(var): a derivative column of D, a row of M^-1 (torque j: column 6 + j of the
         // symmetric inverse), a foot-force column of D, or nothing (base position, padding)
         const double* zsrc = c < 3 ? nullptr
@@ -235,6 +244,29 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
             if (pad) val = 0.0;
             out[r * ld] = (float)val;
             if (out64) out64[(size_t)r * ld64] = val;
+        }
+    }
+    {   // the last 16 columns of B (torques 16, 17, the 12 foot forces, 2 padding columns) on FOUR lanes each, 12 rows per
+        // lane: one lane per column would leave 48 lanes idle for a whole round of 48 rows.  No identity terms here
+        // (r == c and c == 24 + i cannot happen for c >= 64).
+        const int c = 64 + (lane >> 2), part = lane & 3;
+        const bool pad = c >= NX + NU;
+        const double* zsrc = c < 48 + 18 ? S.M + (6 + c - 48) * MS : (pad ? S.zero : S.D + (45 + c - 66) * MS);
+        float* out = B32 + (c - NX);
+        double* out64 = (g.B64 && !pad) ? g.B64 + (size_t)item * NX * NU + (c - NX) : nullptr;
+        for (int rr = 0; rr < NX / 4; ++rr) {
+            const int r = part + 4 * rr;
+            double val;
+            if (r >= 24) val = dt * zsrc[r - 24];
+            else if (r >= 6) val = dt * (dt * zsrc[r]);
+            else {
+                const double* Gm = (r < 3) ? (S.R0 + 3 * r) : (S.E + 3 * (r - 3));
+                const int off = (r < 3) ? 3 : 0;
+                val = dt * (Gm[0] * (dt * zsrc[off]) + Gm[1] * (dt * zsrc[off + 1]) + Gm[2] * (dt * zsrc[off + 2]));
+            }
+            if (pad) val = 0.0;
+            out[r * NUP] = (float)val;
+            if (out64) out64[(size_t)r * NU] = val;
         }
     }
     if (lane < NX) { // f(x_k, u_k)
