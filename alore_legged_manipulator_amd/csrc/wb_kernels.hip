@@ -557,23 +557,40 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
                 // LDS operations of one wavefront complete in order, so the row loads below see it
                 if (round == 0 && wl < 32) S.Quu[wl * LDU + wl] += S.wr[wl];
                 __builtin_amdgcn_wave_barrier();
-                // row r of Quu on lane r (30 columns): pivot rows travel through v_readlane (scalar registers).  The form
-                // with a row on two lanes halves the arithmetic but needs a cross-lane permute per moved element, and a
-                // ds_bpermute costs ~34 cycles next to the LDS traffic of the other wavefronts (480 of them: 16 k cycles,
-                // whether in 30 steps or in 15 steps with 2 x 2 pivots); the 2 padding inputs are an identity block
-                float rowf[NU];
-                const int rr = wl < NU ? wl : 0;
+                // 2 x 2 blocks of 16 (the 2 padding inputs are an identity block inside the second one, so all 32 rows go
+                // through): Quu = [A11 A12; A12' A22],  T = A11^-1 A12,  S = A22 - A12' T,
+                //   Quu^-1 = [A11^-1 + T S^-1 T', -T S^-1; -S^-1 T', S^-1].
+                // The two 16 x 16 inverses are in-register Gauss-Jordan eliminations (16 steps of 16 v_readlane + 16 FMA
+                // instead of 30 x (30 + 30): 12.8 k cycles against 15.4 k for the one-piece elimination); the five
+                // 16 x 16 x 16 products run on the matrix cores of the same wavefront, through the spare 16 rows of the PB buffer.
+                float* T = Qinv + 32 * LDU;               // 16 x 16, stride LDU (PB has 48 rows, Qinv uses 32)
+                float* Q22 = Qinv + 16 * LDU + 16;
+                const int rr = wl & 15;
+                {
+                    float r16v[16];
 #pragma unroll
-                for (int j = 0; j < NU; ++j) rowf[j] = S.Quu[rr * LDU + j];
-                wavela::spd_inverse_rows<float, NU>(rowf, wl);
-                if (wl < NU) {
+                    for (int j = 0; j < 16; ++j) r16v[j] = S.Quu[rr * LDU + j];
+                    wavela::spd_inverse_rows<float, 16>(r16v, wl);
+                    if (wl < 16) {
 #pragma unroll
-                    for (int j = 0; j < NU; ++j) Qinv[wl * LDU + j] = rowf[j];
-                    Qinv[wl * LDU + 30] = 0.f; Qinv[wl * LDU + 31] = 0.f;
-                } else if (wl < 32) {
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) Qinv[wl * LDU + j] = (j == wl) ? 1.f : 0.f;
+                        for (int j = 0; j < 16; ++j) Qinv[wl * LDU + j] = r16v[j];
+                    }
                 }
+                mfma_tile<false, false, 16>(Qinv, LDU, S.Quu + 16, LDU, 0, 0, T, LDU, nullptr, 0, 0.f, nullptr);                      // T = A11^-1 A12
+                mfma_tile<false, false, 16>(S.Quu + 16 * LDU, LDU, T, LDU, 0, 0, Q22, LDU, S.Quu + 16 * LDU + 16, LDU, 0.f, nullptr, -1.f); // S = A22 - A21 T
+                {
+                    float r16v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) r16v[j] = Q22[rr * LDU + j];
+                    wavela::spd_inverse_rows<float, 16>(r16v, wl);
+                    if (wl < 16) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) Q22[wl * LDU + j] = r16v[j];
+                    }
+                }
+                mfma_tile<false, false, 16>(T, LDU, Q22, LDU, 0, 0, Qinv + 16, LDU, nullptr, 0, 0.f, nullptr, -1.f);                 // -T S^-1
+                mfma_tile<false, true, 16>(Q22, LDU, T, LDU, 0, 0, Qinv + 16 * LDU, LDU, nullptr, 0, 0.f, nullptr, -1.f);            // -S^-1 T'
+                mfma_tile<false, true, 16>(Qinv + 16, LDU, T, LDU, 0, 0, Qinv, LDU, Qinv, LDU, 0.f, nullptr, -1.f);                  // A11^-1 + T S^-1 T'
             }
             WB_STAMP(g.stamps, 3)
             __syncthreads();
