@@ -190,18 +190,36 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
     __syncthreads();
     WB_STAMP(g.stamps, 5)
 
-    // ---- M^-1 times the 57 columns that need it (45 derivative columns, 12 foot-force columns)
-    if (lane < 57) {
-        const int col = lane; // 45 derivative columns, then the 12 foot-force columns
-        double r[NV];
+    // ---- M^-1 times the 57 columns that need it (45 derivative columns, 12 foot-force columns) on the float64 matrix
+    //      cores: v_mfma_f64_16x16x4_f64, 2 row tiles x 4 column tiles x 6 k-steps.  Lane l supplies A[l & 15][l >> 4] and
+    //      B[l >> 4][l & 15] (one double each) and receives C[(l >> 4) + 4 r][l & 15], r = 0..3.  Rows >= 24 and columns
+    //      >= 57 are computed from clamped (duplicate) operands and not stored.  D is overwritten in place: a column
+    //      tile's operands are all in registers before its results are stored (one wavefront, LDS in order).
+    {
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        const int r16 = lane & 15, kq = lane >> 4;
+        const int row1 = 16 + r16 < NV ? 16 + r16 : NV - 1;
+        double a0[6], a1[6];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) r[i] = S.D[col * MS + i];
-#pragma unroll 4
-        for (int i = 0; i < NV; ++i) {
-            double acc = 0.0;
+        for (int t = 0; t < 6; ++t) { a0[t] = S.M[r16 * MS + 4 * t + kq]; a1[t] = S.M[row1 * MS + 4 * t + kq]; }
+#pragma unroll 1
+        for (int tj = 0; tj < 4; ++tj) {
+            const int cfull = tj * 16 + r16, col = cfull < NCOL ? cfull : NCOL - 1;
+            double bq[6];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) acc += S.M[i * MS + j] * r[j];
-            S.D[col * MS + i] = acc;
+            for (int t = 0; t < 6; ++t) bq[t] = S.D[col * MS + 4 * t + kq];
+            d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], bq[t], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], bq[t], c1, 0, 0, 0);
+            }
+            if (cfull < NCOL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S.D[col * MS + kq + 4 * r] = c0[r];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) S.D[col * MS + 16 + kq + 4 * r] = c1[r]; // rows 16 .. 23
+            }
         }
     }
     __syncthreads();
