@@ -438,6 +438,38 @@ __device__ __forceinline__ void mfma_tile(const float* A, int lda, const float* 
     tile_store<MIRROR>(mfma_acc<TA, TB, K>(A, lda, Bm, ldb, i0, j0), i0, j0, Cm, ldc, Cinit, ldi, alpha_diag, diag, scale);
 }
 
+// acc += op(A)(i0 .. i0 + 15, k0 .. k0 + 15) X, with the 16 x 16 matrix X held in the C layout of a previous product (lane
+// (c, q) register s = X[4 q + s][c]): an accumulator is the B operand of the next product WITHOUT leaving the registers.
+// The sum over k may visit the 16 rows in any order as long as both operands agree, so k-slot (s, q) stands for row
+// 4 q + s here (the layout the accumulator already has) instead of 4 s + q; only the A operand is fetched accordingly.
+template <bool TA>
+__device__ __forceinline__ f4 mfma_acc_regb(const float* A, int lda, int i0, int k0, f4 x, f4 acc)
+{
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int r16 = l & 15, kq = l >> 4;
+    float a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k = k0 + 4 * kq + s;
+        a[s] = TA ? A[k * lda + i0 + r16] : A[(i0 + r16) * lda + k];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], x[s], acc, 0, 0, 0);
+    return acc;
+}
+// a 16 x 16 tile of an LDS matrix in the C layout
+__device__ __forceinline__ f4 tile_load(const float* M, int ld, int i0, int j0)
+{
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int r16 = l & 15, kq = l >> 4;
+    f4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = M[(i0 + 4 * kq + r) * ld + j0 + r16];
+    return v;
+}
+
 // upper-triangular 16 x 16 tiles of a symmetric 48 x 48 / 32 x 32 result
 __device__ constexpr int SYM3_I[6] = {0, 0, 0, 1, 1, 2}, SYM3_J[6] = {0, 1, 2, 1, 2, 2}, SYM2_I[3] = {0, 0, 1}, SYM2_J[3] = {0, 1, 1};
 
@@ -459,7 +491,6 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     for (int i = tid; i < 48 * 48; i += RIC_THREADS) { const int r = i / 48, c = i % 48; S.P[r * LDX + c] = (r == c) ? (float)QNd[r] : 0.f; }
     if (tid < 48) { S.p[tid] = (float)(QNd[tid] * (xb[(size_t)N * NX + tid] - xr[(size_t)N * NX + tid])); S.wq[tid] = (float)Qd[tid]; }
     else if (tid >= 64 && tid < 96) S.wr[tid - 64] = (tid - 64) < NU ? (float)Rd[tid - 64] : 1.f; // identity on the 2 padding inputs
-    float* const SK = S.PA;  // feedback gain of the stage (32 x 48): PA is dead once Qxx and Qux exist
     __syncthreads();
 
     // A stage's A, B (16-byte pieces) and right-hand sides travel global -> registers -> LDS and are requested AHEAD of
@@ -531,6 +562,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         const int role = wave; // 0 inverts, 1 .. 3 multiply (rotating the role over the wavefronts / SIMDs was measured: no effect)
         const int wl = tid & 63;
         f4 qxx[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f4 kt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // the wavefront's column block of the gain K (rows 0..15, 16..31), C layout
         if (role != 0) {
             const int j0 = (role - 1) * 16;
 #pragma unroll
@@ -556,7 +588,6 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         }
         if (k > 0) RIC_REQUEST_A(k - 1) // lands while Quu is inverted
         float* Qinv = S.PB;   // PB is dead once Quu = B' PB exists
-        float* Rres = S.B;    // B is dead once Qux, Quu and qu exist (32 rows of stride LDX fit: 32 * 49 <= 48 * 33)
         // clamp flags / values of the control limits live in dxk / s (free during the backward sweep / dead after qx, qu):
         // the LDS block must not grow -- 53.6 KB is the last size of which three fit a CU at the hardware's allocation
         // granularity (one more 256 B and only two workgroups are resident: measured 2.8 -> 4.2 ms)
@@ -618,21 +649,30 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             }
             // ---- K0 = -Qinv Qux, then one refinement step against Quu itself (the explicit float32 inverse alone costs a
             //      factor 40 in accuracy): R = Qux + Quu K0, K = K0 - Qinv R.  A COLUMN BLOCK of K needs only the same
-            //      column block of K0 and R, so wavefront w < 3 runs the three products for columns 16 w .. 16 w + 15
-            //      (2 tiles each) back to back without a barrier; the last wavefront does the same for the vector:
+            //      column block of K0 and R, and an accumulator tile is the B operand of the next product as it stands
+            //      (mfma_acc_regb): wavefront w = 1..3 runs the three products of block w - 1 in registers, 48 matrix
+            //      instructions fed by the A operands only; wavefront 0 does the same for the vector:
             //      kff0 = -Qinv qu, r = qu + Quu kff0, kff = kff0 - Qinv r
-            if (wave < 3) {
-                const int j0 = wave * 16;
+            if (role != 0) {
+                const int j0 = (role - 1) * 16;
+                f4 k0t[2], rt[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    mfma_tile<false, false, 32>(Qinv, LDU, S.Qux, LDX, i * 16, j0, SK, LDX, nullptr, 0, 0.f, nullptr, -1.f);
+                for (int i = 0; i < 2; ++i) k0t[i] = -mfma_acc<false, false, 32>(Qinv, LDU, S.Qux, LDX, i * 16, j0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    mfma_tile<false, false, 32>(S.Quu, LDU, SK, LDX, i * 16, j0, Rres, LDX, S.Qux, LDX, 0.f, nullptr);
+                for (int i = 0; i < 2; ++i) {
+                    f4 acc = tile_load(S.Qux, LDX, i * 16, j0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    mfma_tile<false, false, 32>(Qinv, LDU, Rres, LDX, i * 16, j0, SK, LDX, SK, LDX, 0.f, nullptr, -1.f);
-            } else if (wl < 32) {
+                    for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<false>(S.Quu, LDU, i * 16, 16 * t, k0t[t], acc);
+                    rt[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<false>(Qinv, LDU, i * 16, 16 * t, rt[t], acc);
+                    kt[i] = k0t[i] - acc;
+                }
+            } else if (wl < 32) { // role 0
                 const int i = wl;
                 float acc = 0.f;
 #pragma unroll 8
@@ -681,31 +721,38 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             }
             __syncthreads();
         }
-        if (__any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f)) { // clamped inputs do not react to dx
-            for (int i = tid; i < 32 * 48; i += RIC_THREADS)
-                if (clampm[i / 48] != 0.f) SK[(i / 48) * LDX + (i % 48)] = 0.f;
-            __syncthreads();
-        }
-        if (k > 0) RIC_DEPOSIT_B() // S.B (refinement residual) and the stage's vectors are dead; read again after the barrier below
-        // feedback gains to HBM
-        {
-            float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
-            for (int i = tid; i < 32 * 48; i += RIC_THREADS) Kg[i] = SK[(i / 48) * LDX + (i % 48)];
-            if (tid < 32) g.kff[((size_t)b * N + k) * 32 + tid] = S.kff[tid];
-        }
-        // ---- P <- Q + Qxx + Qux' K: the 6 upper-triangular tiles, each on the wavefront that still holds its Qxx tile in
-        //      registers (Qxx never goes through LDS), mirrored on store; p <- qx + Qux' kff on wavefront 0
+        const bool any_clamp = __any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f);
+        if (k > 0) RIC_DEPOSIT_B() // S.B and the stage's vectors are dead; read again after the barrier below
+        // ---- K, kff -> HBM (forward sweep); P <- Q + Qxx + Qux' K: the 6 upper-triangular tiles, each on the wavefront that
+        //      holds its Qxx tile AND its column block of K in registers (neither goes through LDS), mirrored on store;
+        //      p <- qx + Qux' kff on wavefront 0
         if (role != 0) {
+            const int j0 = (role - 1) * 16, c16 = wl & 15, q4 = wl >> 4;
+            float* Kg = g.K + ((size_t)b * N + k) * 32 * 48;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + 4 * q4 + r;
+                    if (any_clamp && clampm[row] != 0.f) kt[t][r] = 0.f; // clamped inputs do not react to dx
+                    Kg[row * 48 + j0 + c16] = kt[t][r];
+                }
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (i < role)
-                    tile_store<true>(mfma_acc<true, false, 32>(S.Qux, LDX, SK, LDX, i * 16, (role - 1) * 16) + qxx[i], i * 16, (role - 1) * 16, S.P, LDX,
-                                     nullptr, 0, 1.f, S.wq);
-        } else if (wl < 48) {
-            const int i = wl;
-            float acc = S.qx[i];
-            for (int j = 0; j < 32; ++j) acc += S.Qux[j * LDX + i] * S.kff[j];
-            S.p[i] = acc;
+                if (i < role) {
+                    f4 acc = qxx[i];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<true>(S.Qux, LDX, i * 16, 16 * t, kt[t], acc);
+                    tile_store<true>(acc, i * 16, j0, S.P, LDX, nullptr, 0, 1.f, S.wq);
+                }
+        } else {
+            if (wl < 32) g.kff[((size_t)b * N + k) * 32 + wl] = S.kff[wl];
+            if (wl < 48) {
+                const int i = wl;
+                float acc = S.qx[i];
+                for (int j = 0; j < 32; ++j) acc += S.Qux[j * LDX + i] * S.kff[j];
+                S.p[i] = acc;
+            }
         }
         __syncthreads();
         WB_STAMP(g.stamps, 8)
