@@ -422,12 +422,12 @@ __device__ __forceinline__ void tile_store(f4 acc, int i0, int j0, float* Cm, in
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + 4 * kq + r, col = j0 + r16;
-        if (MIRROR && row > col) continue; // symmetric result: the upper triangle is computed once and written twice
+        if (MIRROR && i0 == j0 && row > col) continue; // symmetric result: one triangle is computed and written twice
         float v = scale * acc[r];
         if (Cinit) v += Cinit[row * ldi + col];
         if (diag && row == col) v += alpha_diag * diag[row];
         Cm[row * ldc + col] = v;
-        if (MIRROR && row < col) Cm[col * ldc + row] = v;
+        if (MIRROR && (i0 != j0 || row < col)) Cm[col * ldc + row] = v;
     }
 }
 
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         //      them.  The Qxx tiles stay in registers until the end of the stage, where the same wavefront adds Qux' K.  qx = gx + A' s, qu = gu + B' s on the wavefront with fewest tiles.
         const int role = wave; // 0 inverts, 1 .. 3 multiply (rotating the role over the wavefronts / SIMDs was measured: no effect)
         const int wl = tid & 63;
-        f4 qxx[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f4 qxx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // Qxx tiles (j, j) and ((j + 2) % 3, j) of the wavefront's column block j
         f4 kt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // the wavefront's column block of the gain K (rows 0..15, 16..31), C layout
         if (role != 0) {
             const int j0 = (role - 1) * 16;
@@ -571,9 +571,9 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, i * 16, j0, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (i < role) qxx[i] = mfma_acc<true, false, 48>(S.A, LDX, S.PA, LDX, i * 16, j0);
+            // the symmetric Qxx as 6 tiles, two per column block: (j, j) and ((j + 2) % 3, j) -- (0,0) (2,0) | (1,1) (0,1) | (2,2) (1,2)
+            qxx[0] = mfma_acc<true, false, 48>(S.A, LDX, S.PA, LDX, j0, j0);
+            qxx[1] = mfma_acc<true, false, 48>(S.A, LDX, S.PA, LDX, ((role + 1) % 3) * 16, j0);
             const int l = wl;
             if (role == 1 && l < 48) {
                 float acc = S.gx[l];
@@ -738,13 +738,13 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
                     Kg[row * 48 + j0 + c16] = kt[t][r];
                 }
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if (i < role) {
-                    f4 acc = qxx[i];
+            for (int n = 0; n < 2; ++n) {
+                const int i0 = n == 0 ? j0 : ((role + 1) % 3) * 16;
+                f4 acc = qxx[n];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<true>(S.Qux, LDX, i * 16, 16 * t, kt[t], acc);
-                    tile_store<true>(acc, i * 16, j0, S.P, LDX, nullptr, 0, 1.f, S.wq);
-                }
+                for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<true>(S.Qux, LDX, i0, 16 * t, kt[t], acc);
+                tile_store<true>(acc, i0, j0, S.P, LDX, nullptr, 0, 1.f, S.wq);
+            }
         } else {
             if (wl < 32) g.kff[((size_t)b * N + k) * 32 + wl] = S.kff[wl];
             if (wl < 48) {
