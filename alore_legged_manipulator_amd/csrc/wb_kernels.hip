@@ -615,27 +615,24 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
                 float* T = Qinv + 32 * LDU;               // 16 x 16, stride LDU (PB has 48 rows, Qinv uses 32)
                 float* Q22 = Qinv + 16 * LDU + 16;
                 const int rr = wl & 15;
+                const int qc = 4 * (wl >> 4); // lane 16 p + r: columns 4 p .. 4 p + 3 of row r
                 {
-                    float r16v[16];
+                    float rq[4];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) r16v[j] = S.Quu[rr * LDU + j];
-                    wavela::spd_inverse_rows<float, 16>(r16v, wl);
-                    if (wl < 16) {
+                    for (int j = 0; j < 4; ++j) rq[j] = S.Quu[rr * LDU + qc + j];
+                    wavela::spd_inverse16_quarters(rq, wl);
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) Qinv[wl * LDU + j] = r16v[j];
-                    }
+                    for (int j = 0; j < 4; ++j) Qinv[rr * LDU + qc + j] = rq[j];
                 }
                 mfma_tile<false, false, 16>(Qinv, LDU, S.Quu + 16, LDU, 0, 0, T, LDU, nullptr, 0, 0.f, nullptr);                      // T = A11^-1 A12
                 mfma_tile<false, false, 16>(S.Quu + 16 * LDU, LDU, T, LDU, 0, 0, Q22, LDU, S.Quu + 16 * LDU + 16, LDU, 0.f, nullptr, -1.f); // S = A22 - A21 T
                 {
-                    float r16v[16];
+                    float rq[4];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) r16v[j] = Q22[rr * LDU + j];
-                    wavela::spd_inverse_rows<float, 16>(r16v, wl);
-                    if (wl < 16) {
+                    for (int j = 0; j < 4; ++j) rq[j] = Q22[rr * LDU + qc + j];
+                    wavela::spd_inverse16_quarters(rq, wl);
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) Q22[wl * LDU + j] = r16v[j];
-                    }
+                    for (int j = 0; j < 4; ++j) Q22[rr * LDU + qc + j] = rq[j];
                 }
                 mfma_tile<false, false, 16>(T, LDU, Q22, LDU, 0, 0, Qinv + 16, LDU, nullptr, 0, 0.f, nullptr, -1.f);                 // -T S^-1
                 mfma_tile<false, true, 16>(Q22, LDU, T, LDU, 0, 0, Qinv + 16 * LDU, LDU, nullptr, 0, 0.f, nullptr, -1.f);            // -S^-1 T'
