@@ -369,11 +369,11 @@ struct RicArgs {
     const float* vec;    // [B][N][160] right-hand sides written by the stage kernel
 };
 
-// 53.6 KB: three workgroups per CU.  Buffers are reused inside a stage: Qxx is written over P (dead after P A, P B, P d),
-// Quu^-1 lives in PB and the refinement residual in PA (both dead once Qxx, Qux, Quu exist), K lives in B (dead after
-// qu = gu + B' s), and the next cost-to-go accumulates in place over Qxx.
+// 44.2 KB: three workgroups per CU (the register budget of the kernel asks for no more).  P A, Qxx, the gains K0 / R / K
+// and Qux' K never exist in LDS: they are accumulator tiles that the next product takes as its B operand as they stand.
+// Quu^-1 (and the 16 x 16 temporary of its block form) lives in PB, dead once Quu = B' PB exists.
 struct RicLds {
-    float P[48 * LDX], A[48 * LDX], PA[48 * LDX];
+    float P[48 * LDX], A[48 * LDX];
     float B[48 * LDU], PB[48 * LDU];
     float Qux[32 * LDX];
     float Quu[32 * LDU];
@@ -563,17 +563,30 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         const int wl = tid & 63;
         f4 qxx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // Qxx tiles (j, j) and ((j + 2) % 3, j) of the wavefront's column block j
         f4 kt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // the wavefront's column block of the gain K (rows 0..15, 16..31), C layout
+        f4 quxt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}; // ... and of Qux
         if (role != 0) {
             const int j0 = (role - 1) * 16;
+            // PA(:, j) stays in registers (three accumulator tiles) and is the B operand of the products below as it stands
+            f4 pa[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                mfma_tile<false, false, 48>(S.P, LDX, S.A, LDX, i * 16, j0, S.PA, LDX, nullptr, 0, 0.f, nullptr);
+            for (int t = 0; t < 3; ++t) pa[t] = mfma_acc<false, false, 48>(S.P, LDX, S.A, LDX, t * 16, j0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                mfma_tile<true, false, 48>(S.B, LDU, S.PA, LDX, i * 16, j0, S.Qux, LDX, nullptr, 0, 0.f, nullptr);
+            for (int i = 0; i < 2; ++i) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc = mfma_acc_regb<true>(S.B, LDU, i * 16, 16 * t, pa[t], acc);
+                quxt[i] = acc;
+                tile_store<false>(acc, i * 16, j0, S.Qux, LDX, nullptr, 0, 0.f, nullptr); // the cost-to-go tiles of the other wavefronts read it
+            }
             // the symmetric Qxx as 6 tiles, two per column block: (j, j) and ((j + 2) % 3, j) -- (0,0) (2,0) | (1,1) (0,1) | (2,2) (1,2)
-            qxx[0] = mfma_acc<true, false, 48>(S.A, LDX, S.PA, LDX, j0, j0);
-            qxx[1] = mfma_acc<true, false, 48>(S.A, LDX, S.PA, LDX, ((role + 1) % 3) * 16, j0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int i0 = n == 0 ? j0 : ((role + 1) % 3) * 16;
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc = mfma_acc_regb<true>(S.A, LDX, i0, 16 * t, pa[t], acc);
+                qxx[n] = acc;
+            }
             const int l = wl;
             if (role == 1 && l < 48) {
                 float acc = S.gx[l];
@@ -654,10 +667,15 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
                 const int j0 = (role - 1) * 16;
                 f4 k0t[2], rt[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) k0t[i] = -mfma_acc<false, false, 32>(Qinv, LDU, S.Qux, LDX, i * 16, j0);
+                for (int i = 0; i < 2; ++i) {
+                    f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<false>(Qinv, LDU, i * 16, 16 * t, quxt[t], acc);
+                    k0t[i] = -acc;
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    f4 acc = tile_load(S.Qux, LDX, i * 16, j0);
+                    f4 acc = quxt[i];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<false>(S.Quu, LDU, i * 16, 16 * t, k0t[t], acc);
                     rt[i] = acc;
