@@ -458,6 +458,25 @@ __device__ __forceinline__ f4 mfma_acc_regb(const float* A, int lda, int i0, int
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], x[s], acc, 0, 0, 0);
     return acc;
 }
+// the two halves of mfma_acc_regb: the A operand of a 16 x 16 block in the permuted k order, and its application
+template <bool TA>
+__device__ __forceinline__ void load_a4(const float* A, int lda, int i0, int k0, float (&a)[4])
+{
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    const int r16 = l & 15, kq = l >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k = k0 + 4 * kq + s;
+        a[s] = TA ? A[k * lda + i0 + r16] : A[(i0 + r16) * lda + k];
+    }
+}
+__device__ __forceinline__ f4 mfma4(const float (&a)[4], f4 x, f4 acc)
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], x[s], acc, 0, 0, 0);
+    return acc;
+}
 // a 16 x 16 tile of an LDS matrix in the C layout
 __device__ __forceinline__ f4 tile_load(const float* M, int ld, int i0, int j0)
 {
@@ -663,57 +682,63 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             //      (mfma_acc_regb): wavefront w = 1..3 runs the three products of block w - 1 in registers, 48 matrix
             //      instructions fed by the A operands only; wavefront 0 does the same for the vector:
             //      kff0 = -Qinv qu, r = qu + Quu kff0, kff = kff0 - Qinv r
-            if (role != 0) {
-                const int j0 = (role - 1) * 16;
+            {
+                // wavefront 0 runs the same chain on the 32 x 16 "block" [qu | 0 ... 0]: column 0 of its result is kff (the
+                // matrix cores of its SIMD are idle, and three 32-term dot products per lane out of LDS took twice as long)
+                const int c16 = wl & 15, q4 = wl >> 4;
+                f4 in[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) in[t][r] = role != 0 ? quxt[t][r] : (c16 == 0 ? S.qu[16 * t + 4 * q4 + r] : 0.f);
+                // all A operands first (Quu^-1 serves two of the three products): one LDS latency in front of 48 chained
+                // matrix instructions instead of one in front of each product
+                float aq[2][2][4], au[2][2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) { load_a4<false>(Qinv, LDU, i * 16, 16 * t, aq[i][t]); load_a4<false>(S.Quu, LDU, i * 16, 16 * t, au[i][t]); }
                 f4 k0t[2], rt[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<false>(Qinv, LDU, i * 16, 16 * t, quxt[t], acc);
+                    for (int t = 0; t < 2; ++t) acc = mfma4(aq[i][t], in[t], acc);
                     k0t[i] = -acc;
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    f4 acc = quxt[i];
+                    f4 acc = in[i];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<false>(S.Quu, LDU, i * 16, 16 * t, k0t[t], acc);
+                    for (int t = 0; t < 2; ++t) acc = mfma4(au[i][t], k0t[t], acc);
                     rt[i] = acc;
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<false>(Qinv, LDU, i * 16, 16 * t, rt[t], acc);
+                    for (int t = 0; t < 2; ++t) acc = mfma4(aq[i][t], rt[t], acc);
                     kt[i] = k0t[i] - acc;
                 }
-            } else if (wl < 32) { // role 0
-                const int i = wl;
-                float acc = 0.f;
-#pragma unroll 8
-                for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.qu[j];
-                S.kff[i] = -acc;
-                __builtin_amdgcn_wave_barrier(); // one wavefront: its LDS operations complete in order
-                acc = S.qu[i];
-#pragma unroll 8
-                for (int j = 0; j < 32; ++j) acc += S.Quu[i * LDU + j] * S.kff[j];
-                S.duk[i] = acc; // residual of the feed-forward term (duk is free during the backward sweep)
-                __builtin_amdgcn_wave_barrier();
-                acc = 0.f;
-#pragma unroll 8
-                for (int j = 0; j < 32; ++j) acc += Qinv[i * LDU + j] * S.duk[j];
-                __builtin_amdgcn_wave_barrier();
-                const float kf = S.kff[i] - acc;
-                S.kff[i] = kf;
-                if (round == 0) { // torque limits on the feed-forward step of this stage: flags / values for the pass below
-                    float m = 0.f;
-                    if (g.limits && i < b2z1::NJ) {
-                        const float ucur = S.dxn[i], eff = (float)b2z1::EFFORT[i];
-                        const float lo = -eff - ucur, hi = eff - ucur;
-                        if (kf < lo - 1e-4f * eff) { m = 1.f; clampv[i] = lo; }
-                        else if (kf > hi + 1e-4f * eff) { m = 1.f; clampv[i] = hi; }
+                if (role == 0) {
+                    if (c16 == 0) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) S.kff[16 * t + 4 * q4 + r] = kt[t][r];
                     }
-                    clampm[i] = m;
+                    __builtin_amdgcn_wave_barrier(); // one wavefront: its LDS operations complete in order
+                    if (round == 0 && wl < 32) { // torque limits on the feed-forward step of this stage: flags / values for the pass below
+                        const int i = wl;
+                        float m = 0.f;
+                        if (g.limits && i < b2z1::NJ) {
+                            const float kf = S.kff[i], ucur = S.dxn[i], eff = (float)b2z1::EFFORT[i];
+                            const float lo = -eff - ucur, hi = eff - ucur;
+                            if (kf < lo - 1e-4f * eff) { m = 1.f; clampv[i] = lo; }
+                            else if (kf > hi + 1e-4f * eff) { m = 1.f; clampv[i] = hi; }
+                        }
+                        clampm[i] = m;
+                    }
                 }
             }
             __syncthreads();
@@ -762,11 +787,17 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             }
         } else {
             if (wl < 32) g.kff[((size_t)b * N + k) * 32 + wl] = S.kff[wl];
-            if (wl < 48) {
-                const int i = wl;
-                float acc = S.qx[i];
-                for (int j = 0; j < 32; ++j) acc += S.Qux[j * LDX + i] * S.kff[j];
-                S.p[i] = acc;
+            // p <- qx + Qux' kff: column 0 of Qux' [kff | 0 ... 0], the wavefront's own tiles again
+            const int c16 = wl & 15, q4 = wl >> 4;
+#pragma unroll
+            for (int ib = 0; ib < 3; ++ib) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<true>(S.Qux, LDX, ib * 16, 16 * t, kt[t], acc);
+                if (c16 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S.p[ib * 16 + 4 * q4 + r] = S.qx[ib * 16 + 4 * q4 + r] + acc[r];
+                }
             }
         }
         __syncthreads();
