@@ -334,13 +334,17 @@ __global__ __launch_bounds__(64) void rnea_kernel(int n, const double* q, const 
 // which is ONE wavefront's dependent chain and the longest phase of a stage:
 //   1. PB = P B (6 tiles), s = P d + p                                                    | barrier
 //   2. Quu = B' PB (3 upper-triangular tiles, mirrored)                                   | barrier
-//   3. wavefront 0: Quu + R, Quu^-1 (30 x 30, in-register Gauss-Jordan, wave_linalg.h)
-//      wavefront w = 1..3 owns column block j = w - 1: PA(:, j) = P A(:, j), Qux(:, j) = B' PA(:, j), the upper-triangular
-//      tiles of Qxx(., j) = A' PA(:, j) (kept in registers), qx, qu -- no barrier inside a column block   | barrier
-//   4. wavefront w = 0..2, column block w: K0 = -Quu^-1 Qux, R = Qux + Quu K0, K = K0 - Quu^-1 R (one refinement step),
-//      wavefront 3 the same for kff, and the torque-limit test (clamp + re-solve of the free inputs: back to 3.)  | barrier
-//   5. K, kff -> HBM (forward sweep); P <- Q + Qxx + Qux' K on the wavefronts that hold the Qxx tiles, p <- qx + Qux' kff  | barrier
-// The next stage's A, B and right-hand sides are requested into registers during 4. and deposited when their buffers die.
+//   3. wavefront 0: Quu + R, Quu^-1 (2 x 2 blocks of 16: two in-register Gauss-Jordan eliminations on 64 lanes, five
+//      16^3 products; wave_linalg.h)
+//      wavefront w = 1..3 owns column block j = w - 1: PA(:, j) = P A(:, j) -> Qux(:, j) = B' PA(:, j) and two tiles of
+//      Qxx(., j) = A' PA(:, j), as one chain of matrix instructions: an accumulator tile is the next product's B operand
+//      (mfma_acc_regb); PA and Qxx stay in registers; qx, qu                              | barrier
+//   4. wavefront w = 1..3, column block w - 1, again one chain in registers: K0 = -Quu^-1 Qux, R = Qux + Quu K0,
+//      K = K0 - Quu^-1 R (one refinement step); wavefront 0 the same chain on [qu | 0] for kff, and the torque-limit
+//      test (clamp + re-solve of the free inputs: back to 3.)                             | barrier
+//   5. K (from the accumulators), kff -> HBM (forward sweep); P <- Q + Qxx + Qux' K, two tiles per column block, on the
+//      wavefront that holds Qxx and K; p <- qx + Qux' kff on wavefront 0                  | barrier
+// The next stage's A, B and right-hand sides are requested into registers during 3. / 4. and deposited when their buffers die.
 // Forward: dx_0 = x0 - x_0, du_k = K_k dx_k + kff_k, dx_{k+1} = A_k dx_k + B_k du_k + d_k; then x += dx, u += du with
 // the joint torques clipped to the URDF effort limits.
 // =====================================================================================================================
