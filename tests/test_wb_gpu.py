@@ -236,3 +236,26 @@ def test_torque_limits_in_the_riccati_sweep(model):
     eng.rti(1)
     dx_u, du_u = eng.last_step()
     assert np.max(np.abs(du_u - du)) > 1.0
+
+
+def test_result_of_a_problem_is_bit_reproducible_and_independent_of_its_batch_mates(model):
+    """One workgroup per problem, every reduction in a fixed order (matrix instructions, DPP, v_readlane): the step of a
+    problem has the same bits in a batch of 6, alone, and on a second run."""
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    B, N, dt = 6, 10, 0.01
+    x0, xref, uref, xi, ui = make_problems(model, B, N, seed=5)
+    Q, R, QN = weights()
+
+    def run(sel):
+        eng = BatchedWholeBody(len(sel), N, dt)
+        eng.set_weights(Q, R, QN)
+        eng.set_problem(x0[sel], xref[sel], uref[sel])
+        eng.set_iterate(xi[sel], ui[sel])
+        eng.rti(1)
+        return eng.last_step()
+
+    dx_all, du_all = run(list(range(B)))
+    dx_again, du_again = run(list(range(B)))
+    assert np.array_equal(dx_all, dx_again) and np.array_equal(du_all, du_again)
+    dx_one, du_one = run([3])
+    assert np.array_equal(dx_one[0], dx_all[3]) and np.array_equal(du_one[0], du_all[3])
