@@ -166,53 +166,77 @@ __device__ __forceinline__ B2 inv2(const B2& m)
     const double id = 1.0 / (m.a * m.d - m.b * m.c);
     return {m.d * id, -m.b * id, -m.c * id, m.a * id};
 }
-__device__ __forceinline__ B2 shfl_up(const B2& m, int s) { return {__shfl_up(m.a, s), __shfl_up(m.b, s), __shfl_up(m.c, s), __shfl_up(m.d, s)}; }
-__device__ __forceinline__ B2 shfl_down(const B2& m, int s) { return {__shfl_down(m.a, s), __shfl_down(m.b, s), __shfl_down(m.c, s), __shfl_down(m.d, s)}; }
+// neighbour at distance S along the lanes: through the DPP row shifts when all knots sit in one row of 16 lanes (M <= 16:
+// a float64 costs two 32-bit DPP moves at VALU speed), through the LDS permute otherwise (two ds_bpermute per float64,
+// ~100 cycles of latency each time: 64 values per reduction step)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int S, bool DPP> __device__ __forceinline__ double lane_up(double x) { if constexpr (DPP) return dpp_mov64<0x110 + S>(x); else return __shfl_up(x, S); }   // lane i <- lane i - S
+template <int S, bool DPP> __device__ __forceinline__ double lane_down(double x) { if constexpr (DPP) return dpp_mov64<0x100 + S>(x); else return __shfl_down(x, S); } // lane i <- lane i + S
+template <int S, bool DPP> __device__ __forceinline__ B2 lane_up(const B2& m) { return {lane_up<S, DPP>(m.a), lane_up<S, DPP>(m.b), lane_up<S, DPP>(m.c), lane_up<S, DPP>(m.d)}; }
+template <int S, bool DPP> __device__ __forceinline__ B2 lane_down(const B2& m) { return {lane_down<S, DPP>(m.a), lane_down<S, DPP>(m.b), lane_down<S, DPP>(m.c), lane_down<S, DPP>(m.d)}; }
+
+struct PcrState { B2 Lk, Dk, Uk; double r0, r1, r2, r3; };
+
+template <int S, bool DPP>
+__device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk)
+{
+    const B2 Lm = lane_up<S, DPP>(q.Lk), Dm = lane_up<S, DPP>(q.Dk), Um = lane_up<S, DPP>(q.Uk);
+    const double m0 = lane_up<S, DPP>(q.r0), m1 = lane_up<S, DPP>(q.r1), m2 = lane_up<S, DPP>(q.r2), m3 = lane_up<S, DPP>(q.r3);
+    const B2 Lp = lane_down<S, DPP>(q.Lk), Dp = lane_down<S, DPP>(q.Dk), Up = lane_down<S, DPP>(q.Uk);
+    const double p0 = lane_down<S, DPP>(q.r0), p1 = lane_down<S, DPP>(q.r1), p2 = lane_down<S, DPP>(q.r2), p3 = lane_down<S, DPP>(q.r3);
+    const bool hm = act && e - S >= 0, hp = act && e + S < nk;
+    B2 al{0, 0, 0, 0}, ga{0, 0, 0, 0};
+    if (hm) { const B2 t = mul(q.Lk, inv2(Dm)); al = {-t.a, -t.b, -t.c, -t.d}; }
+    if (hp) { const B2 t = mul(q.Uk, inv2(Dp)); ga = {-t.a, -t.b, -t.c, -t.d}; }
+    if (hm) {
+        const B2 t = mul(al, Um);
+        q.Dk = {q.Dk.a + t.a, q.Dk.b + t.b, q.Dk.c + t.c, q.Dk.d + t.d};
+        q.r0 += al.a * m0 + al.b * m1; q.r1 += al.c * m0 + al.d * m1;
+        q.r2 += al.a * m2 + al.b * m3; q.r3 += al.c * m2 + al.d * m3;
+        q.Lk = mul(al, Lm);
+    } else q.Lk = {0, 0, 0, 0};
+    if (hp) {
+        const B2 t = mul(ga, Lp);
+        q.Dk = {q.Dk.a + t.a, q.Dk.b + t.b, q.Dk.c + t.c, q.Dk.d + t.d};
+        q.r0 += ga.a * p0 + ga.b * p1; q.r1 += ga.c * p0 + ga.d * p1;
+        q.r2 += ga.a * p2 + ga.b * p3; q.r3 += ga.c * p2 + ga.d * p3;
+        q.Uk = mul(ga, Up);
+    } else q.Uk = {0, 0, 0, 0};
+}
 
 // rhs / solution: y[d][lane][0..1] in LDS for d = 0, 1 (the caller's layout); all 64 lanes must call
+template <int P>
 __device__ __forceinline__ void knot_pcr(int M, const double* T, double (*y0)[2], double (*y1)[2])
 {
+    constexpr bool DPP = P <= 16; // all knots (<= 15) in one DPP row
     const int e = threadIdx.x, nk = M - 1;
     const bool act = e < nk;
-    B2 Lk{0, 0, 0, 0}, Dk{1, 0, 0, 1}, Uk{0, 0, 0, 0};
-    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+    PcrState q{{0, 0, 0, 0}, {1, 0, 0, 1}, {0, 0, 0, 0}, 0.0, 0.0, 0.0, 0.0};
     if (act) {
         const int k = e + 1;
         const minco::InvT l(T[k - 1]), r(T[k]);
         const minco::Sym2 dg = minco::knot_diag(l, r);
-        Dk = {dg.a, dg.b, dg.b, dg.c};
-        if (k > 1) { const minco::Mat2 u = minco::knot_upper(l); Lk = {u.a, u.c, u.b, u.d}; } // U_{k-1}'
-        if (k < M - 1) { const minco::Mat2 u = minco::knot_upper(r); Uk = {u.a, u.b, u.c, u.d}; }
-        r0 = y0[e][0]; r1 = y0[e][1]; r2 = y1[e][0]; r3 = y1[e][1];
+        q.Dk = {dg.a, dg.b, dg.b, dg.c};
+        if (k > 1) { const minco::Mat2 u = minco::knot_upper(l); q.Lk = {u.a, u.c, u.b, u.d}; } // U_{k-1}'
+        if (k < M - 1) { const minco::Mat2 u = minco::knot_upper(r); q.Uk = {u.a, u.b, u.c, u.d}; }
+        q.r0 = y0[e][0]; q.r1 = y0[e][1]; q.r2 = y1[e][0]; q.r3 = y1[e][1];
     }
-    for (int s = 1; s < nk; s <<= 1) {
-        const B2 Lm = shfl_up(Lk, s), Dm = shfl_up(Dk, s), Um = shfl_up(Uk, s);
-        const double m0 = __shfl_up(r0, s), m1 = __shfl_up(r1, s), m2 = __shfl_up(r2, s), m3 = __shfl_up(r3, s);
-        const B2 Lp = shfl_down(Lk, s), Dp = shfl_down(Dk, s), Up = shfl_down(Uk, s);
-        const double p0 = __shfl_down(r0, s), p1 = __shfl_down(r1, s), p2 = __shfl_down(r2, s), p3 = __shfl_down(r3, s);
-        const bool hm = act && e - s >= 0, hp = act && e + s < nk;
-        B2 al{0, 0, 0, 0}, ga{0, 0, 0, 0};
-        if (hm) { const B2 t = mul(Lk, inv2(Dm)); al = {-t.a, -t.b, -t.c, -t.d}; }
-        if (hp) { const B2 t = mul(Uk, inv2(Dp)); ga = {-t.a, -t.b, -t.c, -t.d}; }
-        if (hm) {
-            const B2 t = mul(al, Um);
-            Dk = {Dk.a + t.a, Dk.b + t.b, Dk.c + t.c, Dk.d + t.d};
-            r0 += al.a * m0 + al.b * m1; r1 += al.c * m0 + al.d * m1;
-            r2 += al.a * m2 + al.b * m3; r3 += al.c * m2 + al.d * m3;
-            Lk = mul(al, Lm);
-        } else Lk = {0, 0, 0, 0};
-        if (hp) {
-            const B2 t = mul(ga, Lp);
-            Dk = {Dk.a + t.a, Dk.b + t.b, Dk.c + t.c, Dk.d + t.d};
-            r0 += ga.a * p0 + ga.b * p1; r1 += ga.c * p0 + ga.d * p1;
-            r2 += ga.a * p2 + ga.b * p3; r3 += ga.c * p2 + ga.d * p3;
-            Uk = mul(ga, Up);
-        } else Uk = {0, 0, 0, 0};
-    }
+    if (1 < nk) pcr_step<1, DPP>(q, act, e, nk);
+    if (2 < nk) pcr_step<2, DPP>(q, act, e, nk);
+    if (4 < nk) pcr_step<4, DPP>(q, act, e, nk);
+    if (8 < nk) pcr_step<8, DPP>(q, act, e, nk);
+    if constexpr (P > 16) { if (16 < nk) pcr_step<16, false>(q, act, e, nk); }
     if (act) {
-        const B2 di = inv2(Dk);
-        y0[e][0] = di.a * r0 + di.b * r1; y0[e][1] = di.c * r0 + di.d * r1;
-        y1[e][0] = di.a * r2 + di.b * r3; y1[e][1] = di.c * r2 + di.d * r3;
+        const B2 di = inv2(q.Dk);
+        y0[e][0] = di.a * q.r0 + di.b * q.r1; y0[e][1] = di.c * q.r0 + di.d * q.r1;
+        y1[e][0] = di.a * q.r2 + di.b * q.r3; y1[e][1] = di.c * q.r2 + di.d * q.r3;
     }
 }
 
@@ -277,7 +301,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     }
     __syncthreads();
     BE_STAMP(2)
-    knot_pcr(M, L.T, L.y[0], L.y[1]);
+    knot_pcr<P>(M, L.T, L.y[0], L.y[1]);
     __syncthreads();
     if (lane < 2)
         for (int k = 1; k < M; ++k) { L.kv[lane][k] = L.y[lane][k - 1][0]; L.ka[lane][k] = L.y[lane][k - 1][1]; }
@@ -556,7 +580,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     }
     __syncthreads();
     BE_STAMP(15)
-    knot_pcr(M, L.T, L.y[0], L.y[1]); // K is symmetric: the same system
+    knot_pcr<P>(M, L.T, L.y[0], L.y[1]); // K is symmetric: the same system
     __syncthreads();
     BE_STAMP(16)
     // way-point and tail gradients: lane = (knot 1..M, dim)
