@@ -62,6 +62,27 @@ __device__ __forceinline__ double wave_sum(double v)
     v += dpp_f64<0x143, 0xC>(0.0, v); // row_bcast31 into rows 2 and 3
     return lane63(v);
 }
+// inclusive prefix sum over the 64 lanes (the scan wave_sum reads its total from), and the suffix sum: lanes reversed
+// (one LDS permute there and one back instead of six dependent ones), the same scan
+__device__ __forceinline__ double wave_prefix(double v)
+{
+    v += dpp_f64<0x111, 0xF>(0.0, v);
+    v += dpp_f64<0x112, 0xF>(0.0, v);
+    v += dpp_f64<0x114, 0xF>(0.0, v);
+    v += dpp_f64<0x118, 0xF>(0.0, v);
+    v += dpp_f64<0x142, 0xA>(0.0, v);
+    v += dpp_f64<0x143, 0xC>(0.0, v);
+    return v;
+}
+__device__ __forceinline__ double wave_suffix(double v)
+{
+    const int rev = 63 - (int)threadIdx.x;
+    return __shfl(wave_prefix(__shfl(v, rev)), rev);
+}
+__device__ __forceinline__ double lane0(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+}
 __device__ __forceinline__ double wave_max(double v)
 {
     v = fmax(v, dpp_f64<0x111, 0xF>(v, v)); // lanes without a source keep `old` = their own value
@@ -409,14 +430,10 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
                 ix = cint * L.fx[n0]; ix += 4.0 * cint * L.fx[n0 + 1]; ix += cint * L.fx[n0 + 2];
                 iy = cint * L.fy[n0]; iy += 4.0 * cint * L.fy[n0 + 1]; iy += cint * L.fy[n0 + 2];
             }
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const double tx = __shfl_up(ix, o), ty = __shfl_up(iy, o);
-                if (lane >= o) { ix += tx; iy += ty; }
-            }
+            ix = wave_prefix(ix); iy = wave_prefix(iy);
             if (p < NP) { L.posx[p + 1] = carry_x + ix; L.posy[p + 1] = carry_y + iy; }
-            carry_x += __shfl(ix, 63);
-            carry_y += __shfl(iy, 63);
+            carry_x += lane63(ix);
+            carry_y += lane63(iy);
         }
     }
     __syncthreads();
@@ -485,14 +502,10 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         for (int r = rounds - 1; r >= 0; --r) {
             const int node = r * 64 + lane;
             double vx = node < NN ? L.fx[node] : 0.0, vy = node < NN ? L.fy[node] : 0.0;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const double tx = __shfl_down(vx, o), ty = __shfl_down(vy, o);
-                if (lane + o < 64) { vx += tx; vy += ty; }
-            }
+            vx = wave_suffix(vx); vy = wave_suffix(vy);
             if (node < NN) { L.fx[node] = vx + carry_x + add_x; L.fy[node] = vy + carry_y + add_y; }
-            carry_x += __shfl(vx, 0);
-            carry_y += __shfl(vy, 0);
+            carry_x += lane0(vx);
+            carry_y += lane0(vy);
         }
     }
     __syncthreads();
@@ -863,11 +876,7 @@ __device__ __attribute__((noinline)) bool final_collision(const Params* __restri
                 iy += w * (d1[1] * sy - d1[0] * xvI * cy);
             }
         }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double tx = __shfl_up(ix, o), ty = __shfl_up(iy, o);
-            if (lane >= o) { ix += tx; iy += ty; }
-        }
+        ix = wave_prefix(ix); iy = wave_prefix(iy);
         if (p < NP) {
             double gx, gy;
             const double sd = esdf(prm.map, carry_x + ix, carry_y + iy, false, 0.0, gx, gy);
