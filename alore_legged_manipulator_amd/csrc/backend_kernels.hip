@@ -346,7 +346,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         L.gdC[(6 * i + 5) * 2 + d] = w * (240.0 * c3 * t3 + 720.0 * c4 * t4 + 1440.0 * c5 * t5);
         double gt = w * (36.0 * c3 * c3 + 288.0 * c4 * c3 * T + 576.0 * c4 * c4 * t2 + 720.0 * c5 * c3 * t2 + 2880.0 * c5 * c4 * t3 +
                          3600.0 * c5 * c5 * t4);
-        gt += __shfl_xor(gt, 1); // the two dimensions of a piece sit on neighbouring lanes
+        gt += dpp_f64<0xB1, 0xF>(0.0, gt); // quad_perm [1, 0, 3, 2]: // the two dimensions of a piece sit on neighbouring lanes
         if (d == 0) L.gdT[i] = gt;
     }
     double cost_part = epart;
@@ -628,7 +628,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         for (int k = 3; k < 6; ++k) val += L.gdC[(6 * i + k) * 2 + d] * dc[k];
         if (i + 1 <= M - 1) val -= L.y[d][i][0] * dE1[0] + L.y[d][i][1] * dE1[1];
         if (i >= 1) val += L.y[d][i - 1][0] * dE0[0] + L.y[d][i - 1][1] * dE0[1];
-        val += __shfl_xor(val, 1);
+        val += dpp_f64<0xB1, 0xF>(0.0, val); // quad_perm [1, 0, 3, 2]
         if (d == 0) {
             const double tau = L.x[2 * (M - 1) + 1 + i];
             L.g[2 * (M - 1) + 1 + i] = (L.gdT[i] + val + e.time_weight) * dt_dtau(tau);
