@@ -1,0 +1,950 @@
+// nmpc_block_kernel.hip -- the "stage-block" form of the batched NMPC real-time iteration (gfx950).
+//
+// Why a second mapping.  nmpc::rti_kernel (nmpc_kernels.hip) gives a problem 32 lanes, one lane per stage, and runs the
+// sequential Riccati sweep row-split over quads, 8-fold redundantly: 2240 vector instructions per problem, almost all
+// of them links of dependent chains (DPP scans, the sweep), which a gfx950 SIMD issues at one per ~4.6 cycles however
+// many wavefronts share it (profiles/r01_d_sq_counters.txt).  Here a problem gets L = 4, 8 or 16 lanes and every lane
+// OWNS S consecutive stages (L * S >= N) with all of their data in registers for the whole launch:
+//   * stage-parallel phases (linearise + Gauss-Newton cost, working-set prediction, KKT/expand, objective) are plain
+//     scalar code over the S stages of the lane -- S independent instruction streams per lane, so the in-order issue
+//     always has independent work (4 cycles per instruction for a lone wavefront, 2 when two share a SIMD);
+//   * the sequential sweeps go lane by lane: lane t runs the scalar Riccati recursion (nmpc_core.h, the same functions
+//     the CPU harness strings together) over its S stages while the other lanes of the group are masked, then hands
+//     the cost-to-go (9 floats) to lane t-1 with one DPP row shift per value; the forward sweep runs the other way.
+//     A sweep costs N scalar stage steps per wavefront whatever L is, and a wavefront carries 64 / L problems: 16 at
+//     L = 4 -- an eighth of the sweep instructions per problem of the wave-per-two-problems kernel;
+//   * prefix / suffix sums of the prediction: serial inside a lane, log2(L) DPP steps across the group.
+// LDS holds only what is read again at the end (W and y of the wavefront's problems, for acado_getObjective) and is
+// the transposition buffer between the reference's per-problem layout in HBM (contiguous per problem, so a wavefront
+// streams 64 / L consecutive problems with 16-byte-per-lane coalesced loads) and the lane-owns-stages registers.
+// Global traffic is the algorithmic minimum as before.
+//
+// Numerics are those of nmpc_kernels.hip / nmpc_core.h (see there for the reference citations); per-problem results
+// do not depend on the batch or on wavefront mates (masked lanes never feed a problem).  Different (L, S) agree to
+// rounding only (summation order of the diagnostics and of the prediction).
+#include "nmpc_kernels.h"
+
+#include <cstdlib>
+
+#include <type_traits>
+
+#include "nmpc_core.h"
+
+namespace nmpc {
+namespace {
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// DPP move inside a row of 16 lanes; lanes without a source keep `old`
+template <int CTRL>
+__device__ __forceinline__ float dppk(float old, float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dppk_i(int old, int x)
+{
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float lane_next(float x) { return dppk<0x101>(x, x); } // row_shl:1  lane i <- lane i + 1
+__device__ __forceinline__ float lane_prev(float x) { return dppk<0x111>(x, x); } // row_shr:1  lane i <- lane i - 1
+
+// value of the first / last lane of the group of L lanes (L = 4: quad_perm, else row_newbcast, gfx90a+)
+template <int L>
+__device__ __forceinline__ float gfirst(float x, int lane)
+{
+    if constexpr (L == 4) return dppk<0x00>(x, x);
+    else if constexpr (L == 16) return dppk<0x150>(x, x);
+    else { const float lo = dppk<0x150>(x, x), hi = dppk<0x158>(x, x); return (lane & 8) ? hi : lo; }
+}
+template <int L>
+__device__ __forceinline__ float glast(float x, int lane)
+{
+    if constexpr (L == 4) return dppk<0xFF>(x, x);
+    else if constexpr (L == 16) return dppk<0x15F>(x, x);
+    else { const float lo = dppk<0x157>(x, x), hi = dppk<0x15F>(x, x); return (lane & 8) ? hi : lo; }
+}
+// inclusive prefix sum over the lanes of a group (row_shr:1, 2, 4, 8; groups are aligned inside DPP rows)
+template <int L>
+__device__ __forceinline__ float gprefix(float x, int j)
+{
+    float v;
+    v = dppk<0x111>(0.0f, x); if (L < 16) v = (j >= 1) ? v : 0.0f; x += v;
+    v = dppk<0x112>(0.0f, x); if (L < 16) v = (j >= 2) ? v : 0.0f; x += v;
+    if constexpr (L >= 8) { v = dppk<0x114>(0.0f, x); if (L < 16) v = (j >= 4) ? v : 0.0f; x += v; }
+    if constexpr (L >= 16) { v = dppk<0x118>(0.0f, x); x += v; }
+    return x;
+}
+template <int L>
+__device__ __forceinline__ int gprefix_max(int x, int j)
+{
+    constexpr int NEG = -2147483647 - 1;
+    int v;
+    v = dppk_i<0x111>(NEG, x); if (L < 16) v = (j >= 1) ? v : NEG; x = max(x, v);
+    v = dppk_i<0x112>(NEG, x); if (L < 16) v = (j >= 2) ? v : NEG; x = max(x, v);
+    if constexpr (L >= 8) { v = dppk_i<0x114>(NEG, x); if (L < 16) v = (j >= 4) ? v : NEG; x = max(x, v); }
+    if constexpr (L >= 16) { v = dppk_i<0x118>(NEG, x); x = max(x, v); }
+    return x;
+}
+template <int L>
+__device__ __forceinline__ float gtotal(float x, int j, int lane) { return glast<L>(gprefix<L>(x, j), lane); }
+template <int L>
+__device__ __forceinline__ int gmax(int x, int j, int lane)
+{
+    return __float_as_int(glast<L>(__int_as_float(gprefix_max<L>(x, j)), lane));
+}
+template <int L>
+__device__ __forceinline__ bool gany(bool pred, int base)
+{
+    const unsigned long long m = __ballot(pred);
+    return ((m >> base) & ((1ull << L) - 1ull)) != 0ull;
+}
+
+// ---- global <-> LDS, coalesced: all loads of a launch are issued before the first LDS store ---------------------
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int U>
+__device__ __forceinline__ void g_issue(const float* g, int total, int lane, float4 (&q)[U], float& tail)
+{
+    const int n4 = total >> 2, rem = total & 3;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = u * 64 + lane;
+        if (i < n4) {
+            const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g) + i); // read once
+            q[u] = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    tail = (lane < rem) ? g[n4 * 4 + lane] : 0.0f; // only the ragged last wavefront has one
+}
+template <int U>
+__device__ __forceinline__ void l_commit(float* l, int total, int lane, const float4 (&q)[U], float tail)
+{
+    const int n4 = total >> 2, rem = total & 3;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = u * 64 + lane;
+        if (i < n4) reinterpret_cast<float4*>(l)[i] = q[u];
+    }
+    if (lane < rem) l[n4 * 4 + lane] = tail;
+}
+template <int U>
+__device__ __forceinline__ void g_store(float* g, const float* l, int total, int lane)
+{
+    const int n4 = total >> 2, rem = total & 3;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = u * 64 + lane;
+        if (i < n4) reinterpret_cast<float4*>(g)[i] = reinterpret_cast<const float4*>(l)[i];
+    }
+    if (lane < rem) g[n4 * 4 + lane] = l[n4 * 4 + lane];
+}
+
+} // namespace
+
+// LDS floats of one wavefront: W and y of its 64 / L problems (the iterate and the bounds pass through the W area
+// before W lands) + 256 floats of scratch for the cold active-set path
+int block_lds_floats(int N, int L) { return (64 / L) * 30 * N + 256; }
+
+template <int L, int S, bool DIAG, bool STAMP>
+__global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
+{
+    extern __shared__ float4 lds_raw[];
+    float* lds = reinterpret_cast<float*>(lds_raw);
+    constexpr int G = 64 / L;
+    constexpr int NMAX = L * S;
+    const int N = p.N;
+    const int lane = threadIdx.x;
+    const int g = lane / L, j = lane % L;
+    const int gbase = lane - j;
+    const int prob0 = blockIdx.x * G;
+    const int np_ = min(G, p.B - prob0);
+    const bool valid = g < np_;
+    const int ge = valid ? g : np_ - 1; // padding groups shadow the last problem, never store
+    const int prob = prob0 + ge;
+    const int nx = 3 * (N + 1), nu = 2 * N;
+    const int top = (N - 1) / S;        // lane that owns stage N - 1 (and the terminal node)
+
+    long long t0 = 0, t1 = 0, t4 = 0, t5 = 0;
+    if (STAMP) t0 = __builtin_amdgcn_s_memtime();
+
+    IrkConst K;
+    K.h = p.h; K.hh = p.hh; K.c1h = p.c1h; K.c2h = p.c2h;
+
+    // LDS map (floats): resident [W | y | scratch]; x, u, dual, od, lb, ub pass through the W area first
+    const int oW = 0, oY = G * 25 * N, oScr = G * 30 * N;
+    const int oX = 0, oU = G * nx, oDL = oU + G * nu, oOD = oDL + G * nu, oLB = oOD + G * nx, oUB = oLB + G * nu;
+
+    // ---- phase 0: coalesced loads of the wavefront's problems -> LDS -> registers of the owning lane
+    float x[S][3], u[S][2], od[S][3], lbv[S][2], ubv[S][2], xN[3];
+    float mu0[S], mu1[S]; // bound multipliers: the incoming dual until the first forward sweep overwrites it
+    float x00, x01, x02, WN[9], yN[3];
+    {
+        constexpr int UX = (G * 3 * (NMAX + 1) / 4 + 63) / 64;
+        constexpr int UU = (G * 2 * NMAX / 4 + 63) / 64;
+        constexpr int UY = (G * 5 * NMAX / 4 + 63) / 64;
+        constexpr int UW = (G * 25 * NMAX / 4 + 63) / 64;
+        float4 qx[UX], qod[UX], qu[UU], qdl[UU], qlb[UU], qub[UU], qy[UY], qW[UW];
+        float tx, tod, tu, tdl, tlb, tub, ty, tW;
+        g_issue<UX>(p.b.x + (size_t)prob0 * nx, np_ * nx, lane, qx, tx);
+        g_issue<UU>(p.b.u + (size_t)prob0 * nu, np_ * nu, lane, qu, tu);
+        g_issue<UU>(p.b.dual + (size_t)prob0 * nu, np_ * nu, lane, qdl, tdl);
+        g_issue<UX>(p.b.od + (size_t)prob0 * nx, np_ * nx, lane, qod, tod);
+        g_issue<UU>(p.b.lbValues + (size_t)prob0 * nu, np_ * nu, lane, qlb, tlb);
+        g_issue<UU>(p.b.ubValues + (size_t)prob0 * nu, np_ * nu, lane, qub, tub);
+        g_issue<UY>(p.b.y + (size_t)prob0 * 5 * N, np_ * 5 * N, lane, qy, ty);
+        g_issue<UW>(p.b.W + (size_t)prob0 * 25 * N, np_ * 25 * N, lane, qW, tW);
+        x00 = p.b.x0[(size_t)prob * 3]; x01 = p.b.x0[(size_t)prob * 3 + 1]; x02 = p.b.x0[(size_t)prob * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) WN[i] = p.b.WN[(size_t)prob * 9 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) yN[i] = p.b.yN[(size_t)prob * 3 + i];
+
+        l_commit<UX>(lds + oX, np_ * nx, lane, qx, tx);
+        l_commit<UU>(lds + oU, np_ * nu, lane, qu, tu);
+        l_commit<UU>(lds + oDL, np_ * nu, lane, qdl, tdl);
+        l_commit<UX>(lds + oOD, np_ * nx, lane, qod, tod);
+        l_commit<UU>(lds + oLB, np_ * nu, lane, qlb, tlb);
+        l_commit<UU>(lds + oUB, np_ * nu, lane, qub, tub);
+        l_commit<UY>(lds + oY, np_ * 5 * N, lane, qy, ty);
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int k = j * S + s;
+            const int kn = min(k, N), kc = min(k, N - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                x[s][c] = lds[oX + ge * nx + 3 * kn + c];
+                od[s][c] = lds[oOD + ge * nx + 3 * kn + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u[s][c] = lds[oU + ge * nu + 2 * kc + c];
+                lbv[s][c] = lds[oLB + ge * nu + 2 * kc + c];
+                ubv[s][c] = lds[oUB + ge * nu + 2 * kc + c];
+            }
+            mu0[s] = lds[oDL + ge * nu + 2 * kc];
+            mu1[s] = lds[oDL + ge * nu + 2 * kc + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xN[c] = lds[oX + ge * nx + 3 * N + c];
+        wave_sync();
+        l_commit<UW>(lds + oW, np_ * 25 * N, lane, qW, tW);
+        wave_sync();
+    }
+
+    // per-stage data of the S stages this lane owns (stage k = j * S + s; slots with k >= N are neutral)
+    // Q, q, a, b carry one more element: the node after the lane's block (the next lane's first node, or the terminal
+    // node, which also sits in its own slot when it falls inside the block) -- what the prediction's adjoint reads
+    float B00[S], B01[S], B10[S], B11[S], B20[S], sa[S + 1], sb[S + 1], d0[S], d1[S], d2[S];
+    float Q00[S + 1], Q01[S + 1], Q02[S + 1], Q11[S + 1], Q12[S + 1], Q22[S + 1], q0[S + 1], q1[S + 1], q2[S + 1];
+    float R00[S], R01[S], R11[S], r0[S], r1[S];
+    float lb0[S], ub0[S], lb1[S], ub1[S];
+    int st0[S], st1[S];
+    float c00[S], c01[S], c02[S], pf0[S], c10[S], c11[S], c12[S], pe1[S], pf1[S];
+    float du0[S], du1[S], dxs[S][3], sbs[S][3];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        du0[s] = du1[s] = 0.0f;
+        c00[s] = c01[s] = c02[s] = pf0[s] = c10[s] = c11[s] = c12[s] = pe1[s] = pf1[s] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dxs[s][c] = sbs[s][c] = 0.0f;
+    }
+    float dxo[3] = {0.f, 0.f, 0.f}, sbo[3] = {0.f, 0.f, 0.f}; // state step / free response leaving the lane's block
+    float QN[6], qN[3];                                       // terminal node (meaningful in lane `top`)
+
+    int status = RET_OK, n_iter = 0;
+    float kkt = 0.0f;
+    long long t_b = 0, t_f = 0, t_pg = 0;
+
+    for (int sqp = 0; sqp < p.n_sqp; ++sqp) {
+        // ---- phase A: linearise, Gauss-Newton cost, bounds on the step, working-set guess from the dual
+        int infeasible = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int k = j * S + s;
+            const bool vs = k < N;
+            const int kc = min(k, N - 1);
+            // node k + 1: the next slot, the first slot of the next lane, or the terminal node
+            float xn[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float nb = (s + 1 < S) ? x[(s + 1 < S) ? s + 1 : s][c] : lane_next(x[0][c]);
+                xn[c] = (k + 1 == N) ? xN[c] : nb;
+            }
+            StageLin lin;
+            ddr_linearize(K, x[s][0], x[s][1], x[s][2], u[s][0], u[s][1], od[s][0], od[s][1], od[s][2], lin);
+            const float* yk = lds + oY + ge * 5 * N + 5 * kc;
+            const float* Wk = lds + oW + ge * 25 * N + 25 * kc;
+            float w[25];
+#pragma unroll
+            for (int i = 0; i < 25; ++i) w[i] = Wk[i];
+            const float e0 = x[s][0] - yk[0], e1 = x[s][1] - yk[1], e2 = x[s][2] - yk[2], e3 = u[s][0] - yk[3],
+                        e4 = u[s][1] - yk[4];
+            const float m = vs ? 1.0f : 0.0f;
+            q0[s] = m * (w[0] * e0 + w[1] * e1 + w[2] * e2 + w[3] * e3 + w[4] * e4);
+            q1[s] = m * (w[5] * e0 + w[6] * e1 + w[7] * e2 + w[8] * e3 + w[9] * e4);
+            q2[s] = m * (w[10] * e0 + w[11] * e1 + w[12] * e2 + w[13] * e3 + w[14] * e4);
+            r0[s] = m * (w[15] * e0 + w[16] * e1 + w[17] * e2 + w[18] * e3 + w[19] * e4);
+            r1[s] = m * (w[20] * e0 + w[21] * e1 + w[22] * e2 + w[23] * e3 + w[24] * e4);
+            Q00[s] = m * w[0]; Q01[s] = m * w[1]; Q02[s] = m * w[2]; Q11[s] = m * w[6]; Q12[s] = m * w[7]; Q22[s] = m * w[12];
+            R00[s] = vs ? w[18] : 1.0f; R01[s] = m * w[19]; R11[s] = vs ? w[24] : 1.0f;
+            B00[s] = m * lin.B00; B01[s] = m * lin.B01; B10[s] = m * lin.B10; B11[s] = m * lin.B11; B20[s] = m * lin.B20;
+            sa[s] = m * lin.a; sb[s] = m * lin.b;
+            d0[s] = m * (lin.phi0 - xn[0]); d1[s] = m * (lin.phi1 - xn[1]); d2[s] = m * (lin.phi2 - xn[2]);
+            const float l0 = m * (lbv[s][0] - u[s][0]), l1 = m * (lbv[s][1] - u[s][1]);
+            const float h0 = m * (ubv[s][0] - u[s][0]), h1 = m * (ubv[s][1] - u[s][1]);
+            lb0[s] = l0; ub0[s] = h0; lb1[s] = l1; ub1[s] = h1;
+            infeasible |= (vs && ((l0 > h0 + 1e-6f) || (l1 > h1 + 1e-6f))) ? 1 : 0;
+            st0[s] = vs ? status_from_dual(mu0[s], l0, h0) : ST_LOWER;
+            st1[s] = vs ? status_from_dual(mu1[s], l1, h1) : ST_LOWER;
+        }
+        {
+            const float e0 = xN[0] - yN[0], e1 = xN[1] - yN[1], e2 = xN[2] - yN[2];
+            QN[0] = WN[0]; QN[1] = WN[1]; QN[2] = WN[2]; QN[3] = WN[4]; QN[4] = WN[5]; QN[5] = WN[8];
+            qN[0] = WN[0] * e0 + WN[1] * e1 + WN[2] * e2;
+            qN[1] = WN[3] * e0 + WN[4] * e1 + WN[5] * e2;
+            qN[2] = WN[6] * e0 + WN[7] * e1 + WN[8] * e2;
+        }
+        { // element [S]: first node of the next lane; the terminal node goes where node N falls
+            Q00[S] = lane_next(Q00[0]); Q01[S] = lane_next(Q01[0]); Q02[S] = lane_next(Q02[0]); Q11[S] = lane_next(Q11[0]);
+            Q12[S] = lane_next(Q12[0]); Q22[S] = lane_next(Q22[0]); q0[S] = lane_next(q0[0]); q1[S] = lane_next(q1[0]);
+            q2[S] = lane_next(q2[0]); sa[S] = lane_next(sa[0]); sb[S] = lane_next(sb[0]);
+            if (j == L - 1) { Q00[S] = Q01[S] = Q02[S] = Q11[S] = Q12[S] = Q22[S] = q0[S] = q1[S] = q2[S] = sa[S] = sb[S] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s <= S; ++s) {
+                if (j * S + s == N) {
+                    Q00[s] = QN[0]; Q01[s] = QN[1]; Q02[s] = QN[2]; Q11[s] = QN[3]; Q12[s] = QN[4]; Q22[s] = QN[5];
+                    q0[s] = qN[0]; q1[s] = qN[1]; q2[s] = qN[2]; sa[s] = 0.0f; sb[s] = 0.0f;
+                }
+            }
+        }
+        infeasible = gany<L>(infeasible != 0, gbase) ? 1 : 0;
+        if (STAMP && sqp == 0) t1 = __builtin_amdgcn_s_memtime();
+
+        const float Dx0 = x00 - gfirst<L>(x[0][0], lane), Dx1 = x01 - gfirst<L>(x[0][1], lane),
+                    Dx2 = x02 - gfirst<L>(x[0][2], lane);
+
+        // ---- working-set prediction for cold starts (see nmpc_kernels.hip): projected Barzilai-Borwein steps on
+        //      the condensed QP, its Hessian applied stage-wise by prefix / suffix sums (serial inside the lane's
+        //      block, DPP scan across the group).  Only a guess: the sweeps below iterate to a fixed point.
+        if (p.pg_steps > 0) {
+            long long tp0 = 0;
+            if (STAMP) tp0 = __builtin_amdgcn_s_memtime();
+            int nonfree = 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) nonfree |= (j * S + s < N) ? (st0[s] | st1[s]) : 0;
+            const bool cold = !gany<L>(nonfree != 0, gbase);
+            // gradient H du + g of the condensed QP at du
+            float g0[S], g1[S];
+            auto apply = [&](const float (&v0)[S], const float (&v1)[S]) {
+                float X0[S], X1[S], X2[S], in2[S];
+                float acc = 0.0f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) { acc += B20[s] * (v0[s] - v1[s]) + d2[s]; X2[s] = acc; }
+                const float ex2 = gprefix<L>(acc, j) - acc + Dx2; // psi entering the block
+#pragma unroll
+                for (int s = 0; s < S; ++s) { in2[s] = (s == 0) ? ex2 : X2[(s > 0) ? s - 1 : 0] + ex2; }
+#pragma unroll
+                for (int s = 0; s < S; ++s) X2[s] += ex2;
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    a0 += sa[s] * in2[s] + B00[s] * v0[s] + B01[s] * v1[s] + d0[s]; X0[s] = a0;
+                    a1 += sb[s] * in2[s] + B10[s] * v0[s] + B11[s] * v1[s] + d1[s]; X1[s] = a1;
+                }
+                const float ex0 = gprefix<L>(a0, j) - a0 + Dx0, ex1 = gprefix<L>(a1, j) - a1 + Dx1;
+                float y0[S], y1[S], y2[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float X0s = X0[s] + ex0, X1s = X1[s] + ex1;
+                    y0[s] = Q00[s + 1] * X0s + Q01[s + 1] * X1s + Q02[s + 1] * X2[s] + q0[s + 1];
+                    y1[s] = Q01[s + 1] * X0s + Q11[s + 1] * X1s + Q12[s + 1] * X2[s] + q1[s + 1];
+                    y2[s] = Q02[s + 1] * X0s + Q12[s + 1] * X1s + Q22[s + 1] * X2[s] + q2[s + 1];
+                }
+                // adjoint at node k + 1: suffix sums
+                float Lx[S], Ly[S], Lp[S];
+                float b0 = 0.0f, b1 = 0.0f;
+#pragma unroll
+                for (int s = S - 1; s >= 0; --s) { b0 += y0[s]; Lx[s] = b0; b1 += y1[s]; Ly[s] = b1; }
+                const float pr0 = gprefix<L>(b0, j), pr1 = gprefix<L>(b1, j);
+                const float es0 = glast<L>(pr0, lane) - pr0, es1 = glast<L>(pr1, lane) - pr1; // sum over the lanes above
+#pragma unroll
+                for (int s = 0; s < S; ++s) { Lx[s] += es0; Ly[s] += es1; }
+                // adjoint at node k + 2: the next slot's, the next lane's first, zero past the end of the group
+                const float nx_edge = (j == L - 1) ? 0.0f : lane_next(Lx[0]);
+                const float ny_edge = (j == L - 1) ? 0.0f : lane_next(Ly[0]);
+                float b2 = 0.0f;
+#pragma unroll
+                for (int s = S - 1; s >= 0; --s) {
+                    const float nxs = (s + 1 < S) ? Lx[(s + 1 < S) ? s + 1 : s] : nx_edge;
+                    const float nys = (s + 1 < S) ? Ly[(s + 1 < S) ? s + 1 : s] : ny_edge;
+                    b2 += y2[s] + sa[s + 1] * nxs + sb[s + 1] * nys;
+                    Lp[s] = b2;
+                }
+                const float pr2 = gprefix<L>(b2, j);
+                const float es2 = glast<L>(pr2, lane) - pr2;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float Lps = Lp[s] + es2;
+                    g0[s] = R00[s] * v0[s] + R01[s] * v1[s] + r0[s] + B00[s] * Lx[s] + B10[s] * Ly[s] + B20[s] * Lps;
+                    g1[s] = R01[s] * v0[s] + R11[s] * v1[s] + r1[s] + B01[s] * Lx[s] + B11[s] * Ly[s] - B20[s] * Lps;
+                }
+            };
+            float is0[S], is1[S], w0[S], w1[S];
+            int hits = 0, badw = 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { w0[s] = 0.0f; w1[s] = 0.0f; }
+            apply(w0, w1);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const bool in = j * S + s < N;
+                is0[s] = in ? rcp_f(fmaxf(R00[s], 1e-20f)) : 0.0f;
+                is1[s] = in ? rcp_f(fmaxf(R11[s], 1e-20f)) : 0.0f;
+                const float j0 = -is0[s] * g0[s], j1 = -is1[s] * g1[s];
+                hits |= (j0 < lb0[s]) | (j0 > ub0[s]) | (j1 < lb1[s]) | (j1 > ub1[s]);
+                badw |= in ? ((!(R00[s] > 0.0f)) | (!(R11[s] > 0.0f))) : 0;
+                w0[s] = clampf(j0, lb0[s], ub0[s]); w1[s] = clampf(j1, lb1[s], ub1[s]);
+            }
+            const bool run = cold && gany<L>(hits != 0, gbase) && !gany<L>(badw != 0, gbase);
+            if (__any(run)) {
+                float pu0[S], pu1[S], pg0[S], pg1[S];
+                int bits[S];
+                auto at_bounds = [&](int s) {
+                    return (w0[s] <= lb0[s] ? 1 : 0) | (w0[s] >= ub0[s] ? 2 : 0) | (w1[s] <= lb1[s] ? 4 : 0) | (w1[s] >= ub1[s] ? 8 : 0);
+                };
+#pragma unroll
+                for (int s = 0; s < S; ++s) { pu0[s] = 0.0f; pu1[s] = 0.0f; pg0[s] = g0[s]; pg1[s] = g1[s]; bits[s] = at_bounds(s); }
+                float alpha = 1.0f;
+                const int max_steps = p.pg_steps + p.pg_steps / 2;
+                int still = 0;
+                bool frozen = !run;
+#pragma unroll 1
+                for (int t = 1; t < max_steps; ++t) {
+                    apply(w0, w1);
+                    float num = 0.0f, den = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float e0 = w0[s] - pu0[s], e1 = w1[s] - pu1[s];
+                        num += R00[s] * e0 * e0 + R11[s] * e1 * e1;
+                        den += e0 * (g0[s] - pg0[s]) + e1 * (g1[s] - pg1[s]);
+                    }
+                    num = gtotal<L>(num, j, lane);
+                    den = gtotal<L>(den, j, lane);
+                    alpha = (den > 1e-30f) ? fminf(fmaxf(num * __builtin_amdgcn_rcpf(den), 1e-3f), 1.0f) : alpha;
+                    int moved = 0;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        pu0[s] = w0[s]; pu1[s] = w1[s]; pg0[s] = g0[s]; pg1[s] = g1[s];
+                        const float n0 = __builtin_amdgcn_fmed3f(w0[s] - alpha * is0[s] * g0[s], lb0[s], ub0[s]);
+                        const float n1 = __builtin_amdgcn_fmed3f(w1[s] - alpha * is1[s] * g1[s], lb1[s], ub1[s]);
+                        w0[s] = frozen ? w0[s] : n0;
+                        w1[s] = frozen ? w1[s] : n1;
+                        const int nb = at_bounds(s);
+                        moved |= (j * S + s < N && nb != bits[s]) ? 1 : 0;
+                        bits[s] = nb;
+                    }
+                    still = gany<L>(moved != 0, gbase) ? 0 : still + 1;
+                    frozen = frozen || (still >= 2 && t + 1 >= p.pg_steps);
+                    if (__all(frozen)) break;
+                }
+                if (run) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        if (j * S + s < N) {
+                            st0[s] = (ub0[s] - lb0[s] > BOUNDTOL) ? ((w0[s] <= lb0[s]) ? ST_LOWER : ((w0[s] >= ub0[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
+                            st1[s] = (ub1[s] - lb1[s] > BOUNDTOL) ? ((w1[s] <= lb1[s]) ? ST_LOWER : ((w1[s] >= ub1[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
+                        }
+                    }
+                }
+            }
+            if (STAMP) t_pg = __builtin_amdgcn_s_memtime() - tp0;
+        }
+
+        // ---- phase B: working-set iterations; the sweeps go lane by lane through the group
+        float V[9];    // cost-to-go travelling down the lanes: P00 P01 P02 P11 P12 P22 p0 p1 p2
+        float Vin[9];  // cost-to-go at the upper end of this lane's block (kept for restarts)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { V[i] = QN[i]; Vin[i] = QN[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { V[6 + i] = qN[i]; Vin[6 + i] = qN[i]; }
+        int pd_fail = 0;
+        bool changed = true;
+        int khi = N - 1;
+        int it = 0;
+        n_iter = 0;
+
+        // state step entering this lane's block: compose the closed-loop maps dx+ = (A + B G) dx + (B h + d) of the
+        // lane's stages (G, h from the policy records and the working set; slots past the horizon are identities
+        // by construction), scan over the lanes, apply to x0 - x[0]
+        auto block_entry = [&](float& o0, float& o1, float& o2) {
+            float m00 = 1.f, m01 = 0.f, m02 = 0.f, m10 = 0.f, m11 = 1.f, m12 = 0.f, m20 = 0.f, m21 = 0.f, m22 = 1.f;
+            float k0 = 0.f, k1 = 0.f, k2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const bool f0 = (st0[s] == ST_FREE), f1 = (st1[s] == ST_FREE);
+                const float b0 = (st0[s] == ST_UPPER) ? ub0[s] : lb0[s], b1 = (st1[s] == ST_UPPER) ? ub1[s] : lb1[s];
+                const float g00 = f0 ? c00[s] : 0.0f, g01 = f0 ? c01[s] : 0.0f, g02 = f0 ? c02[s] : 0.0f;
+                const float h0 = f0 ? pf0[s] : b0;
+                const float g10 = f1 ? c10[s] + pe1[s] * g00 : 0.0f, g11 = f1 ? c11[s] + pe1[s] * g01 : 0.0f,
+                            g12 = f1 ? c12[s] + pe1[s] * g02 : 0.0f;
+                const float h1 = f1 ? pe1[s] * h0 + pf1[s] : b1;
+                const float gd0 = g00 - g10, gd1 = g01 - g11, gd2 = g02 - g12;
+                const float a00 = 1.0f + B00[s] * g00 + B01[s] * g10, a01 = B00[s] * g01 + B01[s] * g11,
+                            a02 = sa[s] + B00[s] * g02 + B01[s] * g12;
+                const float a10 = B10[s] * g00 + B11[s] * g10, a11 = 1.0f + B10[s] * g01 + B11[s] * g11,
+                            a12 = sb[s] + B10[s] * g02 + B11[s] * g12;
+                const float a20 = B20[s] * gd0, a21 = B20[s] * gd1, a22 = 1.0f + B20[s] * gd2;
+                const float cc0 = B00[s] * h0 + B01[s] * h1 + d0[s], cc1 = B10[s] * h0 + B11[s] * h1 + d1[s],
+                            cc2 = B20[s] * (h0 - h1) + d2[s];
+                if (s == 0) {
+                    m00 = a00; m01 = a01; m02 = a02; m10 = a10; m11 = a11; m12 = a12; m20 = a20; m21 = a21; m22 = a22;
+                    k0 = cc0; k1 = cc1; k2 = cc2;
+                } else { // stage map after what is composed so far
+                    const float n00 = a00 * m00 + a01 * m10 + a02 * m20, n01 = a00 * m01 + a01 * m11 + a02 * m21,
+                                n02 = a00 * m02 + a01 * m12 + a02 * m22;
+                    const float n10 = a10 * m00 + a11 * m10 + a12 * m20, n11 = a10 * m01 + a11 * m11 + a12 * m21,
+                                n12 = a10 * m02 + a11 * m12 + a12 * m22;
+                    const float n20 = a20 * m00 + a21 * m10 + a22 * m20, n21 = a20 * m01 + a21 * m11 + a22 * m21,
+                                n22 = a20 * m02 + a21 * m12 + a22 * m22;
+                    const float l0 = a00 * k0 + a01 * k1 + a02 * k2 + cc0, l1 = a10 * k0 + a11 * k1 + a12 * k2 + cc1,
+                                l2 = a20 * k0 + a21 * k1 + a22 * k2 + cc2;
+                    m00 = n00; m01 = n01; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m21 = n21; m22 = n22;
+                    k0 = l0; k1 = l1; k2 = l2;
+                }
+            }
+            // inclusive scan over the lanes: lane j <- f_j o f_{j-1} o ... o f_0
+            auto level = [&](auto tag, int dist) {
+                constexpr int CTRL = decltype(tag)::value;
+                const bool has = (L >= 16) || (j >= dist);
+                auto fetch = [&](float v, float ident) { const float r = dppk<CTRL>(ident, v); return has ? r : ident; };
+                const float g00 = fetch(m00, 1.f), g01 = fetch(m01, 0.f), g02 = fetch(m02, 0.f), g10 = fetch(m10, 0.f),
+                            g11 = fetch(m11, 1.f), g12 = fetch(m12, 0.f), g20 = fetch(m20, 0.f), g21 = fetch(m21, 0.f),
+                            g22 = fetch(m22, 1.f), gc0 = fetch(k0, 0.f), gc1 = fetch(k1, 0.f), gc2 = fetch(k2, 0.f);
+                const float n00 = m00 * g00 + m01 * g10 + m02 * g20, n01 = m00 * g01 + m01 * g11 + m02 * g21,
+                            n02 = m00 * g02 + m01 * g12 + m02 * g22;
+                const float n10 = m10 * g00 + m11 * g10 + m12 * g20, n11 = m10 * g01 + m11 * g11 + m12 * g21,
+                            n12 = m10 * g02 + m11 * g12 + m12 * g22;
+                const float n20 = m20 * g00 + m21 * g10 + m22 * g20, n21 = m20 * g01 + m21 * g11 + m22 * g21,
+                            n22 = m20 * g02 + m21 * g12 + m22 * g22;
+                const float l0 = m00 * gc0 + m01 * gc1 + m02 * gc2 + k0, l1 = m10 * gc0 + m11 * gc1 + m12 * gc2 + k1,
+                            l2 = m20 * gc0 + m21 * gc1 + m22 * gc2 + k2;
+                m00 = n00; m01 = n01; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m21 = n21; m22 = n22;
+                k0 = l0; k1 = l1; k2 = l2;
+            };
+            level(std::integral_constant<int, 0x111>{}, 1);
+            level(std::integral_constant<int, 0x112>{}, 2);
+            if constexpr (L >= 8) level(std::integral_constant<int, 0x114>{}, 4);
+            if constexpr (L >= 16) level(std::integral_constant<int, 0x118>{}, 8);
+            // state step leaving this lane's block; the one entering it is the previous lane's
+            const float l0 = m00 * Dx0 + m01 * Dx1 + m02 * Dx2 + k0, l1 = m10 * Dx0 + m11 * Dx1 + m12 * Dx2 + k1,
+                        l2 = m20 * Dx0 + m21 * Dx1 + m22 * Dx2 + k2;
+            const float p0 = lane_prev(l0), p1 = lane_prev(l1), p2 = lane_prev(l2);
+            o0 = (j == 0) ? Dx0 : p0; o1 = (j == 0) ? Dx1 : p1; o2 = (j == 0) ? Dx2 : p2;
+        };
+        if (DIAG) { // free response (du = 0) entering every stage, for acado_getKKT: A is a shear, so prefix sums do it
+            float loc[S], acc = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { loc[s] = acc; acc += d2[s]; }
+            const float ex2 = gprefix<L>(acc, j) - acc + Dx2;
+#pragma unroll
+            for (int s = 0; s < S; ++s) sbs[s][2] = loc[s] + ex2;
+            sbo[2] = acc + ex2;
+            float l0[S], l1[S], a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                l0[s] = a0; a0 += sa[s] * sbs[s][2] + d0[s];
+                l1[s] = a1; a1 += sb[s] * sbs[s][2] + d1[s];
+            }
+            const float ex0 = gprefix<L>(a0, j) - a0 + Dx0, ex1 = gprefix<L>(a1, j) - a1 + Dx1;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { sbs[s][0] = l0[s] + ex0; sbs[s][1] = l1[s] + ex1; }
+            sbo[0] = a0 + ex0; sbo[1] = a1 + ex1;
+        }
+
+        auto backward_block = [&]() -> int {
+            Value val;
+            val.P.m00 = V[0]; val.P.m01 = V[1]; val.P.m02 = V[2]; val.P.m11 = V[3]; val.P.m12 = V[4]; val.P.m22 = V[5];
+            val.p0 = V[6]; val.p1 = V[7]; val.p2 = V[8];
+            int ok = 1;
+#pragma unroll
+            for (int s = S - 1; s >= 0; --s) {
+                if (j * S + s < N) {
+                    StageQP q;
+                    q.a = sa[s]; q.b = sb[s]; q.B00 = B00[s]; q.B01 = B01[s]; q.B10 = B10[s]; q.B11 = B11[s]; q.B20 = B20[s];
+                    q.d0 = d0[s]; q.d1 = d1[s]; q.d2 = d2[s];
+                    q.Q.m00 = Q00[s]; q.Q.m01 = Q01[s]; q.Q.m02 = Q02[s]; q.Q.m11 = Q11[s]; q.Q.m12 = Q12[s]; q.Q.m22 = Q22[s];
+                    q.q0 = q0[s]; q.q1 = q1[s]; q.q2 = q2[s];
+                    q.R00 = R00[s]; q.R01 = R01[s]; q.R11 = R11[s]; q.r0 = r0[s]; q.r1 = r1[s];
+                    q.st0 = st0[s]; q.st1 = st1[s];
+                    q.v0 = (st0[s] == ST_UPPER) ? ub0[s] : lb0[s];
+                    q.v1 = (st1[s] == ST_UPPER) ? ub1[s] : lb1[s];
+                    Policy pol;
+                    ok &= riccati_step(q, val, pol, true) ? 1 : 0;
+                    c00[s] = pol.c00; c01[s] = pol.c01; c02[s] = pol.c02; pf0[s] = pol.f0;
+                    c10[s] = pol.c10; c11[s] = pol.c11; c12[s] = pol.c12; pe1[s] = pol.e1; pf1[s] = pol.f1;
+                }
+            }
+            V[0] = val.P.m00; V[1] = val.P.m01; V[2] = val.P.m02; V[3] = val.P.m11; V[4] = val.P.m12; V[5] = val.P.m22;
+            V[6] = val.p0; V[7] = val.p1; V[8] = val.p2;
+            return ok;
+        };
+        // backward sweep of the groups flagged `act`, each from the lane that owns its highest stale stage `from`
+        auto backward_sweep = [&](bool act, int from) {
+            __builtin_amdgcn_s_setprio(3);
+            for (int t = top; t >= 0; --t) {
+                const bool mine = act && (j == t) && (t <= from);
+                if (__any(act && t <= from)) {
+                    if (mine) {
+                        if (t == from) {
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) V[i] = Vin[i];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) Vin[i] = V[i];
+                        }
+                        pd_fail |= backward_block() ? 0 : 1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) V[i] = lane_next(V[i]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+
+        for (;;) {
+            long long tb0 = 0;
+            if (STAMP) tb0 = __builtin_amdgcn_s_memtime();
+            backward_sweep(changed, khi / S);
+            long long tf0 = 0;
+            if (STAMP) { tf0 = __builtin_amdgcn_s_memtime(); t_b += tf0 - tb0; }
+
+            // ---- forward sweep: every lane condenses its block into one affine map under the current working set,
+            //      a DPP scan over the lanes gives the state step entering each block, then the lanes walk their own
+            //      stages in parallel (nmpc_core.h: forward_step)
+            const bool active = changed;
+            int new_khi = -1;
+            if (__any(active)) {
+                float e0, e1, e2;
+                block_entry(e0, e1, e2);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    Policy pol;
+                    pol.c00 = c00[s]; pol.c01 = c01[s]; pol.c02 = c02[s]; pol.f0 = pf0[s];
+                    pol.c10 = c10[s]; pol.c11 = c11[s]; pol.c12 = c12[s]; pol.e1 = pe1[s]; pol.f1 = pf1[s];
+                    StageStep o;
+                    forward_step(pol, st0[s], st1[s], e0, e1, e2, lb0[s], ub0[s], lb1[s], ub1[s], o);
+                    const bool moved = (o.nst0 != st0[s]) || (o.nst1 != st1[s]);
+                    if (moved) new_khi = j * S + s; // ascending: the last one is the highest
+                    if (active) {
+                        st0[s] = o.nst0; st1[s] = o.nst1;
+                        du0[s] = o.du0; du1[s] = o.du1; mu0[s] = o.mu0; mu1[s] = o.mu1;
+                        dxs[s][0] = e0; dxs[s][1] = e1; dxs[s][2] = e2;
+                    }
+                    const float n0 = e0 + sa[s] * e2 + B00[s] * o.du0 + B01[s] * o.du1 + d0[s];
+                    const float n1 = e1 + sb[s] * e2 + B10[s] * o.du0 + B11[s] * o.du1 + d1[s];
+                    const float n2 = e2 + B20[s] * (o.du0 - o.du1) + d2[s];
+                    e0 = n0; e1 = n1; e2 = n2;
+                }
+                if (active) { dxo[0] = e0; dxo[1] = e1; dxo[2] = e2; }
+                new_khi = gmax<L>(new_khi, j, lane);
+            }
+            ++it;
+            if (active) {
+                changed = (new_khi >= 0);
+                khi = changed ? new_khi : 0;
+                if (changed) n_iter = it;
+            }
+            if (STAMP) t_f += __builtin_amdgcn_s_memtime() - tf0;
+            if (!__any(changed && it < min(p.max_as_iter, AS_SWITCH))) break;
+        }
+        n_iter = (n_iter == 0) ? 1 : (changed ? n_iter : n_iter + 1); // + the confirming sweep
+
+        // ---- safeguard (nmpc_core.h: AS_SWITCH): primal active-set iteration for the rare problem whose
+        //      primal-dual update has not settled; one change of the working set per sweep.  Cold path.
+        {
+            const bool rescue = changed && it >= AS_SWITCH && it < p.max_as_iter;
+            if (__builtin_expect(__any(rescue) ? 1 : 0, 0)) {
+                float cur0[S], cur1[S];
+                float* scr = lds + oScr;
+                int todo = rescue ? 1 : 0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) { // start: clip the last solution into the box, fix what sits on a bound
+                    const float a0 = (lb0[s] <= ub0[s]) ? clampf(du0[s], lb0[s], ub0[s]) : du0[s];
+                    const float a1 = (lb1[s] <= ub1[s]) ? clampf(du1[s], lb1[s], ub1[s]) : du1[s];
+                    cur0[s] = a0; cur1[s] = a1;
+                    if (rescue && j * S + s < N) {
+                        st0[s] = (ub0[s] - lb0[s] > BOUNDTOL) ? asm_status_of(a0, lb0[s], ub0[s]) : ST_LOWER;
+                        st1[s] = (ub1[s] - lb1[s] > BOUNDTOL) ? asm_status_of(a1, lb1[s], ub1[s]) : ST_LOWER;
+                    }
+                }
+                for (;;) {
+                    backward_sweep(todo == 1, top);
+                    // forward sweep with the ratio test (free controls) and the multiplier test (fixed ones)
+                    float alpha = AS_NONE, viol = 0.0f;
+                    int akey = 0x7fffffff, vkey = 0x7fffffff; // (2 * stage + control) * 4 + bound hit
+                    {
+                        float e0, e1, e2;
+                        block_entry(e0, e1, e2);
+#pragma unroll
+                        for (int s = 0; s < S; ++s) { // slots past the horizon are equality-bounded: they never block or release
+                            const int k = j * S + s;
+                            Policy pol;
+                            pol.c00 = c00[s]; pol.c01 = c01[s]; pol.c02 = c02[s]; pol.f0 = pf0[s];
+                            pol.c10 = c10[s]; pol.c11 = c11[s]; pol.c12 = c12[s]; pol.e1 = pe1[s]; pol.f1 = pf1[s];
+                            StageStep o;
+                            forward_step(pol, st0[s], st1[s], e0, e1, e2, lb0[s], ub0[s], lb1[s], ub1[s], o);
+                            int h;
+                            const float ra = asm_ratio(st0[s], cur0[s], o.du0, lb0[s], ub0[s], h);
+                            if (ra < alpha) { alpha = ra; akey = (2 * k) * 4 + h; }
+                            const float rb = asm_ratio(st1[s], cur1[s], o.du1, lb1[s], ub1[s], h);
+                            if (rb < alpha) { alpha = rb; akey = (2 * k + 1) * 4 + h; }
+                            const float va = asm_violation(st0[s], o.mu0, lb0[s], ub0[s]),
+                                        vb = asm_violation(st1[s], o.mu1, lb1[s], ub1[s]);
+                            if (va > viol) { viol = va; vkey = (2 * k) * 4; }
+                            if (vb > viol) { viol = vb; vkey = (2 * k + 1) * 4; }
+                            if (todo == 1) {
+                                du0[s] = o.du0; du1[s] = o.du1; mu0[s] = o.mu0; mu1[s] = o.mu1;
+                                dxs[s][0] = e0; dxs[s][1] = e1; dxs[s][2] = e2;
+                            }
+                            const float n0 = e0 + sa[s] * e2 + B00[s] * o.du0 + B01[s] * o.du1 + d0[s];
+                            const float n1 = e1 + sb[s] * e2 + B10[s] * o.du0 + B11[s] * o.du1 + d1[s];
+                            const float n2 = e2 + B20[s] * (o.du0 - o.du1) + d2[s];
+                            e0 = n0; e1 = n1; e2 = n2;
+                        }
+                        if (todo == 1) { dxo[0] = e0; dxo[1] = e1; dxo[2] = e2; }
+                    }
+                    if (todo == 1) ++it;
+                    // the group's first blocking bound / worst multiplier: through LDS, lanes in order (ties: lowest stage)
+                    wave_sync();
+                    scr[lane * 4] = alpha; scr[lane * 4 + 1] = __int_as_float(akey);
+                    scr[lane * 4 + 2] = viol; scr[lane * 4 + 3] = __int_as_float(vkey);
+                    wave_sync();
+                    alpha = AS_NONE; viol = 0.0f; akey = 0x7fffffff; vkey = 0x7fffffff;
+                    for (int l = 0; l < L; ++l) {
+                        const float4 e = *reinterpret_cast<const float4*>(scr + (gbase + l) * 4);
+                        if (e.x < alpha) { alpha = e.x; akey = __float_as_int(e.y); }
+                        if (e.z > viol) { viol = e.z; vkey = __float_as_int(e.w); }
+                    }
+                    if (todo == 1) {
+                        const bool blocked = akey != 0x7fffffff;
+                        const bool release = !blocked && vkey != 0x7fffffff;
+                        const float al = blocked ? fmaxf(alpha, 0.0f) : 1.0f;
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const int k = j * S + s;
+                            if (k < N) {
+                                if (st0[s] == ST_FREE) cur0[s] += al * (du0[s] - cur0[s]);
+                                if (st1[s] == ST_FREE) cur1[s] += al * (du1[s] - cur1[s]);
+                                if (blocked && (akey >> 3) == k) {
+                                    const int hit = akey & 3;
+                                    if ((akey >> 2) & 1) { cur1[s] = (hit == ST_UPPER) ? ub1[s] : lb1[s]; st1[s] = hit; }
+                                    else { cur0[s] = (hit == ST_UPPER) ? ub0[s] : lb0[s]; st0[s] = hit; }
+                                }
+                                if (release && (vkey >> 3) == k) {
+                                    if ((vkey >> 2) & 1) st1[s] = ST_FREE; else st0[s] = ST_FREE;
+                                }
+                            }
+                        }
+                        if (!blocked && !release) todo = 0;  // optimal
+                        else if (it >= p.max_as_iter) todo = 2; // cap reached
+                    }
+                    if (!__any(todo == 1)) break;
+                }
+                if (rescue) {
+                    changed = (todo == 2);
+                    n_iter = it;
+                }
+            }
+        }
+        status = infeasible ? RET_INIT_FAILED_INFEASIBILITY
+                            : (pd_fail ? RET_INIT_FAILED_CHOLESKY : (changed ? RET_MAX_NWSR_REACHED : RET_OK));
+        if (STAMP && sqp == 0) t4 = __builtin_amdgcn_s_memtime();
+
+        // ---- phase C: KKT value (acado_getKKT), expand (acado_expand), carry the dual
+        float gd = 0.0f, comp = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int k = j * S + s;
+            if (k < N) {
+                if (DIAG) {
+                    if (k > 0) { // (Q_k sbar_k + q_k)' (dx_k - sbar_k)
+                        const float b0 = sbs[s][0], b1 = sbs[s][1], b2 = sbs[s][2];
+                        const float e0 = dxs[s][0] - b0, e1 = dxs[s][1] - b1, e2 = dxs[s][2] - b2;
+                        gd += (Q00[s] * b0 + Q01[s] * b1 + Q02[s] * b2 + q0[s]) * e0 +
+                              (Q01[s] * b0 + Q11[s] * b1 + Q12[s] * b2 + q1[s]) * e1 +
+                              (Q02[s] * b0 + Q12[s] * b1 + Q22[s] * b2 + q2[s]) * e2;
+                    }
+                    gd += r0[s] * du0[s] + r1[s] * du1[s];
+                    comp += (mu0[s] > 1e-12f) ? fabsf(lb0[s] * mu0[s]) : ((mu0[s] < -1e-12f) ? fabsf(ub0[s] * mu0[s]) : 0.0f);
+                    comp += (mu1[s] > 1e-12f) ? fabsf(lb1[s] * mu1[s]) : ((mu1[s] < -1e-12f) ? fabsf(ub1[s] * mu1[s]) : 0.0f);
+                }
+                x[s][0] += dxs[s][0]; x[s][1] += dxs[s][1]; x[s][2] += dxs[s][2];
+                // a free control may sit up to TOL_PRIMAL outside its box: keep the iterate feasible
+                const float e0 = (lb0[s] <= ub0[s]) ? clampf(du0[s], lb0[s], ub0[s]) : du0[s];
+                const float e1 = (lb1[s] <= ub1[s]) ? clampf(du1[s], lb1[s], ub1[s]) : du1[s];
+                u[s][0] += e0; u[s][1] += e1;
+            }
+        }
+        if (j == top) { // terminal node
+            if (DIAG) {
+                const float b0 = sbo[0], b1 = sbo[1], b2 = sbo[2];
+                const float e0 = dxo[0] - b0, e1 = dxo[1] - b1, e2 = dxo[2] - b2;
+                gd += (QN[0] * b0 + QN[1] * b1 + QN[2] * b2 + qN[0]) * e0 + (QN[1] * b0 + QN[3] * b1 + QN[4] * b2 + qN[1]) * e1 +
+                      (QN[2] * b0 + QN[4] * b1 + QN[5] * b2 + qN[2]) * e2;
+            }
+            xN[0] += dxo[0]; xN[1] += dxo[1]; xN[2] += dxo[2];
+        }
+        if (DIAG) kkt = fabsf(gtotal<L>(gd, j, lane)) + gtotal<L>(comp, j, lane);
+    }
+    if (STAMP) t5 = __builtin_amdgcn_s_memtime();
+
+    // ---- objective at the returned iterate (acado_getObjective), then the iterate back through LDS
+    float obj = 0.0f;
+    if (DIAG) {
+        float part = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int k = j * S + s;
+            if (k < N) {
+                const float* yk = lds + oY + ge * 5 * N + 5 * k;
+                const float* Wk = lds + oW + ge * 25 * N + 25 * k;
+                const float e[5] = {x[s][0] - yk[0], x[s][1] - yk[1], x[s][2] - yk[2], u[s][0] - yk[3], u[s][1] - yk[4]};
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const float tt = e[0] * Wk[c] + e[1] * Wk[5 + c] + e[2] * Wk[10 + c] + e[3] * Wk[15 + c] + e[4] * Wk[20 + c];
+                    acc += e[c] * tt;
+                }
+                part += acc;
+            }
+        }
+        if (j == top) { // the reference uses only the diagonal of WN here (acado_solver.c:1442-1444)
+            const float e0 = xN[0] - yN[0], e1 = xN[1] - yN[1], e2 = xN[2] - yN[2];
+            part += e0 * e0 * WN[0] + e1 * e1 * WN[4] + e2 * e2 * WN[8];
+        }
+        obj = 0.5f * gtotal<L>(part, j, lane);
+    }
+    wave_sync(); // W / y are dead from here: their area becomes the output staging buffer
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int k = j * S + s;
+            if (k < N) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) lds[oX + g * nx + 3 * k + c] = x[s][c];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    lds[oU + g * nu + 2 * k + c] = u[s][c];
+                }
+                lds[oDL + g * nu + 2 * k] = mu0[s];
+                lds[oDL + g * nu + 2 * k + 1] = mu1[s];
+            }
+        }
+        if (j == top) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lds[oX + g * nx + 3 * N + c] = xN[c];
+        }
+    }
+    wave_sync();
+    {
+        constexpr int UX = (G * 3 * (NMAX + 1) / 4 + 63) / 64;
+        constexpr int UU = (G * 2 * NMAX / 4 + 63) / 64;
+        g_store<UX>(p.b.x + (size_t)prob0 * nx, lds + oX, np_ * nx, lane);
+        g_store<UU>(p.b.u + (size_t)prob0 * nu, lds + oU, np_ * nu, lane);
+        g_store<UU>(p.b.dual + (size_t)prob0 * nu, lds + oDL, np_ * nu, lane);
+    }
+    if (valid && j == 0) {
+        p.b.status[prob] = status;
+        p.b.n_iter[prob] = n_iter;
+        if (DIAG && p.b.kkt) p.b.kkt[prob] = kkt;
+        if (DIAG && p.b.obj) p.b.obj[prob] = obj;
+    }
+    if (STAMP && lane == 0 && p.stamps) {
+        long long* o = p.stamps + (size_t)blockIdx.x * 8;
+        const long long t_end = __builtin_amdgcn_s_memtime();
+        o[0] = t1 - t0;    // load + phase A
+        o[1] = t_b;        // backward sweeps
+        o[2] = t_f;        // forward sweeps
+        o[3] = t5 - t4;    // phase C
+        o[4] = t_end - t5; // objective + store
+        o[5] = t_end - t0; // total
+        o[6] = t_pg;       // working-set prediction
+    }
+}
+
+// (L, S) instantiated: (4, 5) (8, 3) (16, 2) for horizons up to 20 / 24 / 32, (16, 4) up to 64
+bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g)
+{
+    if (B <= 0 || N <= 0) return false;
+    const int cus = n_cu > 0 ? n_cu : 256;
+    int L = forced_L;
+    if (L == 0) {
+        // the sweeps cost N scalar stage steps per wavefront whatever L is: spread a small batch over all SIMDs
+        // (one wavefront each), pack a large one
+        L = 16;
+        while (L > 4 && (long)(B + 64 / L - 1) / (64 / L) > 4L * cus) L >>= 1;
+        while (L < 16 && N > L * (L == 4 ? 5 : 3)) L <<= 1;
+    }
+    int S = 0;
+    if (L == 4 && N <= 20) S = 5;
+    else if (L == 8 && N <= 24) S = 3;
+    else if (L == 16 && N <= 32) S = 2;
+    else if (L == 16 && N <= 64) S = 4;
+    if (S == 0) return false;
+    const size_t lds = (size_t)block_lds_floats(N, L) * 4;
+    if ((long)lds > lds_limit_bytes) return false;
+    g->L = L;
+    g->G = 64 / L;
+    g->wpb = 1;
+    g->wreg = 0;
+    g->threads = 64;
+    g->grid = (B + g->G - 1) / g->G;
+    g->RS = S; // stages per lane
+    g->lds_bytes = lds;
+    g->block = 1;
+    return true;
+}
+
+hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
+{
+    const bool stamp = p.stamps != nullptr;
+    const bool diag = stamp || p.b.kkt != nullptr || p.b.obj != nullptr;
+    const void* fn = nullptr;
+    int v = -1;
+#define PICK(LL, SS, idx)                                                                        \
+    if (g.L == LL && g.RS == SS) {                                                               \
+        v = idx * 3 + (stamp ? 2 : (diag ? 0 : 1));                                              \
+        fn = stamp ? (const void*)rti_block_kernel<LL, SS, true, true>                           \
+                   : (diag ? (const void*)rti_block_kernel<LL, SS, true, false>                  \
+                           : (const void*)rti_block_kernel<LL, SS, false, false>);               \
+    }
+    PICK(4, 5, 0)
+    PICK(8, 3, 1)
+    PICK(16, 2, 2)
+    PICK(16, 4, 3)
+#undef PICK
+    if (!fn) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    dev &= 15;
+    static size_t configured[16][12] = {{0}};
+    if (g.lds_bytes > configured[dev][v]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+        if (e != hipSuccess) return e;
+        configured[dev][v] = g.lds_bytes;
+    }
+    void* args[] = {const_cast<RtiParams*>(&p)};
+    e = hipLaunchKernel(fn, dim3(g.grid), dim3(64), args, g.lds_bytes, s);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+} // namespace nmpc

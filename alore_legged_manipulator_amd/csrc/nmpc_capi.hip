@@ -144,9 +144,12 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     if (!cfg || !out) return ALORE_NMPC_E_INVALID;
     *out = nullptr;
     if (cfg->N < 1 || !(cfg->dt > 0.0f)) return ALORE_NMPC_E_INVALID;
-    if (cfg->lanes_per_problem != 0 && cfg->lanes_per_problem != 4 && cfg->lanes_per_problem != 8 &&
-        cfg->lanes_per_problem != 16 && cfg->lanes_per_problem != 32 && cfg->lanes_per_problem != 64)
-        return ALORE_NMPC_E_INVALID;
+    {
+        const int lp = cfg->lanes_per_problem, lw = lp & ~0x100;
+        const bool blk = (lp & 0x100) != 0;
+        if (lp != 0 && !(blk ? (lw == 4 || lw == 8 || lw == 16) : (lw == 4 || lw == 8 || lw == 16 || lw == 32 || lw == 64)))
+            return ALORE_NMPC_E_INVALID;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ALORE_NMPC_E_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return ALORE_NMPC_E_INVALID;
@@ -165,7 +168,10 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     if (h->lds_limit > 160 * 1024) h->lds_limit = 160 * 1024;
     // the horizon must fit the on-chip layout with at least one geometry
     nmpc::LaunchGeom g;
-    if (!nmpc::rti_geometry(1, cfg->N, cfg->lanes_per_problem, h->lds_limit, h->n_cu, &g)) {
+    const bool fits = (cfg->lanes_per_problem & 0x100)
+                          ? nmpc::block_geometry(1, cfg->N, cfg->lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g)
+                          : nmpc::rti_geometry(1, cfg->N, cfg->lanes_per_problem, h->lds_limit, h->n_cu, &g);
+    if (!fits) {
         delete h;
         return ALORE_NMPC_E_UNSUPPORTED;
     }
@@ -387,7 +393,19 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     if (!batch_complete(dev)) return fail(h, ALORE_NMPC_E_INVALID, "rti: batch has NULL members");
     nmpc::LaunchGeom g;
     static const int forced_wpb = getenv("ALORE_NMPC_WPB") ? atoi(getenv("ALORE_NMPC_WPB")) : 0; // diagnostic: 1 or 4
-    if (!nmpc::rti_geometry(B, h->cfg.N, h->cfg.lanes_per_problem, h->lds_limit, h->n_cu, &g, forced_wpb))
+    // Mapping: the stage-block kernel (nmpc_block_kernel.hip) unless the caller forces lanes of the wavefront kernel,
+    // the horizon exceeds its instantiations, or the launch uses what only the wavefront kernel implements (a separate
+    // linearisation point, batch-shared members, members that are not 16-byte aligned).
+    static const char* force_kernel = getenv("ALORE_NMPC_KERNEL"); // diagnostic: "wave" or "block"
+    const int lp = h->cfg.lanes_per_problem;
+    bool use_block = (lp == 0 || (lp & 0x100)) && !(force_kernel && force_kernel[0] == 'w');
+    if (use_block) {
+        const void* ptrs[] = {dev->x, dev->u, dev->od, dev->y, dev->W, dev->lbValues, dev->ubValues, dev->dual};
+        for (const void* q : ptrs) use_block = use_block && ((reinterpret_cast<size_t>(q) & 15) == 0);
+        use_block = use_block && !h->lin_x && !h->shared;
+        use_block = use_block && nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g);
+    }
+    if (!use_block && !nmpc::rti_geometry(B, h->cfg.N, (lp & 0x100) ? 0 : lp, h->lds_limit, h->n_cu, &g, forced_wpb))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: horizon does not fit the LDS layout");
     nmpc::RtiParams p;
     p.b = *dev;
@@ -416,7 +434,7 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
         p.stamps = h->d_stamps;
     }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-    HIP_TRY(h, nmpc::launch_rti(p, g, s));
+    HIP_TRY(h, g.block ? nmpc::launch_rti_block(p, g, s) : nmpc::launch_rti(p, g, s));
     if (h->timing) {
         HIP_TRY(h, hipEventRecord(h->ev1, s));
         h->timed_pending = true;
@@ -841,7 +859,7 @@ int alore_nmpc_get_launch_info(alore_nmpc_handle h, alore_nmpc_launch_info* out)
         HIP_TRY(h, hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
         h->timed_pending = false;
     }
-    out->lanes_per_problem = h->last_geom.L;
+    out->lanes_per_problem = h->last_geom.L | (h->last_geom.block ? 0x100 : 0);
     out->problems_per_block = h->last_geom.G * h->last_geom.wpb;
     out->threads_per_block = h->last_geom.threads;
     out->grid = h->last_geom.grid;

@@ -31,8 +31,9 @@ struct LaunchGeom {
     int wreg;    // 1: W_k of a stage lives in the registers of its lane, not in the LDS staging area
     int threads; // = L * G, multiple of 64
     int grid;
-    int RS;
+    int RS;      // wavefront kernel: LDS floats per problem; stage-block kernel: stages per lane (S)
     size_t lds_bytes;
+    int block;   // 1: stage-block kernel (nmpc_block_kernel.hip), 0: wavefront kernel (nmpc_kernels.hip)
 };
 
 // number of LDS floats one problem needs (before padding) for horizon N
@@ -40,6 +41,10 @@ int rti_row_floats(int N, bool wreg);
 // choose lanes/problem + block shape for (B, N); returns false if N does not fit
 bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int forced_wpb = 0);
 hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
+// stage-block kernel (nmpc_block_kernel.hip): L = 4, 8 or 16 lanes per problem, each lane owns ceil(N / L) stages
+int block_lds_floats(int N, int L);
+bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g);
+hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
 
 hipError_t launch_linearize(const alore_nmpc_batch& b, int B, int N, float dt, const alore_nmpc_lin_out& o,
                             hipStream_t s);

@@ -111,6 +111,7 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
         g->grid = (B + G * wpb - 1) / (G * wpb);
         g->RS = RS;
         g->lds_bytes = (size_t)row_bytes * G * wpb;
+        g->block = 0;
         return true;
     }
     return false;

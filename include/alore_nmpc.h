@@ -52,6 +52,8 @@ extern "C" {
 #define ALORE_NMPC_E_NOMEM (-4)
 #define ALORE_NMPC_E_UNSUPPORTED (-5) /* horizon too long for the on-chip layout */
 
+#define ALORE_NMPC_BLOCK_LANES(L) (0x100 | (L))
+
 typedef struct alore_nmpc_solver *alore_nmpc_handle;
 
 typedef struct {
@@ -61,7 +63,11 @@ typedef struct {
     int max_as_iter; /* cap on working-set sweeps per QP (<=0: default 128; after 16 primal-dual sweeps the
                         solver continues as a primal active-set method, one change per sweep); the
                         reference caps working-set changes at 300, acado_qpoases_interface.hpp:44 */
-    int lanes_per_problem; /* 0 = choose from the batch size; else 4, 8, 16, 32 or 64 */
+    int lanes_per_problem; /* 0 = choose mapping and width from the batch size.  4, 8, 16, 32 or 64: the wavefront
+                              mapping (one lane per stage, sweeps row-split over quads).  ALORE_NMPC_BLOCK_LANES(L),
+                              L = 4, 8 or 16: the stage-block mapping (a lane owns ceil(N / L) consecutive stages in
+                              registers, sweeps lane by lane; horizons up to 64).  alore_nmpc_get_launch_info reports
+                              the choice in the same encoding. */
     int warm_start_steps;  /* projected-gradient steps used to predict the working set of a QP whose
                               first solve hit bounds (<0: default 6; 0: off).  Affects only the number
                               of working-set iterations, never the solution. */

@@ -1,0 +1,102 @@
+"""A/B of the two RTI kernels on identical inputs (GPU box): the wavefront kernel (lanes_per_problem = 32 / 64) against
+the stage-block kernel (ALORE_NMPC_BLOCK_LANES(L)).  Prints the largest differences per output member and, with
+--time, microseconds per launch of each from HIP events around a graph-free loop.
+
+    python tools/ab_block.py [--time] [--wide] [--B 4096] [--N 20] [--sqp 1]
+"""
+import argparse
+import sys
+import os
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from alore_legged_manipulator_amd.nmpc import BatchedNmpc  # noqa: E402
+from alore_legged_manipulator_amd.scenarios import make_batch, make_wide_batch  # noqa: E402
+
+
+def run(B, N, lanes, batch, sqp, ticks=1):
+    eng = BatchedNmpc(B, N, lanes_per_problem=lanes)
+    eng.load(batch)
+    for _ in range(ticks):
+        eng.rti(sqp)
+    out = eng.fetch()
+    info = eng.launch_info()
+    eng.close()
+    return out, info
+
+
+def time_it(B, N, lanes, batch, reps=200, diagnostics=True):
+    import torch
+    slots = 8
+    eng = BatchedNmpc(B, N, lanes_per_problem=lanes, slots=slots, diagnostics=diagnostics)
+    eng.load(batch, slot=None)
+    keep = {k: eng.ts[k].clone() for k in ("x", "u", "dual")}
+    for s in range(slots):
+        eng.rti(1, slot=s)
+    torch.cuda.synchronize()
+    ts = []
+    for r in range(3):
+        for k in keep:
+            eng.ts[k].copy_(keep[k])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 0
+        for i in range(reps // slots):
+            for s in range(slots):
+                eng.rti(1, slot=s)
+                n += 1
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / n)
+    info = eng.launch_info()
+    eng.close()
+    return min(ts), info
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=4096)
+    ap.add_argument("--N", type=int, default=20)
+    ap.add_argument("--sqp", type=int, default=1)
+    ap.add_argument("--ticks", type=int, default=1)
+    ap.add_argument("--wide", action="store_true")
+    ap.add_argument("--time", action="store_true")
+    ap.add_argument("--lanes", type=str, default="0,4,8,16")
+    a = ap.parse_args()
+    B, N = a.B, a.N
+    batch = make_wide_batch(B, N, 3) if a.wide else make_batch(B, N, fast_tail=0.05)
+    ref, info = run(B, N, 32 if N <= 32 else 64, batch, a.sqp, a.ticks)
+    print(f"wave kernel: {info}  status!=0: {(ref['status'] != 0).sum()}  n_iter max {ref['n_iter'].max()}")
+    for l in [int(v) for v in a.lanes.split(",")]:
+        lanes = 0 if l == 0 else (0x100 | l)
+        try:
+            out, info = run(B, N, lanes, batch, a.sqp, a.ticks)
+        except Exception as e:  # noqa: BLE001
+            print(f"block L={l}: {e}")
+            continue
+        line = [f"block L={l}: lanes={info['lanes_per_problem']:#x} grid={info['grid']} lds={info['lds_bytes_per_block']}"]
+        for k in ("x", "u", "dual", "kkt", "obj"):
+            d = np.abs(out[k].astype(np.float64) - ref[k])
+            sc = np.maximum(1.0, np.abs(ref[k]).reshape(B, -1).max(axis=1))
+            rel = (d.reshape(B, -1).max(axis=1) / sc)
+            line.append(f"{k}: {rel.max():.2e}@{int(rel.argmax())}")
+        line.append(f"status eq {np.array_equal(out['status'], ref['status'])} n_iter eq {np.array_equal(out['n_iter'], ref['n_iter'])}"
+                    f" (max {out['n_iter'].max()}) finite {bool(np.isfinite(out['x']).all())}")
+        print("  ".join(line))
+    if a.time:
+        for diag in (True, False):
+            t, info = time_it(B, N, 32 if N <= 32 else 64, batch, diagnostics=diag)
+            print(f"time wave  diag={diag}: {t:8.2f} us/launch  {info}")
+            for l in [int(v) for v in a.lanes.split(",")]:
+                lanes = 0 if l == 0 else (0x100 | l)
+                try:
+                    t, info = time_it(B, N, lanes, batch, diagnostics=diag)
+                    print(f"time block L={l} diag={diag}: {t:8.2f} us/launch  grid={info['grid']} lanes={info['lanes_per_problem']:#x}")
+                except Exception as e:  # noqa: BLE001
+                    print(f"time block L={l}: {e}")
+
+
+if __name__ == "__main__":
+    main()
