@@ -98,6 +98,26 @@ __device__ __forceinline__ int gmax(int x, int j, int lane)
 {
     return __float_as_int(glast<L>(__int_as_float(gprefix_max<L>(x, j)), lane));
 }
+// lexicographic minimum of (v, key) over the lanes of a group, in every lane
+template <int L>
+__device__ __forceinline__ void gmin_pair(float& v, int& key, int j, int lane)
+{
+    auto step = [&](auto tag, int dist) {
+        constexpr int CTRL = decltype(tag)::value;
+        const float pv = dppk<CTRL>(v, v);
+        const int pk = dppk_i<CTRL>(key, key);
+        const bool has = (L >= 16) || (j >= dist);
+        const bool take = has && ((pv < v) || (pv == v && pk < key));
+        v = take ? pv : v;
+        key = take ? pk : key;
+    };
+    step(std::integral_constant<int, 0x111>{}, 1);
+    step(std::integral_constant<int, 0x112>{}, 2);
+    if constexpr (L >= 8) step(std::integral_constant<int, 0x114>{}, 4);
+    if constexpr (L >= 16) step(std::integral_constant<int, 0x118>{}, 8);
+    v = glast<L>(v, lane);
+    key = __float_as_int(glast<L>(__int_as_float(key), lane));
+}
 template <int L>
 __device__ __forceinline__ bool gany(bool pred, int base)
 {
@@ -148,9 +168,12 @@ __device__ __forceinline__ void g_store(float* g, const float* l, int total, int
 
 } // namespace
 
-// LDS floats of one wavefront: W and y of its 64 / L problems (the iterate and the bounds pass through the W area
-// before W lands) + 256 floats of scratch for the cold active-set path
-int block_lds_floats(int N, int L) { return (64 / L) * 30 * N + 256; }
+// LDS floats of one wavefront: W and y of its 64 / L problems, each area padded to whole 256-float DMA pieces
+int block_lds_floats(int N, int L)
+{
+    const int G = 64 / L;
+    return ((G * 25 * N + 255) & ~255) + ((G * 5 * N + 255) & ~255);
+}
 
 template <int L, int S, bool DIAG, bool STAMP>
 __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
@@ -169,6 +192,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     const int ge = valid ? g : np_ - 1; // padding groups shadow the last problem, never store
     const int prob = prob0 + ge;
     const int nx = 3 * (N + 1), nu = 2 * N;
+    const int gw = (p.shared & ALORE_NMPC_SHARED_W) ? 0 : ge; // whose copy of W this group reads
     const int top = (N - 1) / S;        // lane that owns stage N - 1 (and the terminal node)
 
     long long t0 = 0, t1 = 0, t4 = 0, t5 = 0;
@@ -177,67 +201,66 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     IrkConst K;
     K.h = p.h; K.hh = p.hh; K.c1h = p.c1h; K.c2h = p.c2h;
 
-    // LDS map (floats): resident [W | y | scratch]; x, u, dual, od, lb, ub pass through the W area first
-    const int oW = 0, oY = G * 25 * N, oScr = G * 30 * N;
-    const int oX = 0, oU = G * nx, oDL = oU + G * nu, oOD = oDL + G * nu, oLB = oOD + G * nx, oUB = oLB + G * nu;
+    // LDS map (floats): [W | y] of the wavefront's problems, each area a whole number of 256-float DMA pieces; after
+    // the objective the W area is the staging buffer of the outputs
+    const int WA = (G * 25 * N + 255) & ~255, oW = 0, oY = WA;
+    const int oX = 0, oU = G * nx, oDL = oU + G * nu;
 
-    // ---- phase 0: coalesced loads of the wavefront's problems -> LDS -> registers of the owning lane
+    // ---- phase 0.  W and y (read again for the objective) go HBM -> LDS by DMA, no registers: the wavefront's
+    //      problems are contiguous, one instruction moves 1 KB.  The iterate, od, the bounds and the dual are read by
+    //      the lane that owns the stage straight into its registers (12- and 8-byte pieces of one contiguous span).
+    {
+        constexpr int UW = (G * 25 * NMAX + 255) / 256, UY = (G * 5 * NMAX + 255) / 256;
+        auto dma = [&](const float* gsrc, int total, int lds_off, auto utag) {
+            constexpr int U = decltype(utag)::value;
+            const int n4 = total >> 2, rem = total & 3;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u * 64 < n4) { // wavefront-uniform
+                    const int i = min(u * 64 + lane, n4 - 1); // lanes past the end re-read the last piece (their LDS slot is padding)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gsrc + 4 * i),
+                                                     (void __attribute__((address_space(3)))*)(lds + lds_off + u * 256), 16, 0, 0);
+                }
+            }
+            if (rem && lane < rem) lds[lds_off + n4 * 4 + lane] = gsrc[n4 * 4 + lane]; // ragged last wavefront only
+        };
+        if (p.shared & ALORE_NMPC_SHARED_W) dma(p.b.W, 25 * N, oW, std::integral_constant<int, UW>{}); // one copy for the batch
+        else dma(p.b.W + (size_t)prob0 * 25 * N, np_ * 25 * N, oW, std::integral_constant<int, UW>{});
+        dma(p.b.y + (size_t)prob0 * 5 * N, np_ * 5 * N, oY, std::integral_constant<int, UY>{});
+    }
     float x[S][3], u[S][2], od[S][3], lbv[S][2], ubv[S][2], xN[3];
     float mu0[S], mu1[S]; // bound multipliers: the incoming dual until the first forward sweep overwrites it
     float x00, x01, x02, WN[9], yN[3];
     {
-        constexpr int UX = (G * 3 * (NMAX + 1) / 4 + 63) / 64;
-        constexpr int UU = (G * 2 * NMAX / 4 + 63) / 64;
-        constexpr int UY = (G * 5 * NMAX / 4 + 63) / 64;
-        constexpr int UW = (G * 25 * NMAX / 4 + 63) / 64;
-        float4 qx[UX], qod[UX], qu[UU], qdl[UU], qlb[UU], qub[UU], qy[UY], qW[UW];
-        float tx, tod, tu, tdl, tlb, tub, ty, tW;
-        g_issue<UX>(p.b.x + (size_t)prob0 * nx, np_ * nx, lane, qx, tx);
-        g_issue<UU>(p.b.u + (size_t)prob0 * nu, np_ * nu, lane, qu, tu);
-        g_issue<UU>(p.b.dual + (size_t)prob0 * nu, np_ * nu, lane, qdl, tdl);
-        g_issue<UX>(p.b.od + (size_t)prob0 * nx, np_ * nx, lane, qod, tod);
-        g_issue<UU>(p.b.lbValues + (size_t)prob0 * nu, np_ * nu, lane, qlb, tlb);
-        g_issue<UU>(p.b.ubValues + (size_t)prob0 * nu, np_ * nu, lane, qub, tub);
-        g_issue<UY>(p.b.y + (size_t)prob0 * 5 * N, np_ * 5 * N, lane, qy, ty);
-        g_issue<UW>(p.b.W + (size_t)prob0 * 25 * N, np_ * 25 * N, lane, qW, tW);
-        x00 = p.b.x0[(size_t)prob * 3]; x01 = p.b.x0[(size_t)prob * 3 + 1]; x02 = p.b.x0[(size_t)prob * 3 + 2];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) WN[i] = p.b.WN[(size_t)prob * 9 + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) yN[i] = p.b.yN[(size_t)prob * 3 + i];
-
-        l_commit<UX>(lds + oX, np_ * nx, lane, qx, tx);
-        l_commit<UU>(lds + oU, np_ * nu, lane, qu, tu);
-        l_commit<UU>(lds + oDL, np_ * nu, lane, qdl, tdl);
-        l_commit<UX>(lds + oOD, np_ * nx, lane, qod, tod);
-        l_commit<UU>(lds + oLB, np_ * nu, lane, qlb, tlb);
-        l_commit<UU>(lds + oUB, np_ * nu, lane, qub, tub);
-        l_commit<UY>(lds + oY, np_ * 5 * N, lane, qy, ty);
-        wave_sync();
+        typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        const float* gx = p.b.x + (size_t)prob * nx;
+        const float* god = p.b.od + ((p.shared & ALORE_NMPC_SHARED_OD) ? 0 : (size_t)prob * nx);
+        const float* gu = p.b.u + (size_t)prob * nu;
+        const float* gdl = p.b.dual + (size_t)prob * nu;
+        const float* glb = p.b.lbValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * nu);
+        const float* gub = p.b.ubValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * nu);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int k = j * S + s;
             const int kn = min(k, N), kc = min(k, N - 1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                x[s][c] = lds[oX + ge * nx + 3 * kn + c];
-                od[s][c] = lds[oOD + ge * nx + 3 * kn + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                u[s][c] = lds[oU + ge * nu + 2 * kc + c];
-                lbv[s][c] = lds[oLB + ge * nu + 2 * kc + c];
-                ubv[s][c] = lds[oUB + ge * nu + 2 * kc + c];
-            }
-            mu0[s] = lds[oDL + ge * nu + 2 * kc];
-            mu1[s] = lds[oDL + ge * nu + 2 * kc + 1];
+            const f3u vx = *reinterpret_cast<const f3u*>(gx + 3 * kn), vo = *reinterpret_cast<const f3u*>(god + 3 * kn);
+            const f2u vu = *reinterpret_cast<const f2u*>(gu + 2 * kc), vd = *reinterpret_cast<const f2u*>(gdl + 2 * kc),
+                      vl = *reinterpret_cast<const f2u*>(glb + 2 * kc), vh = *reinterpret_cast<const f2u*>(gub + 2 * kc);
+            x[s][0] = vx.x; x[s][1] = vx.y; x[s][2] = vx.z; od[s][0] = vo.x; od[s][1] = vo.y; od[s][2] = vo.z;
+            u[s][0] = vu.x; u[s][1] = vu.y; mu0[s] = vd.x; mu1[s] = vd.y;
+            lbv[s][0] = vl.x; lbv[s][1] = vl.y; ubv[s][0] = vh.x; ubv[s][1] = vh.y;
         }
+        const f3u vn = *reinterpret_cast<const f3u*>(gx + 3 * N);
+        xN[0] = vn.x; xN[1] = vn.y; xN[2] = vn.z;
+        x00 = p.b.x0[(size_t)prob * 3]; x01 = p.b.x0[(size_t)prob * 3 + 1]; x02 = p.b.x0[(size_t)prob * 3 + 2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) xN[c] = lds[oX + ge * nx + 3 * N + c];
-        wave_sync();
-        l_commit<UW>(lds + oW, np_ * 25 * N, lane, qW, tW);
-        wave_sync();
+        for (int i = 0; i < 9; ++i) WN[i] = p.b.WN[((p.shared & ALORE_NMPC_SHARED_W) ? 0 : (size_t)prob * 9) + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) yN[i] = p.b.yN[(size_t)prob * 3 + i];
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the DMA pieces have landed
+    wave_sync();
 
     // per-stage data of the S stages this lane owns (stage k = j * S + s; slots with k >= N are neutral)
     // Q, q, a, b carry one more element: the node after the lane's block (the next lane's first node, or the terminal
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             StageLin lin;
             ddr_linearize(K, x[s][0], x[s][1], x[s][2], u[s][0], u[s][1], od[s][0], od[s][1], od[s][2], lin);
             const float* yk = lds + oY + ge * 5 * N + 5 * kc;
-            const float* Wk = lds + oW + ge * 25 * N + 25 * kc;
+            const float* Wk = lds + oW + gw * 25 * N + 25 * kc;
             float w[25];
 #pragma unroll
             for (int i = 0; i < 25; ++i) w[i] = Wk[i];
@@ -672,7 +695,6 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             const bool rescue = changed && it >= AS_SWITCH && it < p.max_as_iter;
             if (__builtin_expect(__any(rescue) ? 1 : 0, 0)) {
                 float cur0[S], cur1[S];
-                float* scr = lds + oScr;
                 int todo = rescue ? 1 : 0;
 #pragma unroll
                 for (int s = 0; s < S; ++s) { // start: clip the last solution into the box, fix what sits on a bound
@@ -721,17 +743,11 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
                         if (todo == 1) { dxo[0] = e0; dxo[1] = e1; dxo[2] = e2; }
                     }
                     if (todo == 1) ++it;
-                    // the group's first blocking bound / worst multiplier: through LDS, lanes in order (ties: lowest stage)
-                    wave_sync();
-                    scr[lane * 4] = alpha; scr[lane * 4 + 1] = __int_as_float(akey);
-                    scr[lane * 4 + 2] = viol; scr[lane * 4 + 3] = __int_as_float(vkey);
-                    wave_sync();
-                    alpha = AS_NONE; viol = 0.0f; akey = 0x7fffffff; vkey = 0x7fffffff;
-                    for (int l = 0; l < L; ++l) {
-                        const float4 e = *reinterpret_cast<const float4*>(scr + (gbase + l) * 4);
-                        if (e.x < alpha) { alpha = e.x; akey = __float_as_int(e.y); }
-                        if (e.z > viol) { viol = e.z; vkey = __float_as_int(e.w); }
-                    }
+                    // the group's first blocking bound / worst multiplier (ties: lowest stage): lexicographic minima
+                    gmin_pair<L>(alpha, akey, j, lane);
+                    float nviol = -viol;
+                    gmin_pair<L>(nviol, vkey, j, lane);
+                    viol = -nviol;
                     if (todo == 1) {
                         const bool blocked = akey != 0x7fffffff;
                         const bool release = !blocked && vkey != 0x7fffffff;
@@ -814,7 +830,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             const int k = j * S + s;
             if (k < N) {
                 const float* yk = lds + oY + ge * 5 * N + 5 * k;
-                const float* Wk = lds + oW + ge * 25 * N + 25 * k;
+                const float* Wk = lds + oW + gw * 25 * N + 25 * k;
                 const float e[5] = {x[s][0] - yk[0], x[s][1] - yk[1], x[s][2] - yk[2], u[s][0] - yk[3], u[s][1] - yk[4]};
                 float acc = 0.0f;
 #pragma unroll

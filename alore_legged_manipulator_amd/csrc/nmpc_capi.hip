@@ -395,14 +395,14 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     static const int forced_wpb = getenv("ALORE_NMPC_WPB") ? atoi(getenv("ALORE_NMPC_WPB")) : 0; // diagnostic: 1 or 4
     // Mapping: the stage-block kernel (nmpc_block_kernel.hip) unless the caller forces lanes of the wavefront kernel,
     // the horizon exceeds its instantiations, or the launch uses what only the wavefront kernel implements (a separate
-    // linearisation point, batch-shared members, members that are not 16-byte aligned).
+    // linearisation point, members that are not 16-byte aligned).
     static const char* force_kernel = getenv("ALORE_NMPC_KERNEL"); // diagnostic: "wave" or "block"
     const int lp = h->cfg.lanes_per_problem;
     bool use_block = (lp == 0 || (lp & 0x100)) && !(force_kernel && force_kernel[0] == 'w');
     if (use_block) {
         const void* ptrs[] = {dev->x, dev->u, dev->od, dev->y, dev->W, dev->lbValues, dev->ubValues, dev->dual};
         for (const void* q : ptrs) use_block = use_block && ((reinterpret_cast<size_t>(q) & 15) == 0);
-        use_block = use_block && !h->lin_x && !h->shared;
+        use_block = use_block && !h->lin_x;
         use_block = use_block && nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g);
     }
     if (!use_block && !nmpc::rti_geometry(B, h->cfg.N, (lp & 0x100) ? 0 : lp, h->lds_limit, h->n_cu, &g, forced_wpb))

@@ -305,7 +305,9 @@ def test_config3_whole_batch_on_one_gpu(nmpc_mod):
         st, ref, _ = oracle_tick(orc, problem(hb, b))
         assert st == 0 and relerr(out["u"][b].reshape(-1), ref["u"]) < 1e-4 and relerr(out["x"][b].reshape(-1), ref["x"]) < 1e-4
     lo = B - 4096
-    small = nmpc_mod.BatchedNmpc(4096, N)
+    # same lane mapping as the big launch: the library picks the mapping from the batch size, and different
+    # mappings agree to rounding only
+    small = nmpc_mod.BatchedNmpc(4096, N, lanes_per_problem=eng.launch_info()["lanes_per_problem"])
     small.load({k: v[lo:] for k, v in hb.items()})
     small.rti(1)
     so = small.fetch()
@@ -471,3 +473,58 @@ def test_c_abi_result_exchange_over_rccl_single_rank():
     for k in ("x", "u", "status", "kkt"):
         assert torch.equal(out[k].reshape(-1), eng.t[k].reshape(-1)), k
     assert lib.alore_nmpc_comm_destroy(comm) == 0
+
+
+BLOCK = 0x100  # ALORE_NMPC_BLOCK_LANES(L) = 0x100 | L (include/alore_nmpc.h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,lanes", [(20, BLOCK | 4), (20, BLOCK | 8), (20, BLOCK | 16), (7, BLOCK | 4), (24, BLOCK | 8),
+                                     (31, BLOCK | 16), (50, BLOCK | 16), (1, BLOCK | 4), (20, 32), (50, 64)])
+def test_every_lane_mapping_against_the_oracle(nmpc_mod, N, lanes):
+    """Both kernels, every instantiated lane mapping (stage-block L = 4 / 8 / 16 with 5 / 3 / 2 / 4 stages per lane, the
+    wavefront mapping): one tick from the cold start and one warm tick (the dual seeds the working set) of seeded
+    problems, a ragged batch, against the oracle: x, u <= 1e-4 relative (BASELINE.json), multipliers 1e-3."""
+    B = 37
+    batch = make_batch(B, N, seed=31, fast_tail=0.4)
+    eng = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=lanes)
+    eng.load(batch)
+    eng.rti(1)
+    a = eng.fetch()
+    assert eng.launch_info()["lanes_per_problem"] == lanes
+    eng.rti(1)
+    b = eng.fetch()
+    orc = Oracle(N)
+    for p in range(0, B, 3):
+        orc.reset(); orc.initialize_solver(); orc.load(problem(batch, p))
+        for out in (a, b):
+            orc.preparation_step()
+            assert orc.feedback_step() == 0 and out["status"][p] == 0
+            for k, tol in (("x", 1e-4), ("u", 1e-4), ("dual", 1e-3)):
+                assert relerr(out[k][p].reshape(-1), orc.v[k]) < tol, (p, k)
+            assert abs(out["obj"][p] - orc.get_objective()) <= 1e-4 * max(1.0, abs(orc.get_objective()))
+            assert abs(out["kkt"][p] - orc.get_kkt()) <= 2e-3 * max(1.0, orc.get_kkt())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [BLOCK | 4, BLOCK | 8, BLOCK | 16])
+def test_stage_block_kernel_on_the_stress_distribution(nmpc_mod, lanes):
+    """The stage-block kernel on the wide distribution (long working-set iterations, the primal active-set safeguard):
+    every problem solved by both kernels, solutions of the two within 2e-4 of each other (both solve the same strictly
+    convex QPs; the wavefront kernel is the one pinned against the oracle and float64 on this distribution), and the
+    answer of a problem is the same bits wherever it sits in the batch."""
+    from alore_legged_manipulator_amd.scenarios import make_wide_batch
+    B, N = 4099, 20
+    batch = make_wide_batch(B, N, 3)
+    ref = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=32); ref.load(batch); ref.rti(1); want = ref.fetch()
+    eng = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=lanes); eng.load(batch); eng.rti(1); got = eng.fetch()
+    assert (want["status"] == 0).all() and (got["status"] == 0).all()
+    assert (got["n_iter"] > 3).sum() > 50 and got["n_iter"].max() > 16     # restarts and the safeguard are exercised
+    for k in ("x", "u"):
+        d = np.abs(got[k] - want[k]).reshape(B, -1).max(axis=1) / np.maximum(1.0, np.abs(want[k]).reshape(B, -1).max(axis=1))
+        assert d.max() < 2e-4, (k, d.max(), int(d.argmax()))
+    perm = np.random.default_rng(1).permutation(B)
+    e2 = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=lanes); e2.load({k: v[perm] for k, v in batch.items()}); e2.rti(1)
+    o2 = e2.fetch()
+    for k in ("x", "u", "dual", "kkt", "obj", "status", "n_iter"):
+        assert np.array_equal(got[k][perm], o2[k]), k
