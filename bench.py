@@ -101,34 +101,46 @@ def cpu_baseline(N: int, batch: dict, seconds: float) -> dict:
     from oracle.drivers import Oracle, RefAcado, ref_available
 
     cores = usable_cores()
-    nb = batch["x"].shape[0]
-    probs = [problem(batch, b % nb) for b in range(cores)]  # one distinct problem of the bench batch per thread
-    # calibrate on one core
-    o = Oracle(N)
-    o.reset(); o.initialize_solver(); o.load(probs[0])
-    t = o.time_rti(200)
-    per_tick = t / 200
-    chunk = max(50, int(0.05 / max(per_tick, 1e-7)))  # ~50 ms of ticks between looks at the clock
-    counts = [0] * cores
-    deadline = [0.0]
-    def work(tid):
-        orc = Oracle(N)
-        orc.reset(); orc.initialize_solver(); orc.load(probs[tid])
-        while time.perf_counter() < deadline[0]:  # bounded by wall-clock, whatever the host gives each thread
-            orc.time_rti(chunk)
-            counts[tid] += chunk
-    t0 = time.perf_counter()
-    deadline[0] = t0 + seconds
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    [x.start() for x in th]
-    [x.join() for x in th]
-    wall = time.perf_counter() - t0
-    iters = sum(counts) // max(cores, 1)
-    out = {"value": sum(counts) / wall, "unit": "solves/s", "cores": cores, "kind": "port",
+
+    def all_cores(Nh, bt, secs):
+        """every usable core runs its own solver instance on its own problem for `secs` of wall clock"""
+        nb = bt["x"].shape[0]
+        probs = [problem(bt, b % nb) for b in range(cores)]  # one distinct problem of the batch per thread
+        o = Oracle(Nh)
+        o.reset(); o.initialize_solver(); o.load(probs[0])
+        t = o.time_rti(200)  # calibrate on one core
+        per_tick = t / 200
+        chunk = max(50, int(0.05 / max(per_tick, 1e-7)))  # ~50 ms of ticks between looks at the clock
+        counts = [0] * cores
+        deadline = [0.0]
+        def work(tid):
+            orc = Oracle(Nh)
+            orc.reset(); orc.initialize_solver(); orc.load(probs[tid])
+            while time.perf_counter() < deadline[0]:  # bounded by wall-clock, whatever the host gives each thread
+                orc.time_rti(chunk)
+                counts[tid] += chunk
+        t0 = time.perf_counter()
+        deadline[0] = t0 + secs
+        th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        wall = time.perf_counter() - t0
+        return sum(counts) / wall, sum(counts) // max(cores, 1), wall, per_tick
+
+    rate, iters, wall, per_tick = all_cores(N, batch, seconds)
+    out = {"value": rate, "unit": "solves/s", "cores": cores, "kind": "port",
            "sample": f"{cores} problems of the bench batch (one per thread) x ~{iters} RTI ticks each (N={N}, "
                      f"MpcWrapper::solve cold start), oracle/nmpc_oracle.c -O3, {cores} threads (usable cores: affinity "
                      f"mask and cgroup quota), {wall:.1f} s wall",
            "single_core_us_per_solve": per_tick * 1e6}
+    if N != 50:  # the reference's own horizon (SURVEY 8(d)): the same restatement on all cores at N = 50
+        try:
+            from alore_legged_manipulator_amd.scenarios import make_batch
+            r50, it50, w50, pt50 = all_cores(50, make_batch(cores, 50), min(4.0, seconds))
+            out["n50_all_cores"] = {"value": r50, "unit": "solves/s", "cores": cores, "single_core_us_per_solve": pt50 * 1e6,
+                                    "sample": f"N=50, ~{it50} ticks per thread, {w50:.1f} s wall"}
+        except Exception as e:  # pragma: no cover
+            out["n50_all_cores"] = {"error": f"{type(e).__name__}: {e}"}
     if ref_available():  # the reference's own code, N = 50 only: reported next to it, for scale
         try:
             from alore_legged_manipulator_amd.scenarios import make_batch
@@ -139,6 +151,50 @@ def cpu_baseline(N: int, batch: dict, seconds: float) -> dict:
         except Exception as e:  # pragma: no cover
             out["reference_n50_error"] = str(e)
     return out
+
+
+def backend_cpu_baseline(fts, seconds: float = 8.0) -> dict:
+    """oracle/backend_oracle.c `minco_plan` (float64 C restatement of MSPlanner::minco_plan, kind "port": Eigen is not
+    in the image) on the usable host cores, one planner instance per thread, distinct problems of the bench set, for a
+    bounded wall time.  The reference's own budget is 0.05 s per plan (planner_sim.launch:65)."""
+    import threading
+    from oracle.backend_driver import BackendOracle, EsdfGrid
+    cores = usable_cores()
+    grid = EsdfGrid.free(half=20.0)
+    counts = [0] * cores
+    t0 = time.perf_counter()
+    deadline = t0 + seconds
+    def work(tid):
+        o = BackendOracle()
+        i = tid
+        while time.perf_counter() < deadline and i < len(fts):
+            o.minco_plan(grid, fts[i])   # ctypes call: releases the GIL
+            counts[tid] += 1
+            i += cores
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    wall = time.perf_counter() - t0
+    n = sum(counts)
+    return {"value": n / wall, "unit": "plans/s", "cores": cores, "kind": "port",
+            "sample": f"{n} plans of the bench problem set, oracle/backend_oracle.c minco_plan (-O3), {cores} threads, {wall:.1f} s wall",
+            "ms_per_plan_per_core": wall * cores / max(n, 1) * 1e3, "reference_budget_ms_per_plan": 50.0}
+
+
+def ltv_cpu_baseline(lt_cfg, st0, xr, dr, n_relin: int, robots: int = 3) -> dict:
+    """oracle/ltv_mpc_oracle.py `get_cmd` (the reference's QP matrices line by line + a dense active-set solve, NumPy
+    float64, kind "port": OSQP is not vendored) on `robots` robots of the bench set, one thread.  The reference's own
+    budget is a 9.7 ms wall clock per tick (mpc_controller/config/mpc3ms.yaml:4,11)."""
+    from oracle import ltv_mpc_oracle as lo
+    prm = lo.LtvParams()
+    t0 = time.perf_counter()
+    for b in range(robots):
+        out = np.zeros((2, prm.T)); buff = [np.zeros(2) for _ in range(max(prm.delay_num, 0))]
+        lo.get_cmd(list(st0[b]) + [0.0], out, buff, xr[b].T.copy(), dr[b].T.copy(), prm, n_relin)
+    per = (time.perf_counter() - t0) / robots
+    return {"value": 1.0 / per, "unit": "robot-ticks/s", "cores": 1, "kind": "port",
+            "sample": f"{robots} robots of the bench set x {n_relin} relinearisations, oracle/ltv_mpc_oracle.py (NumPy float64), one thread",
+            "ms_per_tick": per * 1e3, "reference_budget_ms_per_tick": 9.7}
 
 
 def wb_cpu_baseline(N, xi, ui, x0, xref, uref):
@@ -254,7 +310,11 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     B, N = a.batch, a.horizon
-    slots = a.steps + a.warmup
+    # a short run (the driver's --steps 20 is 0.4 ms of GPU work) also times LONG_STEPS back-to-back steps and reports
+    # them beside the contract figure (`steady_state`)
+    LONG_STEPS = 200
+    long_steps = LONG_STEPS if (world == 1 and a.steps < LONG_STEPS and a.steps > 0) else 0
+    slots = max(a.steps, long_steps) + a.warmup
     # rank r owns global problems [r*B, (r+1)*B): generated locally from the seeded stream
     batch = make_batch(B, N, offset=rank * B)
     eng = BatchedNmpc(B, N, device=local_rank, lanes_per_problem=a.lanes, slots=slots,
@@ -267,7 +327,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_pass(mode):
+    def timed_pass(mode, K):
         """W untimed + K timed steps with the result exchange `mode`:
         full -- the trajectories (x, u, status, kkt) of EVERY timed batch are all-gathered to every rank, in buckets
                 of `--gather-every` steps issued asynchronously and all completed inside the timed region (eager
@@ -295,14 +355,14 @@ def main():
         # region); not with collectives between the solves.  Capture is thread-local so that the RCCL watchdog thread
         # of a multi-rank run cannot invalidate it; any capture failure falls back to eager launches.
         graph = None
-        if not a.no_graph and not do_gather and a.steps > 0:
+        if not a.no_graph and not do_gather and K > 0:
             try:
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                        run_steps(a.warmup, a.steps)
+                        run_steps(a.warmup, K)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 graph = g
             except Exception as e:
@@ -317,10 +377,10 @@ def main():
         if graph is not None:
             graph.replay()
         else:
-            run_steps(a.warmup, a.steps)
+            run_steps(a.warmup, K)
         ev1.record()
         if gather_last:  # the converged trajectories of the last batch on every rank (x, u, status, kkt)
-            last = a.warmup + a.steps - 1
+            last = a.warmup + K - 1
             gatherer.submit({k: eng.ts[k][last] for k in ("x", "u", "status", "kkt")})
             gatherer.wait()
         barrier()
@@ -334,14 +394,20 @@ def main():
 
     # primary figure: multi-rank runs gather EVERY batch ("both" adds the last-batch-only figure beside it)
     primary = "none" if world == 1 else ("full" if a.gather in ("full", "both") else a.gather)
-    elapsed, dev_ms, used_graph = timed_pass(primary)
+    elapsed, dev_ms, used_graph = timed_pass(primary, a.steps)
+    steady = None
+    if long_steps:
+        el_l, dms_l, g_l = timed_pass("none", long_steps)
+        steady = {"steps": long_steps, "value": float(B) * long_steps / el_l, "ms_per_step": el_l / long_steps * 1e3,
+                  "kernel_ms_avg": dms_l / long_steps, "hip_graph": g_l,
+                  "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_l / long_steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
     do_gather, gather_last = primary == "full", primary == "last"
     alt = None
     if world > 1 and a.gather == "both":
         # secondary figure: it must never cost the primary one (a rank that fails here would hang the others in the
         # collective, so the decision to run it is taken before, not inside, and errors are reported in the line)
         try:
-            el2, dms2, g2 = timed_pass("last")
+            el2, dms2, g2 = timed_pass("last", a.steps)
             alt = {"gather": "last batch only", "value": float(B) * world * a.steps / el2, "ms_per_step": el2 / a.steps * 1e3,
                    "kernel_ms_avg": dms2 / a.steps, "hip_graph": g2}
         except Exception as e:  # pragma: no cover
@@ -368,11 +434,18 @@ def main():
         kern_ms = (alt["kernel_ms_avg"] if (alt is not None and "kernel_ms_avg" in alt) else dev_ms / a.steps)
         bytes_per_launch = algorithmic_bytes_per_solve(N) * B
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC counters: collected by rocprofv3 in separate --pmc passes over this same
+        # command (tools/profile_round.sh, corrected as MI355X_MICROARCH.md prescribes) and kept in profiles/: a
+        # profiler cannot run inside the timed process, so the line names the record it quotes
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(f"B{B}_N{N}", {}).get("bytes_per_launch")
+                rec = json.load(open(tf)).get(f"B{B}_N{N}", {})
+                kname = "rti_block_kernel" if (info["lanes_per_problem"] & 0x100) else "rti_kernel"
+                if rec.get("kernel", kname).find(kname) >= 0:   # only a record of the kernel that ran
+                    traffic = rec.get("bytes_per_launch")
+                    traffic_src = rec.get("source")
             except Exception:
                 traffic = None
         flops_per_solve = 350.0 * N + n_iter_mean * 160.0 * N  # stage-wise algorithm, see DESIGN.md
@@ -391,13 +464,17 @@ def main():
                        "lds_bytes_per_block": info["lds_bytes_per_block"], "hip_graph": used_graph},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "nmpc::rti_kernel", "kernel_ms_avg": kern_ms,
+                         "traffic_source": traffic_src,
+                         "kernel": "nmpc::rti_block_kernel" if (info["lanes_per_problem"] & 0x100) else "nmpc::rti_kernel",
+                         "kernel_ms_avg": kern_ms,
                          "algorithmic_bytes_per_solve": algorithmic_bytes_per_solve(N),
                          "fp32_frac": value / world * flops_per_solve / (FP32_PEAK_TFLOPS * 1e12)},
             "unsolved_problems": n_bad, "working_set_iters_mean": n_iter_mean,
         }
         if alt is not None:
             result["gather_last"] = alt
+        if steady is not None:
+            result["steady_state"] = steady
 
     # ---- extras on rank 0 of a single-GPU run: latency, converged solves, large batch, CPU baseline
     if rank == 0 and world == 1 and not a.no_extras:
@@ -429,12 +506,12 @@ def main():
         e3.load(batch, slot=None)
         e3.rti(15, slot=0); e3.rti(15, slot=1)
         torch.cuda.synchronize(dev)
-        c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
-        c0.record()
+        ev_a = torch.cuda.Event(enable_timing=True); ev_b = torch.cuda.Event(enable_timing=True)
+        ev_a.record()
         for i in range(2, 52):
             e3.rti(15, slot=i)
-        c1.record(); torch.cuda.synchronize(dev)
-        ms15 = c0.elapsed_time(c1) / 50
+        ev_b.record(); torch.cuda.synchronize(dev)
+        ms15 = ev_a.elapsed_time(ev_b) / 50
         it15 = float(e3.ts["n_iter"][2:52].float().mean().item())
         gb15 = algorithmic_bytes_per_solve(N) * B / (ms15 * 1e-3) / 1e9
         fl15 = 15 * 350.0 * N + it15 * 160.0 * N
@@ -455,11 +532,11 @@ def main():
             e4.load(make_batch(Bl, N), slot=None)
             e4.rti(1, slot=0); e4.rti(1, slot=1)
             torch.cuda.synchronize(dev)
-            c0.record()
+            ev_a.record()
             for i in range(2, 24):
                 e4.rti(1, slot=i)
-            c1.record(); torch.cuda.synchronize(dev)
-            msl = c0.elapsed_time(c1) / 22
+            ev_b.record(); torch.cuda.synchronize(dev)
+            msl = ev_a.elapsed_time(ev_b) / 22
             gbs = algorithmic_bytes_per_solve(N) * Bl / (msl * 1e-3) / 1e9
             extras["large_batch"] = {"batch": Bl, "ms_per_launch": msl, "solves_per_s": Bl / (msl * 1e-3),
                                      "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
@@ -479,11 +556,11 @@ def main():
             torch.cuda.synchronize(dev)
             e5.rti(1, slot=0); e5.rti(1, slot=1)
             torch.cuda.synchronize(dev)
-            c0.record()
+            ev_a.record()
             for i in range(2, 24):
                 e5.rti(1, slot=i)
-            c1.record(); torch.cuda.synchronize(dev)
-            msw = c0.elapsed_time(c1) / 22
+            ev_b.record(); torch.cuda.synchronize(dev)
+            msw = ev_a.elapsed_time(ev_b) / 22
             extras["warm_tick"] = {"ms_per_launch": msw, "solves_per_s": B / (msw * 1e-3),
                                    "working_set_iters_mean": float(e5.ts["n_iter"][2:24].float().mean().item()),
                                    "unsolved": int((e5.ts["status"][2:24] != 0).sum().item())}
@@ -556,6 +633,11 @@ def main():
             torch.cuda.synchronize(dev)
             be["closed_loop_100_ticks_ms"] = (time.perf_counter() - t_a) * 1e3
             be["unsolved_last_tick"] = int((e10.t["status"] != 0).sum().item())
+            if not a.no_cpu_baseline:
+                try:
+                    be["cpu_baseline"] = backend_cpu_baseline(fts)
+                except Exception as e:  # pragma: no cover
+                    be["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             extras["backend_to_nmpc_pipeline"] = be
             del e10, pl
         except Exception as e:  # pragma: no cover
@@ -616,12 +698,17 @@ def main():
             t_a = time.perf_counter(); g0 = lt.get_cmd(st0, n_relin=5, reset=True); t_cold = time.perf_counter() - t_a
             t_a = time.perf_counter()
             for i in range(10):
-                c1, s1 = lt.tick(st0, n_relin=5)     # commands + status only (16 B per robot over the bus)
+                cmd_w, st_w = lt.tick(st0, n_relin=5)     # commands + status only (16 B per robot over the bus)
             t_warm = (time.perf_counter() - t_a) / 10
             g1 = lt.get_cmd(st0, n_relin=5)
             extras["ltv_mpc"] = {"robots": B, "relinearisations": 5, "cold_ms": t_cold * 1e3, "warm_ms": t_warm * 1e3,
                                  "robot_ticks_per_s_warm": B / t_warm, "sweeps_last_qp_cold_mean": float(g0["sweeps"].mean()),
                                  "sweeps_last_qp_warm_mean": float(g1["sweeps"].mean()), "unsettled": int((g1["status"] != 0).sum())}
+            if not a.no_cpu_baseline:
+                try:
+                    extras["ltv_mpc"]["cpu_baseline"] = ltv_cpu_baseline(lt.cfg, st0, xr, dr, 5)
+                except Exception as e:  # pragma: no cover
+                    extras["ltv_mpc"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             del lt
         except Exception as e:  # pragma: no cover
             extras["ltv_mpc"] = {"error": f"{type(e).__name__}: {e}"}
@@ -665,11 +752,11 @@ def main():
             e8.set_shared_members(W=True, bounds=True, od=True)
             e8.rti(1, slot=0); e8.rti(1, slot=1)
             torch.cuda.synchronize(dev)
-            c0.record()
+            ev_a.record()
             for i in range(2, 24):
                 e8.rti(1, slot=i)
-            c1.record(); torch.cuda.synchronize(dev)
-            msc = c0.elapsed_time(c1) / 22
+            ev_b.record(); torch.cuda.synchronize(dev)
+            msc = ev_a.elapsed_time(ev_b) / 22
             cbytes = 4 * (19 * N + 19)
             extras["compact_io"] = {"ms_per_launch": msc, "solves_per_s": B / (msc * 1e-3), "bytes_per_solve": cbytes,
                                     "hbm_frac": cbytes * B / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -684,11 +771,11 @@ def main():
             e9.load(batch, slot=None)
             e9.rti(1, slot=0); e9.rti(1, slot=1)
             torch.cuda.synchronize(dev)
-            c0.record()
+            ev_a.record()
             for i in range(2, 24):
                 e9.rti(1, slot=i)
-            c1.record(); torch.cuda.synchronize(dev)
-            msd = c0.elapsed_time(c1) / 22
+            ev_b.record(); torch.cuda.synchronize(dev)
+            msd = ev_a.elapsed_time(ev_b) / 22
             extras["without_diagnostics"] = {"ms_per_launch": msd, "solves_per_s": B / (msd * 1e-3),
                                              "unsolved": int((e9.ts["status"][2:24] != 0).sum().item())}
             del e9
@@ -701,11 +788,11 @@ def main():
             e6.load(make_batch(B, 50), slot=None)
             e6.rti(1, slot=0); e6.rti(1, slot=1)
             torch.cuda.synchronize(dev)
-            c0.record()
+            ev_a.record()
             for i in range(2, 12):
                 e6.rti(1, slot=i)
-            c1.record(); torch.cuda.synchronize(dev)
-            ms50 = c0.elapsed_time(c1) / 10
+            ev_b.record(); torch.cuda.synchronize(dev)
+            ms50 = ev_a.elapsed_time(ev_b) / 10
             extras["reference_horizon_n50"] = {"batch": B, "ms_per_launch": ms50, "solves_per_s": B / (ms50 * 1e-3),
                                                "lanes_per_problem": e6.launch_info()["lanes_per_problem"]}
             del e6
