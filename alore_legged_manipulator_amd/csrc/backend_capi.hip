@@ -229,6 +229,7 @@ int alore_backend_predicted_state(alore_backend_handle h, int count, double reso
                                   const double* start_xytheta, double* xytheta, double* vaj, double* oaj, int* forward)
 {
     if (!h || count < 1 || count > h->B || !time || !(resolution > 0.0)) return fail(h, ALORE_BE_E_INVALID, "predicted_state: bad argument");
+    if (!h->timed || count > h->count) return fail(h, ALORE_BE_E_INVALID, "predicted_state: no finished plan for these slots (alore_backend_plan first)");
     BE_TRY(h, hipSetDevice(h->device));
     const size_t n = count;
     double *d_in = nullptr, *d_out = nullptr;
@@ -347,6 +348,7 @@ int alore_backend_results(alore_backend_handle h, int count, alore_backend_statu
                           void* stream)
 {
     if (!h || count < 1 || count > h->B) return fail(h, ALORE_BE_E_INVALID, "results: bad argument");
+    if (!h->timed || count > h->count) return fail(h, ALORE_BE_E_INVALID, "results: no plan has run for these slots (alore_backend_plan first)");
     BE_TRY(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const size_t P = h->P, n = count;

@@ -196,6 +196,15 @@ __global__ void predicted_state_kernel(PredictArgs g)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= g.count) return;
     const int M = g.n_pieces[b];
+    if (M < 1) { // a slot without a plan: no state to predict (plan_eval would index piece -1)
+        for (int k = 0; k < 3; ++k) {
+            if (g.xyt_out) g.xyt_out[(size_t)b * 3 + k] = 0.0;
+            if (g.vaj_out) g.vaj_out[(size_t)b * 3 + k] = 0.0;
+            if (g.oaj_out) g.oaj_out[(size_t)b * 3 + k] = 0.0;
+        }
+        if (g.forward_out) g.forward_out[b] = 0;
+        return;
+    }
     const double* T = g.T + (size_t)b * g.P;
     const double* coef = g.coef + (size_t)b * g.P * 12;
     const double start_time = g.start_time ? g.start_time[b] : 0.0, time = g.time[b], step = g.step;

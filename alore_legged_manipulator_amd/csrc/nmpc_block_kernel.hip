@@ -591,14 +591,16 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             sbo[0] = a0 + ex0; sbo[1] = a1 + ex1;
         }
 
-        auto backward_block = [&]() -> int {
+        auto backward_block = [&](auto guard_tag) -> int { // guard: only the lane with the terminal node has slots that are not stages
+            constexpr bool GUARD = decltype(guard_tag)::value;
             Value val;
             val.P.m00 = V[0]; val.P.m01 = V[1]; val.P.m02 = V[2]; val.P.m11 = V[3]; val.P.m12 = V[4]; val.P.m22 = V[5];
             val.p0 = V[6]; val.p1 = V[7]; val.p2 = V[8];
             int ok = 1;
 #pragma unroll
             for (int s = S - 1; s >= 0; --s) {
-                if (j * S + s < N) {
+                if (!GUARD || j * S + s < N) { // unguarded: the S stages are one basic block, the scheduler overlaps the
+                                               // tail of one step with the head of the next
                     StageQP q;
                     q.a = sa[s]; q.b = sb[s]; q.B00 = B00[s]; q.B01 = B01[s]; q.B10 = B10[s]; q.B11 = B11[s]; q.B20 = B20[s];
                     q.d0 = d0[s]; q.d1 = d1[s]; q.d2 = d2[s];
@@ -632,7 +634,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
 #pragma unroll
                             for (int i = 0; i < 9; ++i) Vin[i] = V[i];
                         }
-                        pd_fail |= backward_block() ? 0 : 1;
+                        if (t == top) pd_fail |= backward_block(std::true_type{}) ? 0 : 1;
+                        else pd_fail |= backward_block(std::false_type{}) ? 0 : 1;
                     }
 #pragma unroll
                     for (int i = 0; i < 9; ++i) V[i] = lane_next(V[i]);

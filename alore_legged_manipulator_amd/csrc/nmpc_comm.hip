@@ -32,19 +32,21 @@ struct Rccl {
     Result (*GroupStart)() = nullptr;
     Result (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(Result) = nullptr;
+    bool loaded = false; // set only once every symbol has resolved
     bool load(std::string& err)
     {
-        if (so) return true;
+        if (loaded) return true;
         so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!so) { err = std::string("dlopen librccl: ") + dlerror(); return false; }
 #define SYM(field, name)                                                          \
     field = reinterpret_cast<decltype(field)>(dlsym(so, name));                   \
-    if (!field) { err = std::string("librccl lacks ") + name; return false; }
+    if (!field) { err = std::string("librccl lacks ") + name; dlclose(so); so = nullptr; return false; }
         SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
         SYM(AllGather, "ncclAllGather") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
         SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+        loaded = true;
         return true;
     }
 };
@@ -107,7 +109,11 @@ int alore_nmpc_comm_all_gather(alore_nmpc_comm_handle c, const alore_nmpc_batch*
     struct { const void* src; void* dst; size_t count; int type; } m[4] = {
         {local->x, all->x, (size_t)B * 3 * (N + 1), kFloat32}, {local->u, all->u, (size_t)B * 2 * N, kFloat32},
         {local->status, all->status, (size_t)B, kInt32},       {local->kkt, all->kkt, (size_t)B, kFloat32}};
+    // every rank must pass the same set of non-NULL members (a member is skipped when it is NULL on either side):
+    // ranks that disagree would issue different collectives and hang
+    if (!g_rccl.load(g_err)) return ALORE_NMPC_E_HIP;
     Result r = g_rccl.GroupStart();
+    if (r != 0) { g_err = g_rccl.GetErrorString(r); return ALORE_NMPC_E_HIP; } // no group was opened: nothing to close
     for (int i = 0; i < 4 && r == 0; ++i)
         if (m[i].src && m[i].dst) r = g_rccl.AllGather(m[i].src, m[i].dst, m[i].count, m[i].type, c->comm, s);
     const Result e = g_rccl.GroupEnd();

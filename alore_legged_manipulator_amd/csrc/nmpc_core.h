@@ -86,6 +86,16 @@ NMPC_HD float rcp_f(float x)
 #endif
 }
 
+// reciprocal of a Riccati pivot: the hardware reciprocal is accurate to 1 ulp, like the division it stands for
+NMPC_HD float pivot_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
 // sin and cos enter the step only multiplied by h/2 (5e-3 for the reference's dt): the hardware
 // sine/cosine (argument in revolutions, absolute error ~1e-6) perturb the shooting defect by
 // < 1e-8, far inside the float32 rounding of the state itself
@@ -209,7 +219,7 @@ NMPC_HD bool riccati_step(const StageQP& s, Value& V, Policy& pol, bool need_val
     // ---- eliminate control 1
     const bool free1 = (s.st1 == ST_FREE);
     const bool bad1 = free1 && !(H11 > 0.0f);
-    const float inv11 = rcp_f(H11);
+    const float inv11 = pivot_rcp(H11);
     const float w1 = free1 ? inv11 : 0.0f;        // 1/H11 if minimised over
     const float z1 = free1 ? -hu1 * inv11 : s.v1; // value of du1 at dx = 0, du0 = 0
     const float t1 = w1 * H01;
@@ -225,7 +235,7 @@ NMPC_HD bool riccati_step(const StageQP& s, Value& V, Policy& pol, bool need_val
     // ---- eliminate control 0
     const bool free0 = (s.st0 == ST_FREE);
     const bool bad0 = free0 && !(H00r > 0.0f);
-    const float inv00 = rcp_f(H00r);
+    const float inv00 = pivot_rcp(H00r);
     const float w0 = free0 ? inv00 : 0.0f;
     const float z0 = free0 ? -hu0 * inv00 : s.v0;
     const float g0s = free0 ? -w0 : 1.0f;

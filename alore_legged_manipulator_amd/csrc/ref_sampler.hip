@@ -244,7 +244,10 @@ __global__ void traj_from_backend_kernel(RefStore s, BackendView v, int count, d
     const bool ok = v.ok[t] != 0 && M >= 1 && M <= s.P;
     if (i == 0) {
         n_panels[t] = 0;
-        if (!ok) { meta[6] = 0.0; if (v.ok[t] != 0) atomicOr(overflow, 1); }
+        // a failed replan leaves the robot on the trajectory it is tracking: MSPlanner::minco_plan returns false before
+        // final_traj_ is replaced (optimizer.cpp:204-209), nothing is published and the controller carries on.  Only
+        // a plan that succeeded but does not fit the store invalidates the slot (and is reported).
+        if (!ok && v.ok[t] != 0) { meta[6] = 0.0; atomicOr(overflow, 1); }
     }
     if (!ok || i >= M) return;
     s.dur[(size_t)t * s.P + i] = v.T[(size_t)t * v.P + i];

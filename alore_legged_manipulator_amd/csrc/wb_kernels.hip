@@ -1147,6 +1147,7 @@ int alore_wb_set_problem(alore_wb_handle h, int B, const double* x0, const doubl
     if (!h || B <= 0 || B > h->cfg.max_problems || !x0 || !xref || !uref) return fail(h, ALORE_WB_E_INVALID, "set_problem: bad argument");
     WB_TRY(h, hipSetDevice(h->cfg.device));
     const size_t N = h->cfg.horizon;
+    WB_TRY(h, hipDeviceSynchronize()); // work enqueued on the caller's (possibly non-blocking) stream must be done
     WB_TRY(h, hipMemcpy(h->d_x0, x0, sizeof(double) * B * wb::NX, hipMemcpyHostToDevice));
     WB_TRY(h, hipMemcpy(h->d_xref, xref, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyHostToDevice));
     WB_TRY(h, hipMemcpy(h->d_uref, uref, sizeof(double) * B * N * wb::NU, hipMemcpyHostToDevice));
@@ -1157,6 +1158,7 @@ int alore_wb_set_x0(alore_wb_handle h, int B, const double* x0)
 {
     if (!h || B <= 0 || B > h->cfg.max_problems || !x0) return fail(h, ALORE_WB_E_INVALID, "set_x0: bad argument");
     WB_TRY(h, hipSetDevice(h->cfg.device));
+    WB_TRY(h, hipDeviceSynchronize()); // work enqueued on the caller's (possibly non-blocking) stream must be done
     WB_TRY(h, hipMemcpy(h->d_x0, x0, sizeof(double) * B * wb::NX, hipMemcpyHostToDevice));
     return ALORE_WB_OK;
 }
@@ -1175,6 +1177,7 @@ int alore_wb_get_first_input(alore_wb_handle h, int B, double* u0)
     if (!h || B <= 0 || B > h->cfg.max_problems || !u0) return fail(h, ALORE_WB_E_INVALID, "get_first_input: bad argument");
     WB_TRY(h, hipSetDevice(h->cfg.device));
     const size_t N = h->cfg.horizon;
+    WB_TRY(h, hipDeviceSynchronize()); // work enqueued on the caller's (possibly non-blocking) stream must be done
     WB_TRY(h, hipMemcpy2D(u0, sizeof(double) * wb::NU, h->d_u, sizeof(double) * N * wb::NU, sizeof(double) * wb::NU, B, hipMemcpyDeviceToHost));
     return ALORE_WB_OK;
 }
@@ -1184,6 +1187,7 @@ int alore_wb_set_iterate(alore_wb_handle h, int B, const double* x, const double
     if (!h || B <= 0 || B > h->cfg.max_problems || !x || !u) return fail(h, ALORE_WB_E_INVALID, "set_iterate: bad argument");
     WB_TRY(h, hipSetDevice(h->cfg.device));
     const size_t N = h->cfg.horizon;
+    WB_TRY(h, hipDeviceSynchronize()); // work enqueued on the caller's (possibly non-blocking) stream must be done
     WB_TRY(h, hipMemcpy(h->d_x, x, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyHostToDevice));
     WB_TRY(h, hipMemcpy(h->d_u, u, sizeof(double) * B * N * wb::NU, hipMemcpyHostToDevice));
     return ALORE_WB_OK;
@@ -1210,6 +1214,7 @@ int alore_wb_linearize(alore_wb_handle h, int B, double* A, double* Bm, double* 
     double *dA = A ? t.get<double>(n * wb::NX * wb::NX) : nullptr, *dB = Bm ? t.get<double>(n * wb::NX * wb::NU) : nullptr;
     if ((A && !dA) || (Bm && !dB)) return fail(h, ALORE_WB_E_NOMEM, "linearize: hipMalloc");
     wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, dA, dB, nullptr, nullptr, nullptr};
+    WB_TRY(h, hipDeviceSynchronize()); // the iterate may still be written by work on the caller's stream
     wb::stage_kernel<<<(unsigned)n, 64>>>(g);
     WB_TRY(h, hipGetLastError());
     if (A) WB_TRY(h, hipMemcpy(A, dA, sizeof(double) * n * wb::NX * wb::NX, hipMemcpyDeviceToHost));

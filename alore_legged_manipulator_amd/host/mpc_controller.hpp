@@ -275,6 +275,7 @@ private:
 struct RobotNode {
     bool has_odom = false, receive_traj_ = false, at_goal = false;
     bool solve_from_scratch_ = true;          // mpc.cpp:317-320: the first solve of THIS robot resets its iterate
+    bool idle_ticks_ = false;                 // the batch was ticked while this robot was idle: its iterate is stale
     bool pending = false;                     // new_traj_.if_get_traj_
     double new_traj_start_time_ = 0.0, start_time = -1.0, traj_duration = 0.0, new_duration_ = 0.0;
     Polynome msg_, new_msg_;
@@ -379,11 +380,18 @@ public:
             return;
         }
         mpc_wrapper_.sampleDeviceRefs(now, est.data(), icr.data(), goal.data()); // goal: valid after update()
-        for (int b = 0; b < B; ++b) // mpc.cpp:317-320, per robot: x <- est replicated, u <- 0 on its first solve
-            if (solving[b] && robots[b].solve_from_scratch_) {
+        // mpc.cpp:317-320, per robot: x <- est replicated, u <- 0 on its first solve.  The batch launch below also
+        // advances the iterates of idle robots (no odometry / no trajectory / at goal / stopped) against stale
+        // references, which the reference's CmdCallback never does (it returns early): such an iterate is discarded
+        // when the robot starts solving again -- a cold start, never a warm start from something the reference
+        // would not have computed (and a non-finite idle solve cannot leak into the next trajectory).
+        for (int b = 0; b < B; ++b) {
+            if (solving[b] && (robots[b].solve_from_scratch_ || robots[b].idle_ticks_)) {
                 mpc_wrapper_.resetIterate(b, &est[(size_t)b * 3]);
                 robots[b].solve_from_scratch_ = false;
             }
+            robots[b].idle_ticks_ = !solving[b];
+        }
         mpc_wrapper_.update(est.data(), false);
         mpc_wrapper_.prepare(); // the reference's preparation thread (mpc.cpp:336, 394-403)
         for (int b = 0; b < B; ++b) {

@@ -215,7 +215,8 @@ int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int *rob
  * PlanManager::MPCPathPub (plan_manager.hpp:784-831) -> ~traj -> MpcController::TrajCallback -> TrajAnal::setTraj:
  * the optimiser's final coefficients are that spline, so they are copied and only the Simpson checkpoints are
  * built.  xv = ICR.z of the message (0 for the standard differential model).  Problems the planner rejected
- * (ok = 0) leave their slot invalid.  Synchronises the stream; errors as alore_nmpc_refs_set_polynomes. */
+ * (ok = 0) leave their slot as it was: the robot keeps the trajectory it is tracking, as the reference does when
+ * MSPlanner::minco_plan fails (optimizer.cpp:204-209: nothing is published).  Synchronises the stream; errors as alore_nmpc_refs_set_polynomes. */
 int alore_nmpc_refs_set_from_backend(alore_nmpc_handle h, const void *view, int count, double traj_start_time, double xv,
                                      double state_seq_res, int integral_res_int, void *stream);
 /* read one slot back (tests, logging): meta8 = start_time, duration, xv, state_seq_res, n_pieces, n_ckpt,

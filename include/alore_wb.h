@@ -93,7 +93,13 @@ int alore_wb_get_iterate(alore_wb_handle h, int B, double *x, double *u);
 /* linearisation about the current iterate, copied out for inspection: A [B][N][48][48], Bm [B][N][48][30],
  * next [B][N][48] = f(x_k, u_k); any may be NULL */
 int alore_wb_linearize(alore_wb_handle h, int B, double *A, double *Bm, double *next);
-/* n_iter real-time iterations (linearise + Riccati + step) for B problems; asynchronous on `stream` */
+/* n_iter real-time iterations (linearise + Riccati + step) for B problems; asynchronous on `stream`.
+ * Stream contract of this header: only alore_wb_rti and alore_wb_shift_iterate enqueue on the caller's stream (which
+ * may be a non-blocking one).  Every entry point that moves data between host and device (set_problem, set_x0,
+ * set_iterate, get_first_input, get_iterate, last_step, status, linearize) first waits for ALL work on the device
+ * (hipDeviceSynchronize) and has completed its copy when it returns, so a tick
+ *   set_x0 -> rti(stream) -> get_first_input -> shift_iterate(stream)
+ * is ordered on any stream without further synchronisation by the caller. */
 int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void *stream);
 /* the LQ step of the last iteration: dx [B][N+1][48], du [B][N][30] (before clipping), HOST pointers; synchronises */
 int alore_wb_last_step(alore_wb_handle h, int B, double *dx, double *du);
