@@ -8,9 +8,10 @@
 //   predictMotion(xopt)          P:271-302     linear prediction that is published
 //   getRefPoints / smooth_yaw    P:634-690, 538-567
 //
-// Mapping: ONE THREAD PER ROBOT (the per-stage algebra is a 7 x 7 quadratic form: it fits a lane's registers and
-// has no parallelism worth a wavefront), the per-stage records of all robots interleaved ([field][stage][robot])
-// so that the 64 robots of a wavefront read and write whole cache lines.  float64 like the reference.
+// Two kernels.  get_cmd_lanes_kernel (the one that runs): 16 lanes per robot, a lane owns two (four) consecutive
+// stages, stage records in LDS, rollout / published prediction by prefix sums over the lanes, sweeps lane by lane --
+// see its header below.  get_cmd_kernel (ALORE_LTV_KERNEL=thread, kept for A/B): one thread per robot, the per-stage
+// records of all robots interleaved in a global workspace ([field][stage][robot]).  float64 like the reference.
 //
 // The QP is solved exactly by a working-set Riccati method.  State of stage j: xi = (x, y, theta, v_{j-1}, w_{j-1})
 // -- augmenting by the previous input makes the rate penalty Rd and the rate limits stage-local.  Each input
@@ -38,6 +39,7 @@ namespace ltv {
 constexpr int MAXT = 64;
 enum : int { FREE = 0, BOX_LO = 1, BOX_HI = 2, RATE_LO = 3, RATE_HI = 4 };
 constexpr int NF = 38; // doubles per stage record
+constexpr int REC_STRIDE = NF * 4 + 10; // lanes kernel, LDS doubles per stage (4 robots): consecutive lanes 8 dwords apart mod 128
 #define LTV_STAMP(i)                                                                         \
     if (d.stamps && b == 0) {                                                                \
         const long long now_ = (long long)__builtin_readcyclecounter();                      \
@@ -381,6 +383,462 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
     d.cmd[2 * b] = out[2 * dl]; d.cmd[2 * b + 1] = out[2 * dl + 1];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// L = 16 lanes per robot, every lane owns S consecutive stages with their records (38 doubles each) in REGISTERS.
+//   * rollout + linear model: the heading is a prefix sum of the clamped yaw rates, the position a prefix sum of
+//     a cos / sin(heading) dt -- serial inside the lane's block, log2(L) DPP steps across the group; one sincos per
+//     stage, all stages in parallel (the one-thread-per-robot kernel above walks the T steps one after the other and
+//     keeps the records in a global workspace: 143 k + 133 k + 121 k cycles per relinearisation, most of them
+//     memory round trips);
+//   * backward / forward sweeps: the same stage algebra as above, lane by lane; the cost-to-go (20 doubles + the
+//     effective boxes) resp. the augmented state and the chain multipliers travel to the next lane by DPP row shifts;
+//   * the published linear prediction (predictMotion(xopt)): prefix sums again.
+// 4096 robots are 1024 wavefronts (one per SIMD) instead of 64.  Numerics: the sums of the rollout associate
+// differently (1e-16 relative); everything else is the arithmetic of the kernel above.
+template <int CTRL>
+__device__ __forceinline__ double dppd(double old, double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ double next_d(double x) { return dppd<0x101>(x, x); } // lane i <- lane i + 1 (row of 16)
+__device__ __forceinline__ double prev_d(double x) { return dppd<0x111>(x, x); } // lane i <- lane i - 1
+__device__ __forceinline__ int prev_i(int x) { return dppi<0x111>(x, x); }
+// inclusive prefix sum over the 16 lanes of a DPP row
+__device__ __forceinline__ double rowprefix_d(double x)
+{
+    x += dppd<0x111>(0.0, x);
+    x += dppd<0x112>(0.0, x);
+    x += dppd<0x114>(0.0, x);
+    x += dppd<0x118>(0.0, x);
+    return x;
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
+{
+    constexpr int L = 16, G = 4;
+    (void)L;
+    extern __shared__ double lds_rec[]; // stage records: [stage][field][robot of the wavefront], stage stride REC_STRIDE
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    int b = blockIdx.x * G + g;
+    const bool valid = b < d.B;
+    if (!valid) b = d.B - 1; // padding groups shadow the last robot, never store
+    const alore_ltv_config& c = d.c;
+    const int T = c.predict_steps, dl = c.delay_num, K = T - dl;
+    const int top = (K - 1) / S; // lane that owns the last stage
+    const double dt = c.dt;
+    const double umax[2] = {c.max_vel, c.max_omega}, rmax[2] = {c.max_acc * dt, c.max_domega * dt};
+    const double Qp2[3] = {2.0 * c.matrix_q[0], 2.0 * c.matrix_q[1], 2.0 * c.matrix_q[3]};
+    const double Rd2[2] = {2.0 * c.matrix_rd[0], 2.0 * c.matrix_rd[1]};
+    const double Ruu0[2] = {2.0 * (c.matrix_r[0] + c.matrix_q[2]), 2.0 * c.matrix_r[1]};
+    const double tol = 1e-9;
+    double* out = d.output + (size_t)b * T * 2;
+    double* bf = d.buff + (size_t)b * (dl > 0 ? dl : 1) * 2;
+    const double* xrg = d.xref + (size_t)b * T * 3;
+    const double* drg = d.dref + (size_t)b * T * 2;
+    const double* nowp = d.now + (size_t)b * 3; // re-read where needed: three registers less across the sweeps
+
+    // the lane's stages: k = j S + s (valid while k < K); output column of stage k is dl + k
+    int st[S][2];
+    double ua[S], uw[S];           // output of the lane's stages (acceleration-like input a, yaw rate): in/out
+    double xr[S][3], dr0[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int k = j * S + s, kc = min(k, K - 1);
+        const bool vs = k < K;
+        ua[s] = (vs && !d.reset) ? out[2 * (dl + kc)] : 0.0;
+        uw[s] = (vs && !d.reset) ? out[2 * (dl + kc) + 1] : 0.0;
+        st[s][0] = (vs && !d.reset) ? d.st[((size_t)kc * 2) * d.stride + b] : FREE;
+        st[s][1] = (vs && !d.reset) ? d.st[((size_t)kc * 2 + 1) * d.stride + b] : FREE;
+        xr[s][0] = xrg[(dl + kc) * 3]; xr[s][1] = xrg[(dl + kc) * 3 + 1]; xr[s][2] = xrg[(dl + kc) * 3 + 2];
+        dr0[s] = drg[(dl + kc) * 2];
+    }
+    // record field f of stage k of this lane's robot
+    auto REC = [&](int k_, int f) -> double& { return lds_rec[(size_t)k_ * REC_STRIDE + f * 4 + g]; };
+    int sweeps = 0, status = 0;
+    double pos0[3] = {0.0, 0.0, 0.0};
+
+    for (int relin = 0; relin < d.n_relin; ++relin) {
+        // ---- predictMotion.  The first dl columns of the output are the delayed inputs (every lane walks them: dl is 1
+        //      in the reference's configuration); columns dl + k belong to the stages.
+        const double x0 = nowp[0], y0 = nowp[1], th0 = nowp[2];
+        double px = x0, py = y0, pth = th0, pv = 0.0; // now_state.v = 0 (odometry callback)
+        for (int i = 0; i < dl; ++i) {
+            const double* src = (relin == 0) ? out : bf; // solveMPCV copies the delay buffer into the first columns
+            const double a = d.reset ? 0.0 : src[2 * i];
+            const double yd = fmin(fmax(d.reset ? 0.0 : src[2 * i + 1], -c.max_omega), c.max_omega);
+            double sn, cs;
+            sincos(pth, &sn, &cs);
+            px += a * cs * dt; py += a * sn * dt; pth += yd * dt; pv = a;
+        }
+        pos0[0] = px; pos0[1] = py; pos0[2] = pth;
+        {
+            // heading entering stage k: exclusive prefix of the clamped yaw rates
+            double inc[S], acc = 0.0, hd[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const bool vs = j * S + s < K;
+                inc[s] = vs ? fmin(fmax(uw[s], -c.max_omega), c.max_omega) * dt : 0.0;
+                hd[s] = acc; acc += inc[s];
+            }
+            const double ex = rowprefix_d(acc) - acc + pth;
+            double sn[S], cs[S];
+            // speed entering stage k: the input of the stage before (the last delayed input for k = 0)
+            const double a_prev_lane = prev_d(ua[S - 1]);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int k = j * S + s;
+                const bool vs = k < K;
+                hd[s] += ex;
+                sincos(hd[s], &sn[s], &cs[s]);
+                const double v_in = (k == 0) ? pv : ((s == 0) ? a_prev_lane : ua[(s > 0) ? s - 1 : 0]);
+                const double B00 = cs[s] * dt, B10 = sn[s] * dt;
+                const double A02 = -B10 * v_in, A12 = B00 * v_in;
+                if (vs) {
+                    REC(k, 0) = A02; REC(k, 1) = A12; REC(k, 2) = B00; REC(k, 3) = B10; REC(k, 4) = -A02 * hd[s]; REC(k, 5) = -A12 * hd[s];
+                }
+            }
+        }
+        // ---- working-set iterations
+        bool settled = false;
+        sweeps = 0;
+        while (__any(!settled && sweeps < c.max_sweeps)) {
+            const bool act = !settled && sweeps < c.max_sweeps;
+            // backward sweep: cost-to-go V(xi) = 1/2 xi' P xi + p' xi, P symmetric 5 x 5, handed from lane to lane
+            double P[5][5], p[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) { p[r] = 0.0;
+#pragma unroll
+                for (int s2 = 0; s2 < 5; ++s2) P[r][s2] = 0.0; }
+            double lo_eff[2] = {-umax[0], -umax[1]}, hi_eff[2] = {umax[0], umax[1]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int t = top; t >= 0; --t) {
+                // Every lane runs the stage algebra on its own slot with whatever cost-to-go it holds; only lane t holds
+                // the real one and only it stores the record.  (No heavy code under a partial EXEC mask: values that are
+                // live across such a region in the lanes that sit it out did not survive the register allocator's
+                // spilling there.)
+                {
+#pragma unroll
+                    for (int s = S - 1; s >= 0; --s) {
+                        const int k = j * S + s, kc = min(k, K - 1);
+                        if (t * S + s < K) { // wavefront-uniform: the stage of lane t exists
+                            double W_[NF];
+                            const double A02 = REC(kc, 0), A12 = REC(kc, 1), B00 = REC(kc, 2), B10 = REC(kc, 3), C0 = REC(kc, 4), C1 = REC(kc, 5);
+                            const int st1 = st[s][1], st0 = st[s][0];
+                            W_[34] = lo_eff[0]; W_[35] = hi_eff[0]; W_[36] = lo_eff[1]; W_[37] = hi_eff[1];
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) { P[r][r] += Qp2[r]; p[r] -= Qp2[r] * xr[s][r]; }
+                            double sv[5];
+#pragma unroll
+                            for (int r = 0; r < 5; ++r) sv[r] = P[r][0] * C0 + P[r][1] * C1 + p[r];
+                            // Pull-back H = Fw' P Fw, h = Fw' s (columns of Fw: c0 = e0, c1 = e1, c2 = (A02, A12, 1, 0, 0),
+                            // c3 = c4 = 0, c5 = (B00, B10, 0, 1, 0), c6 = (0, 0, dt, 0, 1)) and the two eliminations, on the UPPER
+                            // TRIANGLES only (P is symmetric; the one-thread kernel above carries all entries): 11 + 21 + 15
+                            // two-term updates instead of 49 + 36 + 25 four-term ones
+                            Quad7 q;
+                            double PF[7][5];
+#pragma unroll
+                            for (int r = 0; r < 5; ++r) {
+                                PF[0][r] = P[r][0];
+                                PF[1][r] = P[r][1];
+                                PF[2][r] = A02 * P[r][0] + A12 * P[r][1] + P[r][2];
+                                PF[3][r] = 0.0;
+                                PF[4][r] = 0.0;
+                                PF[5][r] = B00 * P[r][0] + B10 * P[r][1] + P[r][3];
+                                PF[6][r] = dt * P[r][2] + P[r][4];
+                            }
+#pragma unroll
+                            for (int kk = 0; kk < 7; ++kk) {
+                                q.H[0][kk] = PF[kk][0];
+                                q.H[1][kk] = PF[kk][1];
+                                q.H[2][kk] = (kk >= 2) ? A02 * PF[kk][0] + A12 * PF[kk][1] + PF[kk][2] : 0.0;
+                                q.H[3][kk] = 0.0;
+                                q.H[4][kk] = 0.0;
+                                q.H[5][kk] = (kk >= 5) ? B00 * PF[kk][0] + B10 * PF[kk][1] + PF[kk][3] : 0.0;
+                                q.H[6][kk] = (kk >= 6) ? dt * PF[kk][2] + PF[kk][4] : 0.0;
+                            }
+#pragma unroll
+                            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                                for (int s2 = 0; s2 < r; ++s2) q.H[r][s2] = q.H[s2][r]; // mirror
+                            q.h[0] = sv[0];
+                            q.h[1] = sv[1];
+                            q.h[2] = A02 * sv[0] + A12 * sv[1] + sv[2];
+                            q.h[3] = 0.0;
+                            q.h[4] = 0.0;
+                            q.h[5] = B00 * sv[0] + B10 * sv[1] + sv[3];
+                            q.h[6] = dt * sv[2] + sv[4];
+                            q.H[5][5] += Ruu0[0]; q.H[6][6] += Ruu0[1];
+                            q.h[5] += -2.0 * c.matrix_q[2] * dr0[s];
+                            if (k >= 1) {
+#pragma unroll
+                                for (int cc = 0; cc < 2; ++cc) {
+                                    q.H[5 + cc][5 + cc] += Rd2[cc]; q.H[3 + cc][3 + cc] += Rd2[cc];
+                                    q.H[5 + cc][3 + cc] -= Rd2[cc]; q.H[3 + cc][5 + cc] -= Rd2[cc];
+                                }
+                            }
+                            { // eliminate u1 (index 6): u1 = a1 . w[0..5] + f1
+                                double a1[6], f1;
+                                const double inv = 1.0 / q.H[6][6];
+                                const bool fr = st1 == FREE, bx = (st1 == BOX_LO || st1 == BOX_HI);
+#pragma unroll
+                                for (int kk = 0; kk < 6; ++kk) a1[kk] = fr ? -q.H[6][kk] * inv : ((!bx && kk == 4) ? 1.0 : 0.0);
+                                f1 = fr ? -q.h[6] * inv : (bx ? (st1 == BOX_LO ? lo_eff[1] : hi_eff[1]) : (st1 == RATE_LO ? -rmax[1] : rmax[1]));
+#pragma unroll
+                                for (int kk = 0; kk < 6; ++kk) W_[6 + kk] = a1[kk];
+                                W_[12] = f1;
+#pragma unroll
+                                for (int kk = 0; kk < 7; ++kk) W_[13 + kk] = q.H[6][kk];
+                                W_[20] = q.h[6];
+                                const double Hkk = q.H[6][6], hk = q.h[6];
+                                double Hk[6], tr[6];
+#pragma unroll
+                                for (int kk = 0; kk < 6; ++kk) { Hk[kk] = q.H[6][kk]; tr[kk] = Hk[kk] + a1[kk] * Hkk; }
+#pragma unroll
+                                for (int r = 0; r < 6; ++r) {
+                                    q.h[r] += a1[r] * hk + tr[r] * f1;
+#pragma unroll
+                                    for (int s2 = r; s2 < 6; ++s2) {
+                                        q.H[r][s2] += a1[r] * Hk[s2] + tr[r] * a1[s2];
+                                        q.H[s2][r] = q.H[r][s2];
+                                    }
+                                }
+                            }
+                            { // eliminate u0 (index 5): u0 = a0 . xi + f0
+                                double a0[5], f0;
+                                const double inv = 1.0 / q.H[5][5];
+                                const bool fr = st0 == FREE, bx = (st0 == BOX_LO || st0 == BOX_HI);
+#pragma unroll
+                                for (int kk = 0; kk < 5; ++kk) a0[kk] = fr ? -q.H[5][kk] * inv : ((!bx && kk == 3) ? 1.0 : 0.0);
+                                f0 = fr ? -q.h[5] * inv : (bx ? (st0 == BOX_LO ? lo_eff[0] : hi_eff[0]) : (st0 == RATE_LO ? -rmax[0] : rmax[0]));
+#pragma unroll
+                                for (int kk = 0; kk < 5; ++kk) W_[21 + kk] = a0[kk];
+                                W_[26] = f0;
+#pragma unroll
+                                for (int kk = 0; kk < 6; ++kk) W_[27 + kk] = q.H[5][kk];
+                                W_[33] = q.h[5];
+                                const double Hkk = q.H[5][5], hk = q.h[5];
+                                double Hk[5], tr[5];
+#pragma unroll
+                                for (int kk = 0; kk < 5; ++kk) { Hk[kk] = q.H[5][kk]; tr[kk] = Hk[kk] + a0[kk] * Hkk; }
+#pragma unroll
+                                for (int r = 0; r < 5; ++r) {
+                                    p[r] = q.h[r] + a0[r] * hk + tr[r] * f0;
+#pragma unroll
+                                    for (int s2 = r; s2 < 5; ++s2) {
+                                        P[r][s2] = q.H[r][s2] + a0[r] * Hk[s2] + tr[r] * a0[s2];
+                                        P[s2][r] = P[r][s2];
+                                    }
+                                }
+                            }
+                            { // boxes of stage k - 1
+                                const double l0 = lo_eff[0], h0 = hi_eff[0], l1 = lo_eff[1], h1 = hi_eff[1];
+                                lo_eff[0] = (st0 == RATE_LO) ? fmax(-umax[0], l0 + rmax[0]) : -umax[0];
+                                hi_eff[0] = (st0 == RATE_HI) ? fmin(umax[0], h0 - rmax[0]) : umax[0];
+                                lo_eff[1] = (st1 == RATE_LO) ? fmax(-umax[1], l1 + rmax[1]) : -umax[1];
+                                hi_eff[1] = (st1 == RATE_HI) ? fmin(umax[1], h1 - rmax[1]) : umax[1];
+                            }
+                            if (act && j == t) { // the record of the stage: stores only
+#pragma unroll
+                                for (int f = 6; f < NF; ++f) REC(k, f) = W_[f];
+                            }
+                        }
+                    }
+                }
+                // hand the cost-to-go to the lane below (upper triangle)
+                if (t == 0) break;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    p[r] = next_d(p[r]);
+#pragma unroll
+                    for (int s2 = r; s2 < 5; ++s2) { P[r][s2] = next_d(P[r][s2]); P[s2][r] = P[r][s2]; }
+                }
+                lo_eff[0] = next_d(lo_eff[0]); lo_eff[1] = next_d(lo_eff[1]); hi_eff[0] = next_d(hi_eff[0]); hi_eff[1] = next_d(hi_eff[1]);
+            }
+            // forward sweep, lane 0 upwards: inputs, multipliers, violations -> next working set
+            double xi[5] = {pos0[0], pos0[1], pos0[2], 0.0, 0.0};
+            int changes = 0;
+            double chain_mu[2] = {0.0, 0.0};
+            int chain_dir[2] = {0, 0};
+            const bool single = sweeps >= SINGLE_AFTER;
+            double best_sev = -1.0;
+            int best_j = 0, best_c = 0, best_ns = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int t = 0; t <= top; ++t) {
+                const bool commit = act && j == t;
+                {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const int k = j * S + s, kc = min(k, K - 1);
+                        if (t * S + s < K) { // wavefront-uniform
+                            double Rr[NF];
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) Rr[f] = REC(kc, f);
+                            double w7[7];
+#pragma unroll
+                            for (int kk = 0; kk < 5; ++kk) w7[kk] = xi[kk];
+                            double u0 = Rr[26];
+#pragma unroll
+                            for (int kk = 0; kk < 5; ++kk) u0 += Rr[21 + kk] * xi[kk];
+                            w7[5] = u0;
+                            double u1 = Rr[12];
+#pragma unroll
+                            for (int kk = 0; kk < 6; ++kk) u1 += Rr[6 + kk] * w7[kk];
+                            w7[6] = u1;
+                            double g1 = Rr[20], g0 = Rr[33];
+#pragma unroll
+                            for (int kk = 0; kk < 7; ++kk) g1 += Rr[13 + kk] * w7[kk];
+#pragma unroll
+                            for (int kk = 0; kk < 6; ++kk) g0 += Rr[27 + kk] * w7[kk];
+                            const double uu[2] = {u0, u1}, gg[2] = {g0, g1};
+#pragma unroll
+                            for (int cc = 0; cc < 2; ++cc) {
+                                const int sc = st[s][cc];
+                                const double val = uu[cc], prev = xi[3 + cc], grad = gg[cc];
+                                const double lo = Rr[34 + 2 * cc], hi = Rr[35 + 2 * cc];
+                                int ns = sc;
+                                double sev = 0.0;
+                                if (sc == FREE) {
+                                    chain_mu[cc] = 0.0; chain_dir[cc] = 0;
+                                    const double vb = fmax(lo - val, val - hi);
+                                    const double vr = (k >= 1) ? fmax(-rmax[cc] - (val - prev), (val - prev) - rmax[cc]) : -1.0;
+                                    if (vb > tol && vb >= vr) { ns = (val < lo) ? BOX_LO : BOX_HI; sev = vb; }
+                                    else if (vr > tol) { ns = (val - prev < 0.0) ? RATE_LO : RATE_HI; sev = vr; }
+                                } else if (sc == BOX_LO || sc == BOX_HI) {
+                                    const bool lower = (sc == BOX_LO);
+                                    const bool tightened = lower ? (lo > -umax[cc] + 1e-12) : (hi < umax[cc] - 1e-12);
+                                    chain_mu[cc] = tightened ? grad : 0.0;
+                                    chain_dir[cc] = tightened ? (lower ? -1 : 1) : 0;
+                                    if ((lower && grad < -tol) || (!lower && grad > tol)) { ns = FREE; sev = fabs(grad); }
+                                    else if (k >= 1 && fabs(val - prev) > rmax[cc] + tol) { ns = (val - prev < 0.0) ? RATE_LO : RATE_HI; sev = fabs(val - prev) - rmax[cc]; }
+                                } else {
+                                    const bool lower = (sc == RATE_LO);
+                                    if (chain_dir[cc] != (lower ? -1 : 1)) { chain_mu[cc] = 0.0; chain_dir[cc] = 0; }
+                                    const double g_eff = grad - chain_mu[cc];
+                                    if ((lower && g_eff < -tol) || (!lower && g_eff > tol)) {
+                                        ns = (chain_mu[cc] == 0.0) ? FREE : (lower ? BOX_LO : BOX_HI);
+                                        sev = fabs(g_eff);
+                                        chain_mu[cc] = 0.0; chain_dir[cc] = 0;
+                                    }
+                                }
+                                if (ns != sc) {
+                                    ++changes;
+                                    if (!single) st[s][cc] = commit ? ns : st[s][cc];
+                                    else if (sev > best_sev) { best_sev = sev; best_j = k; best_c = cc; best_ns = ns; }
+                                }
+                            }
+                            ua[s] = commit ? u0 : ua[s]; uw[s] = commit ? u1 : uw[s];
+                            const double A02 = Rr[0], A12 = Rr[1], B00 = Rr[2], B10 = Rr[3];
+                            const double nx = xi[0] + A02 * xi[2] + B00 * u0 + Rr[4], ny = xi[1] + A12 * xi[2] + B10 * u0 + Rr[5];
+                            xi[2] = xi[2] + dt * u1; xi[0] = nx; xi[1] = ny; xi[3] = u0; xi[4] = u1;
+                        }
+                    }
+                }
+                if (t == top) break; // the totals stay in the lane of the last stage
+#pragma unroll
+                for (int r = 0; r < 5; ++r) xi[r] = prev_d(xi[r]);
+                chain_mu[0] = prev_d(chain_mu[0]); chain_mu[1] = prev_d(chain_mu[1]);
+                chain_dir[0] = prev_i(chain_dir[0]); chain_dir[1] = prev_i(chain_dir[1]);
+                changes = prev_i(changes); best_sev = prev_d(best_sev);
+                best_j = prev_i(best_j); best_c = prev_i(best_c); best_ns = prev_i(best_ns);
+            }
+            {
+                const int src = (lane & ~15) + top;
+                changes = __shfl(changes, src);
+                best_sev = __shfl(best_sev, src);
+                best_j = __shfl(best_j, src); best_c = __shfl(best_c, src); best_ns = __shfl(best_ns, src);
+            }
+            if (act) {
+                if (single && changes > 0) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        if (j * S + s == best_j) { if (best_c == 0) st[s][0] = best_ns; else st[s][1] = best_ns; }
+                }
+                settled = (changes == 0);
+                ++sweeps;
+            }
+        }
+        status = settled ? 0 : 1;
+    }
+    // ---- predictMotion(xopt): the linear prediction about the rollout of the final output (see the kernel above for
+    //      which rollout the reference uses), by prefix sums; column m of the output drives step m -> m + 1
+    {
+        double* xo = d.xopt + (size_t)b * (T + 1) * 3;
+        const double x0 = nowp[0], y0 = nowp[1], th0 = nowp[2];
+        double bth = th0, bv = 0.0, tx = x0, ty = y0, tth = th0;
+        if (valid && j == 0) { xo[0] = tx; xo[1] = ty; xo[2] = tth; }
+        for (int i = 0; i < dl; ++i) { // the delayed inputs (now the delay buffer), every lane
+            const double u0 = d.reset ? 0.0 : bf[2 * i], u1 = d.reset ? 0.0 : bf[2 * i + 1];
+            const double B00 = cos(bth) * dt, B10 = sin(bth) * dt, A02 = -B10 * bv, A12 = B00 * bv;
+            const double nx = tx + A02 * tth + B00 * u0 - A02 * bth, ny = ty + A12 * tth + B10 * u0 - A12 * bth;
+            tth = tth + dt * u1; tx = nx; ty = ny;
+            if (valid && j == 0) { xo[3 * (i + 1)] = tx; xo[3 * (i + 1) + 1] = ty; xo[3 * (i + 1) + 2] = tth; }
+            bth += fmin(fmax(u1, -c.max_omega), c.max_omega) * dt; bv = u0;
+        }
+        double hb[S], ht[S], ab = 0.0, at = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool vs = j * S + s < K;
+            hb[s] = ab; ht[s] = at;
+            ab += vs ? fmin(fmax(uw[s], -c.max_omega), c.max_omega) * dt : 0.0;
+            at += vs ? dt * uw[s] : 0.0;
+        }
+        const double eb = rowprefix_d(ab) - ab + bth, et = rowprefix_d(at) - at + tth;
+        const double a_prev_lane = prev_d(ua[S - 1]);
+        double ix[S], iy[S], sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int k = j * S + s;
+            const bool vs = k < K;
+            const double bth_k = hb[s] + eb, tth_k = ht[s] + et;
+            const double bv_k = (k == 0) ? bv : ((s == 0) ? a_prev_lane : ua[(s > 0) ? s - 1 : 0]);
+            const double B00 = cos(bth_k) * dt, B10 = sin(bth_k) * dt, A02 = -B10 * bv_k, A12 = B00 * bv_k;
+            sx += vs ? (A02 * tth_k + B00 * ua[s] - A02 * bth_k) : 0.0;
+            sy += vs ? (A12 * tth_k + B10 * ua[s] - A12 * bth_k) : 0.0;
+            ix[s] = sx; iy[s] = sy;
+            ht[s] = tth_k + dt * uw[s]; // heading after the step
+        }
+        const double ex = rowprefix_d(sx) - sx + tx, ey = rowprefix_d(sy) - sy + ty;
+        if (valid) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int k = j * S + s;
+                if (k < K) {
+                    const int i = dl + k + 1;
+                    xo[3 * i] = ix[s] + ex; xo[3 * i + 1] = iy[s] + ey; xo[3 * i + 2] = ht[s];
+                }
+            }
+        }
+    }
+    // ---- state kept between calls: the output (its first columns are the delay buffer), the working set, the buffer
+    const double c0 = __shfl(ua[0], lane & ~15), c1 = __shfl(uw[0], lane & ~15); // stage 0 = the command just computed
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int k = j * S + s;
+            if (k < K) {
+                out[2 * (dl + k)] = ua[s]; out[2 * (dl + k) + 1] = uw[s];
+                d.st[((size_t)k * 2) * d.stride + b] = st[s][0];
+                d.st[((size_t)k * 2 + 1) * d.stride + b] = st[s][1];
+            }
+        }
+        if (j == 0) {
+            for (int i = 0; i < dl; ++i) { out[2 * i] = d.reset ? 0.0 : bf[2 * i]; out[2 * i + 1] = d.reset ? 0.0 : bf[2 * i + 1]; }
+            if (dl > 0) { // output_buff: drop the oldest, append the command just computed
+                for (int i = 0; i + 1 < dl; ++i) { bf[2 * i] = d.reset ? 0.0 : bf[2 * (i + 1)]; bf[2 * i + 1] = d.reset ? 0.0 : bf[2 * (i + 1) + 1]; }
+                bf[2 * (dl - 1)] = c0; bf[2 * (dl - 1) + 1] = c1;
+            }
+            d.sweeps[b] = sweeps;
+            d.status[b] = status;
+            d.cmd[2 * b] = c0; d.cmd[2 * b + 1] = c1;
+        }
+    }
+}
+
 // getRefPoints of the `mpc` node on the trajectory store: thread = (robot, i), then smooth_yaw per robot
 __global__ void ltv_refs_kernel(nmpc::RefStore s, int B, int T, double dt, double now, double* xref, double* dref, int* at_goal)
 {
@@ -586,7 +1044,23 @@ static int ltv_enqueue(alore_ltv_handle h, int B, const double* now_state, int n
     d.ws = h->d_ws; d.st = h->d_st; d.sweeps = h->d_sweeps; d.status = h->d_status; d.cmd = h->d_cmd;
     d.n_relin = n_relin; d.reset = reset;
     d.stamps = h->d_stamps;
-    hipLaunchKernelGGL(ltv::get_cmd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d);
+    // 16 lanes per robot (stages in registers, sweeps lane by lane) unless ALORE_LTV_KERNEL=thread asks for the
+    // one-thread-per-robot kernel (diagnostic A/B)
+    static const char* which = std::getenv("ALORE_LTV_KERNEL");
+    const int K = h->cfg.predict_steps - h->cfg.delay_num;
+    if (which && which[0] == 't')
+        hipLaunchKernelGGL(ltv::get_cmd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d);
+    else if (K <= 32)
+        hipLaunchKernelGGL(ltv::get_cmd_lanes_kernel<2>, dim3((B + 3) / 4), dim3(64), (size_t)K * ltv::REC_STRIDE * sizeof(double), s, d);
+    else {
+        const size_t lds = (size_t)K * ltv::REC_STRIDE * sizeof(double);
+        static bool raised = false;
+        if (!raised) {
+            LTV_TRY(h, hipFuncSetAttribute((const void*)ltv::get_cmd_lanes_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * ltv::REC_STRIDE * 8));
+            raised = true;
+        }
+        hipLaunchKernelGGL(ltv::get_cmd_lanes_kernel<4>, dim3((B + 3) / 4), dim3(64), lds, s, d);
+    }
     LTV_TRY(h, hipGetLastError());
     return ALORE_LTV_OK;
 }

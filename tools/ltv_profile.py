@@ -25,3 +25,9 @@ for i in range(5):
     g1 = lt.get_cmd(st0, n_relin=5)
 t2 = time.perf_counter()
 print(f"B={B}: cold {1e3 * (t1 - t0):.2f} ms, warm {1e3 * (t2 - t1) / 5:.2f} ms per tick (5 relinearisations), unsettled {int((g1['status'] != 0).sum())}")
+# tick entry point (what a controller calls): states up, one launch, 16 B per robot down
+t3 = time.perf_counter()
+for i in range(20):
+    lt.tick(st0, n_relin=5)
+t4 = time.perf_counter()
+print(f"B={B}: alore_ltv_tick warm {1e3 * (t4 - t3) / 20:.3f} ms; sweeps cold mean {g0['sweeps'].mean():.2f} max {g0['sweeps'].max()}, warm mean {g1['sweeps'].mean():.2f}")
