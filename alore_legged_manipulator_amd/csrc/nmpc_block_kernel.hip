@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     float* lds = reinterpret_cast<float*>(lds_raw);
     constexpr int G = 64 / L;
     constexpr int NMAX = L * S;
+    constexpr bool MASKED = (L == 16 && S == 2); // see backward_sweep
     const int N = p.N;
     const int lane = threadIdx.x;
     const int g = lane / L, j = lane % L;
@@ -477,14 +478,13 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
                     frozen = frozen || (still >= 2 && t + 1 >= p.pg_steps);
                     if (__all(frozen)) break;
                 }
-                if (run) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        if (j * S + s < N) {
-                            st0[s] = (ub0[s] - lb0[s] > BOUNDTOL) ? ((w0[s] <= lb0[s]) ? ST_LOWER : ((w0[s] >= ub0[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
-                            st1[s] = (ub1[s] - lb1[s] > BOUNDTOL) ? ((w1[s] <= lb1[s]) ? ST_LOWER : ((w1[s] >= ub1[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
-                        }
-                    }
+                for (int s = 0; s < S; ++s) {
+                    const bool set = run && (j * S + s < N);
+                    const int n0 = (ub0[s] - lb0[s] > BOUNDTOL) ? ((w0[s] <= lb0[s]) ? ST_LOWER : ((w0[s] >= ub0[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
+                    const int n1 = (ub1[s] - lb1[s] > BOUNDTOL) ? ((w1[s] <= lb1[s]) ? ST_LOWER : ((w1[s] >= ub1[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
+                    st0[s] = set ? n0 : st0[s];
+                    st1[s] = set ? n1 : st1[s];
                 }
             }
             if (STAMP) t_pg = __builtin_amdgcn_s_memtime() - tp0;
@@ -591,16 +591,20 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             sbo[0] = a0 + ex0; sbo[1] = a1 + ex1;
         }
 
-        auto backward_block = [&](auto guard_tag) -> int { // guard: only the lane with the terminal node has slots that are not stages
-            constexpr bool GUARD = decltype(guard_tag)::value;
+        // One lane's block of the backward recursion.  EVERY lane of the wavefront runs it on its own slots with whatever
+        // cost-to-go it holds -- only lane t of a sweeping group holds the real one, and only it keeps the policy records
+        // (`mine`, by selects).  No heavy code runs under a partial EXEC mask: values that are live across such a region in
+        // the lanes that sit it out are not safe from the register allocator's spill / reload pairs there (seen in
+        // ltv_mpc.hip).  `t` is wavefront-uniform, so the slots past the horizon are skipped with a uniform branch.
+        auto backward_block = [&](int t, bool mine, auto full_tag) -> int {
+            constexpr bool FULL = decltype(full_tag)::value; // every slot of lane t is a stage: one basic block
             Value val;
             val.P.m00 = V[0]; val.P.m01 = V[1]; val.P.m02 = V[2]; val.P.m11 = V[3]; val.P.m12 = V[4]; val.P.m22 = V[5];
             val.p0 = V[6]; val.p1 = V[7]; val.p2 = V[8];
             int ok = 1;
 #pragma unroll
             for (int s = S - 1; s >= 0; --s) {
-                if (!GUARD || j * S + s < N) { // unguarded: the S stages are one basic block, the scheduler overlaps the
-                                               // tail of one step with the head of the next
+                if (FULL || t * S + s < N) { // wavefront-uniform: the stage of lane t exists
                     StageQP q;
                     q.a = sa[s]; q.b = sb[s]; q.B00 = B00[s]; q.B01 = B01[s]; q.B10 = B10[s]; q.B11 = B11[s]; q.B20 = B20[s];
                     q.d0 = d0[s]; q.d1 = d1[s]; q.d2 = d2[s];
@@ -612,8 +616,10 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
                     q.v1 = (st1[s] == ST_UPPER) ? ub1[s] : lb1[s];
                     Policy pol;
                     ok &= riccati_step(q, val, pol, true) ? 1 : 0;
-                    c00[s] = pol.c00; c01[s] = pol.c01; c02[s] = pol.c02; pf0[s] = pol.f0;
-                    c10[s] = pol.c10; c11[s] = pol.c11; c12[s] = pol.c12; pe1[s] = pol.e1; pf1[s] = pol.f1;
+                    c00[s] = mine ? pol.c00 : c00[s]; c01[s] = mine ? pol.c01 : c01[s]; c02[s] = mine ? pol.c02 : c02[s];
+                    pf0[s] = mine ? pol.f0 : pf0[s];
+                    c10[s] = mine ? pol.c10 : c10[s]; c11[s] = mine ? pol.c11 : c11[s]; c12[s] = mine ? pol.c12 : c12[s];
+                    pe1[s] = mine ? pol.e1 : pe1[s]; pf1[s] = mine ? pol.f1 : pf1[s];
                 }
             }
             V[0] = val.P.m00; V[1] = val.P.m01; V[2] = val.P.m02; V[3] = val.P.m11; V[4] = val.P.m12; V[5] = val.P.m22;
@@ -626,16 +632,27 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             for (int t = top; t >= 0; --t) {
                 const bool mine = act && (j == t) && (t <= from);
                 if (__any(act && t <= from)) {
-                    if (mine) {
-                        if (t == from) {
+                    // lane t of a group that starts here takes the cost-to-go it kept; below, the one handed down is kept
+                    const bool start = mine && (t == from);
+                    if constexpr (MASKED) {
+                        // (16, 2) only: the block of lane t under an EXEC mask (a tenth fewer instructions per sweep:
+                        // no selects).  This instantiation keeps its whole state in VGPRs, and tests/test_masked_regions.py
+                        // checks on every build that no spill / reload / AGPR traffic sits inside the masked region.
+                        if (mine) {
 #pragma unroll
-                            for (int i = 0; i < 9; ++i) V[i] = Vin[i];
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 9; ++i) Vin[i] = V[i];
+                            for (int i = 0; i < 9; ++i) { V[i] = start ? Vin[i] : V[i]; Vin[i] = V[i]; }
+                            const int ok = ((t + 1) * S <= N) ? backward_block(t, true, std::true_type{}) : backward_block(t, true, std::false_type{});
+                            pd_fail |= ok ? 0 : 1;
                         }
-                        if (t == top) pd_fail |= backward_block(std::true_type{}) ? 0 : 1;
-                        else pd_fail |= backward_block(std::false_type{}) ? 0 : 1;
+                    } else {
+                        if (__any(start)) {
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) V[i] = start ? Vin[i] : V[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) Vin[i] = mine ? V[i] : Vin[i];
+                        const int ok = ((t + 1) * S <= N) ? backward_block(t, mine, std::true_type{}) : backward_block(t, mine, std::false_type{});
+                        pd_fail |= (mine && !ok) ? 1 : 0;
                     }
 #pragma unroll
                     for (int i = 0; i < 9; ++i) V[i] = lane_next(V[i]);
@@ -789,27 +806,26 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
         // ---- phase C: KKT value (acado_getKKT), expand (acado_expand), carry the dual
         float gd = 0.0f, comp = 0.0f;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
+        for (int s = 0; s < S; ++s) { // no predicate: slots past the horizon hold zero steps / multipliers (their x, u are never stored)
             const int k = j * S + s;
-            if (k < N) {
-                if (DIAG) {
-                    if (k > 0) { // (Q_k sbar_k + q_k)' (dx_k - sbar_k)
-                        const float b0 = sbs[s][0], b1 = sbs[s][1], b2 = sbs[s][2];
-                        const float e0 = dxs[s][0] - b0, e1 = dxs[s][1] - b1, e2 = dxs[s][2] - b2;
-                        gd += (Q00[s] * b0 + Q01[s] * b1 + Q02[s] * b2 + q0[s]) * e0 +
-                              (Q01[s] * b0 + Q11[s] * b1 + Q12[s] * b2 + q1[s]) * e1 +
-                              (Q02[s] * b0 + Q12[s] * b1 + Q22[s] * b2 + q2[s]) * e2;
-                    }
-                    gd += r0[s] * du0[s] + r1[s] * du1[s];
-                    comp += (mu0[s] > 1e-12f) ? fabsf(lb0[s] * mu0[s]) : ((mu0[s] < -1e-12f) ? fabsf(ub0[s] * mu0[s]) : 0.0f);
-                    comp += (mu1[s] > 1e-12f) ? fabsf(lb1[s] * mu1[s]) : ((mu1[s] < -1e-12f) ? fabsf(ub1[s] * mu1[s]) : 0.0f);
-                }
-                x[s][0] += dxs[s][0]; x[s][1] += dxs[s][1]; x[s][2] += dxs[s][2];
-                // a free control may sit up to TOL_PRIMAL outside its box: keep the iterate feasible
-                const float e0 = (lb0[s] <= ub0[s]) ? clampf(du0[s], lb0[s], ub0[s]) : du0[s];
-                const float e1 = (lb1[s] <= ub1[s]) ? clampf(du1[s], lb1[s], ub1[s]) : du1[s];
-                u[s][0] += e0; u[s][1] += e1;
+            if (DIAG) {
+                // (Q_k sbar_k + q_k)' (dx_k - sbar_k), stages 1 .. N - 1 (the slot of the terminal node, if the lane has it,
+                // carries QN for the prediction: it is added below)
+                const float b0 = sbs[s][0], b1 = sbs[s][1], b2 = sbs[s][2];
+                const float e0 = dxs[s][0] - b0, e1 = dxs[s][1] - b1, e2 = dxs[s][2] - b2;
+                const float tq = (Q00[s] * b0 + Q01[s] * b1 + Q02[s] * b2 + q0[s]) * e0 +
+                                 (Q01[s] * b0 + Q11[s] * b1 + Q12[s] * b2 + q1[s]) * e1 +
+                                 (Q02[s] * b0 + Q12[s] * b1 + Q22[s] * b2 + q2[s]) * e2;
+                gd += (k > 0 && k < N) ? tq : 0.0f;
+                gd += r0[s] * du0[s] + r1[s] * du1[s];
+                comp += (mu0[s] > 1e-12f) ? fabsf(lb0[s] * mu0[s]) : ((mu0[s] < -1e-12f) ? fabsf(ub0[s] * mu0[s]) : 0.0f);
+                comp += (mu1[s] > 1e-12f) ? fabsf(lb1[s] * mu1[s]) : ((mu1[s] < -1e-12f) ? fabsf(ub1[s] * mu1[s]) : 0.0f);
             }
+            x[s][0] += dxs[s][0]; x[s][1] += dxs[s][1]; x[s][2] += dxs[s][2];
+            // a free control may sit up to TOL_PRIMAL outside its box: keep the iterate feasible
+            const float e0 = (lb0[s] <= ub0[s]) ? clampf(du0[s], lb0[s], ub0[s]) : du0[s];
+            const float e1 = (lb1[s] <= ub1[s]) ? clampf(du1[s], lb1[s], ub1[s]) : du1[s];
+            u[s][0] += e0; u[s][1] += e1;
         }
         if (j == top) { // terminal node
             if (DIAG) {
@@ -830,19 +846,17 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
         float part = 0.0f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int k = j * S + s;
-            if (k < N) {
-                const float* yk = lds + oY + ge * 5 * N + 5 * k;
-                const float* Wk = lds + oW + gw * 25 * N + 25 * k;
-                const float e[5] = {x[s][0] - yk[0], x[s][1] - yk[1], x[s][2] - yk[2], u[s][0] - yk[3], u[s][1] - yk[4]};
-                float acc = 0.0f;
+            const int k = j * S + s, kc = min(k, N - 1);
+            const float* yk = lds + oY + ge * 5 * N + 5 * kc;
+            const float* Wk = lds + oW + gw * 25 * N + 25 * kc;
+            const float e[5] = {x[s][0] - yk[0], x[s][1] - yk[1], x[s][2] - yk[2], u[s][0] - yk[3], u[s][1] - yk[4]};
+            float acc = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 5; ++c) {
-                    const float tt = e[0] * Wk[c] + e[1] * Wk[5 + c] + e[2] * Wk[10 + c] + e[3] * Wk[15 + c] + e[4] * Wk[20 + c];
-                    acc += e[c] * tt;
-                }
-                part += acc;
+            for (int c = 0; c < 5; ++c) {
+                const float tt = e[0] * Wk[c] + e[1] * Wk[5 + c] + e[2] * Wk[10 + c] + e[3] * Wk[15 + c] + e[4] * Wk[20 + c];
+                acc += e[c] * tt;
             }
+            part += (k < N) ? acc : 0.0f;
         }
         if (j == top) { // the reference uses only the diagonal of WN here (acado_solver.c:1442-1444)
             const float e0 = xN[0] - yN[0], e1 = xN[1] - yN[1], e2 = xN[2] - yN[2];
