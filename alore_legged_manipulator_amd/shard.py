@@ -67,3 +67,95 @@ class ResultGatherer:
             w.wait()
         self._pending.clear()
         return self._last
+
+
+class HostHooks:
+    """Device hooks of `timed_pass` for a machine without GPUs (the gloo tests): nothing to synchronise, no graphs,
+    the device clock is the host clock."""
+
+    def __init__(self, dist=None, world: int = 1):
+        self.dist, self.world = dist, world
+
+    def sync(self) -> None:
+        pass
+
+    def barrier(self) -> None:
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
+
+    def capture(self, fn):
+        """record fn() once and return a zero-argument replay callable, or None to launch eagerly"""
+        return None
+
+    def device_timer(self):
+        import time
+
+        class T:
+            def start(self_inner):
+                self_inner.t0 = time.perf_counter()
+
+            def stop(self_inner):
+                self_inner.t1 = time.perf_counter()
+
+            def elapsed_ms(self_inner):
+                return (self_inner.t1 - self_inner.t0) * 1e3
+        return T()
+
+    def max_over_ranks(self, values):
+        if self.world == 1:
+            return list(values)
+        import torch
+        t = torch.tensor(list(values), dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+
+def timed_pass(eng, batch, mode: str, K: int, warmup: int, gather_every: int, gatherer, hooks, world: int):
+    """W untimed + K timed steps of `eng` (anything with load(batch, slot=None), rti(1, slot=i) and per-slot result
+    tensors eng.ts[name][slot]) with the result exchange `mode`:
+      full -- the trajectories (x, u, status, kkt) of EVERY timed batch are all-gathered to every rank, in buckets of
+              `gather_every` steps issued asynchronously and all completed inside the timed region (eager launches:
+              collectives sit between the solves);
+      last -- only the last batch's trajectories are exchanged (the K launches may replay as one graph);
+      none -- results stay sharded.
+    Returns (elapsed seconds, device milliseconds, graph used): both times are the MAXIMUM over the ranks, measured
+    between two barriers.  bench.py calls this with the GPU hooks; tests/dist_worker.py with HostHooks under gloo."""
+    import time
+    do_gather = world > 1 and mode == "full"
+    gather_last = world > 1 and mode == "last"
+    ge = max(1, gather_every)
+
+    def run_steps(first, count):
+        for i in range(first, first + count):
+            eng.rti(1, slot=i)
+            if do_gather and ((i - first + 1) % ge == 0 or i == first + count - 1):
+                lo = first + ((i - first) // ge) * ge
+                gatherer.submit({k: eng.ts[k][lo:i + 1] for k in ("x", "u", "status", "kkt")})
+        if do_gather:
+            gatherer.wait()
+
+    eng.load(batch, slot=None)  # every pass starts from the same cold-start iterates in every slot
+    hooks.sync()
+    run_steps(0, warmup)
+    hooks.barrier()
+    replay = None
+    if not do_gather and K > 0:  # never with collectives between the solves
+        replay = hooks.capture(lambda: run_steps(warmup, K))
+    timer = hooks.device_timer()
+    hooks.barrier()
+    t0 = time.perf_counter()
+    timer.start()
+    if replay is not None:
+        replay()
+    else:
+        run_steps(warmup, K)
+    timer.stop()
+    if gather_last:  # the converged trajectories of the last batch on every rank (x, u, status, kkt)
+        last = warmup + K - 1
+        gatherer.submit({k: eng.ts[k][last] for k in ("x", "u", "status", "kkt")})
+        gatherer.wait()
+    hooks.barrier()
+    t1 = time.perf_counter()
+    el, dms = hooks.max_over_ranks([t1 - t0, timer.elapsed_ms()])
+    return el, dms, replay is not None

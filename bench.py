@@ -327,70 +327,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_pass(mode, K):
-        """W untimed + K timed steps with the result exchange `mode`:
-        full -- the trajectories (x, u, status, kkt) of EVERY timed batch are all-gathered to every rank, in buckets
-                of `--gather-every` steps issued asynchronously and all completed inside the timed region (eager
-                launches: collectives sit between the solves);
-        last -- only the last batch's trajectories are exchanged (the K launches replay as one hipGraph);
-        none -- results stay sharded."""
-        do_gather = world > 1 and mode == "full"
-        gather_last = world > 1 and mode == "last"
+    class GpuHooks:
+        """device side of shard.timed_pass: HIP stream synchronisation, hipGraph capture, HIP events"""
 
-        def run_steps(first, count):
-            for i in range(first, first + count):
-                eng.rti(1, slot=i)
-                if do_gather and ((i - first + 1) % ge == 0 or i == first + count - 1):
-                    lo = first + ((i - first) // ge) * ge
-                    gatherer.submit({"x": eng.ts["x"][lo:i + 1], "u": eng.ts["u"][lo:i + 1],
-                                     "status": eng.ts["status"][lo:i + 1], "kkt": eng.ts["kkt"][lo:i + 1]})
-            if do_gather:
-                gatherer.wait()
+        def sync(self):
+            torch.cuda.synchronize(dev)
 
-        eng.load(batch, slot=None)  # every pass starts from the same cold-start iterates in every slot
-        torch.cuda.synchronize(dev)
-        run_steps(0, a.warmup)
-        barrier()
-        # the K timed steps captured once into a hipGraph (K kernel nodes, no host launch overhead inside the timed
-        # region); not with collectives between the solves.  Capture is thread-local so that the RCCL watchdog thread
-        # of a multi-rank run cannot invalidate it; any capture failure falls back to eager launches.
-        graph = None
-        if not a.no_graph and not do_gather and K > 0:
+        def barrier(self):
+            barrier()
+
+        def capture(self, fn):
+            # the K timed steps captured once into a hipGraph (K kernel nodes, no host launch overhead inside the timed
+            # region).  Capture is thread-local so that the RCCL watchdog thread of a multi-rank run cannot invalidate
+            # it; any capture failure falls back to eager launches.
+            if a.no_graph:
+                return None
             try:
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                        run_steps(a.warmup, K)
+                        fn()
                 torch.cuda.current_stream(dev).wait_stream(side)
-                graph = g
+                return g.replay
             except Exception as e:
                 print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
-                graph = None
                 torch.cuda.synchronize(dev)
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        barrier()
-        t0 = time.perf_counter()
-        ev0.record()
-        if graph is not None:
-            graph.replay()
-        else:
-            run_steps(a.warmup, K)
-        ev1.record()
-        if gather_last:  # the converged trajectories of the last batch on every rank (x, u, status, kkt)
-            last = a.warmup + K - 1
-            gatherer.submit({k: eng.ts[k][last] for k in ("x", "u", "status", "kkt")})
-            gatherer.wait()
-        barrier()
-        t1 = time.perf_counter()
-        el, dms = t1 - t0, ev0.elapsed_time(ev1)
-        if world > 1:
-            tt = torch.tensor([el, dms], dtype=torch.float64, device=dev)
+                return None
+
+        def device_timer(self):
+            class T:  # HIP events on the launch stream; read after the barrier that follows the timed region
+                def start(self_inner):
+                    self_inner.e0 = torch.cuda.Event(enable_timing=True)
+                    self_inner.e1 = torch.cuda.Event(enable_timing=True)
+                    self_inner.e0.record()
+
+                def stop(self_inner):
+                    self_inner.e1.record()
+
+                def elapsed_ms(self_inner):
+                    return self_inner.e0.elapsed_time(self_inner.e1)
+            return T()
+
+        def max_over_ranks(self, values):
+            if world == 1:
+                return list(values)
+            tt = torch.tensor(list(values), dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el, dms = float(tt[0].item()), float(tt[1].item())
-        return el, dms, graph is not None
+            return [float(v) for v in tt]
+
+    from alore_legged_manipulator_amd import shard as shard_mod
+    hooks = GpuHooks()
+
+    def timed_pass(mode, K):
+        return shard_mod.timed_pass(eng, batch, mode, K, a.warmup, ge, gatherer, hooks, world)
 
     # primary figure: multi-rank runs gather EVERY batch ("both" adds the last-batch-only figure beside it)
     primary = "none" if world == 1 else ("full" if a.gather in ("full", "both") else a.gather)

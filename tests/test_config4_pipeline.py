@@ -80,3 +80,62 @@ def test_backend_plans_warm_start_the_nmpc_on_the_device():
     # that run at up to 3 m/s: the robots stop near, not on, their goals (3 - 8 m away from the start)
     assert np.all(goal) and np.median(dist) < 0.3 and dist.max() < 1.0, (np.median(dist), dist.max())
     assert np.max(np.abs(vw)) < 0.2
+
+
+def test_config4_share_of_one_gpu_at_full_size():
+    """BASELINE configs[4] at the size ONE GPU of the 8 carries: 4 object classes x 16384 poses / 8 GPUs = 8192 plans.
+    One planner launch, device-to-device hand-over, cold start, closed loop to the end of the plans.  Size-independent
+    checks: every plan found, every tick of every robot solved, the robots end where the small test's robots end;
+    sampled plans are the same bits as the same problems planned in a small batch (independent problems)."""
+    import time
+    import torch
+    from alore_legged_manipulator_amd.backend import BatchedMSPlanner
+    from alore_legged_manipulator_amd.nmpc import BatchedNmpc
+    poses_per_class, N, dt = 2048, 20, 0.01
+    B = 4 * poses_per_class
+    fts = monte_carlo_goals(B, seed=44)
+    pl = BatchedMSPlanner(B, 16)
+    pl.set_free_map(half=20.0)
+    pl.set_problems(fts)
+    t0 = time.perf_counter()
+    pl.plan()
+    res = pl.results()
+    t_plan = time.perf_counter() - t0
+    assert np.all(res["ok"] == 1)
+    idx = np.array([0, 1, 2, 3, 77, 4095, 4096, B - 1])
+    small = BatchedMSPlanner(len(idx), 16)
+    small.set_free_map(half=20.0)
+    rs = small.minco_plan([fts[i] for i in idx])
+    for k in ("T", "coef"):
+        assert np.array_equal(res[k][idx], rs[k]), k
+
+    icr = np.array([CLASSES[b % 4] for b in range(B)])
+    pose0 = np.array([ft.start_xytheta for ft in fts])
+    W = np.tile(np.diag([10, 10, 0.5, 0.1, 0.1]).astype(np.float32), (B, N, 1, 1))
+    WN = np.tile(np.diag([10, 10, 0.5]).astype(np.float32), (B, 1, 1))
+    eng = BatchedNmpc(B, N, dt, diagnostics=False)
+    eng.load({"W": W, "WN": WN})
+    eng.refs_init(max_pieces=16, max_checkpoints=128)
+    eng.refs_set_from_backend(pl)
+    eng.plant_init()
+    eng.plant_set_state(pose0, icr)
+    eng.closed_loop_reset()
+    eng.closed_loop_tick(0.05, delay_num=1)
+    assert bool((eng.t["status"] == 0).all())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.closed_loop_run(0.06, dt, 100, delay_num=1)
+    torch.cuda.synchronize()
+    t_100 = time.perf_counter() - t0
+    assert bool((eng.t["status"] == 0).all())
+    Tmax = float(res["T"].sum(1).max())
+    ticks = int((Tmax + 1.5) / dt) - 100
+    eng.closed_loop_run(0.06 + 100 * dt, dt, ticks, delay_num=1)
+    assert bool((eng.t["status"] == 0).all())
+    pose, vw, goal = eng.plant_get_state()
+    final = np.array([ft.final_xytheta for ft in fts])
+    dist = np.hypot(pose[:, 0] - final[:, 0], pose[:, 1] - final[:, 1])
+    assert np.all(goal) and np.median(dist) < 0.3 and dist.max() < 1.0, (np.median(dist), dist.max())
+    assert np.max(np.abs(vw)) < 0.2
+    print(f"\nconfigs[4] share of one GPU: {B} plans in {t_plan * 1e3:.1f} ms ({B / t_plan:.0f} plans/s incl. results), "
+          f"100 closed-loop ticks of {B} robots in {t_100 * 1e3:.1f} ms ({B * 100 / t_100:.3g} robot-ticks/s)")

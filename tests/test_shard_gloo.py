@@ -27,3 +27,4 @@ def test_two_rank_gather_matches_single_process():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_OK" in r.stdout
+    assert "BENCH_PASS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]   # bench.py's timed passes under gloo
