@@ -371,6 +371,9 @@ struct RicArgs {
     int limits;          // 1: torque limits inside the sweep (control-limited DDP); 0: only the applied inputs are clipped
     long long* stamps;   // optional [32] diagnostic
     const float* vec;    // [B][N][160] right-hand sides written by the stage kernel
+    int cones = 0;       // 1: contact constraints on the 12 foot-force inputs inside the sweep (alore_wb.h)
+    float mu = 0.f;      // friction coefficient of the pyramid
+    const unsigned char* stance = nullptr; // [B][N][4] 1 = foot in contact at that stage; null = every foot, every stage
 };
 
 // 44.2 KB: three workgroups per CU (the register budget of the kernel asks for no more).  P A, Qxx, the gains K0 / R / K
@@ -740,6 +743,19 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
                             const float lo = -eff - ucur, hi = eff - ucur;
                             if (kf < lo - 1e-4f * eff) { m = 1.f; clampv[i] = lo; }
                             else if (kf > hi + 1e-4f * eff) { m = 1.f; clampv[i] = hi; }
+                        } else if (g.cones && i >= b2z1::NJ && i < NU) {
+                            // contact constraints of the foot-force inputs (world frame, flat ground), projected like the
+                            // torque boxes: a foot in the air carries no force; a stance foot pushes (fz >= 0) inside the
+                            // friction pyramid |fx|, |fy| <= mu fz, with fz the projected normal force of this stage
+                            const int foot = (i - b2z1::NJ) / 3, ax = (i - b2z1::NJ) % 3, iz = b2z1::NJ + 3 * foot + 2;
+                            const bool st = g.stance ? g.stance[((size_t)b * N + k) * 4 + foot] != 0 : true;
+                            const float kf = S.kff[i], ucur = S.dxn[i];
+                            const float fz = st ? fmaxf(S.dxn[iz] + S.kff[iz], 0.f) : 0.f;
+                            const float bnd = (ax == 2) ? 3.0e38f : g.mu * fz;
+                            const float lo = ((ax == 2 || !st) ? 0.f : -bnd) - ucur, hi = (st ? bnd : 0.f) - ucur;
+                            const float tol = 1e-4f * fmaxf(1.f, g.mu * fz);
+                            if (kf < lo - tol) { m = 1.f; clampv[i] = lo; }
+                            else if (kf > hi + tol) { m = 1.f; clampv[i] = hi; }
                         }
                         clampm[i] = m;
                     }
@@ -750,11 +766,11 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             if (round == 1) break;
             // "any input clamped?" without __syncthreads_or (its LDS temporary pushes the block past the size of which
             // three fit a CU): every wavefront ballots the 18 flags itself
-            if (!g.limits || !__any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f)) break;
+            if ((!g.limits && !g.cones) || !__any(((tid & 63) < NU) && clampm[tid & 63] != 0.f)) break;
             // masked system, in place: qu first (it needs the unmasked rows of Quu), then Quu
             if (tid < 32) {
                 float acc = S.qu[tid];
-                for (int j = 0; j < b2z1::NJ; ++j) acc += clampm[j] != 0.f ? S.Quu[tid * LDU + j] * clampv[j] : 0.f;
+                for (int j = 0; j < NU; ++j) acc += clampm[j] != 0.f ? S.Quu[tid * LDU + j] * clampv[j] : 0.f;
                 S.duk[tid] = clampm[tid] != 0.f ? -clampv[tid] : acc;
             }
             __syncthreads();
@@ -765,7 +781,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
             }
             __syncthreads();
         }
-        const bool any_clamp = __any(((tid & 63) < b2z1::NJ) && clampm[tid & 63] != 0.f);
+        const bool any_clamp = __any(((tid & 63) < NU) && clampm[tid & 63] != 0.f);
         if (k > 0) RIC_DEPOSIT_B() // S.B and the stage's vectors are dead; read again after the barrier below
         // ---- K, kff -> HBM (forward sweep); P <- Q + Qxx + Qux' K: the 6 upper-triangular tiles, each on the wavefront that
         //      holds its Qxx tile AND its column block of K in registers (neither goes through LDS), mirrored on store;
@@ -902,10 +918,22 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         double* uw = g.u + (size_t)b * N * NU;
         for (int i = tid; i < (N + 1) * NX; i += RIC_THREADS) xw[i] += dxb[i];
         for (int i = tid; i < N * NU; i += RIC_THREADS) {
-            double val = uw[i] + dub[i];
             const int j = i % NU;
+            if (g.cones && j >= b2z1::NJ) continue; // the foot forces: below, one thread per (stage, foot)
+            double val = uw[i] + dub[i];
             if (j < b2z1::NJ) { const double lim = b2z1::EFFORT[j]; val = val > lim ? lim : (val < -lim ? -lim : val); }
             uw[i] = val;
+        }
+        if (g.cones) { // the applied forces satisfy the contact constraints exactly
+            for (int it = tid; it < N * 4; it += RIC_THREADS) {
+                const int kk = it >> 2, foot = it & 3, i0 = kk * NU + b2z1::NJ + 3 * foot;
+                const bool st = g.stance ? g.stance[((size_t)b * N + kk) * 4 + foot] != 0 : true;
+                const double fzr = uw[i0 + 2] + dub[i0 + 2], fz = st ? (fzr > 0.0 ? fzr : 0.0) : 0.0, lim = (double)g.mu * fz;
+                double fx = uw[i0] + dub[i0], fy = uw[i0 + 1] + dub[i0 + 1];
+                fx = fx > lim ? lim : (fx < -lim ? -lim : fx);
+                fy = fy > lim ? lim : (fy < -lim ? -lim : fy);
+                uw[i0] = fx; uw[i0 + 1] = fy; uw[i0 + 2] = fz;
+            }
         }
     }
 }
@@ -949,6 +977,9 @@ struct alore_wb_solver {
     int* d_status = nullptr;
     long long* d_stamps = nullptr; // [64] when ALORE_WB_STAMPS=1
     int limits = 1;                // alore_wb_set_torque_limits
+    int cones = 0;                 // alore_wb_set_contact_constraints
+    float mu = 0.7f;
+    unsigned char* d_stance = nullptr; // [max_problems][N][4], null = all stance
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_lin = -1.f, ms_ric = -1.f;
     bool timed = false;
@@ -1056,7 +1087,7 @@ int alore_wb_destroy(alore_wb_handle h)
             std::fprintf(stderr, "\n");
         }
     }
-    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec};
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -1139,6 +1170,32 @@ int alore_wb_set_torque_limits(alore_wb_handle h, int enable)
 {
     if (!h) return ALORE_WB_E_INVALID;
     h->limits = enable ? 1 : 0;
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_contact_constraints(alore_wb_handle h, int enable, double mu)
+{
+    if (!h || (enable && !(mu > 0.0))) return fail(h, ALORE_WB_E_INVALID, "set_contact_constraints: bad argument");
+    h->cones = enable ? 1 : 0;
+    if (enable) h->mu = (float)mu;
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_contact_schedule(alore_wb_handle h, int B, const unsigned char* stance)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems) return fail(h, ALORE_WB_E_INVALID, "set_contact_schedule: bad argument");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    WB_TRY(h, hipDeviceSynchronize());
+    if (!stance) { // back to "every foot in contact at every stage"
+        if (h->d_stance) { (void)hipFree(h->d_stance); h->d_stance = nullptr; }
+        return ALORE_WB_OK;
+    }
+    const size_t n = (size_t)h->cfg.max_problems * h->cfg.horizon * 4;
+    if (!h->d_stance) {
+        WB_TRY(h, hipMalloc((void**)&h->d_stance, n));
+        WB_TRY(h, hipMemset(h->d_stance, 1, n));
+    }
+    WB_TRY(h, hipMemcpy(h->d_stance, stance, (size_t)B * h->cfg.horizon * 4, hipMemcpyHostToDevice));
     return ALORE_WB_OK;
 }
 
@@ -1242,7 +1299,8 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
         wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps, h->d_xref, h->d_uref, h->d_vec};
         wb::stage_kernel<<<(unsigned)n, 64, 0, s>>>(g);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
-        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec};
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec,
+                       h->cones, h->mu, h->d_stance};
         wb::riccati_kernel<<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
     }

@@ -36,6 +36,8 @@ def _bind(L):
         "alore_wb_aba": (C.c_int, [H, C.c_int, DP, DP, DP, DP]),
         "alore_wb_set_weights": (C.c_int, [H, DP, DP, DP]),
         "alore_wb_set_torque_limits": (C.c_int, [H, C.c_int]),
+        "alore_wb_set_contact_constraints": (C.c_int, [H, C.c_int, C.c_double]),
+        "alore_wb_set_contact_schedule": (C.c_int, [H, C.c_int, C.c_void_p]),
         "alore_wb_set_problem": (C.c_int, [H, C.c_int, DP, DP, DP]),
         "alore_wb_set_x0": (C.c_int, [H, C.c_int, DP]),
         "alore_wb_shift_iterate": (C.c_int, [H, C.c_int, C.c_void_p]),
@@ -127,6 +129,19 @@ class BatchedWholeBody:
 
     def set_torque_limits(self, enable: bool):
         self._check(self.L.alore_wb_set_torque_limits(self.h, 1 if enable else 0))
+
+    def set_contact_constraints(self, enable: bool, mu: float = 0.7):
+        """friction pyramid + unilateral normal force of the stance feet, zero force of the swing feet, inside the sweep"""
+        self._check(self.L.alore_wb_set_contact_constraints(self.h, 1 if enable else 0, float(mu)))
+
+    def set_contact_schedule(self, stance):
+        """stance [B, N, 4] (truthy = foot in contact at that stage), or None for every foot at every stage"""
+        if stance is None:
+            self._check(self.L.alore_wb_set_contact_schedule(self.h, self.B, None))
+            return
+        s = np.ascontiguousarray(np.asarray(stance) != 0, dtype=np.uint8)
+        assert s.shape[1:] == (self.N, 4) and s.shape[0] <= self.B
+        self._check(self.L.alore_wb_set_contact_schedule(self.h, s.shape[0], s.ctypes.data_as(C.c_void_p)))
 
     def set_problem(self, x0, xref, uref):
         x0, xref, uref = _f64(x0, (-1, NX)), _f64(xref, (-1, self.N + 1, NX)), _f64(uref, (-1, self.N, NU))

@@ -93,6 +93,20 @@ int alore_wb_get_iterate(alore_wb_handle h, int B, double *x, double *u);
 /* linearisation about the current iterate, copied out for inspection: A [B][N][48][48], Bm [B][N][48][30],
  * next [B][N][48] = f(x_k, u_k); any may be NULL */
 int alore_wb_linearize(alore_wb_handle h, int B, double *A, double *Bm, double *next);
+/* Contact constraints of the 12 foot-force inputs (world frame, flat ground), the "constraint Jacobians" of this class:
+ *   - a foot that is not in contact at a stage carries no force there (f = 0): alore_wb_set_contact_schedule,
+ *     stance [B][N][4] bytes (1 = in contact), HOST pointer, NULL = every foot at every stage (the default); the
+ *     schedule belongs to the horizon as set and is not moved by alore_wb_shift_iterate;
+ *   - a stance foot can only push, inside the linearised friction cone (pyramid): fz >= 0, |fx| <= mu fz, |fy| <= mu fz.
+ * They are handled INSIDE the Riccati sweep exactly like the torque boxes (control-limited DDP, one projection per
+ * stage): the unconstrained feed-forward step of the stage is computed, the force components that leave their bounds
+ * are clamped -- the tangential bounds from the projected normal force of the same stage --, the free inputs are
+ * re-solved against the clamped ones, the gain rows of clamped inputs are zero; the applied forces satisfy the
+ * constraints exactly.  Off by default (enable = 0: forces are free inputs, as in round 2).  Not modelled: the
+ * acceleration-level consistency J_c qdd + Jdot_c qd = 0 of the stance feet as equality rows (the feet are kept still by
+ * the posture cost only). */
+int alore_wb_set_contact_constraints(alore_wb_handle h, int enable, double mu);
+int alore_wb_set_contact_schedule(alore_wb_handle h, int B, const unsigned char *stance);
 /* n_iter real-time iterations (linearise + Riccati + step) for B problems; asynchronous on `stream`.
  * Stream contract of this header: only alore_wb_rti and alore_wb_shift_iterate enqueue on the caller's stream (which
  * may be a non-blocking one).  Every entry point that moves data between host and device (set_problem, set_x0,

@@ -303,12 +303,42 @@ def solve_lq(A, B, d, Q, R, QN, gx, gu, gN, dx0):
     return dx, du
 
 
-def solve_lq_clamped(A, B, d, Q, R, QN, gx, gu, gN, dx0, u_cur, effort, tol=1e-4):
+def contact_bounds(u_k, kff, mu, stance_k, tol=1e-4):
+    """Bounds on the STEP of the 12 foot-force inputs of one stage under the contact constraints of include/alore_wb.h:
+    swing foot f = 0; stance foot fz >= 0, |fx|, |fy| <= mu fz with fz the projected normal force of this stage.
+    Returns (lo, hi, tolerance), each [12]."""
+    lo, hi, tl = np.zeros(12), np.zeros(12), np.zeros(12)
+    for foot in range(4):
+        iz = 18 + 3 * foot + 2
+        st = bool(stance_k[foot])
+        fz = max(u_k[iz] + kff[iz], 0.0) if st else 0.0
+        for ax in range(3):
+            i = 18 + 3 * foot + ax
+            bnd = np.inf if ax == 2 else mu * fz
+            lo[i - 18] = (0.0 if (ax == 2 or not st) else -bnd) - u_k[i]
+            hi[i - 18] = (bnd if st else 0.0) - u_k[i]
+            tl[i - 18] = tol * max(1.0, mu * fz)
+    return lo, hi, tl
+
+
+def apply_contact_constraints(u, mu, stance):
+    """the applied inputs of one stage inside the contact constraints (what the kernel writes back)"""
+    u = u.copy()
+    for foot in range(4):
+        i0 = 18 + 3 * foot
+        fz = max(u[i0 + 2], 0.0) if stance[foot] else 0.0
+        u[i0] = np.clip(u[i0], -mu * fz, mu * fz); u[i0 + 1] = np.clip(u[i0 + 1], -mu * fz, mu * fz); u[i0 + 2] = fz
+    return u
+
+
+def solve_lq_clamped(A, B, d, Q, R, QN, gx, gu, gN, dx0, u_cur, effort, tol=1e-4, mu=None, stance=None):
     """The stage-wise (Riccati) solution of the same LQ problem with the kernels' treatment of the torque limits
     (control-limited DDP, one projection per stage): the unconstrained feed-forward step of a stage is computed first;
     inputs i < 18 whose step leaves [-effort_i - u_i, effort_i - u_i] are clamped to the limit, the others re-solved
-    against them, the gain rows of the clamped inputs are zero.  Returns dx, du and the number of clamped inputs per stage.
-    float64; with no clamp anywhere it equals solve_lq."""
+    against them, the gain rows of the clamped inputs are zero.  With `mu` the 12 foot-force inputs are treated the same
+    way against the contact constraints (contact_bounds; `stance` [N][4], default all in contact).  `effort` None: no
+    torque limits.  Returns dx, du and the number of clamped inputs per stage.  float64; with no clamp anywhere it
+    equals solve_lq."""
     N = len(A); nx, nu = B[0].shape
     P, p = QN.copy(), gN.copy()
     Ks, ks, nclamp = [None] * N, [None] * N, [0] * N
@@ -317,11 +347,17 @@ def solve_lq_clamped(A, B, d, Q, R, QN, gx, gu, gN, dx0, u_cur, effort, tol=1e-4
         Qxx, Qux, Quu = Q + A[k].T @ PA, B[k].T @ PA, R + B[k].T @ PB
         qx, qu = gx[k] + A[k].T @ s, gu[k] + B[k].T @ s
         kff = -np.linalg.solve(Quu, qu)
-        lo, hi = -effort - u_cur[k][:18], effort - u_cur[k][:18]
         cl = np.zeros(nu, bool); kc = np.zeros(nu)
-        low, high = kff[:18] < lo - tol * effort, kff[:18] > hi + tol * effort
-        cl[:18] = low | high
-        kc[:18] = np.where(low, lo, np.where(high, hi, 0.0))
+        if effort is not None:
+            lo, hi = -effort - u_cur[k][:18], effort - u_cur[k][:18]
+            low, high = kff[:18] < lo - tol * effort, kff[:18] > hi + tol * effort
+            cl[:18] = low | high
+            kc[:18] = np.where(low, lo, np.where(high, hi, 0.0))
+        if mu is not None:
+            lo, hi, tl = contact_bounds(u_cur[k], kff, mu, stance[k] if stance is not None else (1, 1, 1, 1), tol)
+            low, high = kff[18:30] < lo - tl, kff[18:30] > hi + tl
+            cl[18:30] = low | high
+            kc[18:30] = np.where(low, lo, np.where(high, hi, 0.0))
         if cl.any():
             f = ~cl
             kff = kc.copy()

@@ -175,3 +175,34 @@ def test_clamped_riccati_equals_the_kkt_solve_without_clamps_and_respects_limits
     assert sum(nc3) > 0
     # with dx0 = 0 the feed-forward steps are the steps of stage 0: inside the limits there
     assert np.all(np.abs(du3[0, :18]) <= lim + 1e-9)
+
+
+def test_contact_constrained_sweep_restatement():
+    """solve_lq_clamped with the contact constraints on a small random LQ problem: without any active bound it is the
+    plain LQ solution; with a slippery floor and a swing foot the feed-forward forces of every stage satisfy the bounds
+    it states (contact_bounds), and the applied inputs are inside the pyramid."""
+    from oracle.wb_oracle import apply_contact_constraints, contact_bounds, solve_lq, solve_lq_clamped
+    rng = np.random.default_rng(3)
+    N, nx, nu = 6, 8, 30
+    A = [np.eye(nx) + 0.05 * rng.normal(size=(nx, nx)) for _ in range(N)]
+    Bm = [0.1 * rng.normal(size=(nx, nu)) for _ in range(N)]
+    d = [0.01 * rng.normal(size=nx) for _ in range(N)]
+    Q, R, QN = np.eye(nx), 0.1 * np.eye(nu), 2 * np.eye(nx)
+    gx = [rng.normal(size=nx) for _ in range(N)]; gu = [0.01 * rng.normal(size=nu) for _ in range(N)]
+    gN = rng.normal(size=nx); dx0 = 0.1 * rng.normal(size=nx)
+    u = [np.concatenate([np.zeros(18), np.tile([0.0, 0.0, 100.0], 4)]) for _ in range(N)]
+    dx, du = solve_lq(A, Bm, d, Q, R, QN, gx, gu, gN, dx0)
+    cx, cu, nc = solve_lq_clamped(A, Bm, d, Q, R, QN, gx, gu, gN, dx0, u, None, mu=0.9)
+    assert sum(nc) == 0 and np.allclose(cx, dx, atol=1e-9) and np.allclose(cu, du, atol=1e-9)
+    gu2 = [g.copy() for g in gu]
+    for g in gu2:
+        g[18] = 30.0; g[21 + 1] = -40.0                     # pushes fx of foot 0 and fy of foot 1 far out
+    stance = np.ones((N, 4), int); stance[3:, 2] = 0
+    cx, cu, nc = solve_lq_clamped(A, Bm, d, Q, R, QN, gx, gu2, gN, dx0, u, None, mu=0.3, stance=stance)
+    assert sum(nc) > 0
+    for k in range(N):
+        unew = apply_contact_constraints(u[k] + cu[k], 0.3, stance[k])
+        f = unew[18:].reshape(4, 3)
+        assert np.all(f[:, 2] >= 0) and np.all(np.abs(f[:, :2]) <= 0.3 * f[:, 2:3] + 1e-12)
+        if k >= 3:
+            assert np.all(f[2] == 0)
