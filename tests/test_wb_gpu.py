@@ -376,3 +376,42 @@ def test_a_swing_foot_carries_no_force(model):
     eng.rti(1)
     _, u2 = eng.get_iterate()
     assert np.all(u2[:, 6:, 18 + 3 + 2] > 50.0)
+
+
+def test_configs2_full_size_batch():
+    """BASELINE configs[2] at its full size in a test: B = 4096 problems, N = 20, one real-time iteration with torque
+    limits and contact constraints on.  Size-independent checks: every problem reports a finite, applied step; sampled
+    problems have the same bits as the same problems solved in a batch of their own (one workgroup per problem, fixed
+    reduction order); the applied inputs respect the torque limits and the friction pyramids; a second iteration
+    contracts the step."""
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody, model_info
+    from tests.wb_cases import make_problems_fast
+    B, N, dt, mu = 4096, 20, 0.01, 0.6
+    x0, xref, uref, xi, ui = make_problems_fast(B, N, seed=3)
+    Q, R, QN = weights()
+    eng = BatchedWholeBody(B, N, dt)
+    eng.set_weights(Q, R, QN)
+    eng.set_contact_constraints(True, mu)
+    eng.set_problem(x0, xref, uref)
+    eng.set_iterate(xi, ui)
+    eng.rti(1)
+    assert np.all(eng.status() == 0)
+    dx, du = eng.last_step()
+    x1, u1 = eng.get_iterate()
+    assert np.isfinite(dx).all() and np.isfinite(du).all() and np.isfinite(x1).all() and np.isfinite(u1).all()
+    effort = model_info()["effort"]
+    assert np.all(np.abs(u1[:, :, :18]) <= effort + 1e-9)
+    assert _inside_contact_constraints(u1, mu)
+    idx = [0, 1, 63, 64, 2048, 4095]
+    small = BatchedWholeBody(len(idx), N, dt)
+    small.set_weights(Q, R, QN)
+    small.set_contact_constraints(True, mu)
+    small.set_problem(x0[idx], xref[idx], uref[idx])
+    small.set_iterate(xi[idx], ui[idx])
+    small.rti(1)
+    sdx, sdu = small.last_step()
+    assert np.array_equal(sdx, dx[idx]) and np.array_equal(sdu, du[idx])
+    eng.rti(1)
+    dx2, _ = eng.last_step()
+    assert np.all(eng.status() == 0)
+    assert np.median(np.abs(dx2).max(axis=(1, 2))) < 0.5 * np.median(np.abs(dx).max(axis=(1, 2)))
