@@ -197,25 +197,51 @@ def ltv_cpu_baseline(lt_cfg, st0, xr, dr, n_relin: int, robots: int = 3) -> dict
             "ms_per_tick": per * 1e3, "reference_budget_ms_per_tick": 9.7}
 
 
+def _wb_lin_stage(args):
+    from oracle.wb_oracle import Model, linearize
+    x, u = args
+    return linearize(Model(), x, u, 0.01)
+
+
 def wb_cpu_baseline(N, xi, ui, x0, xref, uref):
-    """The float64 NumPy oracle (kind "port": there is no reference implementation of this class) on ONE problem: the
-    linearisation of 4 of its N stages (scaled to N) and the dense KKT solve of its LQ problem, one thread."""
-    from oracle.wb_oracle import Model, linearize, solve_lq
+    """The float64 NumPy oracle (kind "port": there is no reference implementation of this class) on ONE whole problem:
+    the linearisation of all N stages (central differences of the spatial-algebra step), the stages spread over the
+    usable host cores, then the dense KKT solve of its LQ problem on one core."""
+    import multiprocessing as mp
+    from oracle.wb_oracle import solve_lq
     from wb_cases import weights as wb_weights
-    m = Model()
     Q, R, QN = wb_weights()
+    cores = min(usable_cores(), N)
     t0 = time.perf_counter()
-    AB = [linearize(m, xi[0, k], ui[0, k], 0.01) for k in range(4)]
-    t_lin = (time.perf_counter() - t0) * N / 4
-    A = [AB[k % 4][0] for k in range(N)]; Bm = [AB[k % 4][1] for k in range(N)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        AB = pool.map(_wb_lin_stage, [(xi[0, k], ui[0, k]) for k in range(N)])
+    t_lin = time.perf_counter() - t0
+    A = [ab[0] for ab in AB]; Bm = [ab[1] for ab in AB]
     d = [np.zeros(48) for _ in range(N)]
     gx = [Q * (xi[0, k] - xref[0, k]) for k in range(N)]; gu = [R * (ui[0, k] - uref[0, k]) for k in range(N)]
     t0 = time.perf_counter()
     solve_lq(A, Bm, d, np.diag(Q), np.diag(R), np.diag(QN), gx, gu, QN * (xi[0, N] - xref[0, N]), x0[0] - xi[0, 0])
     t_qp = time.perf_counter() - t0
-    return {"value": 1.0 / (t_lin + t_qp), "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": f"one problem: oracle/wb_oracle.py linearize (central differences of the spatial-algebra step) on 4 of {N} "
-                      f"stages, scaled ({t_lin:.1f} s), + dense KKT solve ({t_qp:.2f} s); NumPy float64, one thread"}
+    return {"value": 1.0 / (t_lin + t_qp), "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"one whole problem: oracle/wb_oracle.py linearize on all {N} stages over {cores} processes ({t_lin:.1f} s) + dense "
+                      f"KKT solve on one core ({t_qp:.2f} s); NumPy float64"}
+
+
+def stage_roofline(n_items: int, ms: float) -> dict:
+    """wb::stage_kernel is bound by float64 vector issue: one wavefront per (problem, stage) executes a fixed number of
+    vector instructions (SQ_INSTS_VALU per wavefront from the committed counter pass, profiles/wb_stage_valu.json), a
+    double-precision wave-instruction occupies its SIMD for 4 cycles (FP64 vector peak 78.6 TFLOP/s = half the FP32
+    rate): peak = 1024 SIMDs x 2.4 GHz / 4."""
+    per_wave, src = 12000.0, None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "wb_stage_valu.json")))
+        per_wave, src = float(rec["valu_instructions_per_wavefront"]), rec.get("source")
+    except Exception:
+        pass
+    peak = 1024 * 2.4e9 / 4 / 1e9
+    ach = n_items * per_wave / (ms * 1e-3) / 1e9
+    return {"bound": "valu_f64", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+            "kernel": "wb::stage_kernel", "kernel_ms_avg": ms, "valu_instructions_per_wavefront": per_wave, "counter_source": src}
 
 
 def whole_body_main(a, rank, world, local_rank, torch, dist):
@@ -275,6 +301,7 @@ def whole_body_main(a, rank, world, local_rank, torch, dist):
             "roofline": {"bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
                          "traffic": None, "kernel": "wb::riccati_kernel", "kernel_ms_avg": ric,
                          "mfma_instructions_per_problem_stage": 552},
+            "roofline_stage_kernel": stage_roofline(B * N, lin),
             "kernels_ms": {"wb::stage_kernel": lin, "wb::riccati_kernel": ric},
             "finite": bool(np.isfinite(dx).all() and np.isfinite(du).all()),
             "cpu_baseline": None if a.no_cpu_baseline else wb_cpu_baseline(N, xi, ui, x0, xref, uref)}))

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-3 GPU pass (through gpurun): the bench lines, rocprof kernel stats of the same commands, HBM and SQ counters of
+# the RTI kernel that ships, whole-body / LTV / back_end kernel stats.  Outputs in gpurun_out/<tag>/; condensed into
+# profiles/ by tools/summarize_r03.py.   usage: tools/profile_r03.sh <tag>
+set -u
+TAG=${1:-r03_x}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_driver_flags.json 2>> $OUT/bench.err
+python bench.py --workload whole_body > $OUT/bench_whole_body.json 2> $OUT/bench_wb.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python3 bench.py --no-cpu-baseline --no-extras --no-graph --steps 20 --warmup 5 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python3 bench.py --no-cpu-baseline --no-extras --no-graph --steps 20 --warmup 5 > /dev/null 2> $OUT/pmc_write.err
+tools/profile_sq.sh $TAG 4096 > /dev/null 2>&1
+tools/profile_sq.sh $TAG 32768 > /dev/null 2>&1
+python3 tools/wb_profile.py > $OUT/wb_run.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/wb_trace -o wb -- python3 tools/wb_profile.py > /dev/null 2> $OUT/wb_trace.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/wb_pmc -o wbpmc -- python3 tools/wb_profile.py > /dev/null 2> $OUT/wb_pmc.err
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES -d $OUT/wb_pmc2 -o wbpmc2 -- python3 tools/wb_profile.py > /dev/null 2> $OUT/wb_pmc2.err
+rocprofv3 --kernel-trace --stats -d $OUT/ltv_trace -o ltv -- python3 tools/ltv_profile.py > $OUT/ltv_run.txt 2> $OUT/ltv_trace.err
+rocprofv3 --kernel-trace --stats -d $OUT/be_trace -o be -- python3 tools/be_profile.py > $OUT/be_run.txt 2> $OUT/be_trace.err
+rocprofv3 --kernel-trace --stats -d $OUT/extras_trace -o extras -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 5 > /dev/null 2> $OUT/extras_trace.err
+ls $OUT
+tail -c 400 $OUT/bench.json; echo; cat $OUT/wb_run.txt | tail -3; cat $OUT/ltv_run.txt | tail -2

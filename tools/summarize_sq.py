@@ -2,7 +2,7 @@
 """Condense the rocpd databases of tools/profile_sq.sh into a text table. Usage: summarize_sq.py gpurun_out/<tag> > out"""
 import sqlite3, sys, os
 root = sys.argv[1]
-print("# SQ counters of nmpc::rti_kernel, per launch (mean of 25 eager launches), rocprofv3 --pmc in two passes (tools/profile_sq.sh).")
+print("# SQ counters of the RTI kernel (nmpc::rti_block_kernel since round 3), per launch (mean of 25 eager launches), rocprofv3 --pmc in two passes (tools/profile_sq.sh).")
 print("# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x4 = cycles).\n")
 for B in (4096, 32768):
     vals = {}
@@ -11,14 +11,15 @@ for B in (4096, 32768):
         if not os.path.exists(db):
             continue
         c = sqlite3.connect(db)
-        for name, avg in c.execute("select counter_name, avg(value) from counters_collection where kernel_name like '%rti_kernel%' group by counter_name"):
+        for name, avg in c.execute("select counter_name, avg(value) from counters_collection where kernel_name like '%rti_%kernel%' group by counter_name"):
             vals[name] = avg
     if not vals:
         continue
     w = vals["SQ_WAVES"]
-    print(f"B = {B} (N = 20, L = 32): {int(w)} wavefronts")
+    ppw = B / w
+    print(f"B = {B} (N = 20): {int(w)} wavefronts, {ppw:.0f} problems per wavefront")
     for k in sorted(vals):
         print(f"  {k:22s} {vals[k]:16.1f}   per wavefront {vals[k] / w:10.1f}")
-    print(f"  -> VALU instructions per wavefront {vals['SQ_INSTS_VALU'] / w:.0f} ({vals['SQ_INSTS_VALU'] / w / 2:.0f} per problem), "
+    print(f"  -> VALU instructions per wavefront {vals['SQ_INSTS_VALU'] / w:.0f} ({vals['SQ_INSTS_VALU'] / w / ppw:.0f} per problem), "
           f"wavefront lifetime {4 * vals['SQ_WAVE_CYCLES'] / w:.0f} cycles: issuing {100 * vals['SQ_ACTIVE_INST_ANY'] / vals['SQ_WAVE_CYCLES']:.0f} %, "
           f"parked at s_waitcnt/barrier {100 * vals['SQ_WAIT_ANY'] / vals['SQ_WAVE_CYCLES']:.0f} %, issue-stalled {100 * vals['SQ_WAIT_INST_ANY'] / vals['SQ_WAVE_CYCLES']:.0f} %\n")
