@@ -22,5 +22,7 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIV
 rocprofv3 --kernel-trace --stats -d $OUT/ltv_trace -o ltv -- python3 tools/ltv_profile.py > $OUT/ltv_run.txt 2> $OUT/ltv_trace.err
 rocprofv3 --kernel-trace --stats -d $OUT/be_trace -o be -- python3 tools/be_profile.py > $OUT/be_run.txt 2> $OUT/be_trace.err
 rocprofv3 --kernel-trace --stats -d $OUT/extras_trace -o extras -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 5 > /dev/null 2> $OUT/extras_trace.err
-ls $OUT
-tail -c 400 $OUT/bench.json; echo; cat $OUT/wb_run.txt | tail -3; cat $OUT/ltv_run.txt | tail -2
+python3 tools/summarize_r03.py $OUT $TAG
+# the rocpd databases are large: only the summaries travel back
+find $OUT -mindepth 1 -maxdepth 1 ! -name summary -exec rm -rf {} +
+tail -c 300 $OUT/summary/${TAG}_bench.json; echo

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condense the outputs of tools/profile_r03.sh (gpurun_out/<tag>/) into the text / JSON records kept under profiles/.
+Runs on the GPU box right after the passes (the rocpd databases stay there):  summarize_r03.py <out_dir> <tag>"""
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+dst = os.path.join(out, "summary")
+os.makedirs(dst, exist_ok=True)
+
+
+def run(args, to):
+    r = subprocess.run([sys.executable] + args, capture_output=True, text=True)
+    open(os.path.join(dst, to), "w").write(r.stdout + (("\n# stderr:\n" + r.stderr[-2000:]) if r.returncode else ""))
+
+
+for name, d in (("kernel_stats", "trace"), ("wb_kernel_stats", "wb_trace"), ("ltv_kernel_stats", "ltv_trace"),
+                ("backend_kernel_stats", "be_trace"), ("extras_kernel_stats", "extras_trace")):
+    if os.path.isdir(os.path.join(out, d)):
+        subprocess.run([sys.executable, os.path.join(here, "summarize_prof.py"), os.path.join(out, d), os.path.join(dst, f"{tag}_{name}.txt")])
+run([os.path.join(here, "summarize_sq.py"), out], f"{tag}_sq_counters.txt")
+src = f"profiles/{tag}_* (tools/profile_r03.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, eager launches)"
+run([os.path.join(here, "summarize_pmc.py"), os.path.join(out, "pmc_fetch"), os.path.join(out, "pmc_write"), "B4096_N20",
+     str(4192 * 4096), src], "hbm_traffic.json")
+# whole-body counters: per kernel, per launch
+lines = ["# whole-body kernels, rocprofv3 --pmc (two passes), mean per launch over the launches of tools/wb_profile.py"]
+stage_valu = None
+for d in ("wb_pmc", "wb_pmc2"):
+    for db in glob.glob(os.path.join(out, d, "**", "*_results.db"), recursive=True):
+        c = sqlite3.connect(db)
+        for kname, cname, avg, n in c.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                                              "where kernel_name like '%wb::%' group by kernel_name, counter_name"):
+            short = kname.split("(")[0].split("::")[-1]
+            lines.append(f"{short:18s} {cname:32s} {avg:18.1f}   ({n} launches)")
+            if "stage_kernel" in kname and cname == "SQ_INSTS_VALU":
+                stage_valu = avg
+            if "stage_kernel" in kname and cname == "SQ_WAVES":
+                stage_waves = avg
+open(os.path.join(dst, f"{tag}_wb_counters.txt"), "w").write("\n".join(lines) + "\n")
+if stage_valu:
+    try:
+        per = stage_valu / stage_waves
+    except NameError:
+        per = stage_valu / (4096 * 20)
+    json.dump({"valu_instructions_per_wavefront": per,
+               "source": f"profiles/{tag}_wb_counters.txt (SQ_INSTS_VALU / SQ_WAVES of wb::stage_kernel, B = 4096, N = 20)"},
+              open(os.path.join(dst, "wb_stage_valu.json"), "w"), indent=1)
+for f in ("bench.json", "bench_driver_flags.json", "bench_whole_body.json", "bench_under_rocprof.json", "wb_run.txt", "ltv_run.txt", "be_run.txt"):
+    p = os.path.join(out, f)
+    if os.path.exists(p):
+        open(os.path.join(dst, f"{tag}_{f}"), "w").write(open(p).read())
+print("\n".join(sorted(os.listdir(dst))))
