@@ -463,6 +463,16 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     return ALORE_NMPC_OK;
 }
 
+int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B, int n_sqp, void* stream)
+{
+    if (!h || !batches || count < 1) return fail(h, ALORE_NMPC_E_INVALID, "rti_many: bad argument");
+    for (int i = 0; i < count; ++i) {
+        const int rc = alore_nmpc_rti(h, batches + i, B, n_sqp, stream);
+        if (rc != ALORE_NMPC_OK) return rc;
+    }
+    return ALORE_NMPC_OK;
+}
+
 int alore_nmpc_linearize(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, const alore_nmpc_lin_out* out,
                          void* stream)
 {

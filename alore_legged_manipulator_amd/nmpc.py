@@ -117,6 +117,13 @@ class BatchedNmpc:
         """n_sqp x (acado_preparationStep + acado_feedbackStep) for the whole batch, one launch."""
         self._check(self.lib.alore_nmpc_rti(self.h, C.byref(self._batches[slot]), self.B, int(n_sqp), self._stream()))
 
+    def rti_range(self, first: int, count: int, n_sqp: int = 1) -> None:
+        """one launch per slot first .. first + count - 1, enqueued back to back by ONE call into the library"""
+        if not hasattr(self, "_batch_array"):
+            self._batch_array = (Batch * self.slots)(*self._batches)
+        self._check(self.lib.alore_nmpc_rti_many(self.h, C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch)),
+                                                int(count), self.B, int(n_sqp), self._stream()))
+
     def linearize(self) -> dict:
         torch = self.torch
         d = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.device)

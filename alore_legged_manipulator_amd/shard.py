@@ -127,6 +127,9 @@ def timed_pass(eng, batch, mode: str, K: int, warmup: int, gather_every: int, ga
     ge = max(1, gather_every)
 
     def run_steps(first, count):
+        if not do_gather and count > 0 and hasattr(eng, "rti_range"):
+            eng.rti_range(first, count)  # no collective between the solves: the launches go out from one library call
+            return
         for i in range(first, first + count):
             eng.rti(1, slot=i)
             if do_gather and ((i - first + 1) % ge == 0 or i == first + count - 1):

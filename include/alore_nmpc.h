@@ -141,6 +141,10 @@ int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch 
  * separate calls in the reference, never made by its wrapper) are computed and written
  * when the batch has non-NULL pointers for them, and skipped otherwise. */
 int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int n_sqp, void *stream);
+/* the same for `count` batches of B problems each, one launch per batch enqueued back to back on `stream` from one
+ * call (a host that steps many independent batches -- the slots of a Monte-Carlo sweep -- pays the call overhead of
+ * its language binding once, not per batch) */
+int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch *batches, int count, int B, int n_sqp, void *stream);
 
 /* ACADO split semantics.  The reference prepares (linearises, evaluates h(x,u)) in
  * acado_preparationStep() and solves/expands in acado_feedbackStep(); a caller may change
