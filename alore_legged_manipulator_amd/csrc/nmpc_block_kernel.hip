@@ -51,13 +51,6 @@ __device__ __forceinline__ int dppk_i(int old, int x)
 {
     return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, 0xF, false);
 }
-// every lane has a source (quad_perm, row_ror, row_newbcast): old = 0 + bound_ctrl lets the compiler fold the move into
-// the consuming VOP2 (v_fmac_f32_dpp / v_mul_f32_dpp)
-template <int CTRL>
-__device__ __forceinline__ float dppz(float x)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
 __device__ __forceinline__ float lane_next(float x) { return dppk<0x101>(x, x); } // row_shl:1  lane i <- lane i + 1
 __device__ __forceinline__ float lane_prev(float x) { return dppk<0x111>(x, x); } // row_shr:1  lane i <- lane i - 1
 
@@ -176,12 +169,10 @@ __device__ __forceinline__ void g_store(float* g, const float* l, int total, int
 } // namespace
 
 // LDS floats of one wavefront: W and y of its 64 / L problems, each area padded to whole 256-float DMA pieces
-constexpr int CREC = 68; // floats of a stage record of the cooperative backward sweep (L = 16), see coop_backward
 int block_lds_floats(int N, int L)
 {
     const int G = 64 / L;
-    const int coop = (L == 16) ? G * (N * CREC + (N + 1) * 16) : 0; // stage records + the cost-to-go of every node
-    return ((G * 25 * N + 255) & ~255) + ((G * 5 * N + 255) & ~255) + coop;
+    return ((G * 25 * N + 255) & ~255) + ((G * 5 * N + 255) & ~255);
 }
 
 template <int L, int S, bool DIAG, bool STAMP>
@@ -191,8 +182,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     float* lds = reinterpret_cast<float*>(lds_raw);
     constexpr int G = 64 / L;
     constexpr int NMAX = L * S;
-    constexpr bool MASKED = false;               // (the masked lane-turn form of the sweep: superseded for L = 16 by COOP)
-    constexpr bool COOP = (L == 16);             // backward sweep on the 16 lanes of the group, see coop_backward
+    constexpr bool MASKED = (L == 16 && S == 2); // see backward_sweep
     const int N = p.N;
     const int lane = threadIdx.x;
     const int g = lane / L, j = lane % L;
@@ -215,7 +205,6 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     // LDS map (floats): [W | y] of the wavefront's problems, each area a whole number of 256-float DMA pieces; after
     // the objective the W area is the staging buffer of the outputs
     const int WA = (G * 25 * N + 255) & ~255, oW = 0, oY = WA;
-    const int oC = WA + ((G * 5 * N + 255) & ~255), CPS = N * CREC + (N + 1) * 16; // cooperative sweep: records, then V per node
     const int oX = 0, oU = G * nx, oDL = oU + G * nu;
 
     // ---- phase 0.  W and y (read again for the objective) go HBM -> LDS by DMA, no registers: the wavefront's
@@ -638,191 +627,6 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             return ok;
         };
         // backward sweep of the groups flagged `act`, each from the lane that owns its highest stale stage `from`
-        // ---- cooperative backward sweep (L = 16): one Riccati step on the 16 lanes of the group ------------------------
-        // The cost-to-go in homogeneous form Vh = [[P, p], [p', 0]] (4 x 4, symmetric) has one element per lane: lane
-        // (r, c) = (j >> 2, j & 3) holds Vh[r][c].  With z = (dx, 1), Ah = [[A, d], [0, 1]], Bh = [[B], [0]]:
-        //   T = Vh Ah, U = Vh Bh            quad broadcasts of the lane's own row against per-column coefficients
-        //   Mzz = Qh + Ah' T, G_m[c] = (Bh' T + S)[m][c], G_m[r] = (Ah' U + S')[r][m], Muu = R + Bh' U
-        //                                    rows of T / U arrive by DPP row rotations (row_ror:4j), weighted per row
-        //   the two eliminations (controls 1, 0; free or fixed by arithmetic masks as in rti_kernel's riccati_rows)
-        //   on scalars that every lane fetches with row_newbcast, then Vh <- Mzz - w1 G1 G1' - w0 G0 G0' + affine terms
-        // About 60 vector instructions + 22 LDS reads per stage and lane instead of the 138 of the scalar step that one
-        // lane of the group would run while 15 wait.  Stage data come from per-stage records in LDS that the owning
-        // lanes write once per iteration (coop_write_records); the policy records and the cost-to-go of every node go
-        // back to LDS (restarts, forward sweep).  All lanes run the same code: nothing sits under a partial EXEC mask.
-        const int gr = j >> 2, gc = j & 3;
-        float* crec = lds + oC + ge * CPS;          // records of this group's problem
-        float* cvs = crec + N * CREC;               // Vh of node k at cvs[16 k + 4 r + c]
-        auto coop_write_fix = [&]() {
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int k = j * S + s;
-                if (k < N) {
-                    const bool f0 = (st0[s] == ST_FREE), f1 = (st1[s] == ST_FREE);
-                    *reinterpret_cast<float4*>(crec + k * CREC + 52) =
-                        make_float4(f0 ? 1.0f : 0.0f, f1 ? 1.0f : 0.0f, f0 ? 0.0f : (st0[s] == ST_UPPER ? ub0[s] : lb0[s]),
-                                    f1 ? 0.0f : (st1[s] == ST_UPPER ? ub1[s] : lb1[s]));
-                }
-            }
-        };
-        auto coop_write_records = [&]() {
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int k = j * S + s;
-                if (k < N) { // stores only
-                    float* rc_ = crec + k * CREC;
-                    float4* r4 = reinterpret_cast<float4*>(rc_);
-                    // BH[k][m] (row 3 zero), index 2 k + m
-                    r4[0] = make_float4(B00[s], B01[s], B10[s], B11[s]);
-                    r4[1] = make_float4(B20[s], -B20[s], 0.0f, 0.0f);
-                    // CW[k][c], k = 0..2: c < 2: B[k][c]; c = 2: (a, b, 0)[k]; c = 3: d_k
-                    r4[2] = make_float4(B00[s], B01[s], sa[s], d0[s]);
-                    r4[3] = make_float4(B10[s], B11[s], sb[s], d1[s]);
-                    r4[4] = make_float4(B20[s], -B20[s], 0.0f, d2[s]);
-                    // ZC[j - 1][r]: weights of rot_j(T) in row r of Ah' T: row 2: (b, a, 0), row 3: (d2, d1, d0)
-                    r4[5] = make_float4(0.0f, 0.0f, sb[s], d2[s]);
-                    r4[6] = make_float4(0.0f, 0.0f, sa[s], d1[s]);
-                    r4[7] = make_float4(0.0f, 0.0f, 0.0f, d0[s]);
-                    // Qh, unique entries (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
-                    r4[8] = make_float4(Q00[s], Q01[s], Q02[s], q0[s]);
-                    r4[9] = make_float4(Q11[s], Q12[s], q1[s], Q22[s]);
-                    r4[10] = make_float4(q2[s], 0.0f, 0.0f, 0.0f);
-                    r4[11] = make_float4(R00[s], R01[s], R11[s], 0.0f);
-                    r4[12] = make_float4(r0[s], r1[s], 0.0f, 0.0f);
-                }
-            }
-            if (j == top) { // terminal cost-to-go
-                float* vN = cvs + 16 * N;
-                const float qh[16] = {QN[0], QN[1], QN[2], qN[0], QN[1], QN[3], QN[4], qN[1], QN[2], QN[4], QN[5], qN[2], qN[0], qN[1], qN[2], 0.0f};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) reinterpret_cast<float4*>(vN)[i] = make_float4(qh[4 * i], qh[4 * i + 1], qh[4 * i + 2], qh[4 * i + 3]);
-            }
-        };
-        // role offsets of this lane into a record (floats)
-        const int o_gz0[4] = {2 * ((gr - 0) & 3), 2 * ((gr - 1) & 3), 2 * ((gr - 2) & 3), 2 * ((gr - 3) & 3)};
-        const int o_gzm = gr & 1;                    // Muu rows: m(r) = r & 1
-        const int o_cw = 8 + gc, o_zc = 20 + gr;
-        // Qh index of (r, c): symmetric table above
-        const int qi_lo = min(gr, gc), qi_hi = max(gr, gc);
-        const int o_q = 32 + (qi_lo == 0 ? qi_hi : (qi_lo == 1 ? 3 + qi_hi : (qi_lo == 2 ? 5 + qi_hi : 9)));
-        const float mc3 = (gc == 3) ? 1.0f : 0.0f, mr3 = (gr == 3) ? 1.0f : 0.0f, mlow = (gc < 2) ? 1.0f : 0.0f;
-
-        auto coop_backward = [&](bool act, int khi_) {
-            // every sweeping group starts at the highest stale stage of the wavefront: above its own it recomputes, bit
-            // for bit, what its records already hold (the same inputs)
-            int km = act ? khi_ : -1;
-            km = max(max(__builtin_amdgcn_readlane(km, 0), __builtin_amdgcn_readlane(km, 16)),
-                     max(__builtin_amdgcn_readlane(km, 32), __builtin_amdgcn_readlane(km, 48)));
-            if (km < 0) return;
-            coop_write_fix();
-            wave_sync();
-            __builtin_amdgcn_s_setprio(3);
-            float v = cvs[16 * (km + 1) + j];
-            int fail = 0;
-            struct Coef {
-                float cw0, cw1, cw2, zc1, zc2, zc3, g00, g01, g02, g03, g10, g11, g12, g13, qh;
-                float4 u1, u2, fx;
-            };
-            auto load = [&](Coef& q, int k) {
-                const float* rc_ = crec + k * CREC;
-                q.cw0 = rc_[o_cw]; q.cw1 = rc_[o_cw + 4]; q.cw2 = rc_[o_cw + 8];
-                q.zc1 = rc_[o_zc]; q.zc2 = rc_[o_zc + 4]; q.zc3 = rc_[o_zc + 8];
-                q.g00 = rc_[o_gz0[0]]; q.g01 = rc_[o_gz0[1]]; q.g02 = rc_[o_gz0[2]]; q.g03 = rc_[o_gz0[3]];
-                q.g10 = rc_[o_gz0[0] + 1]; q.g11 = rc_[o_gz0[1] + 1]; q.g12 = rc_[o_gz0[2] + 1]; q.g13 = rc_[o_gz0[3] + 1];
-                q.qh = rc_[o_q];
-                q.u1 = *reinterpret_cast<const float4*>(rc_ + 44); q.u2 = *reinterpret_cast<const float4*>(rc_ + 48);
-                q.fx = *reinterpret_cast<const float4*>(rc_ + 52);
-            };
-            auto step = [&](int k, const Coef& q) {
-                const float R00_ = q.u1.x, R01_ = q.u1.y, R11_ = q.u1.z, r0_ = q.u2.x, r1_ = q.u2.y;
-                const float f0m = q.fx.x, f1m = q.fx.y, v0 = q.fx.z, v1 = q.fx.w, n0m = 1.0f - f0m, n1m = 1.0f - f1m;
-                // T (columns 2, 3; columns 0, 1 of T are those of Vh) and U (columns 0, 1) in one pass
-                float w = (gc < 2) ? 0.0f : v;
-                w = fmaf(dppz<0x00>(v), q.cw0, w);
-                w = fmaf(dppz<0x55>(v), q.cw1, w);
-                w = fmaf(dppz<0xAA>(v), q.cw2, w);
-                const float tt = (gc < 2) ? v : w;
-                float mzz = tt + q.qh;
-                mzz = fmaf(dppz<0x124>(tt), q.zc1, mzz); mzz = fmaf(dppz<0x128>(tt), q.zc2, mzz); mzz = fmaf(dppz<0x12C>(tt), q.zc3, mzz);
-                float gc0 = mc3 * r0_, gc1 = mc3 * r1_;                 // G_m[c], in every row
-                gc0 = fmaf(tt, q.g00, gc0); gc0 = fmaf(dppz<0x124>(tt), q.g01, gc0); gc0 = fmaf(dppz<0x128>(tt), q.g02, gc0); gc0 = fmaf(dppz<0x12C>(tt), q.g03, gc0);
-                gc1 = fmaf(tt, q.g10, gc1); gc1 = fmaf(dppz<0x124>(tt), q.g11, gc1); gc1 = fmaf(dppz<0x128>(tt), q.g12, gc1); gc1 = fmaf(dppz<0x12C>(tt), q.g13, gc1);
-                float mzu = w + mr3 * ((gc == 0) ? r0_ : r1_);         // G_m[r] at lanes (r, m), m < 2
-                mzu = fmaf(dppz<0x124>(w), q.zc1, mzu); mzu = fmaf(dppz<0x128>(w), q.zc2, mzu); mzu = fmaf(dppz<0x12C>(w), q.zc3, mzu);
-                // Muu[m(r)][n] at lanes (r, n), n < 2
-                float muu = (o_gzm == 0) ? ((gc == 0) ? R00_ : R01_) : ((gc == 0) ? R01_ : R11_);
-                muu = fmaf(w, (o_gzm ? q.g10 : q.g00), muu); muu = fmaf(dppz<0x124>(w), (o_gzm ? q.g11 : q.g01), muu);
-                muu = fmaf(dppz<0x128>(w), (o_gzm ? q.g12 : q.g02), muu); muu = fmaf(dppz<0x12C>(w), (o_gzm ? q.g13 : q.g03), muu);
-                const float H00 = dppz<0x150>(muu), H01 = dppz<0x151>(muu), H11 = dppz<0x155>(muu);
-                float hu0 = dppz<0x153>(gc0);
-                const float hu1 = dppz<0x153>(gc1);
-                float gr0 = dppz<0x00>(mzu);                             // G_0[r] in every lane of quad r
-                const float gr1 = dppz<0x55>(mzu);
-                // eliminate control 1, then control 0 (group-uniform scalars; masks 0 / 1, fixed value 0 if free)
-                const bool bad1 = (f1m > 0.0f) && !(H11 > 0.0f);
-                const float w1 = __builtin_amdgcn_rcpf(H11) * f1m;
-                const float z1 = fmaf(-hu1, w1, v1);
-                const float t1 = w1 * H01;
-                const float g1s = n1m - w1;
-                const float pc1 = g1s * gc1, pe1_ = g1s * H01;
-                const float pf1_ = fmaf(f1m, z1, n1m * fmaf(H11, v1, hu1));
-                const float H00r = H00 - t1 * H01;
-                const float hv = H01 * v1;
-                gc0 = fmaf(-t1, gc1, gc0) + mc3 * hv;
-                gr0 = fmaf(-t1, gr1, gr0) + mr3 * hv;
-                hu0 = fmaf(-t1, hu1, hu0) + hv;
-                const bool bad0 = (f0m > 0.0f) && !(H00r > 0.0f);
-                const float w0 = __builtin_amdgcn_rcpf(H00r) * f0m;
-                const float z0 = fmaf(-hu0, w0, v0);
-                const float g0s = n0m - w0;
-                const float pc0 = g0s * gc0;
-                const float pf0_ = fmaf(f0m, z0, n0m * fmaf(H00r, v0, hu0));
-                fail |= (bad0 || bad1) ? 1 : 0;
-                // Vh of node k
-                float xn = mzz;
-                xn = fmaf(-(w1 * gr1), gc1, xn);
-                xn = fmaf(-(w0 * gr0), gc0, xn);
-                xn = fmaf(mc3, fmaf(v1, gr1, v0 * gr0), xn);
-                xn = fmaf(mr3, fmaf(v1, gc1, v0 * gc0), xn);
-                v = xn;
-                // stores only; padding of the record for the lanes that have nothing to say: slots 9 .. 11 of the policy
-                const float pv = (gr == 0) ? ((gc < 3) ? pc0 : pf0_) : ((gr == 1) ? ((gc < 3) ? pc1 : pe1_) : pf1_);
-                const int po = (gr < 2) ? 4 * gr + gc : ((j == 8) ? 8 : 9 + (j & 1));
-                if (act) {
-                    cvs[16 * k + j] = v;
-                    crec[k * CREC + 56 + po] = pv;
-                }
-            };
-            // two coefficient sets: the reads of the next stage are in flight while this one is computed
-            Coef ca, cb;
-            load(ca, km);
-            for (int k = km;;) {
-                if (k > 0) load(cb, k - 1);
-                step(k, ca);
-                if (--k < 0) break;
-                if (k > 0) load(ca, k - 1);
-                step(k, cb);
-                if (--k < 0) break;
-            }
-            __builtin_amdgcn_s_setprio(0);
-            pd_fail |= (act && fail) ? 1 : 0;
-            wave_sync();
-            // the policy records of this lane's stages, for the forward sweep
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int kc = min(j * S + s, N - 1);
-                const float* pl = crec + kc * CREC + 56;
-                const float4 a4 = *reinterpret_cast<const float4*>(pl), b4 = *reinterpret_cast<const float4*>(pl + 4);
-                const float f1_ = pl[8];
-                const bool take = act && (j * S + s < N);
-                c00[s] = take ? a4.x : c00[s]; c01[s] = take ? a4.y : c01[s]; c02[s] = take ? a4.z : c02[s]; pf0[s] = take ? a4.w : pf0[s];
-                c10[s] = take ? b4.x : c10[s]; c11[s] = take ? b4.y : c11[s]; c12[s] = take ? b4.z : c12[s]; pe1[s] = take ? b4.w : pe1[s];
-                pf1[s] = take ? f1_ : pf1[s];
-            }
-        };
-
-        if constexpr (COOP) coop_write_records();
-
         auto backward_sweep = [&](bool act, int from) {
             __builtin_amdgcn_s_setprio(3);
             for (int t = top; t >= 0; --t) {
@@ -860,7 +664,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
         for (;;) {
             long long tb0 = 0;
             if (STAMP) tb0 = __builtin_amdgcn_s_memtime();
-            if constexpr (COOP) coop_backward(changed, khi); else backward_sweep(changed, khi / S);
+            backward_sweep(changed, khi / S);
             long long tf0 = 0;
             if (STAMP) { tf0 = __builtin_amdgcn_s_memtime(); t_b += tf0 - tb0; }
 
@@ -923,7 +727,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
                     }
                 }
                 for (;;) {
-                    if constexpr (COOP) coop_backward(todo == 1, N - 1); else backward_sweep(todo == 1, top);
+                    backward_sweep(todo == 1, top);
                     // forward sweep with the ratio test (free controls) and the multiplier test (fixed ones)
                     float alpha = AS_NONE, viol = 0.0f;
                     int akey = 0x7fffffff, vkey = 0x7fffffff; // (2 * stage + control) * 4 + bound hit
