@@ -417,6 +417,12 @@ __device__ __forceinline__ double rowprefix_d(double x)
     return x;
 }
 
+#define LSTAMP(i)                                                                            \
+    if (d.stamps && blockIdx.x == 0 && lane == 0) {                                          \
+        const long long now_ = (long long)__builtin_readcyclecounter();                      \
+        d.stamps[i] += now_ - d.stamps[7];                                                   \
+        d.stamps[7] = now_;                                                                  \
+    }
 template <int S>
 __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
 {
@@ -461,6 +467,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
     auto REC = [&](int k_, int f) -> double& { return lds_rec[(size_t)k_ * REC_STRIDE + f * 4 + g]; };
     int sweeps = 0, status = 0;
     double pos0[3] = {0.0, 0.0, 0.0};
+    if (d.stamps && blockIdx.x == 0 && lane == 0) d.stamps[7] = (long long)__builtin_readcyclecounter();
 
     for (int relin = 0; relin < d.n_relin; ++relin) {
         // ---- predictMotion.  The first dl columns of the output are the delayed inputs (every lane walks them: dl is 1
@@ -503,6 +510,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                 }
             }
         }
+        LSTAMP(0)
         // ---- working-set iterations
         bool settled = false;
         sweeps = 0;
@@ -659,6 +667,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                 }
                 lo_eff[0] = next_d(lo_eff[0]); lo_eff[1] = next_d(lo_eff[1]); hi_eff[0] = next_d(hi_eff[0]); hi_eff[1] = next_d(hi_eff[1]);
             }
+            LSTAMP(1)
             // forward sweep, lane 0 upwards: inputs, multipliers, violations -> next working set
             double xi[5] = {pos0[0], pos0[1], pos0[2], 0.0, 0.0};
             int changes = 0;
@@ -752,6 +761,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                 best_sev = __shfl(best_sev, src);
                 best_j = __shfl(best_j, src); best_c = __shfl(best_c, src); best_ns = __shfl(best_ns, src);
             }
+            LSTAMP(2)
             if (act) {
                 if (single && changes > 0) {
 #pragma unroll
@@ -814,6 +824,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
             }
         }
     }
+    LSTAMP(3)
     // ---- state kept between calls: the output (its first columns are the delay buffer), the working set, the buffer
     const double c0 = __shfl(ua[0], lane & ~15), c1 = __shfl(uw[0], lane & ~15); // stage 0 = the command just computed
     if (valid) {

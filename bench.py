@@ -630,7 +630,8 @@ def main():
             pl.plan()
             res = pl.results()
             t_b = time.perf_counter()
-            be = {"problems": Bb, "ms_per_launch_device": pl.last_plan_ms(), "ms_wall_incl_results": (t_b - t_a) * 1e3,
+            pl_ms = pl.last_plan_ms()
+            be = {"problems": Bb, "ms_per_launch_device": pl_ms, "ms_wall_incl_results": (t_b - t_a) * 1e3,
                   "plans_per_s": Bb / (pl.last_plan_ms() * 1e-3), "ok": int(res["ok"].sum()),
                   "cost_evaluations_mean": float(res["evals"].mean()), "pieces_mean": float(res["n_pieces"].mean())}
             e10 = BatchedNmpc(Bb, N, device=local_rank, diagnostics=False)
@@ -651,6 +652,19 @@ def main():
             torch.cuda.synchronize(dev)
             be["closed_loop_100_ticks_ms"] = (time.perf_counter() - t_a) * 1e3
             be["unsolved_last_tick"] = int((e10.t["status"] != 0).sum().item())
+            # float64 vector issue model of backend::backend_kernel (one wavefront per plan): instructions per wavefront from
+            # the committed counter pass, a double-precision wave-instruction holds its SIMD for 4 cycles
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "backend_valu.json")))
+                ach = Bb * float(rec["valu_instructions_per_wavefront"]) / (pl_ms * 1e-3) / 1e9
+                peak = 1024 * 2.4e9 / 4 / 1e9
+                be["roofline"] = {"bound": "valu_f64", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+                                  "kernel": "backend::backend_kernel", "kernel_ms_avg": pl_ms,
+                                  "valu_instructions_per_wavefront": float(rec["valu_instructions_per_wavefront"]),
+                                  "counter_source": rec.get("source"),
+                                  "note": "HBM is idle (2.5 KB in / out per plan); a launch lasts as long as its slowest plan"}
+            except Exception:
+                pass
             if not a.no_cpu_baseline:
                 try:
                     be["cpu_baseline"] = backend_cpu_baseline(fts)

@@ -21,6 +21,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_G
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES -d $OUT/wb_pmc2 -o wbpmc2 -- python3 tools/wb_profile.py > /dev/null 2> $OUT/wb_pmc2.err
 rocprofv3 --kernel-trace --stats -d $OUT/ltv_trace -o ltv -- python3 tools/ltv_profile.py > $OUT/ltv_run.txt 2> $OUT/ltv_trace.err
 rocprofv3 --kernel-trace --stats -d $OUT/be_trace -o be -- python3 tools/be_profile.py > $OUT/be_run.txt 2> $OUT/be_trace.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAVES -d $OUT/be_pmc -o bepmc -- python3 tools/be_profile.py > /dev/null 2> $OUT/be_pmc.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAVES -d $OUT/ltv_pmc -o ltvpmc -- python3 tools/ltv_profile.py > /dev/null 2> $OUT/ltv_pmc.err
 rocprofv3 --kernel-trace --stats -d $OUT/extras_trace -o extras -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 5 > /dev/null 2> $OUT/extras_trace.err
 python3 tools/summarize_r03.py $OUT $TAG
 # the rocpd databases are large: only the summaries travel back

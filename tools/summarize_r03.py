@@ -50,6 +50,20 @@ if stage_valu:
     json.dump({"valu_instructions_per_wavefront": per,
                "source": f"profiles/{tag}_wb_counters.txt (SQ_INSTS_VALU / SQ_WAVES of wb::stage_kernel, B = 4096, N = 20)"},
               open(os.path.join(dst, "wb_stage_valu.json"), "w"), indent=1)
+# back_end and LTV counters
+for d, pat, name in (("be_pmc", "%backend_kernel%", "backend"), ("ltv_pmc", "%get_cmd%", "ltv")):
+    rows, vals = [f"# {name}: rocprofv3 --pmc, mean per launch"], {}
+    for db in glob.glob(os.path.join(out, d, "**", "*_results.db"), recursive=True):
+        c = sqlite3.connect(db)
+        for kname, cname, avg, n in c.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                                              "where kernel_name like ? group by kernel_name, counter_name", (pat,)):
+            rows.append(f"{kname.split('(')[0][-40:]:42s} {cname:24s} {avg:18.1f}   ({n} launches)")
+            vals[cname] = avg
+    open(os.path.join(dst, f"{tag}_{name}_counters.txt"), "w").write("\n".join(rows) + "\n")
+    if name == "backend" and "SQ_INSTS_VALU" in vals and "SQ_WAVES" in vals:
+        json.dump({"valu_instructions_per_wavefront": vals["SQ_INSTS_VALU"] / vals["SQ_WAVES"], "wavefronts": vals["SQ_WAVES"],
+                   "source": f"profiles/{tag}_backend_counters.txt (SQ_INSTS_VALU / SQ_WAVES of backend::backend_kernel, tools/be_profile.py)"},
+                  open(os.path.join(dst, "backend_valu.json"), "w"), indent=1)
 for f in ("bench.json", "bench_driver_flags.json", "bench_whole_body.json", "bench_under_rocprof.json", "wb_run.txt", "ltv_run.txt", "be_run.txt"):
     p = os.path.join(out, f)
     if os.path.exists(p):
