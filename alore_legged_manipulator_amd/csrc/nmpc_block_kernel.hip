@@ -51,25 +51,57 @@ __device__ __forceinline__ int dppk_i(int old, int x)
 {
     return __builtin_amdgcn_update_dpp(old, x, CTRL, 0xF, 0xF, false);
 }
-__device__ __forceinline__ float lane_next(float x) { return dppk<0x101>(x, x); } // row_shl:1  lane i <- lane i + 1
-__device__ __forceinline__ float lane_prev(float x) { return dppk<0x111>(x, x); } // row_shr:1  lane i <- lane i - 1
+// DPP move with a row mask: rows outside the mask keep `old`
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dppr(float old, float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, ROWS, 0xF, false));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dppr_i(int old, int x)
+{
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWS, 0xF, false);
+}
+// lane i <- lane i + 1 / lane i - 1.  Groups of up to 16 lanes sit inside a DPP row (row_shl / row_shr: the lane at the
+// end of a row keeps its value); a group of 32 spans two rows and uses the wavefront shifts of gfx9 (the lane at the end
+// of a group then sees its neighbour group's value: every caller treats the edge lanes separately).
+template <int L>
+__device__ __forceinline__ float lane_next(float x)
+{
+    if constexpr (L == 32) return dppk<0x130>(x, x); // wave_shl:1
+    else return dppk<0x101>(x, x);                    // row_shl:1
+}
+template <int L>
+__device__ __forceinline__ float lane_prev(float x)
+{
+    if constexpr (L == 32) return dppk<0x138>(x, x); // wave_shr:1
+    else return dppk<0x111>(x, x);                    // row_shr:1
+}
 
-// value of the first / last lane of the group of L lanes (L = 4: quad_perm, else row_newbcast, gfx90a+)
+// value of the first / last lane of the group of L lanes (L = 4: quad_perm; 8, 16: row_newbcast, gfx90a+; 32: the two
+// group ends through scalar registers)
 template <int L>
 __device__ __forceinline__ float gfirst(float x, int lane)
 {
     if constexpr (L == 4) return dppk<0x00>(x, x);
     else if constexpr (L == 16) return dppk<0x150>(x, x);
-    else { const float lo = dppk<0x150>(x, x), hi = dppk<0x158>(x, x); return (lane & 8) ? hi : lo; }
+    else if constexpr (L == 32) {
+        const int lo = __builtin_amdgcn_readlane(__float_as_int(x), 0), hi = __builtin_amdgcn_readlane(__float_as_int(x), 32);
+        return __int_as_float((lane & 32) ? hi : lo);
+    } else { const float lo = dppk<0x150>(x, x), hi = dppk<0x158>(x, x); return (lane & 8) ? hi : lo; }
 }
 template <int L>
 __device__ __forceinline__ float glast(float x, int lane)
 {
     if constexpr (L == 4) return dppk<0xFF>(x, x);
     else if constexpr (L == 16) return dppk<0x15F>(x, x);
-    else { const float lo = dppk<0x157>(x, x), hi = dppk<0x15F>(x, x); return (lane & 8) ? hi : lo; }
+    else if constexpr (L == 32) {
+        const int lo = __builtin_amdgcn_readlane(__float_as_int(x), 31), hi = __builtin_amdgcn_readlane(__float_as_int(x), 63);
+        return __int_as_float((lane & 32) ? hi : lo);
+    } else { const float lo = dppk<0x157>(x, x), hi = dppk<0x15F>(x, x); return (lane & 8) ? hi : lo; }
 }
-// inclusive prefix sum over the lanes of a group (row_shr:1, 2, 4, 8; groups are aligned inside DPP rows)
+// inclusive prefix sum over the lanes of a group (row_shr:1, 2, 4, 8; groups are aligned inside DPP rows; a group of 32
+// adds the total of its first row to its second: row_bcast:15 into rows 1 and 3)
 template <int L>
 __device__ __forceinline__ float gprefix(float x, int j)
 {
@@ -78,6 +110,7 @@ __device__ __forceinline__ float gprefix(float x, int j)
     v = dppk<0x112>(0.0f, x); if (L < 16) v = (j >= 2) ? v : 0.0f; x += v;
     if constexpr (L >= 8) { v = dppk<0x114>(0.0f, x); if (L < 16) v = (j >= 4) ? v : 0.0f; x += v; }
     if constexpr (L >= 16) { v = dppk<0x118>(0.0f, x); x += v; }
+    if constexpr (L >= 32) { v = dppr<0x142, 0xA>(0.0f, x); x += v; }
     return x;
 }
 template <int L>
@@ -89,6 +122,7 @@ __device__ __forceinline__ int gprefix_max(int x, int j)
     v = dppk_i<0x112>(NEG, x); if (L < 16) v = (j >= 2) ? v : NEG; x = max(x, v);
     if constexpr (L >= 8) { v = dppk_i<0x114>(NEG, x); if (L < 16) v = (j >= 4) ? v : NEG; x = max(x, v); }
     if constexpr (L >= 16) { v = dppk_i<0x118>(NEG, x); x = max(x, v); }
+    if constexpr (L >= 32) { v = dppr_i<0x142, 0xA>(NEG, x); x = max(x, v); }
     return x;
 }
 template <int L>
@@ -102,19 +136,22 @@ __device__ __forceinline__ int gmax(int x, int j, int lane)
 template <int L>
 __device__ __forceinline__ void gmin_pair(float& v, int& key, int j, int lane)
 {
-    auto step = [&](auto tag, int dist) {
+    auto step = [&](auto tag, auto rows, int dist) {
         constexpr int CTRL = decltype(tag)::value;
-        const float pv = dppk<CTRL>(v, v);
-        const int pk = dppk_i<CTRL>(key, key);
+        constexpr int ROWS = decltype(rows)::value;
+        const float pv = dppr<CTRL, ROWS>(v, v);
+        const int pk = dppr_i<CTRL, ROWS>(key, key);
         const bool has = (L >= 16) || (j >= dist);
         const bool take = has && ((pv < v) || (pv == v && pk < key));
         v = take ? pv : v;
         key = take ? pk : key;
     };
-    step(std::integral_constant<int, 0x111>{}, 1);
-    step(std::integral_constant<int, 0x112>{}, 2);
-    if constexpr (L >= 8) step(std::integral_constant<int, 0x114>{}, 4);
-    if constexpr (L >= 16) step(std::integral_constant<int, 0x118>{}, 8);
+    using all = std::integral_constant<int, 0xF>;
+    step(std::integral_constant<int, 0x111>{}, all{}, 1);
+    step(std::integral_constant<int, 0x112>{}, all{}, 2);
+    if constexpr (L >= 8) step(std::integral_constant<int, 0x114>{}, all{}, 4);
+    if constexpr (L >= 16) step(std::integral_constant<int, 0x118>{}, all{}, 8);
+    if constexpr (L >= 32) step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{}, 16);
     v = glast<L>(v, lane);
     key = __float_as_int(glast<L>(__int_as_float(key), lane));
 }
@@ -122,7 +159,8 @@ template <int L>
 __device__ __forceinline__ bool gany(bool pred, int base)
 {
     const unsigned long long m = __ballot(pred);
-    return ((m >> base) & ((1ull << L) - 1ull)) != 0ull;
+    constexpr unsigned long long MASK = (L >= 64) ? ~0ull : ((1ull << (L & 63)) - 1ull);
+    return ((m >> base) & MASK) != 0ull;
 }
 
 // ---- global <-> LDS, coalesced: all loads of a launch are issued before the first LDS store ---------------------
@@ -182,7 +220,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     float* lds = reinterpret_cast<float*>(lds_raw);
     constexpr int G = 64 / L;
     constexpr int NMAX = L * S;
-    constexpr bool MASKED = (L == 16 && S == 2); // see backward_sweep
+    constexpr bool MASKED = (L == 16 && S == 2) || (L == 32 && S == 1); // see backward_sweep
     const int N = p.N;
     const int lane = threadIdx.x;
     const int g = lane / L, j = lane % L;
@@ -299,7 +337,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             float xn[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float nb = (s + 1 < S) ? x[(s + 1 < S) ? s + 1 : s][c] : lane_next(x[0][c]);
+                const float nb = (s + 1 < S) ? x[(s + 1 < S) ? s + 1 : s][c] : lane_next<L>(x[0][c]);
                 xn[c] = (k + 1 == N) ? xN[c] : nb;
             }
             StageLin lin;
@@ -337,9 +375,9 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             qN[2] = WN[6] * e0 + WN[7] * e1 + WN[8] * e2;
         }
         { // element [S]: first node of the next lane; the terminal node goes where node N falls
-            Q00[S] = lane_next(Q00[0]); Q01[S] = lane_next(Q01[0]); Q02[S] = lane_next(Q02[0]); Q11[S] = lane_next(Q11[0]);
-            Q12[S] = lane_next(Q12[0]); Q22[S] = lane_next(Q22[0]); q0[S] = lane_next(q0[0]); q1[S] = lane_next(q1[0]);
-            q2[S] = lane_next(q2[0]); sa[S] = lane_next(sa[0]); sb[S] = lane_next(sb[0]);
+            Q00[S] = lane_next<L>(Q00[0]); Q01[S] = lane_next<L>(Q01[0]); Q02[S] = lane_next<L>(Q02[0]); Q11[S] = lane_next<L>(Q11[0]);
+            Q12[S] = lane_next<L>(Q12[0]); Q22[S] = lane_next<L>(Q22[0]); q0[S] = lane_next<L>(q0[0]); q1[S] = lane_next<L>(q1[0]);
+            q2[S] = lane_next<L>(q2[0]); sa[S] = lane_next<L>(sa[0]); sb[S] = lane_next<L>(sb[0]);
             if (j == L - 1) { Q00[S] = Q01[S] = Q02[S] = Q11[S] = Q12[S] = Q22[S] = q0[S] = q1[S] = q2[S] = sa[S] = sb[S] = 0.0f; }
 #pragma unroll
             for (int s = 0; s <= S; ++s) {
@@ -402,8 +440,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
 #pragma unroll
                 for (int s = 0; s < S; ++s) { Lx[s] += es0; Ly[s] += es1; }
                 // adjoint at node k + 2: the next slot's, the next lane's first, zero past the end of the group
-                const float nx_edge = (j == L - 1) ? 0.0f : lane_next(Lx[0]);
-                const float ny_edge = (j == L - 1) ? 0.0f : lane_next(Ly[0]);
+                const float nx_edge = (j == L - 1) ? 0.0f : lane_next<L>(Lx[0]);
+                const float ny_edge = (j == L - 1) ? 0.0f : lane_next<L>(Ly[0]);
                 float b2 = 0.0f;
 #pragma unroll
                 for (int s = S - 1; s >= 0; --s) {
@@ -543,10 +581,11 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
                 }
             }
             // inclusive scan over the lanes: lane j <- f_j o f_{j-1} o ... o f_0
-            auto level = [&](auto tag, int dist) {
+            auto level = [&](auto tag, auto rows, int dist) {
                 constexpr int CTRL = decltype(tag)::value;
+                constexpr int ROWS = decltype(rows)::value;
                 const bool has = (L >= 16) || (j >= dist);
-                auto fetch = [&](float v, float ident) { const float r = dppk<CTRL>(ident, v); return has ? r : ident; };
+                auto fetch = [&](float v, float ident) { const float r = dppr<CTRL, ROWS>(ident, v); return has ? r : ident; };
                 const float g00 = fetch(m00, 1.f), g01 = fetch(m01, 0.f), g02 = fetch(m02, 0.f), g10 = fetch(m10, 0.f),
                             g11 = fetch(m11, 1.f), g12 = fetch(m12, 0.f), g20 = fetch(m20, 0.f), g21 = fetch(m21, 0.f),
                             g22 = fetch(m22, 1.f), gc0 = fetch(k0, 0.f), gc1 = fetch(k1, 0.f), gc2 = fetch(k2, 0.f);
@@ -561,14 +600,16 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
                 m00 = n00; m01 = n01; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m21 = n21; m22 = n22;
                 k0 = l0; k1 = l1; k2 = l2;
             };
-            level(std::integral_constant<int, 0x111>{}, 1);
-            level(std::integral_constant<int, 0x112>{}, 2);
-            if constexpr (L >= 8) level(std::integral_constant<int, 0x114>{}, 4);
-            if constexpr (L >= 16) level(std::integral_constant<int, 0x118>{}, 8);
+            using all_rows = std::integral_constant<int, 0xF>;
+            level(std::integral_constant<int, 0x111>{}, all_rows{}, 1);
+            level(std::integral_constant<int, 0x112>{}, all_rows{}, 2);
+            if constexpr (L >= 8) level(std::integral_constant<int, 0x114>{}, all_rows{}, 4);
+            if constexpr (L >= 16) level(std::integral_constant<int, 0x118>{}, all_rows{}, 8);
+            if constexpr (L >= 32) level(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{}, 16); // row_bcast:15 into the group's second row
             // state step leaving this lane's block; the one entering it is the previous lane's
             const float l0 = m00 * Dx0 + m01 * Dx1 + m02 * Dx2 + k0, l1 = m10 * Dx0 + m11 * Dx1 + m12 * Dx2 + k1,
                         l2 = m20 * Dx0 + m21 * Dx1 + m22 * Dx2 + k2;
-            const float p0 = lane_prev(l0), p1 = lane_prev(l1), p2 = lane_prev(l2);
+            const float p0 = lane_prev<L>(l0), p1 = lane_prev<L>(l1), p2 = lane_prev<L>(l2);
             o0 = (j == 0) ? Dx0 : p0; o1 = (j == 0) ? Dx1 : p1; o2 = (j == 0) ? Dx2 : p2;
         };
         if (DIAG) { // free response (du = 0) entering every stage, for acado_getKKT: A is a shear, so prefix sums do it
@@ -635,7 +676,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
                     // lane t of a group that starts here takes the cost-to-go it kept; below, the one handed down is kept
                     const bool start = mine && (t == from);
                     if constexpr (MASKED) {
-                        // (16, 2) only: the block of lane t under an EXEC mask (a tenth fewer instructions per sweep:
+                        // (16, 2) and (32, 1) only: the block of lane t under an EXEC mask (a tenth fewer instructions per sweep:
                         // no selects).  This instantiation keeps its whole state in VGPRs, and tests/test_masked_regions.py
                         // checks on every build that no spill / reload / AGPR traffic sits inside the masked region.
                         if (mine) {
@@ -655,7 +696,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
                         pd_fail |= (mine && !ok) ? 1 : 0;
                     }
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) V[i] = lane_next(V[i]);
+                    for (int i = 0; i < 9; ++i) V[i] = lane_next<L>(V[i]);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -912,7 +953,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     }
 }
 
-// (L, S) instantiated: (4, 5) (8, 3) (16, 2) for horizons up to 20 / 24 / 32, (16, 4) up to 64
+// (L, S) instantiated: (4, 5) (8, 3) (16, 2) (32, 1) for horizons up to 20 / 24 / 32 / 32, (16, 4) up to 64
 bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g)
 {
     if (B <= 0 || N <= 0) return false;
@@ -921,15 +962,19 @@ bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, L
     if (L == 0) {
         // the sweeps cost N scalar stage steps per wavefront whatever L is: spread a small batch over all SIMDs
         // (one wavefront each), pack a large one
+        // (measured, profiles/r03_c_block_kernel_experiments.txt: two wavefronts on a SIMD do not issue faster than one,
+        // so L = 32 only pays while every wavefront still has a CU to itself)
         L = 16;
         while (L > 4 && (long)(B + 64 / L - 1) / (64 / L) > 4L * cus) L >>= 1;
         while (L < 16 && N > L * (L == 4 ? 5 : 3)) L <<= 1;
+        if (L == 16 && N <= 32 && (long)(B + 1) / 2 <= (long)cus) L = 32;
     }
     int S = 0;
     if (L == 4 && N <= 20) S = 5;
     else if (L == 8 && N <= 24) S = 3;
     else if (L == 16 && N <= 32) S = 2;
     else if (L == 16 && N <= 64) S = 4;
+    else if (L == 32 && N <= 32) S = 1;
     if (S == 0) return false;
     const size_t lds = (size_t)block_lds_floats(N, L) * 4;
     if ((long)lds > lds_limit_bytes) return false;
@@ -962,13 +1007,14 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
     PICK(8, 3, 1)
     PICK(16, 2, 2)
     PICK(16, 4, 3)
+    PICK(32, 1, 4)
 #undef PICK
     if (!fn) return hipErrorInvalidValue;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     dev &= 15;
-    static size_t configured[16][12] = {{0}};
+    static size_t configured[16][15] = {{0}};
     if (g.lds_bytes > configured[dev][v]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
         if (e != hipSuccess) return e;

@@ -147,7 +147,7 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     {
         const int lp = cfg->lanes_per_problem, lw = lp & ~0x100;
         const bool blk = (lp & 0x100) != 0;
-        if (lp != 0 && !(blk ? (lw == 4 || lw == 8 || lw == 16) : (lw == 4 || lw == 8 || lw == 16 || lw == 32 || lw == 64)))
+        if (lp != 0 && !(blk ? (lw == 4 || lw == 8 || lw == 16 || lw == 32) : (lw == 4 || lw == 8 || lw == 16 || lw == 32 || lw == 64)))
             return ALORE_NMPC_E_INVALID;
     }
     int ndev = 0;

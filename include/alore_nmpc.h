@@ -65,8 +65,8 @@ typedef struct {
                         reference caps working-set changes at 300, acado_qpoases_interface.hpp:44 */
     int lanes_per_problem; /* 0 = choose mapping and width from the batch size.  4, 8, 16, 32 or 64: the wavefront
                               mapping (one lane per stage, sweeps row-split over quads).  ALORE_NMPC_BLOCK_LANES(L),
-                              L = 4, 8 or 16: the stage-block mapping (a lane owns ceil(N / L) consecutive stages in
-                              registers, sweeps lane by lane; horizons up to 64).  alore_nmpc_get_launch_info reports
+                              L = 4, 8, 16 or 32: the stage-block mapping (a lane owns ceil(N / L) consecutive stages in
+                              registers, sweeps lane by lane; horizons up to 64, L = 32 up to 32).  alore_nmpc_get_launch_info reports
                               the choice in the same encoding. */
     int warm_start_steps;  /* projected-gradient steps used to predict the working set of a QP whose
                               first solve hit bounds (<0: default 6; 0: off).  Affects only the number

@@ -480,9 +480,10 @@ BLOCK = 0x100  # ALORE_NMPC_BLOCK_LANES(L) = 0x100 | L (include/alore_nmpc.h)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,lanes", [(20, BLOCK | 4), (20, BLOCK | 8), (20, BLOCK | 16), (7, BLOCK | 4), (24, BLOCK | 8),
-                                     (31, BLOCK | 16), (50, BLOCK | 16), (1, BLOCK | 4), (20, 32), (50, 64)])
+                                     (31, BLOCK | 16), (50, BLOCK | 16), (1, BLOCK | 4), (20, BLOCK | 32), (32, BLOCK | 32),
+                                     (9, BLOCK | 32), (20, 32), (50, 64)])
 def test_every_lane_mapping_against_the_oracle(nmpc_mod, N, lanes):
-    """Both kernels, every instantiated lane mapping (stage-block L = 4 / 8 / 16 with 5 / 3 / 2 / 4 stages per lane, the
+    """Both kernels, every instantiated lane mapping (stage-block L = 4 / 8 / 16 / 32 with 5 / 3 / 2 or 4 / 1 stages per lane, the
     wavefront mapping): one tick from the cold start and one warm tick (the dual seeds the working set) of seeded
     problems, a ragged batch, against the oracle: x, u <= 1e-4 relative (BASELINE.json), multipliers 1e-3."""
     B = 37
@@ -507,7 +508,7 @@ def test_every_lane_mapping_against_the_oracle(nmpc_mod, N, lanes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes", [BLOCK | 4, BLOCK | 8, BLOCK | 16])
+@pytest.mark.parametrize("lanes", [BLOCK | 4, BLOCK | 8, BLOCK | 16, BLOCK | 32])
 def test_stage_block_kernel_on_the_stress_distribution(nmpc_mod, lanes):
     """The stage-block kernel on the wide distribution (long working-set iterations, the primal active-set safeguard):
     every problem solved by both kernels, solutions of the two within 2e-4 of each other (both solve the same strictly

@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--ticks", type=int, default=1)
     ap.add_argument("--wide", action="store_true")
     ap.add_argument("--time", action="store_true")
-    ap.add_argument("--lanes", type=str, default="0,4,8,16")
+    ap.add_argument("--lanes", type=str, default="0,4,8,16,32")
     a = ap.parse_args()
     B, N = a.B, a.N
     batch = make_wide_batch(B, N, 3) if a.wide else make_batch(B, N, fast_tail=0.05)
