@@ -28,6 +28,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/alore_ltv_mpc.h"
@@ -417,6 +418,16 @@ __device__ __forceinline__ double rowprefix_d(double x)
     return x;
 }
 
+// reciprocal of a positive pivot to float64 accuracy: hardware estimate + two Newton steps (the IEEE division sequence is
+// three times as long and sits on the sweep's dependent chain twice per stage)
+__device__ __forceinline__ double pivot_rcp_d(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 #define LSTAMP(i)                                                                            \
     if (d.stamps && blockIdx.x == 0 && lane == 0) {                                          \
         const long long now_ = (long long)__builtin_readcyclecounter();                      \
@@ -524,6 +535,13 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                 for (int s2 = 0; s2 < 5; ++s2) P[r][s2] = 0.0; }
             double lo_eff[2] = {-umax[0], -umax[1]}, hi_eff[2] = {umax[0], umax[1]};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double lin[S][6]; // A02 A12 B00 B10 C0 C1 of the lane's stages: fixed during the sweeps of this relinearisation
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int kc = min(j * S + s, K - 1);
+#pragma unroll
+                for (int f = 0; f < 6; ++f) lin[s][f] = REC(kc, f);
+            }
             for (int t = top; t >= 0; --t) {
                 // Every lane runs the stage algebra on its own slot with whatever cost-to-go it holds; only lane t holds
                 // the real one and only it stores the record.  (No heavy code under a partial EXEC mask: values that are
@@ -532,10 +550,10 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                 {
 #pragma unroll
                     for (int s = S - 1; s >= 0; --s) {
-                        const int k = j * S + s, kc = min(k, K - 1);
+                        const int k = j * S + s;
                         if (t * S + s < K) { // wavefront-uniform: the stage of lane t exists
                             double W_[NF];
-                            const double A02 = REC(kc, 0), A12 = REC(kc, 1), B00 = REC(kc, 2), B10 = REC(kc, 3), C0 = REC(kc, 4), C1 = REC(kc, 5);
+                            const double A02 = lin[s][0], A12 = lin[s][1], B00 = lin[s][2], B10 = lin[s][3], C0 = lin[s][4], C1 = lin[s][5];
                             const int st1 = st[s][1], st0 = st[s][0];
                             W_[34] = lo_eff[0]; W_[35] = hi_eff[0]; W_[36] = lo_eff[1]; W_[37] = hi_eff[1];
 #pragma unroll
@@ -591,7 +609,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                             }
                             { // eliminate u1 (index 6): u1 = a1 . w[0..5] + f1
                                 double a1[6], f1;
-                                const double inv = 1.0 / q.H[6][6];
+                                const double inv = pivot_rcp_d(q.H[6][6]);
                                 const bool fr = st1 == FREE, bx = (st1 == BOX_LO || st1 == BOX_HI);
 #pragma unroll
                                 for (int kk = 0; kk < 6; ++kk) a1[kk] = fr ? -q.H[6][kk] * inv : ((!bx && kk == 4) ? 1.0 : 0.0);
@@ -606,19 +624,24 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                                 double Hk[6], tr[6];
 #pragma unroll
                                 for (int kk = 0; kk < 6; ++kk) { Hk[kk] = q.H[6][kk]; tr[kk] = Hk[kk] + a1[kk] * Hkk; }
+                                double trr[6]; // tr where it can matter for H: the rate-limited case only (exact zero otherwise)
+#pragma unroll
+                                for (int kk = 0; kk < 6; ++kk) trr[kk] = (fr || bx) ? 0.0 : tr[kk];
+                                // H += a Hk' + tr a' on the upper triangle.  tr = Hk + a Hkk vanishes for a free component, a vanishes
+                                // for a boxed one, and a rate-limited one has a = e_4: the second term lives in column 4 only
 #pragma unroll
                                 for (int r = 0; r < 6; ++r) {
                                     q.h[r] += a1[r] * hk + tr[r] * f1;
 #pragma unroll
                                     for (int s2 = r; s2 < 6; ++s2) {
-                                        q.H[r][s2] += a1[r] * Hk[s2] + tr[r] * a1[s2];
+                                        q.H[r][s2] += a1[r] * Hk[s2] + ((s2 == 4) ? trr[r] * a1[4] : 0.0);
                                         q.H[s2][r] = q.H[r][s2];
                                     }
                                 }
                             }
                             { // eliminate u0 (index 5): u0 = a0 . xi + f0
                                 double a0[5], f0;
-                                const double inv = 1.0 / q.H[5][5];
+                                const double inv = pivot_rcp_d(q.H[5][5]);
                                 const bool fr = st0 == FREE, bx = (st0 == BOX_LO || st0 == BOX_HI);
 #pragma unroll
                                 for (int kk = 0; kk < 5; ++kk) a0[kk] = fr ? -q.H[5][kk] * inv : ((!bx && kk == 3) ? 1.0 : 0.0);
@@ -633,12 +656,15 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                                 double Hk[5], tr[5];
 #pragma unroll
                                 for (int kk = 0; kk < 5; ++kk) { Hk[kk] = q.H[5][kk]; tr[kk] = Hk[kk] + a0[kk] * Hkk; }
+                                double trr[5];
+#pragma unroll
+                                for (int kk = 0; kk < 5; ++kk) trr[kk] = (fr || bx) ? 0.0 : tr[kk];
 #pragma unroll
                                 for (int r = 0; r < 5; ++r) {
                                     p[r] = q.h[r] + a0[r] * hk + tr[r] * f0;
 #pragma unroll
-                                    for (int s2 = r; s2 < 5; ++s2) {
-                                        P[r][s2] = q.H[r][s2] + a0[r] * Hk[s2] + tr[r] * a0[s2];
+                                    for (int s2 = r; s2 < 5; ++s2) { // as above; a rate-limited u0 has a = e_3
+                                        P[r][s2] = q.H[r][s2] + a0[r] * Hk[s2] + ((s2 == 3) ? trr[r] * a0[3] : 0.0);
                                         P[s2][r] = P[r][s2];
                                     }
                                 }
@@ -668,98 +694,256 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                 lo_eff[0] = next_d(lo_eff[0]); lo_eff[1] = next_d(lo_eff[1]); hi_eff[0] = next_d(hi_eff[0]); hi_eff[1] = next_d(hi_eff[1]);
             }
             LSTAMP(1)
-            // forward sweep, lane 0 upwards: inputs, multipliers, violations -> next working set
-            double xi[5] = {pos0[0], pos0[1], pos0[2], 0.0, 0.0};
-            int changes = 0;
-            double chain_mu[2] = {0.0, 0.0};
-            int chain_dir[2] = {0, 0};
+            // ---- forward sweep, all lanes at once (the records of a lane's stages do not change during it):
+            //   1. every stage's closed-loop map xi+ = M xi + m from its record (u0 = a0.xi + f0, u1 = a1.(xi, u0) + f1),
+            //      composed over the lane's block;
+            //   2. the state entering every block: L - 1 rounds of "apply the block map, hand to the lane above" -- after
+            //      round r the lanes 0 .. r + 1 hold their true entry state (lane 0 holds pos0 throughout), 25 multiply-adds
+            //      and 5 DPP row shifts a round;
+            //   3. every lane walks its own stages: inputs, gradient rows of the non-free components, violations;
+            //   4. the multiplier chain of the rate-limited runs (a tightened box followed by rate limits of the same
+            //      direction passes its multiplier along): a two-value state per component, by two scans over the stages;
+            //   5. the next working set: every change at once, or (from sweep SINGLE_AFTER on) only the most severe one.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const bool single = sweeps >= SINGLE_AFTER;
+            int changes = 0;
             double best_sev = -1.0;
             int best_j = 0, best_c = 0, best_ns = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int t = 0; t <= top; ++t) {
-                const bool commit = act && j == t;
+            {
+                double Mb[5][5], mb[5]; // block map
+                double xin[5] = {pos0[0], pos0[1], pos0[2], 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int k = j * S + s, kc = min(k, K - 1);
+                    const bool vs = k < K;
+                    double a0[5], b1[5];
+#pragma unroll
+                    for (int kk = 0; kk < 5; ++kk) a0[kk] = REC(kc, 21 + kk);
+                    const double f0 = REC(kc, 26), a15 = REC(kc, 11), f1 = REC(kc, 12);
+#pragma unroll
+                    for (int kk = 0; kk < 5; ++kk) b1[kk] = REC(kc, 6 + kk) + a15 * a0[kk];
+                    const double e1 = f1 + a15 * f0;
+                    const double A02 = REC(kc, 0), A12 = REC(kc, 1), B00 = REC(kc, 2), B10 = REC(kc, 3), C0 = REC(kc, 4), C1 = REC(kc, 5);
+                    if (s == 0) {
+#pragma unroll
+                        for (int cc = 0; cc < 5; ++cc) {
+                            Mb[3][cc] = a0[cc]; Mb[4][cc] = b1[cc];
+                            Mb[0][cc] = B00 * a0[cc] + (cc == 0 ? 1.0 : 0.0) + (cc == 2 ? A02 : 0.0);
+                            Mb[1][cc] = B10 * a0[cc] + (cc == 1 ? 1.0 : 0.0) + (cc == 2 ? A12 : 0.0);
+                            Mb[2][cc] = dt * b1[cc] + (cc == 2 ? 1.0 : 0.0);
+                        }
+                        mb[0] = B00 * f0 + C0; mb[1] = B10 * f0 + C1; mb[2] = dt * e1; mb[3] = f0; mb[4] = e1;
+                    } else {
+                        double n3[5], n4[5], n0[5], n1[5], n2[5];
+#pragma unroll
+                        for (int cc = 0; cc < 5; ++cc) {
+                            n3[cc] = a0[0] * Mb[0][cc] + a0[1] * Mb[1][cc] + a0[2] * Mb[2][cc] + a0[3] * Mb[3][cc] + a0[4] * Mb[4][cc];
+                            n4[cc] = b1[0] * Mb[0][cc] + b1[1] * Mb[1][cc] + b1[2] * Mb[2][cc] + b1[3] * Mb[3][cc] + b1[4] * Mb[4][cc];
+                            n0[cc] = Mb[0][cc] + A02 * Mb[2][cc] + B00 * n3[cc];
+                            n1[cc] = Mb[1][cc] + A12 * Mb[2][cc] + B10 * n3[cc];
+                            n2[cc] = Mb[2][cc] + dt * n4[cc];
+                        }
+                        const double u0c = a0[0] * mb[0] + a0[1] * mb[1] + a0[2] * mb[2] + a0[3] * mb[3] + a0[4] * mb[4] + f0;
+                        const double u1c = b1[0] * mb[0] + b1[1] * mb[1] + b1[2] * mb[2] + b1[3] * mb[3] + b1[4] * mb[4] + e1;
+                        const double c0 = mb[0] + A02 * mb[2] + B00 * u0c + C0, c1 = mb[1] + A12 * mb[2] + B10 * u0c + C1, c2 = mb[2] + dt * u1c;
+#pragma unroll
+                        for (int cc = 0; cc < 5; ++cc) { // stages past the horizon are identities
+                            Mb[0][cc] = vs ? n0[cc] : Mb[0][cc]; Mb[1][cc] = vs ? n1[cc] : Mb[1][cc]; Mb[2][cc] = vs ? n2[cc] : Mb[2][cc];
+                            Mb[3][cc] = vs ? n3[cc] : Mb[3][cc]; Mb[4][cc] = vs ? n4[cc] : Mb[4][cc];
+                        }
+                        mb[0] = vs ? c0 : mb[0]; mb[1] = vs ? c1 : mb[1]; mb[2] = vs ? c2 : mb[2]; mb[3] = vs ? u0c : mb[3]; mb[4] = vs ? u1c : mb[4];
+                    }
+                }
+                for (int r = 0; r < top; ++r) { // wavefront-uniform trip count
+                    double o[5];
+#pragma unroll
+                    for (int rr = 0; rr < 5; ++rr)
+                        o[rr] = Mb[rr][0] * xin[0] + Mb[rr][1] * xin[1] + Mb[rr][2] * xin[2] + Mb[rr][3] * xin[3] + Mb[rr][4] * xin[4] + mb[rr];
+#pragma unroll
+                    for (int rr = 0; rr < 5; ++rr) xin[rr] = dppd<0x111>(xin[rr], o[rr]); // lane 0 of the row keeps pos0
+                }
+                // 3. the lane's own stages
+                double grad[S][2], val[S][2], prv[S][2], lo[S][2], hi[S][2];
                 {
+                    double xi[5] = {xin[0], xin[1], xin[2], xin[3], xin[4]};
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         const int k = j * S + s, kc = min(k, K - 1);
-                        if (t * S + s < K) { // wavefront-uniform
-                            double Rr[NF];
+                        double Rr[NF];
 #pragma unroll
-                            for (int f = 0; f < NF; ++f) Rr[f] = REC(kc, f);
-                            double w7[7];
+                        for (int f = 0; f < NF; ++f) Rr[f] = REC(kc, f);
+                        double w7[7];
 #pragma unroll
-                            for (int kk = 0; kk < 5; ++kk) w7[kk] = xi[kk];
-                            double u0 = Rr[26];
+                        for (int kk = 0; kk < 5; ++kk) w7[kk] = xi[kk];
+                        double u0 = Rr[26];
 #pragma unroll
-                            for (int kk = 0; kk < 5; ++kk) u0 += Rr[21 + kk] * xi[kk];
-                            w7[5] = u0;
-                            double u1 = Rr[12];
+                        for (int kk = 0; kk < 5; ++kk) u0 += Rr[21 + kk] * xi[kk];
+                        w7[5] = u0;
+                        double u1 = Rr[12];
 #pragma unroll
-                            for (int kk = 0; kk < 6; ++kk) u1 += Rr[6 + kk] * w7[kk];
-                            w7[6] = u1;
-                            double g1 = Rr[20], g0 = Rr[33];
+                        for (int kk = 0; kk < 6; ++kk) u1 += Rr[6 + kk] * w7[kk];
+                        w7[6] = u1;
+                        double g1 = Rr[20], g0 = Rr[33];
 #pragma unroll
-                            for (int kk = 0; kk < 7; ++kk) g1 += Rr[13 + kk] * w7[kk];
+                        for (int kk = 0; kk < 7; ++kk) g1 += Rr[13 + kk] * w7[kk];
 #pragma unroll
-                            for (int kk = 0; kk < 6; ++kk) g0 += Rr[27 + kk] * w7[kk];
-                            const double uu[2] = {u0, u1}, gg[2] = {g0, g1};
-#pragma unroll
-                            for (int cc = 0; cc < 2; ++cc) {
-                                const int sc = st[s][cc];
-                                const double val = uu[cc], prev = xi[3 + cc], grad = gg[cc];
-                                const double lo = Rr[34 + 2 * cc], hi = Rr[35 + 2 * cc];
-                                int ns = sc;
-                                double sev = 0.0;
-                                if (sc == FREE) {
-                                    chain_mu[cc] = 0.0; chain_dir[cc] = 0;
-                                    const double vb = fmax(lo - val, val - hi);
-                                    const double vr = (k >= 1) ? fmax(-rmax[cc] - (val - prev), (val - prev) - rmax[cc]) : -1.0;
-                                    if (vb > tol && vb >= vr) { ns = (val < lo) ? BOX_LO : BOX_HI; sev = vb; }
-                                    else if (vr > tol) { ns = (val - prev < 0.0) ? RATE_LO : RATE_HI; sev = vr; }
-                                } else if (sc == BOX_LO || sc == BOX_HI) {
-                                    const bool lower = (sc == BOX_LO);
-                                    const bool tightened = lower ? (lo > -umax[cc] + 1e-12) : (hi < umax[cc] - 1e-12);
-                                    chain_mu[cc] = tightened ? grad : 0.0;
-                                    chain_dir[cc] = tightened ? (lower ? -1 : 1) : 0;
-                                    if ((lower && grad < -tol) || (!lower && grad > tol)) { ns = FREE; sev = fabs(grad); }
-                                    else if (k >= 1 && fabs(val - prev) > rmax[cc] + tol) { ns = (val - prev < 0.0) ? RATE_LO : RATE_HI; sev = fabs(val - prev) - rmax[cc]; }
-                                } else {
-                                    const bool lower = (sc == RATE_LO);
-                                    if (chain_dir[cc] != (lower ? -1 : 1)) { chain_mu[cc] = 0.0; chain_dir[cc] = 0; }
-                                    const double g_eff = grad - chain_mu[cc];
-                                    if ((lower && g_eff < -tol) || (!lower && g_eff > tol)) {
-                                        ns = (chain_mu[cc] == 0.0) ? FREE : (lower ? BOX_LO : BOX_HI);
-                                        sev = fabs(g_eff);
-                                        chain_mu[cc] = 0.0; chain_dir[cc] = 0;
-                                    }
-                                }
-                                if (ns != sc) {
-                                    ++changes;
-                                    if (!single) st[s][cc] = commit ? ns : st[s][cc];
-                                    else if (sev > best_sev) { best_sev = sev; best_j = k; best_c = cc; best_ns = ns; }
-                                }
-                            }
-                            ua[s] = commit ? u0 : ua[s]; uw[s] = commit ? u1 : uw[s];
-                            const double A02 = Rr[0], A12 = Rr[1], B00 = Rr[2], B10 = Rr[3];
-                            const double nx = xi[0] + A02 * xi[2] + B00 * u0 + Rr[4], ny = xi[1] + A12 * xi[2] + B10 * u0 + Rr[5];
-                            xi[2] = xi[2] + dt * u1; xi[0] = nx; xi[1] = ny; xi[3] = u0; xi[4] = u1;
-                        }
+                        for (int kk = 0; kk < 6; ++kk) g0 += Rr[27 + kk] * w7[kk];
+                        grad[s][0] = g0; grad[s][1] = g1; val[s][0] = u0; val[s][1] = u1; prv[s][0] = xi[3]; prv[s][1] = xi[4];
+                        lo[s][0] = Rr[34]; hi[s][0] = Rr[35]; lo[s][1] = Rr[36]; hi[s][1] = Rr[37];
+                        const bool keep = act && (k < K);
+                        ua[s] = keep ? u0 : ua[s]; uw[s] = keep ? u1 : uw[s];
+                        const double nx = xi[0] + Rr[0] * xi[2] + Rr[2] * u0 + Rr[4], ny = xi[1] + Rr[1] * xi[2] + Rr[3] * u0 + Rr[5];
+                        xi[2] = xi[2] + dt * u1; xi[0] = nx; xi[1] = ny; xi[3] = u0; xi[4] = u1;
                     }
                 }
-                if (t == top) break; // the totals stay in the lane of the last stage
+                // 4. multiplier chains.  Per stage and component: what the stage makes of the chain state (mu, dir) it is
+                //    handed -- FREE: clears it; BOX: sets it (its own gradient row if the box was tightened by a rate-limited
+                //    run above, else clear); RATE: keeps it if the direction matches and the row is not violated against it.
+                //    Everything that does not depend on the incoming chain state is worked out once per sweep.
+                bool is_free[S][2], is_box[S][2], lower_[S][2];
+                int ns_fb[S][2], cd_box[S][2];
+                double sev_fb[S][2], cm_box[S][2];
 #pragma unroll
-                for (int r = 0; r < 5; ++r) xi[r] = prev_d(xi[r]);
-                chain_mu[0] = prev_d(chain_mu[0]); chain_mu[1] = prev_d(chain_mu[1]);
-                chain_dir[0] = prev_i(chain_dir[0]); chain_dir[1] = prev_i(chain_dir[1]);
-                changes = prev_i(changes); best_sev = prev_d(best_sev);
-                best_j = prev_i(best_j); best_c = prev_i(best_c); best_ns = prev_i(best_ns);
-            }
-            {
-                const int src = (lane & ~15) + top;
-                changes = __shfl(changes, src);
-                best_sev = __shfl(best_sev, src);
-                best_j = __shfl(best_j, src); best_c = __shfl(best_c, src); best_ns = __shfl(best_ns, src);
+                for (int s = 0; s < S; ++s) {
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const int k = j * S + s;
+                        const int sc = st[s][cc];
+                        const double v = val[s][cc], gr = grad[s][cc], l = lo[s][cc], h = hi[s][cc];
+                        const double dv = v - prv[s][cc];
+                        const bool fr = sc == FREE, bx = (sc == BOX_LO || sc == BOX_HI);
+                        const bool lower = (sc == BOX_LO || sc == RATE_LO);
+                        // FREE: the more violated of box and rate limit becomes active
+                        const double vb = fmax(l - v, v - h);
+                        const double vr = (k >= 1) ? fmax(-rmax[cc] - dv, dv - rmax[cc]) : -1.0;
+                        const bool f_box = vb > tol && vb >= vr, f_rate = !f_box && vr > tol;
+                        const int ns_free = f_box ? ((v < l) ? BOX_LO : BOX_HI) : (f_rate ? ((dv < 0.0) ? RATE_LO : RATE_HI) : FREE);
+                        const double sev_free = f_box ? vb : (f_rate ? vr : 0.0);
+                        // BOX: released by the sign of its multiplier, else handed to a violated rate limit
+                        const bool tightened = lower ? (l > -umax[cc] + 1e-12) : (h < umax[cc] - 1e-12);
+                        const bool b_rel = (lower && gr < -tol) || (!lower && gr > tol);
+                        const bool b_rate = !b_rel && k >= 1 && fabs(dv) > rmax[cc] + tol;
+                        const int ns_box = b_rel ? FREE : (b_rate ? ((dv < 0.0) ? RATE_LO : RATE_HI) : sc);
+                        const double sev_box = b_rel ? fabs(gr) : (b_rate ? fabs(dv) - rmax[cc] : 0.0);
+                        is_free[s][cc] = fr; is_box[s][cc] = bx; lower_[s][cc] = lower;
+                        ns_fb[s][cc] = fr ? ns_free : ns_box; sev_fb[s][cc] = fr ? sev_free : sev_box;
+                        cm_box[s][cc] = (bx && tightened) ? gr : 0.0;
+                        cd_box[s][cc] = (bx && tightened) ? (lower ? -1 : 1) : 0;
+                    }
+                }
+                // a rate-limited stage against the chain state it is handed; FREE / BOX stages replace the state
+                auto chain_step = [&](int s, int cc, double& cm, int& cd, int& ns, double& sev) {
+                    const bool lower = lower_[s][cc];
+                    const int md = lower ? -1 : 1;
+                    const bool match = cd == md;
+                    const double cmr = match ? cm : 0.0;
+                    const double g_eff = grad[s][cc] - cmr;
+                    const bool r_viol = lower ? (g_eff < -tol) : (g_eff > tol);
+                    const bool rate = !(is_free[s][cc] || is_box[s][cc]);
+                    const int ns_rate = r_viol ? ((cmr == 0.0) ? FREE : (lower ? BOX_LO : BOX_HI)) : st[s][cc];
+                    ns = rate ? ns_rate : ns_fb[s][cc];
+                    sev = rate ? (r_viol ? fabs(g_eff) : 0.0) : sev_fb[s][cc];
+                    const bool r_keep = match && !r_viol;
+                    cm = rate ? (r_keep ? cm : 0.0) : cm_box[s][cc];
+                    cd = rate ? (r_keep ? cd : 0) : cd_box[s][cc];
+                };
+                // The state a stage is handed is that of the nearest FREE / BOX stage before it ("setter"; the empty chain before
+                // stage 0) if every rate-limited stage in between kept it, else the empty chain -- two scans over the stages
+                // (serial inside the lane, DPP row shifts across): the setter's state, then "kept so far" with restarts.
+                double in_m[S][2];
+                int in_d[S][2];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    bool has = false;
+                    double lm = 0.0;
+                    int ld = 0;
+                    double e_m[S]; int e_d[S]; bool e_has[S]; // setter state before stage s, from inside the lane
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        e_m[s] = lm; e_d[s] = ld; e_has[s] = has;
+                        const bool set = (j * S + s < K) && (is_free[s][cc] || is_box[s][cc]);
+                        has = has || set; lm = set ? cm_box[s][cc] : lm; ld = set ? cd_box[s][cc] : ld;
+                    }
+                    int hc = has ? 1 : 0;
+                    auto copy_level = [&](auto tag) { // (hc, lm, ld) <- the lane's own if it has a setter, else the one from below
+                        constexpr int CTRL = decltype(tag)::value;
+                        const int oh = dppi<CTRL>(0, hc), od = dppi<CTRL>(0, ld);
+                        const double om = dppd<CTRL>(0.0, lm);
+                        const bool take = hc == 0;
+                        lm = take ? om : lm; ld = take ? od : ld; hc = take ? oh : hc;
+                    };
+                    copy_level(std::integral_constant<int, 0x111>{});
+                    copy_level(std::integral_constant<int, 0x112>{});
+                    copy_level(std::integral_constant<int, 0x114>{});
+                    copy_level(std::integral_constant<int, 0x118>{});
+                    const double xm = dppd<0x111>(0.0, lm); // exclusive: what the lanes below leave (lane 0: the empty chain)
+                    const int xd = dppi<0x111>(0, ld);
+                    int acc = 0, before[S]; // bit 1: a setter seen, bit 0: a rate-limited stage after the last setter dropped the chain
+                    auto combine = [](int l, int r) { return (r & 2) ? r : (l | r); };
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        e_m[s] = e_has[s] ? e_m[s] : xm; e_d[s] = e_has[s] ? e_d[s] : xd;
+                        const bool vs = j * S + s < K;
+                        const bool set = is_free[s][cc] || is_box[s][cc];
+                        const bool lower = lower_[s][cc];
+                        const double g_eff = grad[s][cc] - e_m[s];
+                        const bool keeps = (e_d[s] == (lower ? -1 : 1)) && !(lower ? (g_eff < -tol) : (g_eff > tol));
+                        before[s] = acc;
+                        acc = combine(acc, vs ? (set ? 2 : (keeps ? 0 : 1)) : 0);
+                    }
+                    auto and_level = [&](auto tag) {
+                        constexpr int CTRL = decltype(tag)::value;
+                        acc = combine(dppi<CTRL>(0, acc), acc);
+                    };
+                    and_level(std::integral_constant<int, 0x111>{});
+                    and_level(std::integral_constant<int, 0x112>{});
+                    and_level(std::integral_constant<int, 0x114>{});
+                    and_level(std::integral_constant<int, 0x118>{});
+                    const int xacc = dppi<0x111>(0, acc);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const bool kept = (combine(xacc, before[s]) & 1) == 0;
+                        in_m[s][cc] = kept ? e_m[s] : 0.0;
+                        in_d[s][cc] = kept ? e_d[s] : 0;
+                    }
+                }
+                // 5. the verdicts
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        int ns_; double sev_;
+                        double m_ = in_m[s][cc]; int d_ = in_d[s][cc];
+                        chain_step(s, cc, m_, d_, ns_, sev_);
+                        const bool vs = j * S + s < K;
+                        const bool ch = vs && ns_ != st[s][cc];
+                        changes += ch ? 1 : 0;
+                        const bool better = ch && sev_ > best_sev; // first of the most severe, in stage order
+                        best_sev = better ? sev_ : best_sev; best_j = better ? j * S + s : best_j; best_c = better ? cc : best_c;
+                        best_ns = better ? ns_ : best_ns;
+                        st[s][cc] = (ch && act && !single) ? ns_ : st[s][cc];
+                    }
+                }
+                // group totals: any change; the most severe one (ties: the lowest lane, i.e. the earliest stage)
+                {
+                    const unsigned long long mball = __ballot(changes != 0);
+                    changes = (int)((mball >> (lane & ~15)) & 0xFFFFull);
+                    auto red = [&](auto tag) {
+                        constexpr int CTRL = decltype(tag)::value;
+                        const double osev = dppd<CTRL>(-1.0, best_sev);
+                        const int oj = dppi<CTRL>(0, best_j), oc = dppi<CTRL>(0, best_c), on = dppi<CTRL>(0, best_ns);
+                        const bool take = osev >= best_sev && osev > 0.0; // the value from the lower lanes wins ties
+                        best_sev = take ? osev : best_sev; best_j = take ? oj : best_j; best_c = take ? oc : best_c; best_ns = take ? on : best_ns;
+                    };
+                    if (single) {
+                        red(std::integral_constant<int, 0x111>{});
+                        red(std::integral_constant<int, 0x112>{});
+                        red(std::integral_constant<int, 0x114>{});
+                        red(std::integral_constant<int, 0x118>{});
+                        best_sev = dppd<0x15F>(best_sev, best_sev);
+                        best_j = dppi<0x15F>(best_j, best_j); best_c = dppi<0x15F>(best_c, best_c); best_ns = dppi<0x15F>(best_ns, best_ns);
+                    }
+                }
             }
             LSTAMP(2)
             if (act) {
