@@ -64,6 +64,8 @@ struct Dev {
     int* sweeps;         // [B]
     int* status;         // [B]
     double* cmd;         // [B][2] the command a tick publishes: column delay_num of the output
+    double* cmd_host;    // optional: the same, written straight into pinned host memory (alore_ltv_tick: no copy back)
+    int* status_host;    // optional, with cmd_host
     int n_relin, reset;
     long long* stamps;   // diagnostic (ALORE_LTV_STAMPS=1): cycles of robot 0 in rollout / backward / forward / rest
 };
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
     d.sweeps[b] = sweeps;
     d.status[b] = status;
     d.cmd[2 * b] = out[2 * dl]; d.cmd[2 * b + 1] = out[2 * dl + 1];
+    if (d.cmd_host) { d.cmd_host[2 * b] = out[2 * dl]; d.cmd_host[2 * b + 1] = out[2 * dl + 1]; d.status_host[b] = status; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -611,8 +614,9 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                                 double a1[6], f1;
                                 const double inv = pivot_rcp_d(q.H[6][6]);
                                 const bool fr = st1 == FREE, bx = (st1 == BOX_LO || st1 == BOX_HI);
+                                const double invm = fr ? -inv : 0.0, rate1 = (fr || bx) ? 0.0 : 1.0; // masks instead of per-entry selects
 #pragma unroll
-                                for (int kk = 0; kk < 6; ++kk) a1[kk] = fr ? -q.H[6][kk] * inv : ((!bx && kk == 4) ? 1.0 : 0.0);
+                                for (int kk = 0; kk < 6; ++kk) a1[kk] = (kk == 4) ? q.H[6][kk] * invm + rate1 : q.H[6][kk] * invm;
                                 f1 = fr ? -q.h[6] * inv : (bx ? (st1 == BOX_LO ? lo_eff[1] : hi_eff[1]) : (st1 == RATE_LO ? -rmax[1] : rmax[1]));
 #pragma unroll
                                 for (int kk = 0; kk < 6; ++kk) W_[6 + kk] = a1[kk];
@@ -624,9 +628,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                                 double Hk[6], tr[6];
 #pragma unroll
                                 for (int kk = 0; kk < 6; ++kk) { Hk[kk] = q.H[6][kk]; tr[kk] = Hk[kk] + a1[kk] * Hkk; }
-                                double trr[6]; // tr where it can matter for H: the rate-limited case only (exact zero otherwise)
-#pragma unroll
-                                for (int kk = 0; kk < 6; ++kk) trr[kk] = (fr || bx) ? 0.0 : tr[kk];
+
                                 // H += a Hk' + tr a' on the upper triangle.  tr = Hk + a Hkk vanishes for a free component, a vanishes
                                 // for a boxed one, and a rate-limited one has a = e_4: the second term lives in column 4 only
 #pragma unroll
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                                     q.h[r] += a1[r] * hk + tr[r] * f1;
 #pragma unroll
                                     for (int s2 = r; s2 < 6; ++s2) {
-                                        q.H[r][s2] += a1[r] * Hk[s2] + ((s2 == 4) ? trr[r] * a1[4] : 0.0);
+                                        q.H[r][s2] += a1[r] * Hk[s2] + ((s2 == 4) ? tr[r] * rate1 : 0.0);
                                         q.H[s2][r] = q.H[r][s2];
                                     }
                                 }
@@ -643,8 +645,9 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                                 double a0[5], f0;
                                 const double inv = pivot_rcp_d(q.H[5][5]);
                                 const bool fr = st0 == FREE, bx = (st0 == BOX_LO || st0 == BOX_HI);
+                                const double invm = fr ? -inv : 0.0, rate1 = (fr || bx) ? 0.0 : 1.0;
 #pragma unroll
-                                for (int kk = 0; kk < 5; ++kk) a0[kk] = fr ? -q.H[5][kk] * inv : ((!bx && kk == 3) ? 1.0 : 0.0);
+                                for (int kk = 0; kk < 5; ++kk) a0[kk] = (kk == 3) ? q.H[5][kk] * invm + rate1 : q.H[5][kk] * invm;
                                 f0 = fr ? -q.h[5] * inv : (bx ? (st0 == BOX_LO ? lo_eff[0] : hi_eff[0]) : (st0 == RATE_LO ? -rmax[0] : rmax[0]));
 #pragma unroll
                                 for (int kk = 0; kk < 5; ++kk) W_[21 + kk] = a0[kk];
@@ -656,15 +659,13 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
                                 double Hk[5], tr[5];
 #pragma unroll
                                 for (int kk = 0; kk < 5; ++kk) { Hk[kk] = q.H[5][kk]; tr[kk] = Hk[kk] + a0[kk] * Hkk; }
-                                double trr[5];
-#pragma unroll
-                                for (int kk = 0; kk < 5; ++kk) trr[kk] = (fr || bx) ? 0.0 : tr[kk];
+
 #pragma unroll
                                 for (int r = 0; r < 5; ++r) {
                                     p[r] = q.h[r] + a0[r] * hk + tr[r] * f0;
 #pragma unroll
                                     for (int s2 = r; s2 < 5; ++s2) { // as above; a rate-limited u0 has a = e_3
-                                        P[r][s2] = q.H[r][s2] + a0[r] * Hk[s2] + ((s2 == 3) ? trr[r] * a0[3] : 0.0);
+                                        P[r][s2] = q.H[r][s2] + a0[r] * Hk[s2] + ((s2 == 3) ? tr[r] * rate1 : 0.0);
                                         P[s2][r] = P[r][s2];
                                     }
                                 }
@@ -1030,6 +1031,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
             d.sweeps[b] = sweeps;
             d.status[b] = status;
             d.cmd[2 * b] = c0; d.cmd[2 * b + 1] = c1;
+            if (d.cmd_host) { d.cmd_host[2 * b] = c0; d.cmd_host[2 * b + 1] = c1; d.status_host[b] = status; }
         }
     }
 }
@@ -1228,7 +1230,8 @@ int alore_ltv_refs_from_store(alore_ltv_handle h, void* nmpc, int B, double now,
     return ALORE_LTV_OK;
 }
 
-static int ltv_enqueue(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, hipStream_t s)
+static int ltv_enqueue(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, hipStream_t s,
+                       double* cmd_host = nullptr, int* status_host = nullptr)
 {
     double* hn = (double*)h->h_stage;
     std::memcpy(hn, now_state, sizeof(double) * B * 3);
@@ -1238,6 +1241,7 @@ static int ltv_enqueue(alore_ltv_handle h, int B, const double* now_state, int n
     d.now = h->d_now; d.xref = h->d_xref; d.dref = h->d_dref; d.output = h->d_out; d.buff = h->d_buff; d.xopt = h->d_xopt;
     d.ws = h->d_ws; d.st = h->d_st; d.sweeps = h->d_sweeps; d.status = h->d_status; d.cmd = h->d_cmd;
     d.n_relin = n_relin; d.reset = reset;
+    d.cmd_host = cmd_host; d.status_host = status_host;
     d.stamps = h->d_stamps;
     // 16 lanes per robot (stages in registers, sweeps lane by lane) unless ALORE_LTV_KERNEL=thread asks for the
     // one-thread-per-robot kernel (diagnostic A/B)
@@ -1277,12 +1281,15 @@ int alore_ltv_tick(alore_ltv_handle h, int B, const double* now_state, int n_rel
     if (!h || B < 1 || B > h->B || !now_state || n_relin < 1 || !cmd) return lfail(h, ALORE_LTV_E_INVALID, "tick: bad argument");
     LTV_TRY(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    const int rc = ltv_enqueue(h, B, now_state, n_relin, reset, s);
-    if (rc != ALORE_LTV_OK) return rc;
+    // the kernel writes the 20 bytes per robot a tick returns straight into the pinned slab (device alias of the host
+    // pointer): two copy commands and their completion signals less on the critical path of the tick
     double* sc = (double*)h->h_stage + (size_t)B * 3;
     int* st = (int*)(sc + (size_t)B * 2);
-    LTV_TRY(h, hipMemcpyAsync(sc, h->d_cmd, sizeof(double) * B * 2, hipMemcpyDeviceToHost, s));
-    if (status) LTV_TRY(h, hipMemcpyAsync(st, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    void *dsc = nullptr, *dst = nullptr;
+    LTV_TRY(h, hipHostGetDevicePointer(&dsc, sc, 0));
+    LTV_TRY(h, hipHostGetDevicePointer(&dst, st, 0));
+    const int rc = ltv_enqueue(h, B, now_state, n_relin, reset, s, (double*)dsc, (int*)dst);
+    if (rc != ALORE_LTV_OK) return rc;
     LTV_TRY(h, hipStreamSynchronize(s));
     std::memcpy(cmd, sc, sizeof(double) * B * 2);
     if (status) std::memcpy(status, st, sizeof(int) * B);

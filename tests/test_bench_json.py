@@ -63,3 +63,15 @@ def test_short_bench_run_has_no_errors():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     check_line(line)
     assert line["steady_state"]["steps"] >= 200 and "extras" in line
+
+
+def test_the_traffic_record_the_bench_line_quotes_is_valid_json():
+    """bench.py reads profiles/hbm_traffic.json for roofline.traffic and swallows a parse error as 'no record': a
+    hand-edited record with an unescaped quote silently turned the field into null (round 3)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
+    for key, e in rec.items():
+        assert e["bytes_per_launch"] >= e["algorithmic_bytes_per_launch"] > 0, key
+        assert "kernel" in e and "source" in e, key

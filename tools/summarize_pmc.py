@@ -39,9 +39,9 @@ def main(fetch_dir, write_dir, key, alg, source=None):
         "kernel": "nmpc::rti_block_kernel" if KERNEL_IS_BLOCK[0] else "nmpc::rti_kernel",
         "source": SOURCE[0],
         "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (eager launches); "
-               "per-launch mean of nmpc::rti_kernel. bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 reports half the "
-               "bytes of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM section). 76 % of the input bytes "
-               "(W, y, bounds) are read 16 B/lane, the rest (x, u, od, dual) 4 B/lane, for which the x2 over-corrects: "
+               "per-launch mean of the RTI kernel this record names. bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 reports "
+               "half the bytes of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM section). 76 % of the input bytes "
+               "(W, y, bounds) are read 16 B/lane, the rest (x, u, od, dual) in 8- and 12-byte pieces, for which the x2 over-corrects: "
                "the true figure lies between (FETCH+WRITE)*1024 and this number; the kernel reads every input byte "
                "exactly once (W, y by LDS-DMA, 16 B per lane; the iterate, od, bounds and dual in 8- and 12-byte "
                "pieces per lane since round 3).",
