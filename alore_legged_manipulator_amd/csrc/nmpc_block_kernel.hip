@@ -954,7 +954,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
 }
 
 // (L, S) instantiated: (4, 5) (8, 3) (16, 2) (32, 1) for horizons up to 20 / 24 / 32 / 32, (16, 4) up to 64
-bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g)
+bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int B_in_flight)
 {
     if (B <= 0 || N <= 0) return false;
     const int cus = n_cu > 0 ? n_cu : 256;
@@ -964,10 +964,13 @@ bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, L
         // (one wavefront each), pack a large one
         // (measured, profiles/r03_c_block_kernel_experiments.txt: two wavefronts on a SIMD do not issue faster than one,
         // so L = 32 only pays while every wavefront still has a CU to itself)
+        // B_in_flight: problems of all launches that run concurrently with this one (alore_nmpc_rti_many) -- what fills
+        // the chip is their sum
+        const long Bo = (B_in_flight > B) ? B_in_flight : B;
         L = 16;
-        while (L > 4 && (long)(B + 64 / L - 1) / (64 / L) > 4L * cus) L >>= 1;
+        while (L > 4 && (Bo + 64 / L - 1) / (64 / L) > 4L * cus) L >>= 1;
         while (L < 16 && N > L * (L == 4 ? 5 : 3)) L <<= 1;
-        if (L == 16 && N <= 32 && (long)(B + 1) / 2 <= (long)cus) L = 32;
+        if (L == 16 && N <= 32 && (Bo + 1) / 2 <= (long)cus) L = 32;
     }
     int S = 0;
     if (L == 4 && N <= 20) S = 5;

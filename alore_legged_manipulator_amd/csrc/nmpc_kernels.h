@@ -43,7 +43,7 @@ bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, Lau
 hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
 // stage-block kernel (nmpc_block_kernel.hip): L = 4, 8 or 16 lanes per problem, each lane owns ceil(N / L) stages
 int block_lds_floats(int N, int L);
-bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g);
+bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int B_in_flight = 0);
 hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
 
 hipError_t launch_linearize(const alore_nmpc_batch& b, int B, int N, float dt, const alore_nmpc_lin_out& o,

@@ -117,8 +117,13 @@ class BatchedNmpc:
         """n_sqp x (acado_preparationStep + acado_feedbackStep) for the whole batch, one launch."""
         self._check(self.lib.alore_nmpc_rti(self.h, C.byref(self._batches[slot]), self.B, int(n_sqp), self._stream()))
 
+    def set_launch_overlap(self, ways: int) -> None:
+        """launches of independent slots kept in flight at once by rti_range (alore_nmpc_set_launch_overlap; 1 = in order)"""
+        self._check(self.lib.alore_nmpc_set_launch_overlap(self.h, int(ways)))
+
     def rti_range(self, first: int, count: int, n_sqp: int = 1) -> None:
-        """one launch per slot first .. first + count - 1, enqueued back to back by ONE call into the library"""
+        """one launch per slot first .. first + count - 1 by ONE call into the library (independent slots overlap, see
+        alore_nmpc_rti_many)"""
         if not hasattr(self, "_batch_array"):
             self._batch_array = (Batch * self.slots)(*self._batches)
         self._check(self.lib.alore_nmpc_rti_many(self.h, C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch)),

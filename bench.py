@@ -59,6 +59,8 @@ def parse():
                          "of every step in overlapped buckets (full: eager launches), or keep results sharded (none)")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per all-gather bucket")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--overlap", type=int, default=8, choices=(1, 2, 3, 4, 5, 6, 7, 8),
+                    help="independent batches (steps) kept in flight at once by alore_nmpc_rti_many; 1 = strictly in order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
@@ -346,6 +348,7 @@ def main():
     batch = make_batch(B, N, offset=rank * B)
     eng = BatchedNmpc(B, N, device=local_rank, lanes_per_problem=a.lanes, slots=slots,
                       warm_start_steps=a.warm_start_steps)
+    eng.set_launch_overlap(a.overlap)
     gatherer = ResultGatherer(dist, world) if (world > 1 and a.gather != "none") else None
     ge = max(1, a.gather_every)
 
@@ -413,6 +416,17 @@ def main():
     # primary figure: multi-rank runs gather EVERY batch ("both" adds the last-batch-only figure beside it)
     primary = "none" if world == 1 else ("full" if a.gather in ("full", "both") else a.gather)
     elapsed, dev_ms, used_graph = timed_pass(primary, a.steps)
+    info = eng.launch_info()
+    # the same K steps strictly one after the other (one launch in flight): what a single launch costs, and the figure the
+    # rounds before the overlap quoted
+    in_order = None
+    if world == 1 and a.overlap > 1 and a.steps > 0:
+        eng.set_launch_overlap(1)
+        el_o, dms_o, g_o = timed_pass("none", a.steps)
+        eng.set_launch_overlap(a.overlap)
+        in_order = {"value": float(B) * a.steps / el_o, "ms_per_step": el_o / a.steps * 1e3, "kernel_ms_avg": dms_o / a.steps,
+                    "hip_graph": g_o, "lanes_per_problem": eng.launch_info()["lanes_per_problem"],
+                    "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_o / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
     steady = None
     if long_steps:
         el_l, dms_l, g_l = timed_pass("none", long_steps)
@@ -441,7 +455,6 @@ def main():
         dist.all_reduce(nb)
         n_bad = int(nb.item())
 
-    info = eng.launch_info()
     result = None
     if rank == 0:
         total_solves = float(B) * world * a.steps
@@ -479,12 +492,19 @@ def main():
                        "parallelism": f"independent shards x{world}" + (", result all-gather every step" if do_gather else
                                                                          (", result all-gather of the last step" if gather_last else "")),
                        "lanes_per_problem": info["lanes_per_problem"], "threads_per_block": info["threads_per_block"],
-                       "lds_bytes_per_block": info["lds_bytes_per_block"], "hip_graph": used_graph},
+                       "lds_bytes_per_block": info["lds_bytes_per_block"], "hip_graph": used_graph,
+                       "launches_in_flight": (a.overlap if not do_gather else 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernel": "nmpc::rti_block_kernel" if (info["lanes_per_problem"] & 0x100) else "nmpc::rti_kernel",
                          "kernel_ms_avg": kern_ms,
+                         "launches_in_flight": (a.overlap if not do_gather else 1),
+                         "note": ("achieved = algorithmic bytes of one launch / (HIP-event time of the K launches / K). With "
+                                  "launches_in_flight > 1 consecutive steps (independent batches) overlap on forked streams, so a "
+                                  "profiler's per-kernel duration is about launches_in_flight x kernel_ms_avg; in_order has the "
+                                  "one-launch-at-a-time figures" if a.overlap > 1 else
+                                  "achieved = algorithmic bytes of one launch / (HIP-event time of the K launches / K)"),
                          "algorithmic_bytes_per_solve": algorithmic_bytes_per_solve(N),
                          "fp32_frac": value / world * flops_per_solve / (FP32_PEAK_TFLOPS * 1e12)},
             "unsolved_problems": n_bad, "working_set_iters_mean": n_iter_mean,
@@ -493,6 +513,8 @@ def main():
             result["gather_last"] = alt
         if steady is not None:
             result["steady_state"] = steady
+        if in_order is not None:
+            result["in_order"] = in_order
 
     # ---- extras on rank 0 of a single-GPU run: latency, converged solves, large batch, CPU baseline
     if rank == 0 and world == 1 and not a.no_extras:
