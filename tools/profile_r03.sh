@@ -11,6 +11,7 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_driver_flags.json 2>> $OUT/bench.err
 python bench.py --workload whole_body > $OUT/bench_whole_body.json 2> $OUT/bench_wb.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace_in_order -o trace -- python3 bench.py --no-cpu-baseline --no-extras --overlap 1 > $OUT/bench_in_order_under_rocprof.json 2>> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python3 bench.py --no-cpu-baseline --no-extras --no-graph --steps 20 --warmup 5 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python3 bench.py --no-cpu-baseline --no-extras --no-graph --steps 20 --warmup 5 > /dev/null 2> $OUT/pmc_write.err
 tools/profile_sq.sh $TAG 4096 > /dev/null 2>&1

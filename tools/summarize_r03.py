@@ -19,7 +19,7 @@ def run(args, to):
     open(os.path.join(dst, to), "w").write(r.stdout + (("\n# stderr:\n" + r.stderr[-2000:]) if r.returncode else ""))
 
 
-for name, d in (("kernel_stats", "trace"), ("wb_kernel_stats", "wb_trace"), ("ltv_kernel_stats", "ltv_trace"),
+for name, d in (("kernel_stats", "trace"), ("kernel_stats_in_order", "trace_in_order"), ("wb_kernel_stats", "wb_trace"), ("ltv_kernel_stats", "ltv_trace"),
                 ("backend_kernel_stats", "be_trace"), ("extras_kernel_stats", "extras_trace")):
     if os.path.isdir(os.path.join(out, d)):
         subprocess.run([sys.executable, os.path.join(here, "summarize_prof.py"), os.path.join(out, d), os.path.join(dst, f"{tag}_{name}.txt")])
@@ -64,7 +64,7 @@ for d, pat, name in (("be_pmc", "%backend_kernel%", "backend"), ("ltv_pmc", "%ge
         json.dump({"valu_instructions_per_wavefront": vals["SQ_INSTS_VALU"] / vals["SQ_WAVES"], "wavefronts": vals["SQ_WAVES"],
                    "source": f"profiles/{tag}_backend_counters.txt (SQ_INSTS_VALU / SQ_WAVES of backend::backend_kernel, tools/be_profile.py)"},
                   open(os.path.join(dst, "backend_valu.json"), "w"), indent=1)
-for f in ("bench.json", "bench_driver_flags.json", "bench_whole_body.json", "bench_under_rocprof.json", "wb_run.txt", "ltv_run.txt", "be_run.txt"):
+for f in ("bench.json", "bench_driver_flags.json", "bench_whole_body.json", "bench_under_rocprof.json", "bench_in_order_under_rocprof.json", "wb_run.txt", "ltv_run.txt", "be_run.txt"):
     p = os.path.join(out, f)
     if os.path.exists(p):
         open(os.path.join(dst, f"{tag}_{f}"), "w").write(open(p).read())
