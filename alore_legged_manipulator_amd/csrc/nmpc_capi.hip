@@ -184,6 +184,16 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
         delete h;
         return ALORE_NMPC_E_HIP;
     }
+    // streams / events of alore_nmpc_rti_many: made here, not at first use, so that a first use inside a stream capture
+    // creates nothing
+    bool forks_ok = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) == hipSuccess;
+    for (int w = 0; w < 7 && forks_ok; ++w)
+        forks_ok = hipStreamCreateWithFlags(&h->side[w], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&h->join_ev[w], hipEventDisableTiming) == hipSuccess;
+    if (!forks_ok) {
+        (void)alore_nmpc_destroy(h);
+        return ALORE_NMPC_E_HIP;
+    }
     const char* st = std::getenv("ALORE_NMPC_STAMPS");
     h->stamps = st && st[0] == '1';
     *out = h;
@@ -496,13 +506,6 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     }
     if (ways > 1) {
         HIP_TRY(h, hipSetDevice(h->cfg.device));
-        if (!h->fork_ev) {
-            HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-            for (int w = 0; w < 7; ++w) {
-                HIP_TRY(h, hipStreamCreateWithFlags(&h->side[w], hipStreamNonBlocking));
-                HIP_TRY(h, hipEventCreateWithFlags(&h->join_ev[w], hipEventDisableTiming));
-            }
-        }
         hipStream_t main_s = (hipStream_t)stream;
         HIP_TRY(h, hipEventRecord(h->fork_ev, main_s));
         for (int w = 1; w < ways; ++w) HIP_TRY(h, hipStreamWaitEvent(h->side[w - 1], h->fork_ev, 0));
