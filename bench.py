@@ -12,12 +12,17 @@ started from the cold start of MpcWrapper::solve (x <- x0 replicated, u <- 0).
 Inputs are synthetic (alore_legged_manipulator_amd/scenarios.py),
 resident in HBM before the timed region; every timed step works on its own
 fresh copy of the batch ("slot") so that all steps do identical work and read
-their inputs from HBM rather than from cache.
+their inputs from HBM rather than from cache.  The steps are therefore
+independent batches, and alore_nmpc_rti_many keeps --overlap of them in flight
+(forked streams); `in_order` in the line is the same run with
+one launch at a time.
 
 Multi-GPU (weak scaling): every rank owns its own B problems (block partition
-of the global index, no data-path communication); the result trajectories
-(x, u, status, kkt) are collected with RCCL all-gathers issued asynchronously in
-buckets of several steps, all completed inside the timed region.
+of the global index).  The path has no exchange step, so the headline keeps the
+results sharded -- no data-path collective; passes in which every rank also
+receives every trajectory (x, u, status, kkt by RCCL all-gather: of the last
+batch, or of every batch in asynchronous buckets) are reported beside it under
+`result_exchange`.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).
 """
@@ -55,8 +60,9 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = auto)")
     ap.add_argument("--warm-start-steps", type=int, default=-1, help="working-set prediction steps (-1 = library default)")
     ap.add_argument("--gather", choices=("last", "full", "none", "both"), default="both",
-                    help="multi-GPU: all-gather the trajectories of the last timed step inside the timed region (default), "
-                         "of every step in overlapped buckets (full: eager launches), or keep results sharded (none)")
+                    help="multi-GPU: the headline keeps results sharded (the path has no exchange step); beside it, passes that "
+                         "all-gather the trajectories of the last timed step (last), of every step in overlapped buckets with "
+                         "eager launches (full), both (default) or none")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per all-gather bucket")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--overlap", type=int, default=8, choices=(1, 2, 3, 4, 5, 6, 7, 8),
@@ -413,8 +419,10 @@ def main():
     def timed_pass(mode, K):
         return shard_mod.timed_pass(eng, batch, mode, K, a.warmup, ge, gatherer, hooks, world)
 
-    # primary figure: multi-rank runs gather EVERY batch ("both" adds the last-batch-only figure beside it)
-    primary = "none" if world == 1 else ("full" if a.gather in ("full", "both") else a.gather)
+    # primary figure: the shards are independent (robots do not interact inside the solve), so there is no data-path
+    # collective -- every rank steps its own problems, the barriers and the max over the ranks of the contract remain.
+    # Passes WITH a result exchange (every rank receives every trajectory) are reported beside it (`result_exchange`)
+    primary = "none"
     elapsed, dev_ms, used_graph = timed_pass(primary, a.steps)
     info = eng.launch_info()
     # the same K steps strictly one after the other (one launch in flight): what a single launch costs, and the figure the
@@ -433,17 +441,24 @@ def main():
         steady = {"steps": long_steps, "value": float(B) * long_steps / el_l, "ms_per_step": el_l / long_steps * 1e3,
                   "kernel_ms_avg": dms_l / long_steps, "hip_graph": g_l,
                   "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_l / long_steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    do_gather, gather_last = primary == "full", primary == "last"
-    alt = None
-    if world > 1 and a.gather == "both":
-        # secondary figure: it must never cost the primary one (a rank that fails here would hang the others in the
-        # collective, so the decision to run it is taken before, not inside, and errors are reported in the line)
-        try:
-            el2, dms2, g2 = timed_pass("last", a.steps)
-            alt = {"gather": "last batch only", "value": float(B) * world * a.steps / el2, "ms_per_step": el2 / a.steps * 1e3,
-                   "kernel_ms_avg": dms2 / a.steps, "hip_graph": g2}
-        except Exception as e:  # pragma: no cover
-            alt = {"gather": "last batch only", "error": f"{type(e).__name__}: {e}"}
+    exchange = None
+    if world > 1 and a.gather != "none":
+        # secondary figures: they must never cost the primary one (a rank that fails here would hang the others in the
+        # collective, so the decision to run them is taken before, not inside, and errors are reported in the line)
+        exchange = {}
+        for mode, label in (("last", "last_batch"), ("full", "every_batch")):
+            if a.gather not in (mode, "both"):
+                continue
+            try:
+                el2, dms2, g2 = timed_pass(mode, a.steps)
+                exchange[label] = {"value": float(B) * world * a.steps / el2, "ms_per_step": el2 / a.steps * 1e3,
+                                   "kernel_ms_avg": dms2 / a.steps, "hip_graph": g2,
+                                   "what": ("x, u, status, kkt of the last timed batch all-gathered to every rank inside the timed region"
+                                            if mode == "last" else
+                                            f"x, u, status, kkt of EVERY timed batch all-gathered to every rank in buckets of {ge} steps, "
+                                            "eager launches in order")}
+            except Exception as e:  # pragma: no cover
+                exchange[label] = {"error": f"{type(e).__name__}: {e}"}
 
     # every timed step must have solved every problem
     st = eng.ts["status"][a.warmup:a.warmup + a.steps]
@@ -462,7 +477,7 @@ def main():
         ms_per_step = elapsed / a.steps * 1e3
         # average launch duration of the dominant kernel: HIP events on the launch stream around the K back-to-back
         # launches (multi-rank: of the pass without collectives between the launches)
-        kern_ms = (alt["kernel_ms_avg"] if (alt is not None and "kernel_ms_avg" in alt) else dev_ms / a.steps)
+        kern_ms = dev_ms / a.steps
         bytes_per_launch = algorithmic_bytes_per_solve(N) * B
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: collected by rocprofv3 in separate --pmc passes over this same
@@ -489,17 +504,16 @@ def main():
                                    "one real-time iteration (prepare+feedback) per problem from the "
                                    "MpcWrapper::solve cold start, full reference I/O contract",
                        "batch_per_gpu": B, "global_batch": B * world, "horizon": N, "dt": 0.01,
-                       "parallelism": f"independent shards x{world}" + (", result all-gather every step" if do_gather else
-                                                                         (", result all-gather of the last step" if gather_last else "")),
+                       "parallelism": f"independent shards x{world}, results stay sharded",
                        "lanes_per_problem": info["lanes_per_problem"], "threads_per_block": info["threads_per_block"],
                        "lds_bytes_per_block": info["lds_bytes_per_block"], "hip_graph": used_graph,
-                       "launches_in_flight": (a.overlap if not do_gather else 1)},
+                       "launches_in_flight": a.overlap},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernel": "nmpc::rti_block_kernel" if (info["lanes_per_problem"] & 0x100) else "nmpc::rti_kernel",
                          "kernel_ms_avg": kern_ms,
-                         "launches_in_flight": (a.overlap if not do_gather else 1),
+                         "launches_in_flight": a.overlap,
                          "note": ("achieved = algorithmic bytes of one launch / (HIP-event time of the K launches / K). With "
                                   "launches_in_flight > 1 consecutive steps (independent batches) overlap on forked streams, so a "
                                   "profiler's per-kernel duration is about launches_in_flight x kernel_ms_avg; in_order has the "
@@ -509,8 +523,8 @@ def main():
                          "fp32_frac": value / world * flops_per_solve / (FP32_PEAK_TFLOPS * 1e12)},
             "unsolved_problems": n_bad, "working_set_iters_mean": n_iter_mean,
         }
-        if alt is not None:
-            result["gather_last"] = alt
+        if exchange:
+            result["result_exchange"] = exchange
         if steady is not None:
             result["steady_state"] = steady
         if in_order is not None:
