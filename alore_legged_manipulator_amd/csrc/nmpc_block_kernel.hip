@@ -213,7 +213,7 @@ int block_lds_floats(int N, int L)
     return ((G * 25 * N + 255) & ~255) + ((G * 5 * N + 255) & ~255);
 }
 
-template <int L, int S, bool DIAG, bool STAMP>
+template <int L, int S, bool DIAG, bool STAMP, bool ONCE>
 __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
 {
     extern __shared__ float4 lds_raw[];
@@ -325,7 +325,10 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     float kkt = 0.0f;
     long long t_b = 0, t_f = 0, t_pg = 0;
 
-    for (int sqp = 0; sqp < p.n_sqp; ++sqp) {
+    // ONCE: one real-time iteration per launch (the control tick): no loop, so the members that only feed the linearisation
+    // (od, the raw bounds) are dead after phase A instead of live across the whole body
+    const int n_sqp = ONCE ? 1 : p.n_sqp;
+    for (int sqp = 0; sqp < n_sqp; ++sqp) {
         // ---- phase A: linearise, Gauss-Newton cost, bounds on the step, working-set guess from the dual
         int infeasible = 0;
 #pragma unroll
@@ -997,14 +1000,17 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
 {
     const bool stamp = p.stamps != nullptr;
     const bool diag = stamp || p.b.kkt != nullptr || p.b.obj != nullptr;
+    const bool once = p.n_sqp == 1;
     const void* fn = nullptr;
     int v = -1;
-#define PICK(LL, SS, idx)                                                                        \
-    if (g.L == LL && g.RS == SS) {                                                               \
-        v = idx * 3 + (stamp ? 2 : (diag ? 0 : 1));                                              \
-        fn = stamp ? (const void*)rti_block_kernel<LL, SS, true, true>                           \
-                   : (diag ? (const void*)rti_block_kernel<LL, SS, true, false>                  \
-                           : (const void*)rti_block_kernel<LL, SS, false, false>);               \
+#define PICK(LL, SS, idx)                                                                                 \
+    if (g.L == LL && g.RS == SS) {                                                                        \
+        v = idx * 5 + (stamp ? 4 : ((diag ? 0 : 1) + (once ? 2 : 0)));                                    \
+        fn = stamp ? (const void*)rti_block_kernel<LL, SS, true, true, false>                             \
+                   : (diag ? (once ? (const void*)rti_block_kernel<LL, SS, true, false, true>             \
+                                   : (const void*)rti_block_kernel<LL, SS, true, false, false>)           \
+                           : (once ? (const void*)rti_block_kernel<LL, SS, false, false, true>            \
+                                   : (const void*)rti_block_kernel<LL, SS, false, false, false>));        \
     }
     PICK(4, 5, 0)
     PICK(8, 3, 1)
@@ -1017,7 +1023,7 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     dev &= 15;
-    static size_t configured[16][15] = {{0}};
+    static size_t configured[16][25] = {{0}};
     if (g.lds_bytes > configured[dev][v]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
         if (e != hipSuccess) return e;

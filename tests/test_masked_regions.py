@@ -46,7 +46,7 @@ def test_no_spill_traffic_inside_the_masked_backward_sweep():
             if "s_endpgm" in ln:
                 name = None
     masked = {k: v for k, v in kernels.items() if "ILi16ELi2E" in k or "ILi32ELi1E" in k}
-    assert len(masked) == 6, sorted(kernels)          # diag / no-diag / stamped instantiations of (16, 2) and (32, 1)
+    assert len(masked) == 10, sorted(kernels)         # diag / no-diag, each also as the single-iteration build, and the stamped one, of (16, 2) and (32, 1)
     for k, lines in masked.items():
         windows, cur = [], None
         for ln in lines:
