@@ -54,7 +54,7 @@ struct alore_nmpc_solver {
     char* stage_down = nullptr;
     size_t stage_up_cap = 0, stage_down_cap = 0;
     // alore_nmpc_rti_many: launches of independent batches in flight at once (side streams forked from the caller's)
-    int overlap = 4;
+    int overlap = 8;
     int in_flight_B = 0; // set by alore_nmpc_rti_many around its launches: problems of the launches that overlap
     hipStream_t side[7] = {};
     hipEvent_t fork_ev = nullptr, join_ev[7] = {};
