@@ -460,7 +460,11 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
     double* bf = d.buff + (size_t)b * (dl > 0 ? dl : 1) * 2;
     const double* xrg = d.xref + (size_t)b * T * 3;
     const double* drg = d.dref + (size_t)b * T * 2;
-    const double* nowp = d.now + (size_t)b * 3; // re-read where needed: three registers less across the sweeps
+    // the measured state: read once from wherever the host put it (device memory, or the pinned slab itself on the tick
+    // path: one trip over the bus) into LDS behind the records, re-read from there where needed (no registers held)
+    double* nowp = lds_rec + (size_t)K * REC_STRIDE + g * 3;
+    if (j < 3) nowp[j] = d.now[(size_t)b * 3 + j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // the lane's stages: k = j S + s (valid while k < K); output column of stage k is dl + k
     int st[S][2];
@@ -1235,27 +1239,35 @@ static int ltv_enqueue(alore_ltv_handle h, int B, const double* now_state, int n
 {
     double* hn = (double*)h->h_stage;
     std::memcpy(hn, now_state, sizeof(double) * B * 3);
-    LTV_TRY(h, hipMemcpyAsync(h->d_now, hn, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
     ltv::Dev d{};
     d.c = h->cfg; d.B = B; d.stride = h->B;
-    d.now = h->d_now; d.xref = h->d_xref; d.dref = h->d_dref; d.output = h->d_out; d.buff = h->d_buff; d.xopt = h->d_xopt;
+    static const char* which = std::getenv("ALORE_LTV_KERNEL");
+    const bool thread_kernel = which && which[0] == 't';
+    if (cmd_host && !thread_kernel) { // tick path: the lanes kernel reads the states once, straight from the pinned slab
+        void* dn = nullptr;
+        LTV_TRY(h, hipHostGetDevicePointer(&dn, hn, 0));
+        d.now = (const double*)dn;
+    } else {
+        LTV_TRY(h, hipMemcpyAsync(h->d_now, hn, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
+        d.now = h->d_now;
+    }
+    d.xref = h->d_xref; d.dref = h->d_dref; d.output = h->d_out; d.buff = h->d_buff; d.xopt = h->d_xopt;
     d.ws = h->d_ws; d.st = h->d_st; d.sweeps = h->d_sweeps; d.status = h->d_status; d.cmd = h->d_cmd;
     d.n_relin = n_relin; d.reset = reset;
     d.cmd_host = cmd_host; d.status_host = status_host;
     d.stamps = h->d_stamps;
     // 16 lanes per robot (stages in registers, sweeps lane by lane) unless ALORE_LTV_KERNEL=thread asks for the
     // one-thread-per-robot kernel (diagnostic A/B)
-    static const char* which = std::getenv("ALORE_LTV_KERNEL");
     const int K = h->cfg.predict_steps - h->cfg.delay_num;
-    if (which && which[0] == 't')
+    if (thread_kernel)
         hipLaunchKernelGGL(ltv::get_cmd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d);
     else if (K <= 32)
-        hipLaunchKernelGGL(ltv::get_cmd_lanes_kernel<2>, dim3((B + 3) / 4), dim3(64), (size_t)K * ltv::REC_STRIDE * sizeof(double), s, d);
+        hipLaunchKernelGGL(ltv::get_cmd_lanes_kernel<2>, dim3((B + 3) / 4), dim3(64), ((size_t)K * ltv::REC_STRIDE + 16) * sizeof(double), s, d);
     else {
-        const size_t lds = (size_t)K * ltv::REC_STRIDE * sizeof(double);
+        const size_t lds = ((size_t)K * ltv::REC_STRIDE + 16) * sizeof(double);
         static bool raised = false;
         if (!raised) {
-            LTV_TRY(h, hipFuncSetAttribute((const void*)ltv::get_cmd_lanes_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * ltv::REC_STRIDE * 8));
+            LTV_TRY(h, hipFuncSetAttribute((const void*)ltv::get_cmd_lanes_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (64 * ltv::REC_STRIDE + 16) * 8));
             raised = true;
         }
         hipLaunchKernelGGL(ltv::get_cmd_lanes_kernel<4>, dim3((B + 3) / 4), dim3(64), lds, s, d);
