@@ -499,7 +499,12 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
         bool distinct = true; // a batch listed twice (two consecutive iterations of the same problems) must stay in order
         for (int i = 0; i < count && distinct; ++i)
             for (int k = i + 1; k < count; ++k)
-                if (batches[i].x == batches[k].x || batches[i].u == batches[k].u || batches[i].dual == batches[k].dual) { distinct = false; break; }
+                if (batches[i].x == batches[k].x || batches[i].u == batches[k].u || batches[i].dual == batches[k].dual ||
+                    batches[i].status == batches[k].status || batches[i].n_iter == batches[k].n_iter ||
+                    (batches[i].kkt && batches[i].kkt == batches[k].kkt) || (batches[i].obj && batches[i].obj == batches[k].obj)) {
+                    distinct = false; // shared output arrays: keep the order the caller wrote
+                    break;
+                }
         if (!distinct) ways = 1;
     } else {
         ways = 1;
