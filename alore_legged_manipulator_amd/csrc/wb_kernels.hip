@@ -59,9 +59,15 @@ struct StageArgs {
     const double* xref = nullptr; // [B][N+1][48]  with uref and vec: the stage's right-hand sides for the Riccati kernel
     const double* uref = nullptr; // [B][N][30]
     float* vec = nullptr;         // [n][160]: defect f(x_k, u_k) - x_{k+1} | x_k - xref_k | u_k (32) | u_k - uref_k (32), float32
+    // contact-consistency penalty 1/2 rho |J_c(q_k) v_k|^2 over the stance feet (alore_wb_set_contact_penalty): per stage the
+    // scaled Jacobian sqrt(rho) J_c (rows of swing feet zero) [12][24] and the Gauss-Newton gradient rho J_c' (J_c v_k) [24]
+    float* pen = nullptr;         // [n][PEN]
+    double rho = 0.0;
+    const unsigned char* stance = nullptr; // [n][4]
 };
 
 constexpr int VEC = 160; // floats per stage in StageArgs::vec
+constexpr int PEN = 12 * 24 + 24; // floats per stage in StageArgs::pen
 constexpr int MS = 25; // row stride of M / column stride of D in LDS (doubles)
 
 struct StageLds {
@@ -76,6 +82,7 @@ struct StageLds {
     double xn[NX], xr[NX], ur[32]; // x_{k+1}, xref_k, uref_k: fetched with the stage's inputs, used for StageArgs::vec at the end
 };
 
+template <bool PENALTY>
 __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
 {
     __shared__ StageLds S;
@@ -147,6 +154,29 @@ __global__ __launch_bounds__(64, 2) void stage_kernel(StageArgs g)
     WB_STAMP(g.stamps, 2)
             if (g.a64 && lane < NV) g.a64[(size_t)item * NV + lane] = S.a[lane];
             if (lane < NV) S.vn[lane] = S.v[lane] + g.dt * S.a[lane];
+            if (PENALTY) { // the foot columns of pass 0 ARE the contact Jacobian: D[45 + i][r] = J_c[i][r] (world-frame point velocity)
+                float* pk = g.pen + (size_t)item * PEN;
+                const unsigned char* stc = g.stance ? g.stance + (size_t)item * 4 : nullptr;
+                double* rt = &S.Gq[0][0]; // 12 doubles of scratch: Gq is written after pass 1
+                if (lane < 12) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NV; ++r) acc += S.D[(45 + lane) * MS + r] * S.v[r];
+                    rt[lane] = (!stc || stc[lane / 3]) ? g.rho * acc : 0.0;
+                }
+                __syncthreads();
+                if (lane < NV) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) acc += S.D[(45 + i) * MS + lane] * rt[i];
+                    pk[288 + lane] = (float)acc;
+                }
+                const double sq = sqrt(g.rho);
+                for (int e = lane; e < 288; e += 64) {
+                    const int i = e / 24, r = e % 24;
+                    pk[e] = (!stc || stc[i / 3]) ? (float)(sq * S.D[(45 + i) * MS + r]) : 0.f;
+                }
+            }
             __syncthreads();
     WB_STAMP(g.stamps, 3)
         }
@@ -374,6 +404,7 @@ struct RicArgs {
     int cones = 0;       // 1: contact constraints on the 12 foot-force inputs inside the sweep (alore_wb.h)
     float mu = 0.f;      // friction coefficient of the pyramid
     const unsigned char* stance = nullptr; // [B][N][4] 1 = foot in contact at that stage; null = every foot, every stage
+    const float* pen = nullptr;            // [B][N][PEN] contact-consistency penalty written by the stage kernel (StageArgs::pen)
 };
 
 // 44.2 KB: three workgroups per CU (the register budget of the kernel asks for no more).  P A, Qxx, the gains K0 / R / K
@@ -501,6 +532,7 @@ __device__ constexpr int SYM3_I[6] = {0, 0, 0, 1, 1, 2}, SYM3_J[6] = {0, 1, 2, 1
 
 constexpr int RIC_WAVES = 4, RIC_THREADS = 64 * RIC_WAVES, RIC_LAST = 64 * (RIC_WAVES - 1); // RIC_LAST: first thread of the last wave
 
+template <bool PENALTY>
 __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -527,7 +559,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     const int ia0 = tid, ia1 = tid + RIC_THREADS, ia2 = (tid + 2 * RIC_THREADS) < 48 * 12 ? tid + 2 * RIC_THREADS : 48 * 12 - 1;
     const int ib0 = tid, ib1 = (tid + RIC_THREADS) < 48 * 8 ? tid + RIC_THREADS : 48 * 8 - 1;
     float4 pa0, pa1, pa2, pb0, pb1;
-    float pvec;
+    float pvec, ppen = 0.f;
 #define RIC_REQUEST_A(kk)                                                                                    \
     {                                                                                                        \
         const float4* Ag_ = reinterpret_cast<const float4*>(g.A32 + ((size_t)b * N + (kk)) * NX * NX);       \
@@ -538,6 +570,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         const float4* Bg_ = reinterpret_cast<const float4*>(g.B32 + ((size_t)b * N + (kk)) * NX * NUP);      \
         pb0 = Bg_[ib0]; pb1 = Bg_[ib1];                                                                      \
         pvec = g.vec[((size_t)b * N + (kk)) * VEC + vi];                                                     \
+        if (PENALTY && tid >= 72 && tid < 96) ppen = g.pen[((size_t)b * N + (kk)) * PEN + 288 + tid - 72];     \
     }
 #define RIC_PUT4(base, ld, per_row, idx, v)                                                                  \
     { float* dst_ = (base) + ((idx) / (per_row)) * (ld) + 4 * ((idx) % (per_row)); dst_[0] = (v).x; dst_[1] = (v).y; dst_[2] = (v).z; dst_[3] = (v).w; }
@@ -552,7 +585,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         if (tid + RIC_THREADS < 48 * 8) RIC_PUT4(S.B, LDU, 8, ib1, pb1)                                      \
         /* d | gx = Q (x - xref) | current input (for the torque limits; dxn is free during the backward sweep) | gu = R (u - uref) */ \
         if (tid < 48) S.d[tid] = pvec;                                                                       \
-        else if (tid < 96) S.gx[tid - 48] = S.wq[tid - 48] * pvec;                                           \
+        else if (tid < 96) S.gx[tid - 48] = S.wq[tid - 48] * pvec + ppen; /* + rho J_c' (J_c v) on the velocities */ \
         else if (tid < 128) S.dxn[tid - 96] = pvec;                                                          \
         else if (tid < 160) S.gu[tid - 128] = S.wr[tid - 128] * pvec;                                        \
     }
@@ -797,12 +830,33 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
                     if (any_clamp && clampm[row] != 0.f) kt[t][r] = 0.f; // clamped inputs do not react to dx
                     Kg[row * 48 + j0 + c16] = kt[t][r];
                 }
+            // contact-consistency penalty: + rho J_c' J_c on the velocity block (state indices 24 .. 47), i.e. on the tiles
+            // (1,1) (1,2) (2,2).  The operands come straight from HBM into the lanes: lane (c16, q4) supplies
+            // Jext[4 t + q4][16 m + c16], Jext = [0 (12 x 24) | sqrt(rho) J_c], for column blocks m = 1, 2
+            float ja[3] = {0.f, 0.f, 0.f}, jb[3] = {0.f, 0.f, 0.f};
+            if (PENALTY && role >= 2) {
+                const float* Jg = g.pen + ((size_t)b * N + k) * PEN;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int kk = 4 * t + q4;
+                    ja[t] = (c16 >= 8) ? Jg[kk * 24 + c16 - 8] : 0.f;
+                    jb[t] = Jg[kk * 24 + 8 + c16];
+                }
+            }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int i0 = n == 0 ? j0 : ((role + 1) % 3) * 16;
                 f4 acc = qxx[n];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc = mfma_acc_regb<true>(S.Qux, LDX, i0, 16 * t, kt[t], acc);
+                if (PENALTY && role >= 2 && (n == 0 || role == 3)) { // role 2: (1,1); role 3: (2,2) and (1,2)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const float av = (role == 2 || n == 1) ? ja[t] : jb[t]; // rows: block 1 for (1,1) and (1,2), block 2 for (2,2)
+                        const float bv = (role == 2) ? ja[t] : jb[t];          // columns: the wavefront's own block
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    }
+                }
                 tile_store<true>(acc, i0, j0, S.P, LDX, nullptr, 0, 1.f, S.wq);
             }
         } else {
@@ -980,6 +1034,8 @@ struct alore_wb_solver {
     int cones = 0;                 // alore_wb_set_contact_constraints
     float mu = 0.7f;
     unsigned char* d_stance = nullptr; // [max_problems][N][4], null = all stance
+    float* d_pen = nullptr;            // [max_problems][N][PEN], allocated by alore_wb_set_contact_penalty
+    double rho = 0.0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_lin = -1.f, ms_ric = -1.f;
     bool timed = false;
@@ -1087,7 +1143,7 @@ int alore_wb_destroy(alore_wb_handle h)
             std::fprintf(stderr, "\n");
         }
     }
-    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance};
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance, h->d_pen};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -1148,7 +1204,7 @@ int alore_wb_forward_dynamics(alore_wb_handle h, int n, const double* q, const d
     WB_TRY(h, hipMemcpy(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
     WB_TRY(h, hipMemcpy(du, u, sizeof(double) * n * wb::NU, hipMemcpyHostToDevice));
     wb::StageArgs g{dx, du, 1, n, h->cfg.dt, dA, dB, dn, nullptr, nullptr, dM, da, nullptr};
-    wb::stage_kernel<<<n, 64>>>(g);
+    wb::stage_kernel<false><<<n, 64>>>(g);
     WB_TRY(h, hipGetLastError());
     if (M) WB_TRY(h, hipMemcpy(M, dM, sizeof(double) * n * 576, hipMemcpyDeviceToHost));
     if (a) WB_TRY(h, hipMemcpy(a, da, sizeof(double) * n * 24, hipMemcpyDeviceToHost));
@@ -1178,6 +1234,18 @@ int alore_wb_set_contact_constraints(alore_wb_handle h, int enable, double mu)
     if (!h || (enable && !(mu > 0.0))) return fail(h, ALORE_WB_E_INVALID, "set_contact_constraints: bad argument");
     h->cones = enable ? 1 : 0;
     if (enable) h->mu = (float)mu;
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_contact_penalty(alore_wb_handle h, double rho)
+{
+    if (!h || !(rho >= 0.0) || !(rho < 1e12)) return fail(h, ALORE_WB_E_INVALID, "set_contact_penalty: rho must be finite and >= 0");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    WB_TRY(h, hipDeviceSynchronize());
+    if (rho > 0.0 && !h->d_pen) {
+        if (zalloc(&h->d_pen, (size_t)h->cfg.max_problems * h->cfg.horizon * wb::PEN) != hipSuccess) return fail(h, ALORE_WB_E_NOMEM, "set_contact_penalty: device memory");
+    }
+    h->rho = rho;
     return ALORE_WB_OK;
 }
 
@@ -1272,7 +1340,7 @@ int alore_wb_linearize(alore_wb_handle h, int B, double* A, double* Bm, double* 
     if ((A && !dA) || (Bm && !dB)) return fail(h, ALORE_WB_E_NOMEM, "linearize: hipMalloc");
     wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, dA, dB, nullptr, nullptr, nullptr};
     WB_TRY(h, hipDeviceSynchronize()); // the iterate may still be written by work on the caller's stream
-    wb::stage_kernel<<<(unsigned)n, 64>>>(g);
+    wb::stage_kernel<false><<<(unsigned)n, 64>>>(g);
     WB_TRY(h, hipGetLastError());
     if (A) WB_TRY(h, hipMemcpy(A, dA, sizeof(double) * n * wb::NX * wb::NX, hipMemcpyDeviceToHost));
     if (Bm) WB_TRY(h, hipMemcpy(Bm, dB, sizeof(double) * n * wb::NX * wb::NU, hipMemcpyDeviceToHost));
@@ -1290,18 +1358,24 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
     const size_t n = (size_t)B * N;
     static bool lds_set[16] = {false};
     if (!lds_set[h->cfg.device & 15]) {
-        WB_TRY(h, hipFuncSetAttribute((const void*)wb::riccati_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wb::RicLds)));
+        WB_TRY(h, hipFuncSetAttribute((const void*)wb::riccati_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wb::RicLds)));
+        WB_TRY(h, hipFuncSetAttribute((const void*)wb::riccati_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wb::RicLds)));
         lds_set[h->cfg.device & 15] = true;
     }
     for (int it = 0; it < n_iter; ++it) {
         const bool last = it == n_iter - 1;
         if (last) WB_TRY(h, hipEventRecord(h->ev[0], s));
         wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps, h->d_xref, h->d_uref, h->d_vec};
-        wb::stage_kernel<<<(unsigned)n, 64, 0, s>>>(g);
+        const bool pen = h->rho > 0.0 && h->d_pen;
+        if (pen) { g.pen = h->d_pen; g.rho = h->rho; g.stance = h->d_stance; }
+        if (pen) wb::stage_kernel<true><<<(unsigned)n, 64, 0, s>>>(g);
+        else wb::stage_kernel<false><<<(unsigned)n, 64, 0, s>>>(g);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
         wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec,
                        h->cones, h->mu, h->d_stance};
-        wb::riccati_kernel<<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
+        if (pen) r.pen = h->d_pen;
+        if (pen) wb::riccati_kernel<true><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
+        else wb::riccati_kernel<false><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
     }
     WB_TRY(h, hipGetLastError());

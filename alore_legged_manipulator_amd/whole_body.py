@@ -38,6 +38,7 @@ def _bind(L):
         "alore_wb_set_torque_limits": (C.c_int, [H, C.c_int]),
         "alore_wb_set_contact_constraints": (C.c_int, [H, C.c_int, C.c_double]),
         "alore_wb_set_contact_schedule": (C.c_int, [H, C.c_int, C.c_void_p]),
+        "alore_wb_set_contact_penalty": (C.c_int, [H, C.c_double]),
         "alore_wb_set_problem": (C.c_int, [H, C.c_int, DP, DP, DP]),
         "alore_wb_set_x0": (C.c_int, [H, C.c_int, DP]),
         "alore_wb_shift_iterate": (C.c_int, [H, C.c_int, C.c_void_p]),
@@ -133,6 +134,10 @@ class BatchedWholeBody:
     def set_contact_constraints(self, enable: bool, mu: float = 0.7):
         """friction pyramid + unilateral normal force of the stance feet, zero force of the swing feet, inside the sweep"""
         self._check(self.L.alore_wb_set_contact_constraints(self.h, 1 if enable else 0, float(mu)))
+
+    def set_contact_penalty(self, rho: float):
+        """1/2 rho |J_c(q_k) v_k|^2 over the stance feet in the stage cost (alore_wb_set_contact_penalty; 0 = off)"""
+        self._check(self.L.alore_wb_set_contact_penalty(self.h, float(rho)))
 
     def set_contact_schedule(self, stance):
         """stance [B, N, 4] (truthy = foot in contact at that stage), or None for every foot at every stage"""

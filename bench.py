@@ -739,6 +739,13 @@ def main():
             # symmetric products only their upper-triangular tiles) and 24 tiles with K = 32 (8 each) = 552
             # v_mfma_f32_16x16x4_f32 of 2048 flops (SQ_INSTS_MFMA agrees: profiles/)
             mfma_flops = N * ((15 + 15) * 12 + (6 * 3 + 6) * 8) * 2048.0
+            # the same iteration with the constraint terms on: friction pyramids + the contact-consistency penalty on J_c v
+            wbe.set_contact_constraints(True, 0.7)
+            wbe.set_contact_penalty(1000.0)
+            wbe.set_iterate(xiw, uiw)
+            wbe.rti(1); torch.cuda.synchronize(dev)
+            lin3_ms, ric3_ms = wbe.last_times()
+            con_ok = bool((wbe.status() == 0).all())
             extras["whole_body_b2z1"] = {"problems": Bw, "horizon": N, "ms_linearize": lin_ms, "ms_riccati": ric_ms,
                                          "ms_wall_one_rti": (t_b - t_a) * 1e3, "solves_per_s": Bw / ((lin_ms + ric_ms) * 1e-3),
                                          "mfma_f32_TFLOPs_riccati": Bw * mfma_flops / (ric_ms * 1e-3) / 1e12,
@@ -746,6 +753,8 @@ def main():
                                          "stages_with_a_saturated_torque_frac": sat,
                                          "second_iteration": {"ms_linearize": lin2_ms, "ms_riccati": ric2_ms,
                                                               "solves_per_s": Bw / ((lin2_ms + ric2_ms) * 1e-3)},
+                                         "with_contact_constraints_and_penalty": {"ms_linearize": lin3_ms, "ms_riccati": ric3_ms,
+                                                                                  "solves_per_s": Bw / ((lin3_ms + ric3_ms) * 1e-3), "all_steps_applied": con_ok},
                                          "first_step_max": float(np.max(np.abs(dxw))), "finite": bool(np.isfinite(dxw).all() and np.isfinite(duw).all())}
             del wbe
         except Exception as e:  # pragma: no cover

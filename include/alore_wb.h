@@ -102,11 +102,20 @@ int alore_wb_linearize(alore_wb_handle h, int B, double *A, double *Bm, double *
  * stage): the unconstrained feed-forward step of the stage is computed, the force components that leave their bounds
  * are clamped -- the tangential bounds from the projected normal force of the same stage --, the free inputs are
  * re-solved against the clamped ones, the gain rows of clamped inputs are zero; the applied forces satisfy the
- * constraints exactly.  Off by default (enable = 0: forces are free inputs, as in round 2).  Not modelled: the
- * acceleration-level consistency J_c qdd + Jdot_c qd = 0 of the stance feet as equality rows (the feet are kept still by
- * the posture cost only). */
+ * constraints exactly.  Off by default (enable = 0: forces are free inputs, as in round 2).  The kinematic side -- stance
+ * feet do not move -- is alore_wb_set_contact_penalty below (velocity level, as a penalty on J_c v); hard equality rows
+ * J_c qdd + Jdot_c qd = 0 are not modelled. */
 int alore_wb_set_contact_constraints(alore_wb_handle h, int enable, double mu);
 int alore_wb_set_contact_schedule(alore_wb_handle h, int B, const unsigned char *stance);
+/* Contact consistency of the stance feet through the contact Jacobian J_c(q) (12 x 24: world-frame velocity of the four foot
+ * points per unit generalized velocity -- the transpose of the map that takes the foot forces into the dynamics): the stage
+ * cost gains  1/2 rho | J_c(q_k) v_k |^2  over the feet in contact at stage k (contact schedule above), i.e. the constraint
+ * J_c v = 0 (stance feet do not move) as a quadratic penalty, Gauss-Newton: rho J_c' J_c on the velocity block of the stage
+ * Hessian (added to the cost-to-go on the matrix cores), rho J_c' (J_c v_k) on its gradient; J_c is evaluated at the current
+ * iterate by the linearisation kernel (its foot-force columns).  rho = 0 (default): off, the feet are held by the posture cost
+ * only.  The violation |J_c v| of the iterate shrinks like 1 / rho; rho of 1e3 .. 1e4 keeps it below a millimetre per second
+ * on the test motions without hurting the conditioning of the float32 sweep. */
+int alore_wb_set_contact_penalty(alore_wb_handle h, double rho);
 /* n_iter real-time iterations (linearise + Riccati + step) for B problems; asynchronous on `stream`.
  * Stream contract of this header: only alore_wb_rti and alore_wb_shift_iterate enqueue on the caller's stream (which
  * may be a non-blocking one).  Every entry point that moves data between host and device (set_problem, set_x0,

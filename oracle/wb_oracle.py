@@ -127,6 +127,18 @@ class Model:
                 fx[b] = fx[b] + np.concatenate([np.cross(self.foot_point[k], fb), fb])
         return fx
 
+    def contact_jacobian(self, q):
+        """J_c (12 x 24): world-frame velocity of the four foot points per unit generalized velocity (base omega, base v in
+        base coordinates, joint rates).  Row 3 foot + axis is minus the generalized force of a unit foot force along that
+        world axis (RNEA = ... - J_c' f) -- the route the GPU stage kernel takes as well; tests/test_wb_oracle.py checks it
+        against finite differences of foot_positions along qdot."""
+        z = np.zeros(self.nv)
+        J = np.zeros((12, self.nv))
+        for i in range(12):
+            f = np.zeros(12); f[i] = 1.0
+            J[i] = -self.rnea(q, z, z, f_world=f, gravity=False)
+        return J
+
     def foot_positions(self, q):
         _, Rw, pw = self.transforms(q)
         return np.array([pw[self.foot_body[k]] + Rw[self.foot_body[k]] @ self.foot_point[k] for k in range(4)])
@@ -281,7 +293,7 @@ def solve_lq(A, B, d, Q, R, QN, gx, gu, gN, dx0):
     ox = lambda k: k * (nx + nu)
     ou = lambda k: k * (nx + nu) + nx
     for k in range(N):
-        H[ox(k):ox(k) + nx, ox(k):ox(k) + nx] = Q
+        H[ox(k):ox(k) + nx, ox(k):ox(k) + nx] = _stage_Q(Q, k)   # Q: one matrix, or a list of N (stage-dependent Hessians)
         H[ou(k):ou(k) + nu, ou(k):ou(k) + nu] = R
         g[ox(k):ox(k) + nx] = gx[k]; g[ou(k):ou(k) + nu] = gu[k]
     H[ox(N):ox(N) + nx, ox(N):ox(N) + nx] = QN
@@ -301,6 +313,23 @@ def solve_lq(A, B, d, Q, R, QN, gx, gu, gN, dx0):
     dx = np.array([z[ox(k):ox(k) + nx] for k in range(N + 1)])
     du = np.array([z[ou(k):ou(k) + nu] for k in range(N)])
     return dx, du
+
+
+def contact_penalty(model, x_k, rho, stance_k=None):
+    """Gauss-Newton terms of the contact-consistency penalty 1/2 rho |J_c(q_k) v_k|^2 over the stance feet of one stage
+    (include/alore_wb.h: alore_wb_set_contact_penalty): (Qadd [48][48], gadd [48]) to add to the stage Hessian / gradient."""
+    nq = model.nv
+    J = model.contact_jacobian(x_k[:nq])
+    if stance_k is not None:
+        J = J * np.repeat(np.asarray(stance_k, float), 3)[:, None]
+    Qadd = np.zeros((2 * nq, 2 * nq)); gadd = np.zeros(2 * nq)
+    Qadd[nq:, nq:] = rho * J.T @ J
+    gadd[nq:] = rho * J.T @ (J @ x_k[nq:])
+    return Qadd, gadd
+
+
+def _stage_Q(Q, k):
+    return Q[k] if isinstance(Q, (list, tuple)) else Q
 
 
 def contact_bounds(u_k, kff, mu, stance_k, tol=1e-4):
@@ -344,7 +373,7 @@ def solve_lq_clamped(A, B, d, Q, R, QN, gx, gu, gN, dx0, u_cur, effort, tol=1e-4
     Ks, ks, nclamp = [None] * N, [None] * N, [0] * N
     for k in range(N - 1, -1, -1):
         PA, PB, s = P @ A[k], P @ B[k], P @ d[k] + p
-        Qxx, Qux, Quu = Q + A[k].T @ PA, B[k].T @ PA, R + B[k].T @ PB
+        Qxx, Qux, Quu = _stage_Q(Q, k) + A[k].T @ PA, B[k].T @ PA, R + B[k].T @ PB
         qx, qu = gx[k] + A[k].T @ s, gu[k] + B[k].T @ s
         kff = -np.linalg.solve(Quu, qu)
         cl = np.zeros(nu, bool); kc = np.zeros(nu)

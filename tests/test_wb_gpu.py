@@ -415,3 +415,91 @@ def test_configs2_full_size_batch():
     dx2, _ = eng.last_step()
     assert np.all(eng.status() == 0)
     assert np.median(np.abs(dx2).max(axis=(1, 2))) < 0.5 * np.median(np.abs(dx).max(axis=(1, 2)))
+
+
+def _stance_foot_speed(model, x, stance=None):
+    """|J_c(q_k) v_k| of the stance feet along one trajectory x [N+1][48], per stage"""
+    out = []
+    for k in range(x.shape[0]):
+        J = model.contact_jacobian(x[k, :24])
+        w = J @ x[k, 24:]
+        if stance is not None and k < len(stance):
+            w = w * np.repeat(np.asarray(stance[k], float), 3)
+        out.append(np.linalg.norm(w))
+    return np.array(out)
+
+
+def test_contact_penalty_step_matches_the_float64_restatement(model):
+    """alore_wb_set_contact_penalty: the stage cost gains 1/2 rho |J_c(q_k) v_k|^2 over the stance feet (the constraint
+    Jacobian of 'stance feet do not move', Gauss-Newton).  The LQ step of the kernels (J_c from the stage kernel's foot-force
+    columns, rho J_c' J_c added to the cost-to-go tiles on the matrix cores, float32) against a float64 dense KKT solve of the
+    same problem with the oracle's own J_c (a different formulation of the kinematics); one foot swings from stage 6 on and
+    must carry no penalty there."""
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    from oracle.wb_oracle import contact_penalty, solve_lq
+    B, N, dt = 3, 20, 0.01
+    x0, xref, uref, xi, ui = make_problems(model, B, N, seed=21, spread=0.5)
+    stance = np.ones((B, N, 4), np.uint8)
+    stance[:, 6:, 2] = 0
+    Q, R, QN = weights()
+    # the float32 sweep loses accuracy with the stiffness of the penalty (rho J_c' J_c of 1e3 against velocity weights of 0.5 - 2)
+    for rho, tol in ((200.0, 1e-3), (2000.0, 5e-3)):
+        eng = BatchedWholeBody(B, N, dt)
+        eng.set_weights(Q, R, QN)
+        eng.set_torque_limits(False)
+        eng.set_contact_penalty(rho)
+        eng.set_contact_schedule(stance)
+        eng.set_problem(x0, xref, uref)
+        eng.set_iterate(xi, ui)
+        eng._lin = eng.linearize()
+        eng.rti(1)
+        dx, du = eng.last_step()
+        assert (eng.status() == 0).all()
+        worst = 0.0
+        for b in range(B):
+            A, Bm, d, Qd, Rd, QNd, gx, gu, gN, dx0 = _lq_inputs(model, eng, xi, ui, x0, xref, uref, Q, R, QN, b, N)
+            Ql, gl = [], []
+            for k in range(N):
+                Qa, ga = contact_penalty(model, xi[b, k], rho, stance[b, k])
+                Ql.append(Qd + Qa); gl.append(gx[k] + ga)
+            rx, ru = solve_lq(A, Bm, d, Ql, Rd, QNd, gl, gu, gN, dx0)
+            worst = max(worst, np.max(np.abs(dx[b] - rx)) / np.max(np.abs(rx)), np.max(np.abs(du[b] - ru)) / np.max(np.abs(ru)))
+            # and the penalty does change the step: without it the restatement is somewhere else
+            fx, fu = solve_lq(A, Bm, d, Qd, Rd, QNd, gx, gu, gN, dx0)
+            assert np.max(np.abs(fx - rx)) > 50 * np.max(np.abs(dx[b] - rx))
+        print(f"contact penalty rho = {rho}: worst rel dev of the float32 LQ step from the float64 KKT solve {worst:.2e}")
+        assert worst < tol
+
+
+def test_contact_penalty_keeps_the_stance_feet_still(model):
+    """Started with random joint rates, the posture cost alone lets the stance feet slide while the robot settles; with the
+    penalty on J_c v the foot-point speeds of the returned trajectory drop by an order of magnitude (soft constraint:
+    ~1 / rho), the swing foot stays free to move, and the iteration still contracts."""
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    B, N, dt = 2, 20, 0.01
+    x0, xref, uref, xi, ui = make_problems(model, B, N, seed=33, spread=0.6)
+    stance = np.ones((B, N, 4), np.uint8)
+    stance[:, :, 3] = 0
+    Q, R, QN = weights()
+    res = {}
+    for rho in (0.0, 5000.0):
+        eng = BatchedWholeBody(B, N, dt)
+        eng.set_weights(Q, R, QN)
+        eng.set_torque_limits(False)
+        eng.set_contact_penalty(rho)
+        eng.set_contact_schedule(stance)
+        eng.set_problem(x0, xref, uref)
+        eng.set_iterate(xi, ui)
+        for _ in range(4):
+            eng.rti(1)
+        assert (eng.status() == 0).all()
+        x1, _ = eng.get_iterate()
+        dxl, _ = eng.last_step()
+        res[rho] = (np.array([_stance_foot_speed(model, x1[b], stance[b])[2:].mean() for b in range(B)]), np.max(np.abs(dxl)), x1)
+    free, held = res[0.0][0], res[5000.0][0]
+    print(f"mean stance-foot speed over stages 2..N: free {free}, penalised {held}; last steps {res[0.0][1]:.2e} / {res[5000.0][1]:.2e}")
+    assert np.all(held < 0.1 * free) and np.all(free > 0.02)
+    assert res[5000.0][1] < 1e-2                       # the Gauss-Newton iteration has settled with the penalty too
+    # the swing foot is not held: its point still moves in the penalised solution
+    J = model.contact_jacobian(res[5000.0][2][0, 3, :24])
+    assert np.linalg.norm((J @ res[5000.0][2][0, 3, 24:])[9:12]) > 5 * held[0]

@@ -206,3 +206,25 @@ def test_contact_constrained_sweep_restatement():
         assert np.all(f[:, 2] >= 0) and np.all(np.abs(f[:, :2]) <= 0.3 * f[:, 2:3] + 1e-12)
         if k >= 3:
             assert np.all(f[2] == 0)
+
+
+def test_contact_jacobian_is_the_velocity_of_the_foot_points(model):
+    """J_c from the force route (minus the generalized force of unit foot forces) maps a generalized velocity to the
+    world-frame velocity of the four foot points: compared with central differences of foot_positions along qdot(q, v);
+    and the penalty terms are its Gauss-Newton Hessian / gradient (swing feet masked out)."""
+    from oracle.wb_oracle import contact_penalty
+    rng = np.random.default_rng(4)
+    q = np.zeros(24); q[2] = 0.45
+    q[3:6] = rng.uniform(-0.3, 0.3, 3)
+    q[6:] = rng.uniform(-0.5, 0.5, 18)
+    v = rng.uniform(-1.0, 1.0, 24)
+    J = model.contact_jacobian(q)
+    h = 1e-6
+    qd = model.qdot(q, v)
+    fd = (model.foot_positions(q + h * qd) - model.foot_positions(q - h * qd)).reshape(-1) / (2 * h)
+    assert np.max(np.abs(J @ v - fd)) < 1e-6 * max(1.0, np.max(np.abs(fd)))
+    x = np.concatenate([q, v])
+    Qa, ga = contact_penalty(model, x, 50.0, stance_k=(1, 0, 1, 1))
+    Jm = J.copy(); Jm[3:6] = 0.0
+    assert np.allclose(Qa[24:, 24:], 50.0 * Jm.T @ Jm) and np.allclose(ga[24:], 50.0 * Jm.T @ (Jm @ v))
+    assert not Qa[:24].any() and not Qa[:, :24].any() and not ga[:24].any()
