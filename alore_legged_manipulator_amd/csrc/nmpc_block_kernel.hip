@@ -615,26 +615,6 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             const float p0 = lane_prev<L>(l0), p1 = lane_prev<L>(l1), p2 = lane_prev<L>(l2);
             o0 = (j == 0) ? Dx0 : p0; o1 = (j == 0) ? Dx1 : p1; o2 = (j == 0) ? Dx2 : p2;
         };
-        if (DIAG) { // free response (du = 0) entering every stage, for acado_getKKT: A is a shear, so prefix sums do it
-            float loc[S], acc = 0.0f;
-#pragma unroll
-            for (int s = 0; s < S; ++s) { loc[s] = acc; acc += d2[s]; }
-            const float ex2 = gprefix<L>(acc, j) - acc + Dx2;
-#pragma unroll
-            for (int s = 0; s < S; ++s) sbs[s][2] = loc[s] + ex2;
-            sbo[2] = acc + ex2;
-            float l0[S], l1[S], a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                l0[s] = a0; a0 += sa[s] * sbs[s][2] + d0[s];
-                l1[s] = a1; a1 += sb[s] * sbs[s][2] + d1[s];
-            }
-            const float ex0 = gprefix<L>(a0, j) - a0 + Dx0, ex1 = gprefix<L>(a1, j) - a1 + Dx1;
-#pragma unroll
-            for (int s = 0; s < S; ++s) { sbs[s][0] = l0[s] + ex0; sbs[s][1] = l1[s] + ex1; }
-            sbo[0] = a0 + ex0; sbo[1] = a1 + ex1;
-        }
-
         // One lane's block of the backward recursion.  EVERY lane of the wavefront runs it on its own slots with whatever
         // cost-to-go it holds -- only lane t of a sweeping group holds the real one, and only it keeps the policy records
         // (`mine`, by selects).  No heavy code runs under a partial EXEC mask: values that are live across such a region in
@@ -848,7 +828,45 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
         if (STAMP && sqp == 0) t4 = __builtin_amdgcn_s_memtime();
 
         // ---- phase C: KKT value (acado_getKKT), expand (acado_expand), carry the dual
+        if (DIAG) { // free response (du = 0) entering every stage, for acado_getKKT: A is a shear, so prefix sums do it
+                    // (here and not before the sweeps: nine registers per lane less across them)
+            float loc[S], acc = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { loc[s] = acc; acc += d2[s]; }
+            const float ex2 = gprefix<L>(acc, j) - acc + Dx2;
+#pragma unroll
+            for (int s = 0; s < S; ++s) sbs[s][2] = loc[s] + ex2;
+            sbo[2] = acc + ex2;
+            float l0[S], l1[S], a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                l0[s] = a0; a0 += sa[s] * sbs[s][2] + d0[s];
+                l1[s] = a1; a1 += sb[s] * sbs[s][2] + d1[s];
+            }
+            const float ex0 = gprefix<L>(a0, j) - a0 + Dx0, ex1 = gprefix<L>(a1, j) - a1 + Dx1;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { sbs[s][0] = l0[s] + ex0; sbs[s][1] = l1[s] + ex1; }
+            sbo[0] = a0 + ex0; sbo[1] = a1 + ex1;
+        }
+
         float gd = 0.0f, comp = 0.0f;
+        if constexpr (ONCE) {
+            // single-iteration build: the iterate was only needed for the linearisation; it is read again here (L2 / MALL) so
+            // that x, u do not occupy 5 S + 3 registers per lane through the prediction and the sweeps
+            typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+            const float* gx = p.b.x + (size_t)prob * nx;
+            const float* gu = p.b.u + (size_t)prob * nu;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int k = j * S + s;
+                const f3u vx = *reinterpret_cast<const f3u*>(gx + 3 * min(k, N));
+                const f2u vu = *reinterpret_cast<const f2u*>(gu + 2 * min(k, N - 1));
+                x[s][0] = vx.x; x[s][1] = vx.y; x[s][2] = vx.z; u[s][0] = vu.x; u[s][1] = vu.y;
+            }
+            const f3u vn = *reinterpret_cast<const f3u*>(gx + 3 * N);
+            xN[0] = vn.x; xN[1] = vn.y; xN[2] = vn.z;
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) { // no predicate: slots past the horizon hold zero steps / multipliers (their x, u are never stored)
             const int k = j * S + s;
@@ -903,8 +921,14 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             part += (k < N) ? acc : 0.0f;
         }
         if (j == top) { // the reference uses only the diagonal of WN here (acado_solver.c:1442-1444)
-            const float e0 = xN[0] - yN[0], e1 = xN[1] - yN[1], e2 = xN[2] - yN[2];
-            part += e0 * e0 * WN[0] + e1 * e1 * WN[4] + e2 * e2 * WN[8];
+            float w0 = WN[0], w4 = WN[4], w8 = WN[8], y0 = yN[0], y1 = yN[1], y2 = yN[2];
+            if constexpr (ONCE) { // read again instead of held since phase A
+                const float* gW = p.b.WN + ((p.shared & ALORE_NMPC_SHARED_W) ? 0 : (size_t)prob * 9);
+                const float* gy = p.b.yN + (size_t)prob * 3;
+                w0 = gW[0]; w4 = gW[4]; w8 = gW[8]; y0 = gy[0]; y1 = gy[1]; y2 = gy[2];
+            }
+            const float e0 = xN[0] - y0, e1 = xN[1] - y1, e2 = xN[2] - y2;
+            part += e0 * e0 * w0 + e1 * e1 * w4 + e2 * e2 * w8;
         }
         obj = 0.5f * gtotal<L>(part, j, lane);
     }
