@@ -861,8 +861,9 @@ def main():
         # the reference's own generated horizon (N = 50), same batch size: next to the compiled reference's
         # single-core time in cpu_baseline.reference_n50_single_core_us_per_solve
         try:
-            e6 = BatchedNmpc(B, 50, device=local_rank, slots=12)
-            e6.load(make_batch(B, 50), slot=None)
+            e6 = BatchedNmpc(B, 50, device=local_rank, slots=42)
+            b50 = make_batch(B, 50)
+            e6.load(b50, slot=None)
             e6.rti(1, slot=0); e6.rti(1, slot=1)
             torch.cuda.synchronize(dev)
             ev_a.record()
@@ -870,8 +871,21 @@ def main():
                 e6.rti(1, slot=i)
             ev_b.record(); torch.cuda.synchronize(dev)
             ms50 = ev_a.elapsed_time(ev_b) / 10
+            lanes50 = e6.launch_info()["lanes_per_problem"]
+            # the same with launches in flight (alore_nmpc_rti_many, eager): 40 fresh slots
+            e6.set_launch_overlap(a.overlap)
+            e6.load(b50, slot=None)
+            e6.rti_range(0, 2)
+            torch.cuda.synchronize(dev)
+            ev_a.record()
+            e6.rti_range(2, 40)
+            ev_b.record(); torch.cuda.synchronize(dev)
+            ms50f = ev_a.elapsed_time(ev_b) / 40
             extras["reference_horizon_n50"] = {"batch": B, "ms_per_launch": ms50, "solves_per_s": B / (ms50 * 1e-3),
-                                               "lanes_per_problem": e6.launch_info()["lanes_per_problem"]}
+                                               "lanes_per_problem": lanes50,
+                                               "in_flight": {"launches_in_flight": a.overlap, "ms_per_step": ms50f, "solves_per_s": B / (ms50f * 1e-3),
+                                                             "hbm_frac": algorithmic_bytes_per_solve(50) * B / (ms50f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                             "unsolved": int((e6.ts["status"][2:42] != 0).sum().item())}}
             del e6
         except Exception as e:  # pragma: no cover
             extras["reference_horizon_n50"] = {"error": str(e)}
