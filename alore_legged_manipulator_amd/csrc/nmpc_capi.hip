@@ -54,10 +54,10 @@ struct alore_nmpc_solver {
     char* stage_down = nullptr;
     size_t stage_up_cap = 0, stage_down_cap = 0;
     // alore_nmpc_rti_many: launches of independent batches in flight at once (side streams forked from the caller's)
-    int overlap = 8;
+    int overlap = 16;
     int in_flight_B = 0; // set by alore_nmpc_rti_many around its launches: problems of the launches that overlap
-    hipStream_t side[7] = {};
-    hipEvent_t fork_ev = nullptr, join_ev[7] = {};
+    hipStream_t side[31] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[31] = {};
     hipEvent_t stage_up_done = nullptr; // the copies out of stage_up enqueued by the last upload
     // diagnostic phase stamps (env ALORE_NMPC_STAMPS=1): per-phase cycle shares, printed at destroy
     bool stamps = false;
@@ -187,7 +187,7 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     // streams / events of alore_nmpc_rti_many: made here, not at first use, so that a first use inside a stream capture
     // creates nothing
     bool forks_ok = hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) == hipSuccess;
-    for (int w = 0; w < 7 && forks_ok; ++w)
+    for (int w = 0; w < 31 && forks_ok; ++w)
         forks_ok = hipStreamCreateWithFlags(&h->side[w], hipStreamNonBlocking) == hipSuccess &&
                    hipEventCreateWithFlags(&h->join_ev[w], hipEventDisableTiming) == hipSuccess;
     if (!forks_ok) {
@@ -217,7 +217,7 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
         std::fprintf(stderr, "\n");
     }
     if (h->d_stamps) (void)hipFree(h->d_stamps);
-    for (int w = 0; w < 7; ++w) {
+    for (int w = 0; w < 31; ++w) {
         if (h->side[w]) (void)hipStreamDestroy(h->side[w]);
         if (h->join_ev[w]) (void)hipEventDestroy(h->join_ev[w]);
     }
@@ -493,7 +493,7 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     // per B = 4096 batch at W = 2 (profiles/r03_d_*).  Everything is complete when the caller's stream is; capturable.
     int ways = h->overlap;
     if (const char* e = std::getenv("ALORE_NMPC_OVERLAP")) ways = std::atoi(e);
-    ways = ways < 1 ? 1 : (ways > 8 ? 8 : ways);
+    ways = ways < 1 ? 1 : (ways > 32 ? 32 : ways);
     if (ways > count) ways = count;
     if (ways > 1 && !h->timing && count <= 4096) {
         bool distinct = true; // a batch listed twice (two consecutive iterations of the same problems) must stay in order
@@ -536,7 +536,7 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
 
 int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways)
 {
-    if (!h || ways < 1 || ways > 8) return fail(h, ALORE_NMPC_E_INVALID, "set_launch_overlap: ways must be 1 .. 8");
+    if (!h || ways < 1 || ways > 32) return fail(h, ALORE_NMPC_E_INVALID, "set_launch_overlap: ways must be 1 .. 32");
     h->overlap = ways;
     return ALORE_NMPC_OK;
 }

@@ -65,7 +65,7 @@ def parse():
                          "eager launches (full), both (default) or none")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per all-gather bucket")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--overlap", type=int, default=8, choices=(1, 2, 3, 4, 5, 6, 7, 8),
+    ap.add_argument("--overlap", type=int, default=16, choices=tuple(range(1, 33)),
                     help="independent batches (steps) kept in flight at once by alore_nmpc_rti_many; 1 = strictly in order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")

@@ -144,12 +144,12 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int 
 /* the same for `count` batches of B problems each, one launch per batch, from one call (a host that steps many
  * independent batches -- the slots of a Monte-Carlo sweep, the shards of a fleet -- pays the call overhead of its language
  * binding once).  A launch is a burst of HBM reads followed by sweeps during which HBM idles, so independent batches are
- * kept `ways` at a time in flight (alore_nmpc_set_launch_overlap, default 8): they go round-robin onto internal streams
+ * kept `ways` at a time in flight (alore_nmpc_set_launch_overlap, 1 .. 32, default 16): they go round-robin onto internal streams
  * forked from and joined back into `stream` -- every batch is complete when the work enqueued on `stream` is, and the call
  * can be captured into a hipGraph.  A batch listed more than once (successive iterations of the same problems) keeps the
  * whole call in order on `stream`, as does ways = 1. */
 int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch *batches, int count, int B, int n_sqp, void *stream);
-int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 8 */
+int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
 
 /* ACADO split semantics.  The reference prepares (linearises, evaluates h(x,u)) in
  * acado_preparationStep() and solves/expands in acado_feedbackStep(); a caller may change

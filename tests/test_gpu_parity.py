@@ -532,7 +532,7 @@ def test_stage_block_kernel_on_the_stress_distribution(nmpc_mod, lanes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ways", [1, 2, 3, 8])
+@pytest.mark.parametrize("ways", [1, 2, 3, 8, 32])
 def test_overlapped_launches_of_independent_slots_give_the_in_order_bits(nmpc_mod, ways):
     """alore_nmpc_rti_many keeps `ways` independent batches in flight on streams forked from / joined into the caller's:
     every slot's results are the bits of the same slot solved alone, eagerly and replayed from a hipGraph; a batch listed
