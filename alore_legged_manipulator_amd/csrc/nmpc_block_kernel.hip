@@ -3,7 +3,7 @@
 // Why a second mapping.  nmpc::rti_kernel (nmpc_kernels.hip) gives a problem 32 lanes, one lane per stage, and runs the
 // sequential Riccati sweep row-split over quads, 8-fold redundantly: 2240 vector instructions per problem, almost all
 // of them links of dependent chains (DPP scans, the sweep), which a gfx950 SIMD issues at one per ~4.6 cycles however
-// many wavefronts share it (profiles/r01_d_sq_counters.txt).  Here a problem gets L = 4, 8 or 16 lanes and every lane
+// many wavefronts share it (profiles/r01_d_sq_counters.txt).  Here a problem gets L = 4, 8, 16 or 32 lanes and every lane
 // OWNS S consecutive stages (L * S >= N) with all of their data in registers for the whole launch:
 //   * stage-parallel phases (linearise + Gauss-Newton cost, working-set prediction, KKT/expand, objective) are plain
 //     scalar code over the S stages of the lane -- S independent instruction streams per lane, so the in-order issue
@@ -18,6 +18,12 @@
 // the transposition buffer between the reference's per-problem layout in HBM (contiguous per problem, so a wavefront
 // streams 64 / L consecutive problems with 16-byte-per-lane coalesced loads) and the lane-owns-stages registers.
 // Global traffic is the algorithmic minimum as before.
+//
+// Builds: DIAG (KKT value and objective wanted), STAMP (phase stamps, diagnostic), ONCE (n_sqp = 1, the control tick: no
+// iteration loop, so od / the raw bounds die after the linearisation and the iterate, WN, yN are read again at the end
+// instead of held -- (4, 5) 435 registers instead of 512 + scratch, (16, 2) 252: two wavefronts per SIMD).
+// Which (L, S) runs: block_geometry() below -- the widest L whose wavefronts, over ALL launches in flight
+// (alore_nmpc_rti_many, nmpc_capi.hip), still fit one per SIMD.
 //
 // Numerics are those of nmpc_kernels.hip / nmpc_core.h (see there for the reference citations); per-problem results
 // do not depend on the batch or on wavefront mates (masked lanes never feed a problem).  Different (L, S) agree to
