@@ -5,7 +5,7 @@
 //
 //   g++ -std=c++17 -Iinclude examples/nmpc_batch.cpp -Lalore_legged_manipulator_amd -lalore_nmpc \
 //       -Wl,-rpath,$PWD/alore_legged_manipulator_amd -o nmpc_batch
-//   ./nmpc_batch in.bin out.bin
+//   ./nmpc_batch in.bin out.bin [slots]
 //
 // in.bin : int32 B, int32 N, then float32 x[B][(N+1)*3] u[B][N*2] od[B][(N+1)*3] y[B][N*5] yN[B][3] W[B][N*25] WN[B][9]
 //          x0[B][3] lbValues[B][N*2] ubValues[B][N*2] dual[B][N*2]
@@ -69,6 +69,52 @@ int main(int argc, char** argv)
     int solved = 0;
     for (int s : status) solved += s == 0;
     std::printf("B=%d N=%d solved=%d\n", B, N, solved);
+
+    // Optional third argument K: the same batch in K independent device slots, all stepped by ONE alore_nmpc_rti_many call
+    // (launches kept in flight on forked streams, joined into the caller's stream); every slot must return the bits of the
+    // single launch above.  The lane mapping is pinned for this part: the automatic choice packs for the launches in flight,
+    // and different mappings agree to rounding only.
+    if (argc > 3) {
+        const int K = std::atoi(argv[3]);
+        if (K < 2 || K > 64) { std::fprintf(stderr, "slots must be 2 .. 64\n"); return 1; }
+        alore_nmpc_launch_info info{};
+        CHECK(alore_nmpc_get_launch_info(h, &info));
+        alore_nmpc_handle h2 = nullptr;
+        alore_nmpc_config cfg2 = cfg;
+        cfg2.lanes_per_problem = info.lanes_per_problem;
+        {
+            const int rc_ = alore_nmpc_create(&cfg2, &h2);
+            if (rc_ != ALORE_NMPC_OK) { std::fprintf(stderr, "second handle: %d\n", rc_); return 2; }
+        }
+        std::vector<alore_nmpc_batch> slots(K);
+        std::vector<float> x_in(nx), u_in(nu);
+        {   // the inputs again (x, u were overwritten by the download above)
+            FILE* f2 = std::fopen(argv[1], "rb");
+            if (!f2 || std::fseek(f2, 8, SEEK_SET) != 0 || std::fread(x_in.data(), 4, nx, f2) != nx || std::fread(u_in.data(), 4, nu, f2) != nu) return 1;
+            std::fclose(f2);
+        }
+        host.x = x_in.data(); host.u = u_in.data();
+        for (int k = 0; k < K; ++k) {
+            if (alore_nmpc_batch_alloc(h2, B, &slots[k]) != ALORE_NMPC_OK || alore_nmpc_batch_upload(h2, &slots[k], &host, B, nullptr) != ALORE_NMPC_OK) {
+                std::fprintf(stderr, "slot %d: %s\n", k, alore_nmpc_last_error(h2));
+                return 2;
+            }
+        }
+        if (alore_nmpc_rti_many(h2, slots.data(), K, B, 1, nullptr) != ALORE_NMPC_OK) { std::fprintf(stderr, "rti_many: %s\n", alore_nmpc_last_error(h2)); return 2; }
+        int identical = 0;
+        std::vector<float> xs(nx), us(nu), ks(B);
+        std::vector<int> ss(B);
+        for (int k = 0; k < K; ++k) {
+            alore_nmpc_batch b2{};
+            b2.x = xs.data(); b2.u = us.data(); b2.status = ss.data(); b2.kkt = ks.data();
+            if (alore_nmpc_batch_download(h2, &slots[k], &b2, B, nullptr) != ALORE_NMPC_OK) return 2;
+            identical += (xs == x.v && us == u.v && ss == status && ks == kkt) ? 1 : 0;
+            (void)alore_nmpc_batch_free(h2, &slots[k]);
+        }
+        std::printf("slots=%d identical=%d\n", K, identical);
+        (void)alore_nmpc_destroy(h2);
+        if (identical != K) return 4;
+    }
     CHECK(alore_nmpc_batch_free(h, &dev));
     CHECK(alore_nmpc_destroy(h));
     return solved == B ? 0 : 3;

@@ -39,8 +39,9 @@ def test_cpp_host_equals_the_python_binding():
             np.array([B, N], np.int32).tofile(f)
             for k in ORDER:
                 np.ascontiguousarray(batch[k], np.float32).tofile(f)
-        r = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+        r = subprocess.run([exe, fin, fout, "6"], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
+        assert "slots=6 identical=6" in r.stdout, r.stdout      # alore_nmpc_rti_many: six slots in flight, the single launch's bits
         raw = np.fromfile(fout, np.float32)
     nx, nu = B * (N + 1) * 3, B * N * 2
     x_c, u_c = raw[:nx], raw[nx:nx + nu]
