@@ -147,7 +147,9 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int 
  * kept `ways` at a time in flight (alore_nmpc_set_launch_overlap, 1 .. 32, default 16): they go round-robin onto internal streams
  * forked from and joined back into `stream` -- every batch is complete when the work enqueued on `stream` is, and the call
  * can be captured into a hipGraph.  A batch listed more than once (successive iterations of the same problems) keeps the
- * whole call in order on `stream`, as does ways = 1. */
+ * whole call in order on `stream`, as does ways = 1.  With lanes_per_problem = 0 the lane mapping is chosen for ALL problems
+ * in flight (more problems per wavefront than alore_nmpc_rti would pick for one batch of B): results of different mappings
+ * agree to float32 rounding; pin lanes_per_problem where the bits of a single alore_nmpc_rti launch are wanted. */
 int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch *batches, int count, int B, int n_sqp, void *stream);
 int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
 
