@@ -583,3 +583,29 @@ def test_overlapped_launches_of_independent_slots_give_the_in_order_bits(nmpc_mo
     torch.cuda.synchronize()
     for k in ("x", "u", "dual", "status"):
         assert torch.equal(rep.ts[k], two.ts[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [BLOCK | 4, BLOCK | 16])
+def test_launches_in_flight_with_two_iterations_and_shared_members(nmpc_mod, lanes):
+    """alore_nmpc_rti_many on the builds that keep the iteration loop (n_sqp = 2), with W / bounds / od read from one shared
+    copy, five slots in flight: the bits of slot-by-slot launches."""
+    import torch
+    B, N, slots = 300, 20, 5
+    batch = make_batch(B, N, seed=8, fast_tail=0.3)
+    batch["od"][:] = batch["od"][0]
+    ref = nmpc_mod.BatchedNmpc(B, N, slots=slots, lanes_per_problem=lanes)
+    ref.load(batch, slot=None)
+    ref.set_shared_members(W=True, bounds=True, od=True)
+    for s in range(slots):
+        ref.rti(2, slot=s)
+    torch.cuda.synchronize()
+    eng = nmpc_mod.BatchedNmpc(B, N, slots=slots, lanes_per_problem=lanes)
+    eng.load(batch, slot=None)
+    eng.set_shared_members(W=True, bounds=True, od=True)
+    eng.set_launch_overlap(5)
+    eng.rti_range(0, slots, n_sqp=2)
+    torch.cuda.synchronize()
+    assert (eng.ts["status"] == 0).all()
+    for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj"):
+        assert torch.equal(eng.ts[k], ref.ts[k]), k
