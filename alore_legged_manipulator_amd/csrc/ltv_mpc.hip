@@ -1065,8 +1065,10 @@ __global__ void ltv_refs_kernel(nmpc::RefStore s, int B, int T, double dt, doubl
     minco::eval_pv(dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
     minco::eval_pv(dur, coef, np, tq, p3, v3);
     const double* ck = s.ckpt + ((size_t)r * s.C + index) * 2;
-    const double X = ck[0] + diff_t / 6.0 * (minco::xdot(p1, v1, xv) + 4.0 * minco::xdot(p2, v2, xv) + minco::xdot(p3, v3, xv));
-    const double Y = ck[1] + diff_t / 6.0 * (minco::ydot(p1, v1, xv) + 4.0 * minco::ydot(p2, v2, xv) + minco::ydot(p3, v3, xv));
+    double xd1, yd1, xd2, yd2, xd3, yd3; // one sincos per Simpson node
+    minco::xydot(p1, v1, xv, xd1, yd1); minco::xydot(p2, v2, xv, xd2, yd2); minco::xydot(p3, v3, xv, xd3, yd3);
+    const double X = ck[0] + diff_t / 6.0 * (xd1 + 4.0 * xd2 + xd3);
+    const double Y = ck[1] + diff_t / 6.0 * (yd1 + 4.0 * yd2 + yd3);
     double psi = p3[0];
     while (psi > M_PI) psi -= 2 * M_PI;
     while (psi < -M_PI) psi += 2 * M_PI;

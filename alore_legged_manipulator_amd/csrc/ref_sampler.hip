@@ -48,14 +48,25 @@ __global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
     if (index < 0) index = 0; // now before start_time: the reference indexes out of bounds here; extrapolate from node 0
     const double floor_t = index * res, diff_t = tq - floor_t;
     double p1[2], p2[2], p3[2], v1[2], v2[2], v3[2];
-    eval_pv(dur, coef, np, floor_t, p1, v1);
-    eval_pv(dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
-    eval_pv(dur, coef, np, tq, p3, v3);
-    auto xd = [&](const double* p, const double* v) { return minco::xdot(p, v, xv); };
-    auto yd = [&](const double* p, const double* v) { return minco::ydot(p, v, xv); };
+    constexpr int PRE = 16; // piece durations fetched up front (independent loads); longer trajectories walk on in memory
+    double dreg[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) dreg[i] = dur[min(i, np - 1)];
+    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, floor_t, p1, v1);
+    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
+    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, tq, p3, v3);
+    // minco::xdot / ydot of the three Simpson nodes with ONE sincos per node (they call cos and sin separately: twelve
+    // float64 trigonometric evaluations per thread were most of this kernel)
+    double xd1, yd1, xd2, yd2, xd3, yd3;
+    {
+        double sn, cs;
+        sincos(p1[0], &sn, &cs); xd1 = v1[1] * cs + v1[0] * xv * sn; yd1 = v1[1] * sn - v1[0] * xv * cs;
+        sincos(p2[0], &sn, &cs); xd2 = v2[1] * cs + v2[0] * xv * sn; yd2 = v2[1] * sn - v2[0] * xv * cs;
+        sincos(p3[0], &sn, &cs); xd3 = v3[1] * cs + v3[0] * xv * sn; yd3 = v3[1] * sn - v3[0] * xv * cs;
+    }
     const double* ck = s.ckpt + ((size_t)r * s.C + index) * 2;
-    const double X = ck[0] + diff_t / 6.0 * (xd(p1, v1) + 4.0 * xd(p2, v2) + xd(p3, v3));
-    const double Y = ck[1] + diff_t / 6.0 * (yd(p1, v1) + 4.0 * yd(p2, v2) + yd(p3, v3));
+    const double X = ck[0] + diff_t / 6.0 * (xd1 + 4.0 * xd2 + xd3);
+    const double Y = ck[1] + diff_t / 6.0 * (yd1 + 4.0 * yd2 + yd3);
     double psi = p3[0];
     while (psi > M_PI) psi -= 2 * M_PI; // normlize_theta
     while (psi < -M_PI) psi += 2 * M_PI;
@@ -303,16 +314,21 @@ __global__ void plant_kernel(alore_nmpc_batch b, int B, int N, int node, const d
     const double desired_w = (right - left) / (yl - yr);
     double x = pose[(size_t)r * 3], y = pose[(size_t)r * 3 + 1], th = pose[(size_t)r * 3 + 2];
     double v = vw[(size_t)r * 2], w = vw[(size_t)r * 2 + 1];
+    // the heading changes once per substep: its sine / cosine after the update are those the next substep starts with --
+    // one sincos per substep instead of four separate evaluations
+    double sn, cs;
+    sincos(th, &sn, &cs);
     for (int s = 0; s < p.substeps; ++s) {
         if (fabs(v - desired_v) >= p.pose_pub_period * p.max_a) v += p.pose_pub_period * p.max_a * (desired_v - v) / fabs(desired_v - v);
         else v = desired_v;
         if (fabs(w - desired_w) >= p.pose_pub_period * p.max_domega) w += p.pose_pub_period * p.max_domega * (desired_w - w) / fabs(desired_w - w);
         else w = desired_w;
-        x += v * p.propa_period * cos(th);
-        y += v * p.propa_period * sin(th);
+        x += v * p.propa_period * cs;
+        y += v * p.propa_period * sn;
         th += w * p.propa_period;
-        x -= vy * p.propa_period * sin(th);
-        y += vy * p.propa_period * cos(th);
+        sincos(th, &sn, &cs);
+        x -= vy * p.propa_period * sn;
+        y += vy * p.propa_period * cs;
     }
     pose[(size_t)r * 3] = x; pose[(size_t)r * 3 + 1] = y; pose[(size_t)r * 3 + 2] = th;
     vw[(size_t)r * 2] = v; vw[(size_t)r * 2 + 1] = w;
