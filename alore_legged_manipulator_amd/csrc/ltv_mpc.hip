@@ -367,7 +367,9 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
         // runs at the top of each pass); `prev_out` is not kept, so the published path uses the final output for
         // both roles -- identical once the relinearisation has converged.
         for (int i = 1; i <= T; ++i) {
-            const double B00 = cos(bth) * dt, B10 = sin(bth) * dt, A02 = -B10 * bv, A12 = B00 * bv;
+            double sb_, cb_;
+            sincos(bth, &sb_, &cb_);
+            const double B00 = cb_ * dt, B10 = sb_ * dt, A02 = -B10 * bv, A12 = B00 * bv;
             const double u0 = out[2 * (i - 1)], u1 = out[2 * (i - 1) + 1];
             const double nx = tx + A02 * tth + B00 * u0 - A02 * bth, ny = ty + A12 * tth + B10 * u0 - A12 * bth;
             tth = tth + dt * u1; tx = nx; ty = ny;
@@ -972,7 +974,9 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
         if (valid && j == 0) { xo[0] = tx; xo[1] = ty; xo[2] = tth; }
         for (int i = 0; i < dl; ++i) { // the delayed inputs (now the delay buffer), every lane
             const double u0 = d.reset ? 0.0 : bf[2 * i], u1 = d.reset ? 0.0 : bf[2 * i + 1];
-            const double B00 = cos(bth) * dt, B10 = sin(bth) * dt, A02 = -B10 * bv, A12 = B00 * bv;
+            double sb_, cb_;
+            sincos(bth, &sb_, &cb_);
+            const double B00 = cb_ * dt, B10 = sb_ * dt, A02 = -B10 * bv, A12 = B00 * bv;
             const double nx = tx + A02 * tth + B00 * u0 - A02 * bth, ny = ty + A12 * tth + B10 * u0 - A12 * bth;
             tth = tth + dt * u1; tx = nx; ty = ny;
             if (valid && j == 0) { xo[3 * (i + 1)] = tx; xo[3 * (i + 1) + 1] = ty; xo[3 * (i + 1) + 2] = tth; }
@@ -995,7 +999,9 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
             const bool vs = k < K;
             const double bth_k = hb[s] + eb, tth_k = ht[s] + et;
             const double bv_k = (k == 0) ? bv : ((s == 0) ? a_prev_lane : ua[(s > 0) ? s - 1 : 0]);
-            const double B00 = cos(bth_k) * dt, B10 = sin(bth_k) * dt, A02 = -B10 * bv_k, A12 = B00 * bv_k;
+            double sb_, cb_;
+            sincos(bth_k, &sb_, &cb_);
+            const double B00 = cb_ * dt, B10 = sb_ * dt, A02 = -B10 * bv_k, A12 = B00 * bv_k;
             sx += vs ? (A02 * tth_k + B00 * ua[s] - A02 * bth_k) : 0.0;
             sy += vs ? (A12 * tth_k + B10 * ua[s] - A12 * bth_k) : 0.0;
             ix[s] = sx; iy[s] = sy;
