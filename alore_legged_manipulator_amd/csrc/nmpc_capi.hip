@@ -881,6 +881,39 @@ int alore_nmpc_refs_at_goal(alore_nmpc_handle h, int B, int* at_goal, void* stre
     return ALORE_NMPC_OK;
 }
 
+namespace {
+static __global__ void pack_input_column_kernel(const float* u, const int* status, int B, int N, int node, float* cmd, int* st)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    cmd[2 * b] = u[((size_t)b * N + node) * 2];
+    cmd[2 * b + 1] = u[((size_t)b * N + node) * 2 + 1];
+    if (st) st[b] = status[b];
+}
+} // namespace
+
+int alore_nmpc_input_column(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int node, float* cmd, int* status, void* stream)
+{
+    if (!h || !dev || !dev->u || B <= 0 || node < 0 || node >= h->cfg.N || !cmd || (status && !dev->status))
+        return fail(h, ALORE_NMPC_E_INVALID, "input_column: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)B * 12;
+    if (int rc = grow_stage(h, h->stage_down, h->stage_down_cap, need)) return rc;
+    // the pack kernel writes the 12 bytes per problem straight into the pinned slab (device alias of the host pointer)
+    void* dalias = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer(&dalias, h->stage_down, 0));
+    float* dc = (float*)dalias;
+    int* ds = (int*)(dc + (size_t)B * 2);
+    hipLaunchKernelGGL(pack_input_column_kernel, dim3((B + 255) / 256), dim3(256), 0, s, dev->u, dev->status, B, h->cfg.N, node, dc,
+                       status ? ds : nullptr);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::memcpy(cmd, h->stage_down, sizeof(float) * B * 2);
+    if (status) std::memcpy(status, h->stage_down + sizeof(float) * B * 2, sizeof(int) * B);
+    return ALORE_NMPC_OK;
+}
+
 int alore_nmpc_set_shared_members(alore_nmpc_handle h, unsigned mask)
 {
     if (!h || (mask & ~(unsigned)(ALORE_NMPC_SHARED_W | ALORE_NMPC_SHARED_BOUNDS | ALORE_NMPC_SHARED_OD)))

@@ -138,6 +138,7 @@ public:
     void resetIterate(int b, const double state[3])
     {
         refreshStates(); // the whole mirror is uploaded with the next update: it must be current first
+        refreshInputs();
         for (int k = 0; k <= kSamples; ++k)
             for (int i = 0; i < 3; ++i) x_[((size_t)b * (kSamples + 1) + k) * 3 + i] = (float)state[i];
         std::fill(u_.begin() + (size_t)b * 2 * kSamples, u_.begin() + (size_t)(b + 1) * 2 * kSamples, 0.f);
@@ -187,7 +188,9 @@ public:
     }
 
     // mpc_wrapper.cpp:279-373 for all robots at once: states = B x 3
-    bool update(const double* states, bool do_preparation = true)
+    // cmd_node >= 0: only the inputs of that node (what the tick publishes) and the status come back with the launch;
+    // the full input member follows on demand (getInputs / getInput of another node), like the predicted states
+    bool update(const double* states, bool do_preparation = true, int cmd_node = -1)
     {
         if (!acado_is_prepared_) return false;
         for (size_t i = 0; i < (size_t)B * 3; ++i) x0_[i] = (float)states[i];
@@ -200,11 +203,20 @@ public:
         alore_nmpc_batch run = dev_; // the wrapper never asks for KKT value or objective (nor does the reference's)
         run.kkt = nullptr; run.obj = nullptr;
         check(alore_nmpc_rti(h_, &run, B, 1, nullptr));
-        alore_nmpc_batch out{}; // the tick needs the inputs and the status; the predicted states come on demand
-        out.u = u_.data(); out.status = status_.data();
         x_stale_ = true;
-        check(alore_nmpc_batch_download(h_, &dev_, &out, B, nullptr));
         if (pending_goal_) { check(alore_nmpc_refs_at_goal(h_, B, pending_goal_, nullptr)); pending_goal_ = nullptr; }
+        if (cmd_node >= 0 && cmd_node < kSamples) {
+            cmd_.resize((size_t)B * 2);
+            check(alore_nmpc_input_column(h_, &dev_, B, cmd_node, cmd_.data(), status_.data(), nullptr)); // waits for the stream
+            cmd_node_ = cmd_node;
+            u_stale_ = true;
+        } else {
+            alore_nmpc_batch out{}; // the tick needs the inputs and the status; the predicted states come on demand
+            out.u = u_.data(); out.status = status_.data();
+            check(alore_nmpc_batch_download(h_, &dev_, &out, B, nullptr));
+            cmd_node_ = -1;
+            u_stale_ = false;
+        }
         if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("hipStreamSynchronize");
         acado_is_prepared_ = false;
         if (do_preparation) acado_is_prepared_ = true; // the preparation is fused into the next launch
@@ -232,13 +244,28 @@ public:
     }
     void getInputs(int b, double* out /* 2 x N col-major */) const
     {
+        refreshInputs();
         for (int i = 0; i < 2 * kSamples; ++i) out[i] = u_[(size_t)b * 2 * kSamples + i];
     }
-    double getInput(int b, int node, int which) const { return u_[((size_t)b * kSamples + node) * 2 + which]; }
+    double getInput(int b, int node, int which) const
+    {
+        if (u_stale_ && node == cmd_node_) return cmd_[(size_t)b * 2 + which];
+        refreshInputs();
+        return u_[((size_t)b * kSamples + node) * 2 + which];
+    }
     int getStatus(int b) const { return status_[b]; }
     double getTimestep() const { return dt_; }
 
 private:
+    void refreshInputs() const
+    {
+        if (!u_stale_) return;
+        alore_nmpc_batch out{};
+        out.u = const_cast<float*>(u_.data());
+        check(alore_nmpc_batch_download(h_, &dev_, &out, B, nullptr));
+        if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("hipStreamSynchronize");
+        u_stale_ = false;
+    }
     void refreshStates() const
     {
         if (!x_stale_) return;
@@ -263,6 +290,9 @@ private:
     alore_nmpc_handle h_ = nullptr;
     alore_nmpc_batch dev_{};
     std::vector<float> x_, u_, od_, y_, yN_, W_, WN_, x0_;
+    std::vector<float> cmd_;           // inputs of node cmd_node_ of the last launch
+    int cmd_node_ = -1;
+    mutable bool u_stale_ = false;     // u_ is behind the device (only cmd_ was fetched)
     std::vector<int> status_;
     bool acado_is_prepared_ = false, dirty_costs_ = true, dirty_iterate_ = true, device_refs_ = false;
     mutable bool x_stale_ = false; // x_ lags the device copy (downloaded on demand)
@@ -392,7 +422,7 @@ public:
             }
             robots[b].idle_ticks_ = !solving[b];
         }
-        mpc_wrapper_.update(est.data(), false);
+        mpc_wrapper_.update(est.data(), false, node); // only column `node` of the inputs crosses the bus with the tick
         mpc_wrapper_.prepare(); // the reference's preparation thread (mpc.cpp:336, 394-403)
         for (int b = 0; b < B; ++b) {
             if (!solving[b]) continue;

@@ -117,6 +117,15 @@ class BatchedNmpc:
         """n_sqp x (acado_preparationStep + acado_feedbackStep) for the whole batch, one launch."""
         self._check(self.lib.alore_nmpc_rti(self.h, C.byref(self._batches[slot]), self.B, int(n_sqp), self._stream()))
 
+    def input_column(self, node: int, slot: int = 0):
+        """inputs of one node of every problem and the status (alore_nmpc_input_column): (cmd [B][2] float32, status [B])"""
+        import numpy as np
+        cmd = np.empty((self.B, 2), np.float32)
+        st = np.empty(self.B, np.int32)
+        self._check(self.lib.alore_nmpc_input_column(self.h, C.byref(self._batches[slot]), self.B, int(node),
+                                                     cmd.ctypes.data_as(C.POINTER(C.c_float)), st.ctypes.data_as(C.POINTER(C.c_int)), self._stream()))
+        return cmd, st
+
     def set_launch_overlap(self, ways: int) -> None:
         """launches of independent slots kept in flight at once by rti_range (alore_nmpc_set_launch_overlap; 1 = in order)"""
         self._check(self.lib.alore_nmpc_set_launch_overlap(self.h, int(ways)))

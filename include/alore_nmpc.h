@@ -129,6 +129,11 @@ int alore_nmpc_batch_download(alore_nmpc_handle h, const alore_nmpc_batch *dev, 
                               int B, void *stream);
 /* fill lbValues/ubValues with the model's baked bounds -3/+3
  * (acado_solver.c:1088-1288, from UAV_CAR_model.cpp:97-101) */
+/* What a control tick publishes: the inputs of ONE node of every problem (the reference's cmdPub reads column delay_num of
+ * acadoVariables.u, mpc.cpp:502-509) and, optionally, the solver status.  cmd [B][2], status [B] or NULL: HOST pointers.
+ * 12 bytes per problem leave the device (packed by a kernel straight into pinned memory) instead of the whole input
+ * member; waits for `stream`. */
+int alore_nmpc_input_column(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int node, float *cmd, int *status, void *stream);
 int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, void *stream);
 
 /* ---- the hot path -------------------------------------------------------- */

@@ -609,3 +609,19 @@ def test_launches_in_flight_with_two_iterations_and_shared_members(nmpc_mod, lan
     assert (eng.ts["status"] == 0).all()
     for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj"):
         assert torch.equal(eng.ts[k], ref.ts[k]), k
+
+
+@pytest.mark.gpu
+def test_input_column_is_the_column_of_the_downloaded_inputs(nmpc_mod):
+    """alore_nmpc_input_column: the 12 bytes per problem a control tick publishes (inputs of one node + status), packed on the
+    device into pinned memory, against the full download."""
+    B, N = 777, 20
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    eng.load(make_batch(B, N, seed=2, fast_tail=0.3))
+    eng.rti(1)
+    full = eng.fetch()
+    for node in (0, 1, N - 1):
+        cmd, st = eng.input_column(node)
+        assert np.array_equal(cmd, full["u"][:, node, :]) and np.array_equal(st, full["status"])
+    with pytest.raises(Exception):
+        eng.input_column(N)
