@@ -37,7 +37,7 @@ struct alore_nmpc_solver {
     nmpc::PlantParams plant{};
     bool has_plant = false;
     // Polynome -> store on the device: staging + workspace for chunks of kPolyChunk messages
-    static constexpr int kPolyChunk = 256;
+    static constexpr int kPolyChunk = 2048;
     char* d_poly = nullptr;       // packed message arrays (layout: poly_layout)
     double* d_knot = nullptr;     // [chunk][2][traj_ws_doubles(P)] workspace of the spline kernel
     int* d_panels = nullptr;      // [chunk]
@@ -656,14 +656,20 @@ int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int* rob
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     const int P = h->refs.P, CH = alore_nmpc_solver::kPolyChunk, Pi = (P > 1 ? P - 1 : 1);
-    const PolyLayout L = poly_layout(CH, P);
+    const PolyLayout Lmax = poly_layout(CH, P);
     if (!h->d_poly) {
-        HIP_TRY(h, hipMalloc((void**)&h->d_poly, L.end));
+        HIP_TRY(h, hipMalloc((void**)&h->d_poly, Lmax.end));
         HIP_TRY(h, hipMalloc((void**)&h->d_knot, sizeof(double) * CH * 2 * nmpc::traj_ws_doubles(P)));
         HIP_TRY(h, hipMalloc((void**)&h->d_panels, sizeof(int) * CH));
         HIP_TRY(h, hipMalloc((void**)&h->d_overflow, sizeof(int)));
     }
-    const size_t need = (size_t)CH * h->refs.C * integral_res_int * 2;
+    // messages per round: as many as the staging allows (one upload, three kernels and one wait per round), fewer when the
+    // Simpson increments of a round ([C x res_int x 2] doubles per message) would pass 512 MB
+    const size_t inc_per_msg = (size_t)h->refs.C * integral_res_int * 2;
+    int chunk = (int)(((size_t)512 << 20) / (inc_per_msg * sizeof(double)));
+    chunk = chunk < 64 ? 64 : (chunk > CH ? CH : chunk);
+    if (chunk > count) chunk = count < 1 ? 1 : count;
+    const size_t need = (size_t)chunk * inc_per_msg;
     if (need > h->inc_doubles) {
         if (h->d_inc) (void)hipFree(h->d_inc);
         h->d_inc = nullptr;
@@ -671,9 +677,10 @@ int alore_nmpc_refs_set_polynomes(alore_nmpc_handle h, int count, const int* rob
         h->inc_doubles = need;
     }
     HIP_TRY(h, hipMemsetAsync(h->d_overflow, 0, sizeof(int), s));
+    const PolyLayout L = poly_layout(chunk, P); // staging laid out for the round size in use: a single message stays a small copy
     std::vector<char> pack(L.end);
-    for (int base = 0; base < count; base += CH) {
-        const int n = (count - base < CH) ? count - base : CH;
+    for (int base = 0; base < count; base += chunk) {
+        const int n = (count - base < chunk) ? count - base : chunk;
         std::fill(pack.begin(), pack.end(), 0);
         int* p_robot = reinterpret_cast<int*>(pack.data() + L.robot);
         int* p_np = reinterpret_cast<int*>(pack.data() + L.n_pieces);
