@@ -20,18 +20,15 @@ namespace nmpc {
 
 using minco::eval_pv;
 
-// one thread per (robot, node j); j = 0..N
-__global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, double dt, double now,
-                                  const double* est /* [B][3] */, const double* icr /* [B][3] xv yr yl */, int* at_goal,
-                                  double* psi_raw /* [B][N+1] normalised headings for the unwrap pass, or null */)
+// node j of robot r: everything of getRefPoints / setTrajectory / setICRParameters for that node; returns false when the
+// robot has no trajectory (nothing written), else the normalised heading in `psi_out` (also written to y / yN as float)
+__device__ __forceinline__ bool ref_sample_node(const RefStore& s, const alore_nmpc_batch& b, int N, double dt, double now,
+                                                const double* est, const double* icr, int* at_goal, int r, int j, double& psi_out)
 {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)B * (N + 1)) return;
-    const int r = (int)(t / (N + 1)), j = (int)(t % (N + 1));
     const double* m = s.meta + (size_t)r * 8;
     if (m[6] == 0.0) { // no trajectory yet: leave the references alone, and the robot is not at a goal
         if (j == 0 && at_goal) at_goal[r] = 0;
-        return;
+        return false;
     }
     const double start_time = m[0], duration = m[1], xv = m[2], res = m[3];
     const int np = (int)m[4], nc = (int)m[5];
@@ -70,7 +67,7 @@ __global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
     double psi = p3[0];
     while (psi > M_PI) psi -= 2 * M_PI; // normlize_theta
     while (psi < -M_PI) psi += 2 * M_PI;
-    if (psi_raw) psi_raw[t] = psi;
+    psi_out = psi;
     const double yr = icr[(size_t)r * 3 + 1], yl = icr[(size_t)r * 3 + 2];
     const double vr = inside ? v3[1] - v3[0] * yr : 0.0, vl = inside ? v3[1] - v3[0] * yl : 0.0;
     if (j < N) {
@@ -86,6 +83,51 @@ __global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
         float* x0 = const_cast<float*>(b.x0) + (size_t)r * 3;
         x0[0] = (float)est[(size_t)r * 3]; x0[1] = (float)est[(size_t)r * 3 + 1]; x0[2] = (float)est[(size_t)r * 3 + 2];
         if (at_goal) at_goal[r] = (t_cur > duration + 1.0) ? 1 : 0;
+    }
+    return true;
+}
+
+// one thread per (robot, node j); j = 0..N
+__global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, double dt, double now,
+                                  const double* est /* [B][3] */, const double* icr /* [B][3] xv yr yl */, int* at_goal,
+                                  double* psi_raw /* [B][N+1] normalised headings for the unwrap pass, or null */)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * (N + 1)) return;
+    const int r = (int)(t / (N + 1)), j = (int)(t % (N + 1));
+    double psi = 0.0;
+    if (ref_sample_node(s, b, N, dt, now, est, icr, at_goal, r, j, psi) && psi_raw) psi_raw[t] = psi;
+}
+
+// The same with smooth_yaw in the same launch: a robot's nodes sit on G consecutive lanes of one wavefront (G = 32 or 64
+// >= N + 1), the sequential walk of the reference (node i is unwrapped against the already unwrapped node i - 1; node 0
+// against the measured heading) hands the value from lane to lane by shuffles, all in float64 and cast afterwards like
+// ref_unwrap_kernel below.  Replaces two launches and the round trip of the raw headings through memory.
+template <int G>
+__global__ void ref_sample_smooth_kernel(RefStore s, alore_nmpc_batch b, int B, int N, double dt, double now, const double* est,
+                                         const double* icr, int* at_goal)
+{
+    const int per_block = blockDim.x / G;
+    const int r0 = blockIdx.x * per_block + threadIdx.x / G, j = threadIdx.x % G;
+    const bool in_range = r0 < B && j <= N;
+    const int r = r0 < B ? r0 : B - 1;
+    double cur = 0.0;
+    const bool have = in_range && ref_sample_node(s, b, N, dt, now, est, icr, at_goal, r, j, cur);
+    const double th = est[(size_t)r * 3 + 2];
+    const int base = (threadIdx.x & 63) - j; // first lane of the group inside the wavefront
+    double prev = th;                          // what this node is unwrapped against (lane 0: the measured heading)
+    for (int i = 0; i <= N; ++i) {             // wavefront-uniform
+        if (j == i) {
+            double dyaw = cur - prev;
+            while (dyaw >= M_PI / 2) { cur -= M_PI * 2; dyaw = cur - prev; }
+            while (dyaw <= -M_PI / 2) { cur += M_PI * 2; dyaw = cur - prev; }
+        }
+        const double c = __shfl(cur, base + i);
+        if (j == i + 1) prev = c;
+    }
+    if (have) {
+        if (j < N) const_cast<float*>(b.y)[((size_t)r * N + j) * 5 + 2] = (float)cur;
+        else const_cast<float*>(b.yN)[(size_t)r * 3 + 2] = (float)cur;
     }
 }
 
@@ -366,6 +408,11 @@ hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B
     const long total = (long)B * (N + 1);
     const int threads = 128;
     const unsigned blocks = (unsigned)((total + threads - 1) / threads);
+    if (do_smooth && N + 1 <= 64) { // sampling and smooth_yaw in one launch
+        if (N + 1 <= 32) hipLaunchKernelGGL(ref_sample_smooth_kernel<32>, dim3((B + 3) / 4), dim3(128), 0, st, s, b, B, N, dt, now, est, icr, at_goal);
+        else hipLaunchKernelGGL(ref_sample_smooth_kernel<64>, dim3((B + 1) / 2), dim3(128), 0, st, s, b, B, N, dt, now, est, icr, at_goal);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(ref_sample_kernel, dim3(blocks), dim3(threads), 0, st, s, b, B, N, dt, now, est, icr, at_goal,
                        do_smooth ? psi_scratch : nullptr);
     if (do_smooth) {
