@@ -1067,9 +1067,13 @@ __global__ void ltv_refs_kernel(nmpc::RefStore s, int B, int T, double dt, doubl
     if (index < 0) index = 0;
     const double floor_t = index * res, diff_t = tq - floor_t;
     double p1[2], p2[2], p3[2], v1[2], v2[2], v3[2];
-    minco::eval_pv(dur, coef, np, floor_t, p1, v1);
-    minco::eval_pv(dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
-    minco::eval_pv(dur, coef, np, tq, p3, v3);
+    constexpr int PRE = 16; // piece durations fetched up front (independent loads), as in nmpc::ref_sample_node
+    double dreg[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) dreg[k] = dur[min(k, np - 1)];
+    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, floor_t, p1, v1);
+    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
+    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, tq, p3, v3);
     const double* ck = s.ckpt + ((size_t)r * s.C + index) * 2;
     double xd1, yd1, xd2, yd2, xd3, yd3; // one sincos per Simpson node
     minco::xydot(p1, v1, xv, xd1, yd1); minco::xydot(p2, v2, xv, xd2, yd2); minco::xydot(p3, v3, xv, xd3, yd3);
@@ -1090,13 +1094,19 @@ __global__ void ltv_unwrap_kernel(nmpc::RefStore s, int B, int T, const double* 
     if (r >= B || s.meta[(size_t)r * 8 + 6] == 0.0) return;
     double* x = xref + (size_t)r * T * 3;
     const double th = est[(size_t)r * 3 + 2];
-    double dy = x[2] - th;
-    while (dy >= M_PI / 2) { x[2] -= 2 * M_PI; dy = x[2] - th; }
-    while (dy <= -M_PI / 2) { x[2] += 2 * M_PI; dy = x[2] - th; }
+    // the walk in registers (the headings were read, changed and read again in memory: several dependent round trips per node)
+    double prev = x[2];
+    double dy = prev - th;
+    while (dy >= M_PI / 2) { prev -= 2 * M_PI; dy = prev - th; }
+    while (dy <= -M_PI / 2) { prev += 2 * M_PI; dy = prev - th; }
+    x[2] = prev;
     for (int i = 0; i + 1 < T; ++i) {
-        dy = x[3 * (i + 1) + 2] - x[3 * i + 2];
-        while (dy >= M_PI / 2) { x[3 * (i + 1) + 2] -= 2 * M_PI; dy = x[3 * (i + 1) + 2] - x[3 * i + 2]; }
-        while (dy <= -M_PI / 2) { x[3 * (i + 1) + 2] += 2 * M_PI; dy = x[3 * (i + 1) + 2] - x[3 * i + 2]; }
+        double cur = x[3 * (i + 1) + 2];
+        dy = cur - prev;
+        while (dy >= M_PI / 2) { cur -= 2 * M_PI; dy = cur - prev; }
+        while (dy <= -M_PI / 2) { cur += 2 * M_PI; dy = cur - prev; }
+        x[3 * (i + 1) + 2] = cur;
+        prev = cur;
     }
 }
 
