@@ -35,12 +35,10 @@
 #include "minco_spline.h"
 #include "nmpc_kernels.h"
 
+#include "ltv_mpc.h"
+
 namespace ltv {
 
-constexpr int MAXT = 64;
-enum : int { FREE = 0, BOX_LO = 1, BOX_HI = 2, RATE_LO = 3, RATE_HI = 4 };
-constexpr int NF = 38; // doubles per stage record
-constexpr int REC_STRIDE = NF * 4 + 10; // lanes kernel, LDS doubles per stage (4 robots): consecutive lanes 8 dwords apart mod 128
 #define LTV_STAMP(i)                                                                         \
     if (d.stamps && b == 0) {                                                                \
         const long long now_ = (long long)__builtin_readcyclecounter();                      \
@@ -48,27 +46,6 @@ constexpr int REC_STRIDE = NF * 4 + 10; // lanes kernel, LDS doubles per stage (
         d.stamps[7] = now_;                                                                  \
     }
 constexpr int SINGLE_AFTER = 24; // from this sweep on only the most severe change is applied (breaks cycles)
-
-struct Dev {
-    alore_ltv_config c;
-    int B;               // robots in this launch
-    int stride;          // robot stride of the interleaved arrays (= max_robots)
-    const double* now;   // [B][3]
-    const double* xref;  // [B][T][3]
-    const double* dref;  // [B][T][2]
-    double* output;      // [B][T][2]  in/out (previous output -> new output)
-    double* buff;        // [B][d][2]  in/out
-    double* xopt;        // [B][T+1][3]
-    double* ws;          // [T][NF][stride]
-    int* st;             // [T][2][stride] working set (kept between calls: warm start)
-    int* sweeps;         // [B]
-    int* status;         // [B]
-    double* cmd;         // [B][2] the command a tick publishes: column delay_num of the output
-    double* cmd_host;    // optional: the same, written straight into pinned host memory (alore_ltv_tick: no copy back)
-    int* status_host;    // optional, with cmd_host
-    int n_relin, reset;
-    long long* stamps;   // diagnostic (ALORE_LTV_STAMPS=1): cycles of robot 0 in rollout / backward / forward / rest
-};
 
 struct Quad7 { // symmetric 7 x 7 form H and vector h in w = (xi0..4, u0, u1); only the entries that can be non-zero are kept dense
     double H[7][7];
@@ -100,6 +77,19 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
     }
     const double x0 = d.now[(size_t)b * 3], y0 = d.now[(size_t)b * 3 + 1], th0 = d.now[(size_t)b * 3 + 2];
     int sweeps = 0, status = 0;
+    { // this file is built without NaN / Inf semantics: a robot with a non-finite input is not solved at all (bit tests)
+        bool bad = non_finite_bits(x0) || non_finite_bits(y0) || non_finite_bits(th0);
+        for (int i = 0; i < 3 * T; ++i) bad = bad || non_finite_bits(xr[i]);
+        for (int i = 0; i < 2 * T; ++i) bad = bad || non_finite_bits(dr[i]) || non_finite_bits(out[i]);
+        for (int i = 0; i < 2 * dl; ++i) bad = bad || non_finite_bits(bf[i]);
+        if (bad) {
+            d.sweeps[b] = 0;
+            d.status[b] = STATUS_NON_FINITE;
+            d.cmd[2 * b] = 0.0; d.cmd[2 * b + 1] = 0.0;
+            if (d.cmd_host) { d.cmd_host[2 * b] = 0.0; d.cmd_host[2 * b + 1] = 0.0; d.status_host[b] = STATUS_NON_FINITE; }
+            return;
+        }
+    }
 
     if (d.stamps && b == 0) d.stamps[7] = (long long)__builtin_readcyclecounter();
     for (int relin = 0; relin < d.n_relin; ++relin) {
@@ -483,6 +473,27 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
         xr[s][0] = xrg[(dl + kc) * 3]; xr[s][1] = xrg[(dl + kc) * 3 + 1]; xr[s][2] = xrg[(dl + kc) * 3 + 2];
         dr0[s] = drg[(dl + kc) * 2];
     }
+    // This file is built without NaN / Inf semantics.  A robot with a non-finite measured state, reference or stored output
+    // (bit tests) is not solved: its inputs are replaced by zeros so that the arithmetic of its 16 lanes stays finite next to
+    // its wavefront mates, it gets status 2 and a zero command, and its stored output / working set / delay buffer stay.
+    bool poisoned;
+    {
+        bool bad = (j < 3) && non_finite_bits(nowp[j]);
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            bad = bad || non_finite_bits(ua[s]) || non_finite_bits(uw[s]) || non_finite_bits(xr[s][0]) || non_finite_bits(xr[s][1]) ||
+                  non_finite_bits(xr[s][2]) || non_finite_bits(dr0[s]);
+        if (!d.reset)
+            for (int i = j; i < 2 * dl; i += 16) bad = bad || non_finite_bits(out[i]) || non_finite_bits(bf[i]);
+        poisoned = ((__ballot(bad) >> (lane & ~15)) & 0xffffull) != 0ull;
+        if (poisoned) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) { ua[s] = uw[s] = 0.0; xr[s][0] = xr[s][1] = xr[s][2] = 0.0; dr0[s] = 0.0; st[s][0] = st[s][1] = FREE; }
+            if (j < 3) nowp[j] = 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const int zero_hist = (d.reset || poisoned) ? 1 : 0; // the delayed inputs read as zeros
     // record field f of stage k of this lane's robot
     auto REC = [&](int k_, int f) -> double& { return lds_rec[(size_t)k_ * REC_STRIDE + f * 4 + g]; };
     int sweeps = 0, status = 0;
@@ -496,8 +507,8 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
         double px = x0, py = y0, pth = th0, pv = 0.0; // now_state.v = 0 (odometry callback)
         for (int i = 0; i < dl; ++i) {
             const double* src = (relin == 0) ? out : bf; // solveMPCV copies the delay buffer into the first columns
-            const double a = d.reset ? 0.0 : src[2 * i];
-            const double yd = fmin(fmax(d.reset ? 0.0 : src[2 * i + 1], -c.max_omega), c.max_omega);
+            const double a = zero_hist ? 0.0 : src[2 * i];
+            const double yd = fmin(fmax(zero_hist ? 0.0 : src[2 * i + 1], -c.max_omega), c.max_omega);
             double sn, cs;
             sincos(pth, &sn, &cs);
             px += a * cs * dt; py += a * sn * dt; pth += yd * dt; pv = a;
@@ -973,7 +984,7 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
         double bth = th0, bv = 0.0, tx = x0, ty = y0, tth = th0;
         if (valid && j == 0) { xo[0] = tx; xo[1] = ty; xo[2] = tth; }
         for (int i = 0; i < dl; ++i) { // the delayed inputs (now the delay buffer), every lane
-            const double u0 = d.reset ? 0.0 : bf[2 * i], u1 = d.reset ? 0.0 : bf[2 * i + 1];
+            const double u0 = zero_hist ? 0.0 : bf[2 * i], u1 = zero_hist ? 0.0 : bf[2 * i + 1];
             double sb_, cb_;
             sincos(bth, &sb_, &cb_);
             const double B00 = cb_ * dt, B10 = sb_ * dt, A02 = -B10 * bv, A12 = B00 * bv;
@@ -1022,7 +1033,14 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
     LSTAMP(3)
     // ---- state kept between calls: the output (its first columns are the delay buffer), the working set, the buffer
     const double c0 = __shfl(ua[0], lane & ~15), c1 = __shfl(uw[0], lane & ~15); // stage 0 = the command just computed
-    if (valid) {
+    if (valid && poisoned) {
+        if (j == 0) {
+            d.sweeps[b] = 0;
+            d.status[b] = STATUS_NON_FINITE;
+            d.cmd[2 * b] = 0.0; d.cmd[2 * b + 1] = 0.0;
+            if (d.cmd_host) { d.cmd_host[2 * b] = 0.0; d.cmd_host[2 * b + 1] = 0.0; d.status_host[b] = STATUS_NON_FINITE; }
+        }
+    } else if (valid) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int k = j * S + s;
@@ -1046,338 +1064,24 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
     }
 }
 
-// getRefPoints of the `mpc` node on the trajectory store: thread = (robot, i), then smooth_yaw per robot
-__global__ void ltv_refs_kernel(nmpc::RefStore s, int B, int T, double dt, double now, double* xref, double* dref, int* at_goal)
+hipError_t launch_get_cmd(const Dev& d, bool thread_kernel, hipStream_t s)
 {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)B * T) return;
-    const int r = (int)(t / T), i = (int)(t % T);
-    const double* m = s.meta + (size_t)r * 8;
-    if (m[6] == 0.0) { if (i == 0 && at_goal) at_goal[r] = 0; return; }
-    const double duration = m[1], xv = m[2], res = m[3];
-    const int np = (int)m[4], nc = (int)m[5];
-    const double* dur = s.dur + (size_t)r * s.P;
-    const double* coef = s.coef + (size_t)r * s.P * 12;
-    const double t_cur = now - m[0];
-    double temp_t = t_cur + dt;
-    for (int k = 0; k < i; ++k) temp_t += dt;
-    const double tq = (temp_t <= duration) ? temp_t : duration;
-    int index = (int)floor(tq / res);
-    if (index > nc - 1) index = nc - 1;
-    if (index < 0) index = 0;
-    const double floor_t = index * res, diff_t = tq - floor_t;
-    double p1[2], p2[2], p3[2], v1[2], v2[2], v3[2];
-    constexpr int PRE = 16; // piece durations fetched up front (independent loads), as in nmpc::ref_sample_node
-    double dreg[PRE];
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) dreg[k] = dur[min(k, np - 1)];
-    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, floor_t, p1, v1);
-    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, floor_t + diff_t / 2.0, p2, v2);
-    minco::eval_pv_pre<PRE>(dreg, dur, coef, np, tq, p3, v3);
-    const double* ck = s.ckpt + ((size_t)r * s.C + index) * 2;
-    double xd1, yd1, xd2, yd2, xd3, yd3; // one sincos per Simpson node
-    minco::xydot(p1, v1, xv, xd1, yd1); minco::xydot(p2, v2, xv, xd2, yd2); minco::xydot(p3, v3, xv, xd3, yd3);
-    const double X = ck[0] + diff_t / 6.0 * (xd1 + 4.0 * xd2 + xd3);
-    const double Y = ck[1] + diff_t / 6.0 * (yd1 + 4.0 * yd2 + yd3);
-    double psi = p3[0];
-    while (psi > M_PI) psi -= 2 * M_PI;
-    while (psi < -M_PI) psi += 2 * M_PI;
-    double* xo = xref + ((size_t)r * T + i) * 3;
-    xo[0] = X; xo[1] = Y; xo[2] = psi;
-    dref[((size_t)r * T + i) * 2] = v3[1];
-    dref[((size_t)r * T + i) * 2 + 1] = v3[0];
-    if (i == 0 && at_goal) at_goal[r] = (t_cur > duration + 1.0) ? 1 : 0;
-}
-__global__ void ltv_unwrap_kernel(nmpc::RefStore s, int B, int T, const double* est, double* xref)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= B || s.meta[(size_t)r * 8 + 6] == 0.0) return;
-    double* x = xref + (size_t)r * T * 3;
-    const double th = est[(size_t)r * 3 + 2];
-    // the walk in registers (the headings were read, changed and read again in memory: several dependent round trips per node)
-    double prev = x[2];
-    double dy = prev - th;
-    while (dy >= M_PI / 2) { prev -= 2 * M_PI; dy = prev - th; }
-    while (dy <= -M_PI / 2) { prev += 2 * M_PI; dy = prev - th; }
-    x[2] = prev;
-    for (int i = 0; i + 1 < T; ++i) {
-        double cur = x[3 * (i + 1) + 2];
-        dy = cur - prev;
-        while (dy >= M_PI / 2) { cur -= 2 * M_PI; dy = cur - prev; }
-        while (dy <= -M_PI / 2) { cur += 2 * M_PI; dy = cur - prev; }
-        x[3 * (i + 1) + 2] = cur;
-        prev = cur;
+    const int B = d.B, K = d.c.predict_steps - d.c.delay_num;
+    if (thread_kernel)
+        hipLaunchKernelGGL(get_cmd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d);
+    else if (K <= 32)
+        hipLaunchKernelGGL(get_cmd_lanes_kernel<2>, dim3((B + 3) / 4), dim3(64), ((size_t)K * REC_STRIDE + 16) * sizeof(double), s, d);
+    else {
+        const size_t lds = ((size_t)K * REC_STRIDE + 16) * sizeof(double);
+        static bool raised = false;
+        if (!raised) {
+            const hipError_t e = hipFuncSetAttribute((const void*)get_cmd_lanes_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (64 * REC_STRIDE + 16) * 8);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+        hipLaunchKernelGGL(get_cmd_lanes_kernel<4>, dim3((B + 3) / 4), dim3(64), lds, s, d);
     }
+    return hipGetLastError();
 }
 
 } // namespace ltv
-
-// internal accessor of the NMPC handle's trajectory store (nmpc_capi.hip)
-extern "C" int alore_nmpc_internal_refstore(void* nmpc_handle, nmpc::RefStore* out, int* capacity, int* device);
-
-struct alore_ltv_solver {
-    alore_ltv_config cfg;
-    int device = 0, B = 0;
-    std::string err;
-    double *d_now = nullptr, *d_xref = nullptr, *d_dref = nullptr, *d_out = nullptr, *d_buff = nullptr, *d_xopt = nullptr, *d_ws = nullptr,
-           *d_est = nullptr, *d_cmd = nullptr;
-    int *d_st = nullptr, *d_sweeps = nullptr, *d_status = nullptr, *d_goal = nullptr;
-    long long* d_stamps = nullptr;
-    char* h_stage = nullptr; // pinned
-    size_t stage_bytes = 0;
-};
-
-namespace {
-int lfail(alore_ltv_handle h, int code, const char* what, hipError_t e = hipSuccess)
-{
-    if (h) { h->err = what; if (e != hipSuccess) { h->err += ": "; h->err += hipGetErrorString(e); } }
-    return code;
-}
-#define LTV_TRY(h, call)                                                  \
-    do {                                                                  \
-        hipError_t e_ = (call);                                           \
-        if (e_ != hipSuccess) return lfail(h, ALORE_LTV_E_HIP, #call, e_); \
-    } while (0)
-template <class T>
-hipError_t zalloc(T** p, size_t n)
-{
-    hipError_t e = hipMalloc((void**)p, sizeof(T) * (n ? n : 1));
-    if (e == hipSuccess) e = hipMemset(*p, 0, sizeof(T) * (n ? n : 1));
-    return e;
-}
-void lfree(alore_ltv_handle h)
-{
-    void* ptrs[] = {h->d_now, h->d_xref, h->d_dref, h->d_out, h->d_buff, h->d_xopt, h->d_ws, h->d_est, h->d_st, h->d_sweeps, h->d_status, h->d_goal, h->d_cmd};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
-}
-} // namespace
-
-extern "C" {
-
-void alore_ltv_default_config(alore_ltv_config* c)
-{
-    std::memset(c, 0, sizeof(*c));
-    c->dt = 0.01; c->predict_steps = 30; c->delay_num = 1;
-    c->matrix_q[0] = 15.0; c->matrix_q[1] = 15.0; c->matrix_q[2] = 0.0; c->matrix_q[3] = 1.0;
-    c->matrix_r[0] = 0.0; c->matrix_r[1] = 0.0;
-    c->matrix_rd[0] = 1.0; c->matrix_rd[1] = 0.05;
-    c->max_vel = 3.0; c->min_vel = 0.0; c->max_omega = 3.0; c->max_acc = 2.0; c->max_domega = 4.0;
-    c->max_sweeps = 64;
-}
-
-int alore_ltv_create(const alore_ltv_config* cfg, int device, int max_robots, alore_ltv_handle* out)
-{
-    if (!cfg || !out || max_robots < 1) return ALORE_LTV_E_INVALID;
-    *out = nullptr;
-    if (cfg->predict_steps < 2 || cfg->predict_steps > ltv::MAXT || cfg->delay_num < 0 || cfg->delay_num >= cfg->predict_steps - 1 ||
-        !(cfg->dt > 0.0))
-        return ALORE_LTV_E_INVALID;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ALORE_LTV_E_NO_DEVICE;
-    if (device < 0 || device >= ndev) return ALORE_LTV_E_INVALID;
-    if (hipSetDevice(device) != hipSuccess) return ALORE_LTV_E_NO_DEVICE;
-    alore_ltv_solver* h = new (std::nothrow) alore_ltv_solver;
-    if (!h) return ALORE_LTV_E_NOMEM;
-    h->cfg = *cfg;
-    if (h->cfg.max_sweeps <= 0) h->cfg.max_sweeps = 64;
-    h->device = device;
-    h->B = max_robots;
-    const size_t B = max_robots, T = cfg->predict_steps, dl = cfg->delay_num > 0 ? cfg->delay_num : 1;
-    hipError_t e = hipSuccess;
-    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    A(zalloc(&h->d_now, B * 3)); A(zalloc(&h->d_xref, B * T * 3)); A(zalloc(&h->d_dref, B * T * 2)); A(zalloc(&h->d_out, B * T * 2));
-    A(zalloc(&h->d_buff, B * dl * 2)); A(zalloc(&h->d_xopt, B * (T + 1) * 3)); A(zalloc(&h->d_ws, T * ltv::NF * B)); A(zalloc(&h->d_est, B * 3));
-    if (std::getenv("ALORE_LTV_STAMPS")) A(zalloc(&h->d_stamps, (size_t)8));
-    A(zalloc(&h->d_st, T * 2 * B)); A(zalloc(&h->d_sweeps, B)); A(zalloc(&h->d_status, B)); A(zalloc(&h->d_goal, B)); A(zalloc(&h->d_cmd, B * 2));
-    h->stage_bytes = sizeof(double) * B * ((T + 1) * 3 + T * 5 + 8) + sizeof(int) * B * 4 + 1024;
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_stage, h->stage_bytes, hipHostMallocDefault);
-    if (e != hipSuccess) { lfree(h); delete h; return e == hipErrorOutOfMemory ? ALORE_LTV_E_NOMEM : ALORE_LTV_E_HIP; }
-    *out = h;
-    return ALORE_LTV_OK;
-}
-
-int alore_ltv_destroy(alore_ltv_handle h)
-{
-    if (!h) return ALORE_LTV_E_INVALID;
-    (void)hipSetDevice(h->device);
-    if (h->d_stamps) {
-        long long st[8];
-        if (hipMemcpy(st, h->d_stamps, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
-            std::fprintf(stderr, "[alore_ltv stamps] robot 0, cycles: rollout %lld, backward %lld, forward %lld, rest %lld\n", st[0], st[1], st[2], st[3]);
-        (void)hipFree(h->d_stamps);
-    }
-    lfree(h);
-    delete h;
-    return ALORE_LTV_OK;
-}
-const char* alore_ltv_last_error(alore_ltv_handle h) { return h ? h->err.c_str() : "null handle"; }
-
-int alore_ltv_set_refs(alore_ltv_handle h, int B, const double* xref, const double* dref, void* stream)
-{
-    if (!h || B < 1 || B > h->B || !xref || !dref) return lfail(h, ALORE_LTV_E_INVALID, "set_refs: bad argument");
-    LTV_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t T = h->cfg.predict_steps;
-    double* hx = (double*)h->h_stage;
-    double* hd = hx + (size_t)B * T * 3;
-    std::memcpy(hx, xref, sizeof(double) * B * T * 3);
-    std::memcpy(hd, dref, sizeof(double) * B * T * 2);
-    LTV_TRY(h, hipMemcpyAsync(h->d_xref, hx, sizeof(double) * B * T * 3, hipMemcpyHostToDevice, s));
-    LTV_TRY(h, hipMemcpyAsync(h->d_dref, hd, sizeof(double) * B * T * 2, hipMemcpyHostToDevice, s));
-    LTV_TRY(h, hipStreamSynchronize(s)); // the slab is reused
-    return ALORE_LTV_OK;
-}
-
-int alore_ltv_refs_from_store(alore_ltv_handle h, void* nmpc, int B, double now, const double* est, int* at_goal, void* stream)
-{
-    if (!h || !nmpc || B < 1 || B > h->B || !est) return lfail(h, ALORE_LTV_E_INVALID, "refs_from_store: bad argument");
-    nmpc::RefStore rs;
-    int cap = 0, dev = -1;
-    if (alore_nmpc_internal_refstore(nmpc, &rs, &cap, &dev) != 0 || cap < B || dev != h->device)
-        return lfail(h, ALORE_LTV_E_INVALID, "refs_from_store: the NMPC handle has no trajectory store for B robots on this device");
-    LTV_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const int T = h->cfg.predict_steps;
-    double* he = (double*)h->h_stage;
-    std::memcpy(he, est, sizeof(double) * B * 3);
-    LTV_TRY(h, hipMemcpyAsync(h->d_est, he, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
-    const long total = (long)B * T;
-    hipLaunchKernelGGL(ltv::ltv_refs_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, s, rs, B, T, h->cfg.dt, now, h->d_xref, h->d_dref,
-                       h->d_goal);
-    hipLaunchKernelGGL(ltv::ltv_unwrap_kernel, dim3((B + 63) / 64), dim3(64), 0, s, rs, B, T, h->d_est, h->d_xref);
-    LTV_TRY(h, hipGetLastError());
-    if (at_goal) LTV_TRY(h, hipMemcpyAsync(at_goal, h->d_goal, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    LTV_TRY(h, hipStreamSynchronize(s));
-    return ALORE_LTV_OK;
-}
-
-static int ltv_enqueue(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, hipStream_t s,
-                       double* cmd_host = nullptr, int* status_host = nullptr)
-{
-    double* hn = (double*)h->h_stage;
-    std::memcpy(hn, now_state, sizeof(double) * B * 3);
-    ltv::Dev d{};
-    d.c = h->cfg; d.B = B; d.stride = h->B;
-    static const char* which = std::getenv("ALORE_LTV_KERNEL");
-    const bool thread_kernel = which && which[0] == 't';
-    if (cmd_host && !thread_kernel) { // tick path: the lanes kernel reads the states once, straight from the pinned slab
-        void* dn = nullptr;
-        LTV_TRY(h, hipHostGetDevicePointer(&dn, hn, 0));
-        d.now = (const double*)dn;
-    } else {
-        LTV_TRY(h, hipMemcpyAsync(h->d_now, hn, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
-        d.now = h->d_now;
-    }
-    d.xref = h->d_xref; d.dref = h->d_dref; d.output = h->d_out; d.buff = h->d_buff; d.xopt = h->d_xopt;
-    d.ws = h->d_ws; d.st = h->d_st; d.sweeps = h->d_sweeps; d.status = h->d_status; d.cmd = h->d_cmd;
-    d.n_relin = n_relin; d.reset = reset;
-    d.cmd_host = cmd_host; d.status_host = status_host;
-    d.stamps = h->d_stamps;
-    // 16 lanes per robot (stages in registers, sweeps lane by lane) unless ALORE_LTV_KERNEL=thread asks for the
-    // one-thread-per-robot kernel (diagnostic A/B)
-    const int K = h->cfg.predict_steps - h->cfg.delay_num;
-    if (thread_kernel)
-        hipLaunchKernelGGL(ltv::get_cmd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d);
-    else if (K <= 32)
-        hipLaunchKernelGGL(ltv::get_cmd_lanes_kernel<2>, dim3((B + 3) / 4), dim3(64), ((size_t)K * ltv::REC_STRIDE + 16) * sizeof(double), s, d);
-    else {
-        const size_t lds = ((size_t)K * ltv::REC_STRIDE + 16) * sizeof(double);
-        static bool raised = false;
-        if (!raised) {
-            LTV_TRY(h, hipFuncSetAttribute((const void*)ltv::get_cmd_lanes_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (64 * ltv::REC_STRIDE + 16) * 8));
-            raised = true;
-        }
-        hipLaunchKernelGGL(ltv::get_cmd_lanes_kernel<4>, dim3((B + 3) / 4), dim3(64), lds, s, d);
-    }
-    LTV_TRY(h, hipGetLastError());
-    return ALORE_LTV_OK;
-}
-
-int alore_ltv_get_cmd(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, void* stream)
-{
-    if (!h || B < 1 || B > h->B || !now_state || n_relin < 1) return lfail(h, ALORE_LTV_E_INVALID, "get_cmd: bad argument");
-    LTV_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const int rc = ltv_enqueue(h, B, now_state, n_relin, reset, s);
-    if (rc != ALORE_LTV_OK) return rc;
-    LTV_TRY(h, hipStreamSynchronize(s)); // the staging slab is reused by the next call
-    return ALORE_LTV_OK;
-}
-
-// one control tick: states in, getCmd, commands (and status) out -- one upload, one launch, one download, one wait
-int alore_ltv_tick(alore_ltv_handle h, int B, const double* now_state, int n_relin, int reset, double* cmd, int* status, void* stream)
-{
-    if (!h || B < 1 || B > h->B || !now_state || n_relin < 1 || !cmd) return lfail(h, ALORE_LTV_E_INVALID, "tick: bad argument");
-    LTV_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    // the kernel writes the 20 bytes per robot a tick returns straight into the pinned slab (device alias of the host
-    // pointer): two copy commands and their completion signals less on the critical path of the tick
-    double* sc = (double*)h->h_stage + (size_t)B * 3;
-    int* st = (int*)(sc + (size_t)B * 2);
-    void *dsc = nullptr, *dst = nullptr;
-    LTV_TRY(h, hipHostGetDevicePointer(&dsc, sc, 0));
-    LTV_TRY(h, hipHostGetDevicePointer(&dst, st, 0));
-    const int rc = ltv_enqueue(h, B, now_state, n_relin, reset, s, (double*)dsc, (int*)dst);
-    if (rc != ALORE_LTV_OK) return rc;
-    LTV_TRY(h, hipStreamSynchronize(s));
-    std::memcpy(cmd, sc, sizeof(double) * B * 2);
-    if (status) std::memcpy(status, st, sizeof(int) * B);
-    return ALORE_LTV_OK;
-}
-
-int alore_ltv_results(alore_ltv_handle h, int B, double* output, double* xopt, int* sweeps, int* status, void* stream)
-{
-    if (!h || B < 1 || B > h->B) return lfail(h, ALORE_LTV_E_INVALID, "results: bad argument");
-    LTV_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t T = h->cfg.predict_steps;
-    // through the pinned slab of the handle (a device-to-pageable copy is staged by the runtime in small pieces with a host
-    // wait per piece): layout  output | xopt | sweeps | status
-    char* base = h->h_stage;
-    double* so = (double*)base;
-    double* sx = so + (size_t)B * T * 2;
-    int* ss = (int*)(sx + (size_t)B * (T + 1) * 3);
-    int* st = ss + B;
-    if (output) LTV_TRY(h, hipMemcpyAsync(so, h->d_out, sizeof(double) * B * T * 2, hipMemcpyDeviceToHost, s));
-    if (xopt) LTV_TRY(h, hipMemcpyAsync(sx, h->d_xopt, sizeof(double) * B * (T + 1) * 3, hipMemcpyDeviceToHost, s));
-    if (sweeps) LTV_TRY(h, hipMemcpyAsync(ss, h->d_sweeps, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    if (status) LTV_TRY(h, hipMemcpyAsync(st, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    LTV_TRY(h, hipStreamSynchronize(s));
-    if (output) std::memcpy(output, so, sizeof(double) * B * T * 2);
-    if (xopt) std::memcpy(xopt, sx, sizeof(double) * B * (T + 1) * 3);
-    if (sweeps) std::memcpy(sweeps, ss, sizeof(int) * B);
-    if (status) std::memcpy(status, st, sizeof(int) * B);
-    return ALORE_LTV_OK;
-}
-
-int alore_ltv_commands(alore_ltv_handle h, int B, double* cmd, int* status, void* stream)
-{
-    if (!h || B < 1 || B > h->B || !cmd) return lfail(h, ALORE_LTV_E_INVALID, "commands: bad argument");
-    LTV_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t T = h->cfg.predict_steps, dl = h->cfg.delay_num;
-    double* sc = (double*)h->h_stage;
-    int* st = (int*)(sc + (size_t)B * 2);
-    // column delay_num of every robot's output, packed by the kernel (16 bytes per robot)
-    LTV_TRY(h, hipMemcpyAsync(sc, h->d_cmd, sizeof(double) * B * 2, hipMemcpyDeviceToHost, s));
-    if (status) LTV_TRY(h, hipMemcpyAsync(st, h->d_status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
-    LTV_TRY(h, hipStreamSynchronize(s));
-    std::memcpy(cmd, sc, sizeof(double) * B * 2);
-    if (status) std::memcpy(status, st, sizeof(int) * B);
-    return ALORE_LTV_OK;
-}
-
-int alore_ltv_set_state(alore_ltv_handle h, int B, const double* output, const double* buff, void* stream)
-{
-    if (!h || B < 1 || B > h->B) return lfail(h, ALORE_LTV_E_INVALID, "set_state: bad argument");
-    LTV_TRY(h, hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    const size_t T = h->cfg.predict_steps, dl = h->cfg.delay_num;
-    if (output) LTV_TRY(h, hipMemcpyAsync(h->d_out, output, sizeof(double) * B * T * 2, hipMemcpyHostToDevice, s));
-    if (buff && dl > 0) LTV_TRY(h, hipMemcpyAsync(h->d_buff, buff, sizeof(double) * B * dl * 2, hipMemcpyHostToDevice, s));
-    LTV_TRY(h, hipStreamSynchronize(s));
-    return ALORE_LTV_OK;
-}
-
-} // extern "C"

@@ -219,8 +219,11 @@ int block_lds_floats(int N, int L)
     return ((G * 25 * N + 255) & ~255) + ((G * 5 * N + 255) & ~255);
 }
 
+// One grid serves up to GROUP_MAX independent batches (alore_nmpc_rti_many): the descriptors travel by value in the kernel
+// arguments, block -> (batch, block of the batch) by one division.  The pointers of a workgroup's batch are
+// wavefront-uniform (scalar loads from the kernel-argument segment); a single batch is the group of one.
 template <int L, int S, bool DIAG, bool STAMP, bool ONCE>
-__global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
+__global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const RtiGroup grp)
 {
     extern __shared__ float4 lds_raw[];
     float* lds = reinterpret_cast<float*>(lds_raw);
@@ -231,7 +234,9 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     const int lane = threadIdx.x;
     const int g = lane / L, j = lane % L;
     const int gbase = lane - j;
-    const int prob0 = blockIdx.x * G;
+    const int bi = (grp.count > 1) ? (int)blockIdx.x / grp.blocks_per_batch : 0;
+    const alore_nmpc_batch& pb = grp.b[bi];
+    const int prob0 = ((int)blockIdx.x - bi * grp.blocks_per_batch) * G;
     const int np_ = min(G, p.B - prob0);
     const bool valid = g < np_;
     const int ge = valid ? g : np_ - 1; // padding groups shadow the last problem, never store
@@ -269,9 +274,9 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             }
             if (rem && lane < rem) lds[lds_off + n4 * 4 + lane] = gsrc[n4 * 4 + lane]; // ragged last wavefront only
         };
-        if (p.shared & ALORE_NMPC_SHARED_W) dma(p.b.W, 25 * N, oW, std::integral_constant<int, UW>{}); // one copy for the batch
-        else dma(p.b.W + (size_t)prob0 * 25 * N, np_ * 25 * N, oW, std::integral_constant<int, UW>{});
-        dma(p.b.y + (size_t)prob0 * 5 * N, np_ * 5 * N, oY, std::integral_constant<int, UY>{});
+        if (p.shared & ALORE_NMPC_SHARED_W) dma(pb.W, 25 * N, oW, std::integral_constant<int, UW>{}); // one copy for the batch
+        else dma(pb.W + (size_t)prob0 * 25 * N, np_ * 25 * N, oW, std::integral_constant<int, UW>{});
+        dma(pb.y + (size_t)prob0 * 5 * N, np_ * 5 * N, oY, std::integral_constant<int, UY>{});
     }
     float x[S][3], u[S][2], od[S][3], lbv[S][2], ubv[S][2], xN[3];
     float mu0[S], mu1[S]; // bound multipliers: the incoming dual until the first forward sweep overwrites it
@@ -279,12 +284,12 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     {
         typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
         typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-        const float* gx = p.b.x + (size_t)prob * nx;
-        const float* god = p.b.od + ((p.shared & ALORE_NMPC_SHARED_OD) ? 0 : (size_t)prob * nx);
-        const float* gu = p.b.u + (size_t)prob * nu;
-        const float* gdl = p.b.dual + (size_t)prob * nu;
-        const float* glb = p.b.lbValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * nu);
-        const float* gub = p.b.ubValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * nu);
+        const float* gx = pb.x + (size_t)prob * nx;
+        const float* god = pb.od + ((p.shared & ALORE_NMPC_SHARED_OD) ? 0 : (size_t)prob * nx);
+        const float* gu = pb.u + (size_t)prob * nu;
+        const float* gdl = pb.dual + (size_t)prob * nu;
+        const float* glb = pb.lbValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * nu);
+        const float* gub = pb.ubValues + ((p.shared & ALORE_NMPC_SHARED_BOUNDS) ? 0 : (size_t)prob * nu);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int k = j * S + s;
@@ -298,11 +303,11 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
         }
         const f3u vn = *reinterpret_cast<const f3u*>(gx + 3 * N);
         xN[0] = vn.x; xN[1] = vn.y; xN[2] = vn.z;
-        x00 = p.b.x0[(size_t)prob * 3]; x01 = p.b.x0[(size_t)prob * 3 + 1]; x02 = p.b.x0[(size_t)prob * 3 + 2];
+        x00 = pb.x0[(size_t)prob * 3]; x01 = pb.x0[(size_t)prob * 3 + 1]; x02 = pb.x0[(size_t)prob * 3 + 2];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) WN[i] = p.b.WN[((p.shared & ALORE_NMPC_SHARED_W) ? 0 : (size_t)prob * 9) + i];
+        for (int i = 0; i < 9; ++i) WN[i] = pb.WN[((p.shared & ALORE_NMPC_SHARED_W) ? 0 : (size_t)prob * 9) + i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) yN[i] = p.b.yN[(size_t)prob * 3 + i];
+        for (int i = 0; i < 3; ++i) yN[i] = pb.yN[(size_t)prob * 3 + i];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the DMA pieces have landed
     wave_sync();
@@ -347,7 +352,9 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float nb = (s + 1 < S) ? x[(s + 1 < S) ? s + 1 : s][c] : lane_next<L>(x[0][c]);
-                xn[c] = (k + 1 == N) ? xN[c] : nb;
+                // slots past the horizon take 0, not the shifted value: for the last lane of a group that is the NEXT problem's
+                // node 0, and 0 * NaN of a broken neighbour must not enter this problem's defects
+                xn[c] = (k + 1 == N) ? xN[c] : ((k + 1 < N) ? nb : 0.0f);
             }
             StageLin lin;
             ddr_linearize(K, x[s][0], x[s][1], x[s][2], u[s][0], u[s][1], od[s][0], od[s][1], od[s][2], lin);
@@ -861,8 +868,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
             // that x, u do not occupy 5 S + 3 registers per lane through the prediction and the sweeps
             typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
             typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-            const float* gx = p.b.x + (size_t)prob * nx;
-            const float* gu = p.b.u + (size_t)prob * nu;
+            const float* gx = pb.x + (size_t)prob * nx;
+            const float* gu = pb.u + (size_t)prob * nu;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int k = j * S + s;
@@ -929,8 +936,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
         if (j == top) { // the reference uses only the diagonal of WN here (acado_solver.c:1442-1444)
             float w0 = WN[0], w4 = WN[4], w8 = WN[8], y0 = yN[0], y1 = yN[1], y2 = yN[2];
             if constexpr (ONCE) { // read again instead of held since phase A
-                const float* gW = p.b.WN + ((p.shared & ALORE_NMPC_SHARED_W) ? 0 : (size_t)prob * 9);
-                const float* gy = p.b.yN + (size_t)prob * 3;
+                const float* gW = pb.WN + ((p.shared & ALORE_NMPC_SHARED_W) ? 0 : (size_t)prob * 9);
+                const float* gy = pb.yN + (size_t)prob * 3;
                 w0 = gW[0]; w4 = gW[4]; w8 = gW[8]; y0 = gy[0]; y1 = gy[1]; y2 = gy[2];
             }
             const float e0 = xN[0] - y0, e1 = xN[1] - y1, e2 = xN[2] - y2;
@@ -963,15 +970,15 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p)
     {
         constexpr int UX = (G * 3 * (NMAX + 1) / 4 + 63) / 64;
         constexpr int UU = (G * 2 * NMAX / 4 + 63) / 64;
-        g_store<UX>(p.b.x + (size_t)prob0 * nx, lds + oX, np_ * nx, lane);
-        g_store<UU>(p.b.u + (size_t)prob0 * nu, lds + oU, np_ * nu, lane);
-        g_store<UU>(p.b.dual + (size_t)prob0 * nu, lds + oDL, np_ * nu, lane);
+        g_store<UX>(pb.x + (size_t)prob0 * nx, lds + oX, np_ * nx, lane);
+        g_store<UU>(pb.u + (size_t)prob0 * nu, lds + oU, np_ * nu, lane);
+        g_store<UU>(pb.dual + (size_t)prob0 * nu, lds + oDL, np_ * nu, lane);
     }
     if (valid && j == 0) {
-        p.b.status[prob] = status;
-        p.b.n_iter[prob] = n_iter;
-        if (DIAG && p.b.kkt) p.b.kkt[prob] = kkt;
-        if (DIAG && p.b.obj) p.b.obj[prob] = obj;
+        pb.status[prob] = status;
+        pb.n_iter[prob] = n_iter;
+        if (DIAG && pb.kkt) pb.kkt[prob] = kkt;
+        if (DIAG && pb.obj) pb.obj[prob] = obj;
     }
     if (STAMP && lane == 0 && p.stamps) {
         long long* o = p.stamps + (size_t)blockIdx.x * 8;
@@ -1028,8 +1035,20 @@ bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, L
 
 hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t s)
 {
+    RtiGroup grp;
+    grp.count = 1;
+    grp.blocks_per_batch = g.grid;
+    grp.b[0] = p.b;
+    return launch_rti_block_group(p, grp, g, s);
+}
+
+// `grp.count` batches of p.B problems each in one grid (g.grid = blocks of ONE batch); every batch of the group has the
+// same set of diagnostics pointers (checked by the caller)
+hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const LaunchGeom& g, hipStream_t s)
+{
+    if (grp.count < 1 || grp.count > GROUP_MAX || grp.blocks_per_batch != g.grid) return hipErrorInvalidValue;
     const bool stamp = p.stamps != nullptr;
-    const bool diag = stamp || p.b.kkt != nullptr || p.b.obj != nullptr;
+    const bool diag = stamp || grp.b[0].kkt != nullptr || grp.b[0].obj != nullptr;
     const bool once = p.n_sqp == 1;
     const void* fn = nullptr;
     int v = -1;
@@ -1059,8 +1078,8 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
         if (e != hipSuccess) return e;
         configured[dev][v] = g.lds_bytes;
     }
-    void* args[] = {const_cast<RtiParams*>(&p)};
-    e = hipLaunchKernel(fn, dim3(g.grid), dim3(64), args, g.lds_bytes, s);
+    void* args[] = {const_cast<RtiParams*>(&p), const_cast<RtiGroup*>(&grp)};
+    e = hipLaunchKernel(fn, dim3((unsigned)g.grid * (unsigned)grp.count), dim3(64), args, g.lds_bytes, s);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }

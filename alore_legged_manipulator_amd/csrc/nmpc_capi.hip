@@ -1,6 +1,7 @@
 // nmpc_capi.hip -- implementation of the C ABI declared in include/alore_nmpc.h.
 // Thin host layer: argument checks, launch geometry, HIP stream/event plumbing.
 // There is no CPU path behind this ABI: without a GPU alore_nmpc_create fails.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,7 +56,7 @@ struct alore_nmpc_solver {
     size_t stage_up_cap = 0, stage_down_cap = 0;
     // alore_nmpc_rti_many: launches of independent batches in flight at once (side streams forked from the caller's)
     int overlap = 16;
-    int in_flight_B = 0; // set by alore_nmpc_rti_many around its launches: problems of the launches that overlap
+    int many_mode = 0; // alore_nmpc_rti_many: 0 = groups of batches per grid, 1 = one launch per batch on forked streams
     hipStream_t side[31] = {};
     hipEvent_t fork_ev = nullptr, join_ev[31] = {};
     hipEvent_t stage_up_done = nullptr; // the copies out of stage_up enqueued by the last upload
@@ -406,41 +407,50 @@ int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch*
     return ALORE_NMPC_OK;
 }
 
-int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream)
+namespace {
+
+// may this batch run on the stage-block kernel (nmpc_block_kernel.hip)?  Not when the caller forces lanes of the wavefront
+// kernel, a separate linearisation point is set, or a member is not 16-byte aligned.
+bool block_eligible(alore_nmpc_handle h, const alore_nmpc_batch* dev)
 {
-    if (!h || !dev || B <= 0 || n_sqp < 1) return fail(h, ALORE_NMPC_E_INVALID, "rti: bad argument");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    static const char* force_kernel = getenv("ALORE_NMPC_KERNEL"); // diagnostic: "wave" or "block"
+    const int lp = h->cfg.lanes_per_problem;
+    bool ok = (lp == 0 || (lp & 0x100)) && !(force_kernel && force_kernel[0] == 'w') && !h->lin_x;
+    const void* ptrs[] = {dev->x, dev->u, dev->od, dev->y, dev->W, dev->lbValues, dev->ubValues, dev->dual};
+    for (const void* q : ptrs) ok = ok && ((reinterpret_cast<size_t>(q) & 15) == 0);
+    return ok;
+}
+
+void fill_params(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, const nmpc::LaunchGeom& g, nmpc::RtiParams* p)
+{
+    p->b = *dev;
+    p->B = B;
+    p->N = h->cfg.N;
+    p->n_sqp = n_sqp;
+    p->max_as_iter = h->cfg.max_as_iter;
+    p->pg_steps = h->cfg.warm_start_steps;
+    p->shared = h->shared;
+    p->RS = g.RS;
+    const nmpc::IrkConst K = nmpc::make_irk(h->cfg.dt);
+    p->h = K.h; p->hh = K.hh; p->c1h = K.c1h; p->c2h = K.c2h;
+    p->stamps = nullptr;
+    p->lin_x = h->lin_x;
+    p->lin_u = h->lin_u;
+}
+
+// one launch for one batch; B_in_flight = problems of all launches that run concurrently with it (0: only this one)
+int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream, int B_in_flight)
+{
     if (!batch_complete(dev)) return fail(h, ALORE_NMPC_E_INVALID, "rti: batch has NULL members");
     nmpc::LaunchGeom g;
     static const int forced_wpb = getenv("ALORE_NMPC_WPB") ? atoi(getenv("ALORE_NMPC_WPB")) : 0; // diagnostic: 1 or 4
-    // Mapping: the stage-block kernel (nmpc_block_kernel.hip) unless the caller forces lanes of the wavefront kernel,
-    // the horizon exceeds its instantiations, or the launch uses what only the wavefront kernel implements (a separate
-    // linearisation point, members that are not 16-byte aligned).
-    static const char* force_kernel = getenv("ALORE_NMPC_KERNEL"); // diagnostic: "wave" or "block"
     const int lp = h->cfg.lanes_per_problem;
-    bool use_block = (lp == 0 || (lp & 0x100)) && !(force_kernel && force_kernel[0] == 'w');
-    if (use_block) {
-        const void* ptrs[] = {dev->x, dev->u, dev->od, dev->y, dev->W, dev->lbValues, dev->ubValues, dev->dual};
-        for (const void* q : ptrs) use_block = use_block && ((reinterpret_cast<size_t>(q) & 15) == 0);
-        use_block = use_block && !h->lin_x;
-        use_block = use_block && nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g, h->in_flight_B);
-    }
+    const bool use_block = block_eligible(h, dev) &&
+                           nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight);
     if (!use_block && !nmpc::rti_geometry(B, h->cfg.N, (lp & 0x100) ? 0 : lp, h->lds_limit, h->n_cu, &g, forced_wpb))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: horizon does not fit the LDS layout");
     nmpc::RtiParams p;
-    p.b = *dev;
-    p.B = B;
-    p.N = h->cfg.N;
-    p.n_sqp = n_sqp;
-    p.max_as_iter = h->cfg.max_as_iter;
-    p.pg_steps = h->cfg.warm_start_steps;
-    p.shared = h->shared;
-    p.RS = g.RS;
-    const nmpc::IrkConst K = nmpc::make_irk(h->cfg.dt);
-    p.h = K.h; p.hh = K.hh; p.c1h = K.c1h; p.c2h = K.c2h;
-    p.stamps = nullptr;
-    p.lin_x = h->lin_x;
-    p.lin_u = h->lin_u;
+    fill_params(h, dev, B, n_sqp, g, &p);
     hipStream_t s = (hipStream_t)stream;
     if (h->stamps) {
         const size_t need = (size_t)g.grid * g.wpb * 8; // one record per wavefront
@@ -483,54 +493,171 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int 
     return ALORE_NMPC_OK;
 }
 
+// Are the batches independent problem sets?  Every array a batch WRITES (x, u, dual, status, n_iter, kkt, obj) must be
+// disjoint, as an address range, from every array another batch reads or writes.  One sort of the 15 x count ranges and a
+// sweep that remembers, for writes and for all ranges, the two furthest-reaching ranges of distinct batches.
+bool batches_independent(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B)
+{
+    struct Range { size_t lo, hi; int id; bool write; };
+    std::vector<Range> r;
+    r.reserve((size_t)count * kNumMembers);
+    const int N = h->cfg.N;
+    for (int i = 0; i < count; ++i) {
+        for (int m = 0; m < kNumMembers; ++m) {
+            const void* q = member_ptr(batches + i, kMembers[m]);
+            if (!q) continue;
+            const size_t off = kMembers[m].offset;
+            const bool write = off == offsetof(alore_nmpc_batch, x) || off == offsetof(alore_nmpc_batch, u) ||
+                               off == offsetof(alore_nmpc_batch, dual) || off == offsetof(alore_nmpc_batch, status) ||
+                               off == offsetof(alore_nmpc_batch, n_iter) || off == offsetof(alore_nmpc_batch, kkt) ||
+                               off == offsetof(alore_nmpc_batch, obj);
+            bool one_copy = false; // members that are ONE copy for the batch (alore_nmpc_set_shared_members)
+            if (h->shared & ALORE_NMPC_SHARED_W) one_copy = one_copy || off == offsetof(alore_nmpc_batch, W) || off == offsetof(alore_nmpc_batch, WN);
+            if (h->shared & ALORE_NMPC_SHARED_BOUNDS) one_copy = one_copy || off == offsetof(alore_nmpc_batch, lbValues) || off == offsetof(alore_nmpc_batch, ubValues);
+            if (h->shared & ALORE_NMPC_SHARED_OD) one_copy = one_copy || off == offsetof(alore_nmpc_batch, od);
+            const size_t bytes = (size_t)(one_copy ? 1 : B) * kMembers[m].per_problem(N) * 4;
+            const size_t lo = reinterpret_cast<size_t>(q);
+            r.push_back({lo, lo + bytes, i, write});
+        }
+    }
+    std::sort(r.begin(), r.end(), [](const Range& a, const Range& b) { return a.lo < b.lo; });
+    struct Top2 { size_t hi[2] = {0, 0}; int id[2] = {-1, -1};
+        void add(size_t h_, int i_) {
+            if (i_ == id[0]) { if (h_ > hi[0]) hi[0] = h_; }
+            else if (h_ > hi[0]) { if (id[0] != -1) { hi[1] = hi[0]; id[1] = id[0]; } hi[0] = h_; id[0] = i_; }
+            else if (i_ == id[1]) { if (h_ > hi[1]) hi[1] = h_; }
+            else if (h_ > hi[1]) { hi[1] = h_; id[1] = i_; }
+        }
+        bool other_reaches(size_t lo, int i_) const { return (id[0] != -1 && id[0] != i_ && hi[0] > lo) || (id[1] != -1 && id[1] != i_ && hi[1] > lo); }
+    } writes, all;
+    for (const Range& q : r) {
+        if (writes.other_reaches(q.lo, q.id)) return false;          // somebody else writes into what this batch touches
+        if (q.write && all.other_reaches(q.lo, q.id)) return false;  // this batch writes into what somebody else touches
+        all.add(q.hi, q.id);
+        if (q.write) writes.add(q.hi, q.id);
+    }
+    return true;
+}
+
+// `count` (<= GROUP_MAX) independent batches on the stage-block kernel as ONE grid (nmpc_block_kernel.hip: RtiGroup)
+int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B, int n_sqp, void* stream, int B_in_flight)
+{
+    nmpc::LaunchGeom g;
+    if (!nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight))
+        return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti_many: horizon does not fit the stage-block kernel");
+    nmpc::RtiParams p;
+    fill_params(h, batches, B, n_sqp, g, &p);
+    nmpc::RtiGroup grp;
+    grp.count = count;
+    grp.blocks_per_batch = g.grid;
+    for (int i = 0; i < count; ++i) grp.b[i] = batches[i];
+    HIP_TRY(h, nmpc::launch_rti_block_group(p, grp, g, (hipStream_t)stream));
+    h->last_geom = g;
+    h->last_geom.grid = g.grid * count;
+    h->have_geom = true;
+    return ALORE_NMPC_OK;
+}
+
+} // namespace
+
+int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream)
+{
+    if (!h || !dev || B <= 0 || n_sqp < 1) return fail(h, ALORE_NMPC_E_INVALID, "rti: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    return rti_one(h, dev, B, n_sqp, stream, 0);
+}
+
 int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B, int n_sqp, void* stream)
 {
-    if (!h || !batches || count < 1) return fail(h, ALORE_NMPC_E_INVALID, "rti_many: bad argument");
-    // The batches are independent problems sets (distinct in/out arrays; checked).  Enqueued on ONE stream the launches
-    // run one after the other, and every launch is a burst of HBM reads (all wavefronts load at once) followed by
-    // sweeps during which HBM idles.  With h->overlap = W > 1 the launches go round-robin onto W streams forked from and
-    // joined back into the caller's stream, so the load phase of one batch runs under the sweeps of another: 20.5 -> 15.9 us
-    // per B = 4096 batch at W = 2 (profiles/r03_d_*).  Everything is complete when the caller's stream is; capturable.
+    if (!h || !batches || count < 1 || B <= 0 || n_sqp < 1) return fail(h, ALORE_NMPC_E_INVALID, "rti_many: bad argument");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (int i = 0; i < count; ++i)
+        if (!batch_complete(batches + i)) return fail(h, ALORE_NMPC_E_INVALID, "rti_many: batch has NULL members");
+    // Independent batches (checked: address ranges) are kept in flight together.  Default: GROUPS -- up to GROUP_MAX batches
+    // per grid of the stage-block kernel (one launch, one graph node, no ramp and drain between the batches; the lane
+    // mapping is chosen for all problems of the grid).  alore_nmpc_set_many_mode(h, 1): STREAMS -- one launch per batch,
+    // round-robin over `overlap` internal streams forked from and joined back into the caller's (the round-3 form; also
+    // what batches that cannot use the stage-block kernel get).  A batch listed twice (successive iterations of the same
+    // problems), overlap = 1 or per-launch timing keep the launches in order on `stream`.
     int ways = h->overlap;
     if (const char* e = std::getenv("ALORE_NMPC_OVERLAP")) ways = std::atoi(e);
     ways = ways < 1 ? 1 : (ways > 32 ? 32 : ways);
     if (ways > count) ways = count;
-    if (ways > 1 && !h->timing && count <= 4096) {
-        bool distinct = true; // a batch listed twice (two consecutive iterations of the same problems) must stay in order
-        for (int i = 0; i < count && distinct; ++i)
-            for (int k = i + 1; k < count; ++k)
-                if (batches[i].x == batches[k].x || batches[i].u == batches[k].u || batches[i].dual == batches[k].dual ||
-                    batches[i].status == batches[k].status || batches[i].n_iter == batches[k].n_iter ||
-                    (batches[i].kkt && batches[i].kkt == batches[k].kkt) || (batches[i].obj && batches[i].obj == batches[k].obj)) {
-                    distinct = false; // shared output arrays: keep the order the caller wrote
-                    break;
-                }
-        if (!distinct) ways = 1;
-    } else {
-        ways = 1;
-    }
-    if (ways > 1) {
-        HIP_TRY(h, hipSetDevice(h->cfg.device));
-        hipStream_t main_s = (hipStream_t)stream;
-        HIP_TRY(h, hipEventRecord(h->fork_ev, main_s));
-        for (int w = 1; w < ways; ++w) HIP_TRY(h, hipStreamWaitEvent(h->side[w - 1], h->fork_ev, 0));
-        int rc = ALORE_NMPC_OK;
-        h->in_flight_B = (long)B * ways > 0x7fffffffL ? 0x7fffffff : B * ways; // the automatic lane mapping packs for all of them
-        for (int i = 0; i < count && rc == ALORE_NMPC_OK; ++i) {
-            const int w = i % ways;
-            rc = alore_nmpc_rti(h, batches + i, B, n_sqp, w == 0 ? (void*)main_s : (void*)h->side[w - 1]);
+    if (ways > 1 && (h->timing || h->stamps || !batches_independent(h, batches, count, B))) ways = 1;
+    if (ways == 1) {
+        for (int i = 0; i < count; ++i) {
+            const int rc = rti_one(h, batches + i, B, n_sqp, stream, 0);
+            if (rc != ALORE_NMPC_OK) return rc;
         }
-        h->in_flight_B = 0;
-        for (int w = 1; w < ways; ++w) { // join even after a failed launch: the side streams must not stay forked
-            HIP_TRY(h, hipEventRecord(h->join_ev[w - 1], h->side[w - 1]));
-            HIP_TRY(h, hipStreamWaitEvent(main_s, h->join_ev[w - 1], 0));
+        return ALORE_NMPC_OK;
+    }
+    int mode = h->many_mode;
+    if (const char* e = std::getenv("ALORE_NMPC_MANY")) mode = (e[0] == 's') ? 1 : 0; // diagnostic: "streams" / "groups"
+    bool groups = mode == 0;
+    if (groups) {
+        nmpc::LaunchGeom g;
+        groups = nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B);
+        for (int i = 0; i < count && groups; ++i)
+            groups = block_eligible(h, batches + i) && (batches[i].kkt != nullptr) == (batches[0].kkt != nullptr) &&
+                     (batches[i].obj != nullptr) == (batches[0].obj != nullptr);
+    }
+    hipStream_t main_s = (hipStream_t)stream;
+    const long clampB = 0x7fffffffL;
+    if (groups) {
+        // equal groups of at most GROUP_MAX batches, one grid each, in order on the caller's stream (a profiler's per-kernel
+        // duration is then the time the group took).  ALORE_NMPC_GROUP_STREAMS=2 (diagnostic): successive groups alternate
+        // between the caller's stream and one side stream so that the tail of one grid runs under the head of the next.
+        static const bool alternate = getenv("ALORE_NMPC_GROUP_STREAMS") && atoi(getenv("ALORE_NMPC_GROUP_STREAMS")) == 2;
+        const int n_groups = (count + nmpc::GROUP_MAX - 1) / nmpc::GROUP_MAX;
+        const int per = (count + n_groups - 1) / n_groups;
+        const bool two = alternate && n_groups > 1;
+        const long inflight = (long)B * per * (two ? 2 : 1);
+        const int Bf = (int)(inflight > clampB ? clampB : inflight);
+        if (two) {
+            HIP_TRY(h, hipEventRecord(h->fork_ev, main_s));
+            HIP_TRY(h, hipStreamWaitEvent(h->side[0], h->fork_ev, 0));
+        }
+        int rc = ALORE_NMPC_OK;
+        for (int gi = 0, first = 0; first < count && rc == ALORE_NMPC_OK; ++gi, first += per) {
+            const int n = (count - first < per) ? count - first : per;
+            rc = rti_group(h, batches + first, n, B, n_sqp, (two && (gi & 1)) ? (void*)h->side[0] : (void*)main_s, Bf);
+        }
+        if (two) { // join even after a failed launch: the side stream must not stay forked (an open capture would be lost)
+            const hipError_t e1 = hipEventRecord(h->join_ev[0], h->side[0]);
+            const hipError_t e2 = hipStreamWaitEvent(main_s, h->join_ev[0], 0);
+            if (rc == ALORE_NMPC_OK && e1 != hipSuccess) return fail(h, ALORE_NMPC_E_HIP, "rti_many: join", e1);
+            if (rc == ALORE_NMPC_OK && e2 != hipSuccess) return fail(h, ALORE_NMPC_E_HIP, "rti_many: join", e2);
         }
         return rc;
     }
-    for (int i = 0; i < count; ++i) {
-        const int rc = alore_nmpc_rti(h, batches + i, B, n_sqp, stream);
-        if (rc != ALORE_NMPC_OK) return rc;
+    // STREAMS
+    HIP_TRY(h, hipEventRecord(h->fork_ev, main_s));
+    int forked = 0;
+    int rc = ALORE_NMPC_OK;
+    for (int w = 1; w < ways && rc == ALORE_NMPC_OK; ++w) {
+        const hipError_t e = hipStreamWaitEvent(h->side[w - 1], h->fork_ev, 0);
+        if (e != hipSuccess) rc = fail(h, ALORE_NMPC_E_HIP, "rti_many: fork", e);
+        else forked = w;
     }
+    const long inflight = (long)B * ways;
+    const int Bf = (int)(inflight > clampB ? clampB : inflight); // the automatic lane mapping packs for all of them
+    for (int i = 0; i < count && rc == ALORE_NMPC_OK; ++i) {
+        const int w = i % ways;
+        rc = rti_one(h, batches + i, B, n_sqp, w == 0 ? (void*)main_s : (void*)h->side[w - 1], Bf);
+    }
+    for (int w = 1; w <= forked; ++w) { // join every forked stream, whatever happened above
+        const hipError_t e1 = hipEventRecord(h->join_ev[w - 1], h->side[w - 1]);
+        const hipError_t e2 = hipStreamWaitEvent(main_s, h->join_ev[w - 1], 0);
+        if (rc == ALORE_NMPC_OK && e1 != hipSuccess) rc = fail(h, ALORE_NMPC_E_HIP, "rti_many: join", e1);
+        if (rc == ALORE_NMPC_OK && e2 != hipSuccess) rc = fail(h, ALORE_NMPC_E_HIP, "rti_many: join", e2);
+    }
+    return rc;
+}
+
+int alore_nmpc_set_many_mode(alore_nmpc_handle h, int mode)
+{
+    if (!h || mode < 0 || mode > 1) return fail(h, ALORE_NMPC_E_INVALID, "set_many_mode: 0 (groups) or 1 (streams)");
+    h->many_mode = mode;
     return ALORE_NMPC_OK;
 }
 

@@ -24,6 +24,14 @@ struct RtiParams {
     unsigned shared; // ALORE_NMPC_SHARED_* bits: members that are ONE copy for the whole batch (problem stride 0)
 };
 
+// up to GROUP_MAX independent batches served by one grid of the stage-block kernel (by value in the kernel arguments: 24 x 120 B of the 4 KB they hold)
+constexpr int GROUP_MAX = 24;
+struct RtiGroup {
+    int count;            // batches in this launch
+    int blocks_per_batch; // workgroups per batch: block -> batch by division
+    alore_nmpc_batch b[GROUP_MAX];
+};
+
 struct LaunchGeom {
     int L;       // lanes per problem
     int G;       // problems per wavefront
@@ -45,6 +53,7 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
 int block_lds_floats(int N, int L);
 bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int B_in_flight = 0);
 hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
+hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const LaunchGeom& g, hipStream_t s);
 
 hipError_t launch_linearize(const alore_nmpc_batch& b, int B, int N, float dt, const alore_nmpc_lin_out& o,
                             hipStream_t s);

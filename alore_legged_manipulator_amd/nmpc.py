@@ -130,9 +130,16 @@ class BatchedNmpc:
         """launches of independent slots kept in flight at once by rti_range (alore_nmpc_set_launch_overlap; 1 = in order)"""
         self._check(self.lib.alore_nmpc_set_launch_overlap(self.h, int(ways)))
 
+    def set_many_mode(self, mode: str) -> None:
+        """how rti_range keeps independent slots in flight (alore_nmpc_set_many_mode): "groups" -- up to 24 slots per grid,
+        the default -- or "streams" -- one launch per slot on forked streams"""
+        self._check(self.lib.alore_nmpc_set_many_mode(self.h, {"groups": 0, "streams": 1}[mode]))
+
     def rti_range(self, first: int, count: int, n_sqp: int = 1) -> None:
-        """one launch per slot first .. first + count - 1 by ONE call into the library (independent slots overlap, see
+        """slots first .. first + count - 1 by ONE call into the library (independent slots are solved together, see
         alore_nmpc_rti_many)"""
+        if first < 0 or count < 1 or first + count > self.slots:
+            raise ValueError(f"rti_range: slots {first} .. {first + count - 1} outside 0 .. {self.slots - 1}")
         if not hasattr(self, "_batch_array"):
             self._batch_array = (Batch * self.slots)(*self._batches)
         self._check(self.lib.alore_nmpc_rti_many(self.h, C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch)),

@@ -67,12 +67,45 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--overlap", type=int, default=16, choices=tuple(range(1, 33)),
                     help="independent batches (steps) kept in flight at once by alore_nmpc_rti_many; 1 = strictly in order")
+    ap.add_argument("--many-mode", choices=("groups", "streams"), default="groups",
+                    help="how alore_nmpc_rti_many keeps the steps in flight: groups of up to 24 batches per grid (one launch, "
+                         "default) or one launch per batch on forked streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
     ap.add_argument("--workload", choices=("planar", "whole_body"), default="planar",
                     help="planar = BASELINE configs[1] (the headline); whole_body = configs[2] (B2+Z1, one line with an MFMA roofline block)")
     return ap.parse_args()
+
+
+def parity_spot_check(eng, batch, N, warmup, K, hooks, per_slot=32, tol=1e-4):
+    """Outside every timed region: reload the cold-start iterate, solve the K timed slots exactly as the timed pass does
+    (one alore_nmpc_rti_many call), fetch the first, middle and last of them and compare `per_slot` seeded problems of each
+    with the CPU oracle (oracle/nmpc_oracle.c, bit-exact with the compiled reference at N = 50) on x and u, relative to
+    max(1, |ref|_inf) like the parity tests.  The oracle is the checker here, never the thing measured."""
+    from alore_legged_manipulator_amd.scenarios import problem
+    from oracle.drivers import Oracle
+    eng.load(batch, slot=None)
+    hooks.sync()
+    eng.rti_range(warmup, K)
+    hooks.sync()
+    orc = Oracle(N)
+    B = batch["x"].shape[0]
+    slots = sorted({warmup, warmup + K // 2, warmup + K - 1})
+    worst, n = 0.0, 0
+    for si, s in enumerate(slots):
+        out = eng.fetch(names=("x", "u", "status"), slot=s)
+        picks = np.random.default_rng([20260206, si]).choice(B, size=min(per_slot, B), replace=False)
+        for b in picks:
+            orc.reset(); orc.initialize_solver(); orc.load(problem(batch, int(b))); orc.preparation_step()
+            ok = orc.feedback_step() == 0 and int(out["status"][b]) == 0
+            for k in ("x", "u"):
+                ref = orc.v[k]
+                err = float(np.max(np.abs(out[k][b].reshape(-1) - ref)) / max(1.0, float(np.max(np.abs(ref)))))
+                worst = max(worst, err if ok else float("inf"))
+            n += 1
+    return {"worst_rel": worst, "problems": n, "slots": slots, "tolerance": tol, "ok": bool(worst < tol),
+            "against": "oracle/nmpc_oracle.c (float32 restatement, bit-exact with the compiled reference at N = 50)"}
 
 
 def usable_cores() -> int:
@@ -355,6 +388,7 @@ def main():
     eng = BatchedNmpc(B, N, device=local_rank, lanes_per_problem=a.lanes, slots=slots,
                       warm_start_steps=a.warm_start_steps)
     eng.set_launch_overlap(a.overlap)
+    eng.set_many_mode(a.many_mode)
     gatherer = ResultGatherer(dist, world) if (world > 1 and a.gather != "none") else None
     ge = max(1, a.gather_every)
 
@@ -460,6 +494,12 @@ def main():
             except Exception as e:  # pragma: no cover
                 exchange[label] = {"error": f"{type(e).__name__}: {e}"}
 
+    # parity of what was timed: the headline pass is run once more (untimed; the in_order / steady_state passes reloaded the
+    # slots) and 32 seeded problems of each of 3 timed slots are compared with the CPU oracle at BASELINE.json's 1e-4
+    spot = None
+    if rank == 0 and a.steps > 0:
+        spot = parity_spot_check(eng, batch, N, a.warmup, a.steps, hooks)
+
     # every timed step must have solved every problem
     st = eng.ts["status"][a.warmup:a.warmup + a.steps]
     n_bad = int((st != 0).sum().item())
@@ -478,6 +518,11 @@ def main():
         # average launch duration of the dominant kernel: HIP events on the launch stream around the K back-to-back
         # launches (multi-rank: of the pass without collectives between the launches)
         kern_ms = dev_ms / a.steps
+        if a.overlap > 1 and a.many_mode == "groups" and (info["lanes_per_problem"] & 0x100):
+            n_launches = (a.steps + 23) // 24
+            per_launch = (a.steps + n_launches - 1) // n_launches
+        else:
+            n_launches, per_launch = a.steps, 1
         bytes_per_launch = algorithmic_bytes_per_solve(N) * B
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: collected by rocprofv3 in separate --pmc passes over this same
@@ -507,22 +552,35 @@ def main():
                        "parallelism": f"independent shards x{world}, results stay sharded",
                        "lanes_per_problem": info["lanes_per_problem"], "threads_per_block": info["threads_per_block"],
                        "lds_bytes_per_block": info["lds_bytes_per_block"], "hip_graph": used_graph,
-                       "launches_in_flight": a.overlap},
+                       "launches_in_flight": a.overlap, "many_mode": a.many_mode if a.overlap > 1 else "in order",
+                       "resident_problems": B * (min(a.overlap, a.steps) if a.many_mode == "streams" else min(24, a.steps)) if a.overlap > 1 else B,
+                       "headline_is": ("throughput of independent B-problem batches solved together (alore_nmpc_rti_many); "
+                                       "the one-batch-at-a-time figure is in_order") if a.overlap > 1 else "one batch at a time"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "kernel": "nmpc::rti_block_kernel" if (info["lanes_per_problem"] & 0x100) else "nmpc::rti_kernel",
                          "kernel_ms_avg": kern_ms,
                          "launches_in_flight": a.overlap,
-                         "note": ("achieved = algorithmic bytes of one launch / (HIP-event time of the K launches / K). With "
-                                  "launches_in_flight > 1 consecutive steps (independent batches) overlap on forked streams, so a "
-                                  "profiler's per-kernel duration is about launches_in_flight x kernel_ms_avg; in_order has the "
-                                  "one-launch-at-a-time figures" if a.overlap > 1 else
+                         "batches_per_launch": per_launch, "kernel_launches": n_launches,
+                         "kernel_ms_per_launch": dev_ms / n_launches,
+                         "note": ("achieved = algorithmic bytes of one B-problem batch / kernel_ms_avg, kernel_ms_avg = HIP-event time of "
+                                  "the timed region / K batches.  many_mode groups: one grid of nmpc::rti_block_kernel serves "
+                                  "batches_per_launch batches (alore_nmpc_rti_many), the grids run one after the other on the launch "
+                                  "stream, so a profiler's average duration of that kernel is kernel_ms_per_launch = batches_per_launch x "
+                                  "kernel_ms_avg and the ratio bytes / duration is the same.  many_mode streams: one launch per batch on "
+                                  "forked streams, per-kernel durations overlap.  in_order has the one-batch-at-a-time figures"
+                                  if a.overlap > 1 else
                                   "achieved = algorithmic bytes of one launch / (HIP-event time of the K launches / K)"),
                          "algorithmic_bytes_per_solve": algorithmic_bytes_per_solve(N),
                          "fp32_frac": value / world * flops_per_solve / (FP32_PEAK_TFLOPS * 1e12)},
             "unsolved_problems": n_bad, "working_set_iters_mean": n_iter_mean,
         }
+        if spot is not None:
+            result["parity_spot_check"] = spot
+            if not spot["ok"]:  # a fast kernel whose results differ from the reference's is not measured
+                result["value"] = None
+                result["error"] = f"parity spot check failed: worst relative error {spot['worst_rel']:.3e} > {spot['tolerance']}"
         if exchange:
             result["result_exchange"] = exchange
         if steady is not None:

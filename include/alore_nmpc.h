@@ -146,16 +146,26 @@ int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch 
  * separate calls in the reference, never made by its wrapper) are computed and written
  * when the batch has non-NULL pointers for them, and skipped otherwise. */
 int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int n_sqp, void *stream);
-/* the same for `count` batches of B problems each, one launch per batch, from one call (a host that steps many
- * independent batches -- the slots of a Monte-Carlo sweep, the shards of a fleet -- pays the call overhead of its language
- * binding once).  A launch is a burst of HBM reads followed by sweeps during which HBM idles, so independent batches are
- * kept `ways` at a time in flight (alore_nmpc_set_launch_overlap, 1 .. 32, default 16): they go round-robin onto internal streams
- * forked from and joined back into `stream` -- every batch is complete when the work enqueued on `stream` is, and the call
- * can be captured into a hipGraph.  A batch listed more than once (successive iterations of the same problems) keeps the
- * whole call in order on `stream`, as does ways = 1.  With lanes_per_problem = 0 the lane mapping is chosen for ALL problems
- * in flight (more problems per wavefront than alore_nmpc_rti would pick for one batch of B): results of different mappings
- * agree to float32 rounding; pin lanes_per_problem where the bits of a single alore_nmpc_rti launch are wanted. */
+/* the same for `count` batches of B problems each from one call (a host that steps many independent batches -- the slots
+ * of a Monte-Carlo sweep, the shards of a fleet).  One batch alone is a burst of HBM reads followed by sweeps during which
+ * HBM idles, and at B = 4096 it leaves three SIMDs of four empty, so INDEPENDENT batches (checked: no array one batch
+ * writes may overlap, as an address range, an array another batch reads or writes) are solved together:
+ *   groups  (default, alore_nmpc_set_many_mode(h, 0)): up to 24 batches per grid of the stage-block kernel -- their
+ *           descriptors travel in the kernel arguments, a workgroup finds its batch by one division -- so 20 batches are
+ *           ONE launch (one hipGraph node when captured), with no ramp and drain between them; more than 24 batches go
+ *           out as equal groups, one grid each, in order on `stream`;
+ *   streams (alore_nmpc_set_many_mode(h, 1); also the fallback for batches the stage-block kernel cannot take: forced
+ *           wavefront mapping, unaligned members, a separate linearisation point): one launch per batch, round-robin over
+ *           `ways` internal streams forked from and joined back into `stream` (alore_nmpc_set_launch_overlap, 1 .. 32,
+ *           default 16).
+ * Either way every batch is complete when the work enqueued on `stream` is, and the call can be captured into a hipGraph.
+ * A batch listed more than once (successive iterations of the same problems), ways = 1 or per-launch timing
+ * (alore_nmpc_set_timing) keep the launches in order on `stream`, one per batch.  With lanes_per_problem = 0 the lane
+ * mapping is chosen for ALL problems in flight (more problems per wavefront than alore_nmpc_rti would pick for one batch
+ * of B): results of different mappings agree to float32 rounding; pin lanes_per_problem where the bits of a single
+ * alore_nmpc_rti launch are wanted. */
 int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch *batches, int count, int B, int n_sqp, void *stream);
+int alore_nmpc_set_many_mode(alore_nmpc_handle h, int mode); /* 0 = groups (default), 1 = streams */
 int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
 
 /* ACADO split semantics.  The reference prepares (linearises, evaluates h(x,u)) in

@@ -87,3 +87,29 @@ def test_comm_argument_checks():
     assert lib.alore_nmpc_comm_create(2, 2, uid, 0, C.byref(comm)) == -1      # rank out of range
     assert lib.alore_nmpc_comm_create(0, 0, uid, 0, C.byref(comm)) == -1
     assert lib.alore_nmpc_comm_destroy(None) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,lanes", [(19, 0x100 | 4), (16, 0x100 | 4), (22, 0x100 | 8), (31, 0x100 | 16), (20, 0x100 | 4), (20, 0x100 | 16), (20, 0x100 | 32), (20, 32)])
+def test_a_problem_full_of_nan_does_not_touch_its_wavefront_mates(N, lanes):
+    """Horizons that leave neutral slots in the last lane of a group (N = 19 at five stages per lane, 22 at three, 31 at two)
+    next to a problem whose iterate is NaN / Inf (mpc_controller.hpp expects idle, non-finite solves inside a batch): every
+    other problem returns the bits it returns when the broken one is healthy."""
+    from alore_legged_manipulator_amd.nmpc import BatchedNmpc
+    from alore_legged_manipulator_amd.scenarios import make_batch
+    B = 67
+    batch = make_batch(B, N, seed=17, fast_tail=0.4)
+    eng = BatchedNmpc(B, N, lanes_per_problem=lanes)
+    eng.load(batch); eng.rti(1); want = eng.fetch()
+    broken = {k: v.copy() for k, v in batch.items()}
+    sick = [3, 16, 41, 66]
+    broken["x"][3] = np.nan
+    broken["u"][16] = np.inf
+    broken["x0"][41] = np.nan; broken["y"][41] = np.nan
+    broken["x"][66, 0] = -np.inf
+    e2 = BatchedNmpc(B, N, lanes_per_problem=lanes)
+    e2.load(broken); e2.rti(1); got = e2.fetch()
+    good = np.array([b for b in range(B) if b not in sick])
+    assert (want["status"] == 0).all()
+    for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj"):
+        assert np.array_equal(got[k][good], want[k][good]), k
