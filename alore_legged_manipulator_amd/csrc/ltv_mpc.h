@@ -41,11 +41,12 @@ struct Dev {
 // stored previous output of the robot is NaN or Inf -- nothing is solved for it, its command is zero, its stored state stays
 constexpr int STATUS_OK = 0, STATUS_SWEEP_CAP = 1, STATUS_NON_FINITE = 2;
 
-// is the float64 value NaN or +-Inf?  By bit pattern: holds under -fno-honor-nans / -fno-honor-infinities as well
-__host__ __device__ inline bool non_finite_bits(double v)
+// is the float64 value stored at p NaN or +-Inf?  Decided on the BITS, read from memory as an integer: holds in a file built
+// with -fno-honor-nans / -fno-honor-infinities, where a test on a floating-point VALUE (a comparison, even a bit cast of it)
+// may be folded away
+__host__ __device__ inline bool non_finite_at(const double* p)
 {
-    unsigned long long u;
-    __builtin_memcpy(&u, &v, 8);
+    const unsigned long long u = *reinterpret_cast<const volatile unsigned long long*>(p); // volatile: never merged with the float64 load of the same address
     return ((u >> 52) & 0x7ffull) == 0x7ffull;
 }
 

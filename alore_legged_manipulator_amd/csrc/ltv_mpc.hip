@@ -78,10 +78,11 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
     const double x0 = d.now[(size_t)b * 3], y0 = d.now[(size_t)b * 3 + 1], th0 = d.now[(size_t)b * 3 + 2];
     int sweeps = 0, status = 0;
     { // this file is built without NaN / Inf semantics: a robot with a non-finite input is not solved at all (bit tests)
-        bool bad = non_finite_bits(x0) || non_finite_bits(y0) || non_finite_bits(th0);
-        for (int i = 0; i < 3 * T; ++i) bad = bad || non_finite_bits(xr[i]);
-        for (int i = 0; i < 2 * T; ++i) bad = bad || non_finite_bits(dr[i]) || non_finite_bits(out[i]);
-        for (int i = 0; i < 2 * dl; ++i) bad = bad || non_finite_bits(bf[i]);
+        bool bad = false;
+        for (int i = 0; i < 3; ++i) bad = bad || non_finite_at(d.now + (size_t)b * 3 + i);
+        for (int i = 0; i < 3 * T; ++i) bad = bad || non_finite_at(xr + i);
+        for (int i = 0; i < 2 * T; ++i) bad = bad || non_finite_at(dr + i) || non_finite_at(out + i);
+        for (int i = 0; i < 2 * dl; ++i) bad = bad || non_finite_at(bf + i);
         if (bad) {
             d.sweeps[b] = 0;
             d.status[b] = STATUS_NON_FINITE;
@@ -478,13 +479,16 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
     // its wavefront mates, it gets status 2 and a zero command, and its stored output / working set / delay buffer stay.
     bool poisoned;
     {
-        bool bad = (j < 3) && non_finite_bits(nowp[j]);
+        bool bad = (j < 3) && non_finite_at(d.now + (size_t)b * 3 + j);
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-            bad = bad || non_finite_bits(ua[s]) || non_finite_bits(uw[s]) || non_finite_bits(xr[s][0]) || non_finite_bits(xr[s][1]) ||
-                  non_finite_bits(xr[s][2]) || non_finite_bits(dr0[s]);
+        for (int s = 0; s < S; ++s) {
+            const int kc = min(j * S + s, K - 1);
+            bad = bad || non_finite_at(xrg + (dl + kc) * 3) || non_finite_at(xrg + (dl + kc) * 3 + 1) || non_finite_at(xrg + (dl + kc) * 3 + 2) ||
+                  non_finite_at(drg + (dl + kc) * 2);
+            if (!d.reset) bad = bad || non_finite_at(out + 2 * (dl + kc)) || non_finite_at(out + 2 * (dl + kc) + 1);
+        }
         if (!d.reset)
-            for (int i = j; i < 2 * dl; i += 16) bad = bad || non_finite_bits(out[i]) || non_finite_bits(bf[i]);
+            for (int i = j; i < 2 * dl; i += 16) bad = bad || non_finite_at(out + i) || non_finite_at(bf + i);
         poisoned = ((__ballot(bad) >> (lane & ~15)) & 0xffffull) != 0ull;
         if (poisoned) {
 #pragma unroll

@@ -235,7 +235,14 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
     const int g = lane / L, j = lane % L;
     const int gbase = lane - j;
     const int bi = (grp.count > 1) ? (int)blockIdx.x / grp.blocks_per_batch : 0;
-    const alore_nmpc_batch& pb = grp.b[bi];
+    // the workgroup's batch: entry bi of the table, or (batches laid out at constant strides, any number of them) the first
+    // batch with every member pointer advanced by bi strides -- wavefront-uniform either way
+    alore_nmpc_batch pb = grp.b[grp.strided ? 0 : bi];
+    if (grp.strided) {
+        char** q = reinterpret_cast<char**>(&pb);
+#pragma unroll
+        for (int i = 0; i < 15; ++i) q[i] = q[i] ? q[i] + (long long)bi * grp.stride[i] : q[i];
+    }
     const int prob0 = ((int)blockIdx.x - bi * grp.blocks_per_batch) * G;
     const int np_ = min(G, p.B - prob0);
     const bool valid = g < np_;
@@ -1038,6 +1045,7 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
     RtiGroup grp;
     grp.count = 1;
     grp.blocks_per_batch = g.grid;
+    grp.strided = 0;
     grp.b[0] = p.b;
     return launch_rti_block_group(p, grp, g, s);
 }
@@ -1046,7 +1054,8 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
 // same set of diagnostics pointers (checked by the caller)
 hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const LaunchGeom& g, hipStream_t s)
 {
-    if (grp.count < 1 || grp.count > GROUP_MAX || grp.blocks_per_batch != g.grid) return hipErrorInvalidValue;
+    if (grp.count < 1 || (!grp.strided && grp.count > GROUP_MAX) || grp.blocks_per_batch != g.grid) return hipErrorInvalidValue;
+    if ((long long)g.grid * grp.count > 0x7fffffffLL) return hipErrorInvalidValue;
     const bool stamp = p.stamps != nullptr;
     const bool diag = stamp || grp.b[0].kkt != nullptr || grp.b[0].obj != nullptr;
     const bool once = p.n_sqp == 1;

@@ -539,8 +539,10 @@ bool batches_independent(alore_nmpc_handle h, const alore_nmpc_batch* batches, i
     return true;
 }
 
-// `count` (<= GROUP_MAX) independent batches on the stage-block kernel as ONE grid (nmpc_block_kernel.hip: RtiGroup)
-int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B, int n_sqp, void* stream, int B_in_flight)
+// `count` independent batches on the stage-block kernel as ONE grid (nmpc_block_kernel.hip: RtiGroup): by table
+// (count <= GROUP_MAX) or, with `stride`, by constant member strides (any count)
+int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B, int n_sqp, void* stream, int B_in_flight,
+              const long long* stride)
 {
     nmpc::LaunchGeom g;
     if (!nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight))
@@ -550,12 +552,37 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
     nmpc::RtiGroup grp;
     grp.count = count;
     grp.blocks_per_batch = g.grid;
-    for (int i = 0; i < count; ++i) grp.b[i] = batches[i];
+    grp.strided = stride ? 1 : 0;
+    grp.pad_ = 0;
+    for (int m = 0; m < 15; ++m) grp.stride[m] = stride ? stride[m] : 0;
+    const int n_tab = stride ? 1 : count;
+    for (int i = 0; i < n_tab; ++i) grp.b[i] = batches[i];
     HIP_TRY(h, nmpc::launch_rti_block_group(p, grp, g, (hipStream_t)stream));
     h->last_geom = g;
     h->last_geom.grid = g.grid * count;
     h->have_geom = true;
     return ALORE_NMPC_OK;
+}
+
+// Do the batches sit at constant strides -- batch i = batch 0 with every member pointer advanced by i * stride[member] bytes
+// (the slots of one arena, the slices of one tensor per member)?  stride[] in the member order of alore_nmpc_batch.
+bool constant_strides(const alore_nmpc_batch* batches, int count, long long* stride)
+{
+    if (count < 2) return false;
+    const char* const* p0 = reinterpret_cast<const char* const*>(batches);
+    const char* const* p1 = reinterpret_cast<const char* const*>(batches + 1);
+    for (int m = 0; m < 15; ++m) {
+        if ((p0[m] == nullptr) != (p1[m] == nullptr)) return false;
+        stride[m] = p0[m] ? (long long)(p1[m] - p0[m]) : 0;
+    }
+    for (int i = 2; i < count; ++i) {
+        const char* const* pi = reinterpret_cast<const char* const*>(batches + i);
+        for (int m = 0; m < 15; ++m) {
+            if ((pi[m] == nullptr) != (p0[m] == nullptr)) return false;
+            if (p0[m] && pi[m] != p0[m] + (long long)i * stride[m]) return false;
+        }
+    }
+    return true;
 }
 
 } // namespace
@@ -604,9 +631,17 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     hipStream_t main_s = (hipStream_t)stream;
     const long clampB = 0x7fffffffL;
     if (groups) {
-        // equal groups of at most GROUP_MAX batches, one grid each, in order on the caller's stream (a profiler's per-kernel
-        // duration is then the time the group took).  ALORE_NMPC_GROUP_STREAMS=2 (diagnostic): successive groups alternate
-        // between the caller's stream and one side stream so that the tail of one grid runs under the head of the next.
+        // Batches at constant strides (the slots of one arena): ONE grid for all of them, whatever their number.  Otherwise
+        // equal groups of at most GROUP_MAX batches (descriptor table in the kernel arguments), one grid each, in order on the
+        // caller's stream.  ALORE_NMPC_GROUP_STREAMS=2 (diagnostic): successive table groups alternate between the caller's
+        // stream and one side stream so that the tail of one grid runs under the head of the next.
+        long long stride[15];
+        nmpc::LaunchGeom g1;
+        (void)nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g1, B);
+        if (constant_strides(batches, count, stride) && (long long)g1.grid * count <= 0x7fffffffLL) {
+            const long inflight = (long)B * count;
+            return rti_group(h, batches, count, B, n_sqp, stream, (int)(inflight > clampB ? clampB : inflight), stride);
+        }
         static const bool alternate = getenv("ALORE_NMPC_GROUP_STREAMS") && atoi(getenv("ALORE_NMPC_GROUP_STREAMS")) == 2;
         const int n_groups = (count + nmpc::GROUP_MAX - 1) / nmpc::GROUP_MAX;
         const int per = (count + n_groups - 1) / n_groups;
@@ -620,7 +655,7 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
         int rc = ALORE_NMPC_OK;
         for (int gi = 0, first = 0; first < count && rc == ALORE_NMPC_OK; ++gi, first += per) {
             const int n = (count - first < per) ? count - first : per;
-            rc = rti_group(h, batches + first, n, B, n_sqp, (two && (gi & 1)) ? (void*)h->side[0] : (void*)main_s, Bf);
+            rc = rti_group(h, batches + first, n, B, n_sqp, (two && (gi & 1)) ? (void*)h->side[0] : (void*)main_s, Bf, nullptr);
         }
         if (two) { // join even after a failed launch: the side stream must not stay forked (an open capture would be lost)
             const hipError_t e1 = hipEventRecord(h->join_ev[0], h->side[0]);

@@ -29,8 +29,13 @@ constexpr int GROUP_MAX = 24;
 struct RtiGroup {
     int count;            // batches in this launch
     int blocks_per_batch; // workgroups per batch: block -> batch by division
+    int strided;          // 1: batch i = b[0] with every member pointer advanced by i * stride[member] bytes (any count);
+                          // 0: batch i = b[i] (count <= GROUP_MAX)
+    int pad_;
+    long long stride[15]; // bytes, in the member order of alore_nmpc_batch
     alore_nmpc_batch b[GROUP_MAX];
 };
+static_assert(sizeof(alore_nmpc_batch) == 15 * sizeof(void*), "alore_nmpc_batch is 15 pointers");
 
 struct LaunchGeom {
     int L;       // lanes per problem

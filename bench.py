@@ -68,8 +68,8 @@ def parse():
     ap.add_argument("--overlap", type=int, default=16, choices=tuple(range(1, 33)),
                     help="independent batches (steps) kept in flight at once by alore_nmpc_rti_many; 1 = strictly in order")
     ap.add_argument("--many-mode", choices=("groups", "streams"), default="groups",
-                    help="how alore_nmpc_rti_many keeps the steps in flight: groups of up to 24 batches per grid (one launch, "
-                         "default) or one launch per batch on forked streams")
+                    help="how alore_nmpc_rti_many keeps the steps in flight: one grid over all of them (default) or one launch per "
+                         "batch on forked streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
@@ -519,8 +519,7 @@ def main():
         # launches (multi-rank: of the pass without collectives between the launches)
         kern_ms = dev_ms / a.steps
         if a.overlap > 1 and a.many_mode == "groups" and (info["lanes_per_problem"] & 0x100):
-            n_launches = (a.steps + 23) // 24
-            per_launch = (a.steps + n_launches - 1) // n_launches
+            n_launches, per_launch = 1, a.steps   # the slots sit at constant strides: one grid for the K batches
         else:
             n_launches, per_launch = a.steps, 1
         bytes_per_launch = algorithmic_bytes_per_solve(N) * B
@@ -553,7 +552,7 @@ def main():
                        "lanes_per_problem": info["lanes_per_problem"], "threads_per_block": info["threads_per_block"],
                        "lds_bytes_per_block": info["lds_bytes_per_block"], "hip_graph": used_graph,
                        "launches_in_flight": a.overlap, "many_mode": a.many_mode if a.overlap > 1 else "in order",
-                       "resident_problems": B * (min(a.overlap, a.steps) if a.many_mode == "streams" else min(24, a.steps)) if a.overlap > 1 else B,
+                       "resident_problems": B * (min(a.overlap, a.steps) if a.many_mode == "streams" else a.steps) if a.overlap > 1 else B,
                        "headline_is": ("throughput of independent B-problem batches solved together (alore_nmpc_rti_many); "
                                        "the one-batch-at-a-time figure is in_order") if a.overlap > 1 else "one batch at a time"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -565,10 +564,10 @@ def main():
                          "batches_per_launch": per_launch, "kernel_launches": n_launches,
                          "kernel_ms_per_launch": dev_ms / n_launches,
                          "note": ("achieved = algorithmic bytes of one B-problem batch / kernel_ms_avg, kernel_ms_avg = HIP-event time of "
-                                  "the timed region / K batches.  many_mode groups: one grid of nmpc::rti_block_kernel serves "
-                                  "batches_per_launch batches (alore_nmpc_rti_many), the grids run one after the other on the launch "
-                                  "stream, so a profiler's average duration of that kernel is kernel_ms_per_launch = batches_per_launch x "
-                                  "kernel_ms_avg and the ratio bytes / duration is the same.  many_mode streams: one launch per batch on "
+                                  "the timed region / K batches.  many_mode groups: ONE grid of nmpc::rti_block_kernel serves the K "
+                                  "batches of the timed region (alore_nmpc_rti_many; the slots sit at constant strides), so a profiler's "
+                                  "duration of that launch is kernel_ms_per_launch = K x kernel_ms_avg and the ratio bytes / duration is "
+                                  "the same.  many_mode streams: one launch per batch on "
                                   "forked streams, per-kernel durations overlap.  in_order has the one-batch-at-a-time figures"
                                   if a.overlap > 1 else
                                   "achieved = algorithmic bytes of one launch / (HIP-event time of the K launches / K)"),

@@ -150,10 +150,12 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int 
  * of a Monte-Carlo sweep, the shards of a fleet).  One batch alone is a burst of HBM reads followed by sweeps during which
  * HBM idles, and at B = 4096 it leaves three SIMDs of four empty, so INDEPENDENT batches (checked: no array one batch
  * writes may overlap, as an address range, an array another batch reads or writes) are solved together:
- *   groups  (default, alore_nmpc_set_many_mode(h, 0)): up to 24 batches per grid of the stage-block kernel -- their
- *           descriptors travel in the kernel arguments, a workgroup finds its batch by one division -- so 20 batches are
- *           ONE launch (one hipGraph node when captured), with no ramp and drain between them; more than 24 batches go
- *           out as equal groups, one grid each, in order on `stream`;
+ *   groups  (default, alore_nmpc_set_many_mode(h, 0)): ONE grid of the stage-block kernel for all batches (one launch, one
+ *           hipGraph node when captured, no ramp and drain between the batches; a workgroup finds its batch by one division)
+ *           when the batches sit at constant strides -- batch i = batch 0 with every member pointer advanced by i times a
+ *           per-member stride, as the slots of one arena or the slices of one tensor per member do -- whatever their number;
+ *           batches scattered in memory travel as a table of up to 24 descriptors in the kernel arguments, more of them as
+ *           equal groups, one grid each, in order on `stream`;
  *   streams (alore_nmpc_set_many_mode(h, 1); also the fallback for batches the stage-block kernel cannot take: forced
  *           wavefront mapping, unaligned members, a separate linearisation point): one launch per batch, round-robin over
  *           `ways` internal streams forked from and joined back into `stream` (alore_nmpc_set_launch_overlap, 1 .. 32,

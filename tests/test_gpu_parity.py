@@ -508,7 +508,7 @@ def test_every_lane_mapping_against_the_oracle(nmpc_mod, N, lanes):
 
 
 def check_against_oracle_and_float64(batch, out, u_in, picks, N, tag):
-    """The rule of test_wide_problems_three_ticks_against_oracle for one cold tick: never more than 5e-4 from the oracle;
+    """The rule of test_wide_problems_three_ticks_against_oracle for one cold tick: never more than 1e-3 from the oracle;
     wherever the kernel is more than 1e-4 (BASELINE.json) from the oracle it must be closer than the oracle to the float64
     minimiser of the oracle's own condensed QP and within 1e-4 of it."""
     orc = Oracle(N)
@@ -517,13 +517,13 @@ def check_against_oracle_and_float64(batch, out, u_in, picks, N, tag):
         orc.reset(); orc.initialize_solver(); orc.load(problem(batch, b)); orc.preparation_step()
         assert orc.feedback_step() == 0 and out["status"][b] == 0, (tag, b)
         eu, ex = relerr(out["u"][b].reshape(-1), orc.v["u"]), relerr(out["x"][b].reshape(-1), orc.v["x"])
-        assert eu < 5e-4 and ex < 5e-4, (tag, b, eu, ex)
         n = 2 * N
         du_true = exact_box_qp(orc.v["H"].reshape(n, n), orc.v["g"], orc.v["lb"], orc.v["ub"])
         scale = max(1.0, float(np.max(np.abs(orc.v["u"]))))
         ek = float(np.max(np.abs((out["u"][b].reshape(-1).astype(np.float64) - u_in[b].reshape(-1)) - du_true))) / scale
         er = float(np.max(np.abs(orc.v["dx"].astype(np.float64) - du_true))) / scale
         err_k.append(ek); err_r.append(er)
+        assert eu < 1e-3 and ex < 1e-3, (tag, b, eu, ex, ek, er)   # hard cap; the criterion follows
         if max(eu, ex) >= 1e-4:
             loose += 1
             assert ek < er and ek < 1e-4, (tag, b, eu, ex, ek, er)
@@ -536,7 +536,7 @@ def check_against_oracle_and_float64(batch, out, u_in, picks, N, tag):
 @pytest.mark.parametrize("lanes", [BLOCK | 4, BLOCK | 8, BLOCK | 16, BLOCK | 32])
 def test_stage_block_kernel_on_the_stress_distribution(nmpc_mod, lanes):
     """Every lane mapping of the stage-block kernel on the wide distribution (long working-set iterations, the primal
-    active-set safeguard), pinned directly: >= 400 problems per mapping -- every 11th and every one that needed 10 or more
+    active-set safeguard), pinned directly: >= 400 problems per mapping -- every 9th and every one that needed 10 or more
     working-set iterations -- against the ORACLE and the float64 minimiser of its condensed QP by the rule of
     test_wide_problems_three_ticks_against_oracle, and the answer of a problem is the same bits wherever it sits in the
     batch (permutation)."""
@@ -547,7 +547,7 @@ def test_stage_block_kernel_on_the_stress_distribution(nmpc_mod, lanes):
     assert eng.launch_info()["lanes_per_problem"] == lanes
     assert (got["status"] == 0).all()
     assert (got["n_iter"] > 3).sum() > 50 and got["n_iter"].max() > 16     # restarts and the safeguard are exercised
-    picks = sorted(set(range(0, B, 11)) | set(np.nonzero(got["n_iter"] >= 10)[0].tolist()))
+    picks = sorted(set(range(0, B, 9)) | set(np.nonzero(got["n_iter"] >= 10)[0].tolist()))
     assert len(picks) >= 400
     check_against_oracle_and_float64(batch, got, batch["u"], picks, N, f"stress L={lanes & 0xff}")
     perm = np.random.default_rng(1).permutation(B)
@@ -607,12 +607,16 @@ def test_what_the_bench_times_is_pinned(nmpc_mod, mode):
 
 
 @pytest.mark.gpu
-def test_groups_of_batches_ragged_and_more_than_one_grid(nmpc_mod):
-    """alore_nmpc_rti_many in groups mode beyond one grid: 53 slots (three groups alternating over two streams) of a ragged
-    batch (B not a multiple of the problems per wavefront), automatic mapping: the bits of slot-by-slot launches with the
-    mapping pinned; canaries around the slots stay intact."""
+@pytest.mark.parametrize("layout", ["strided", "scattered"])
+def test_groups_of_batches_ragged_and_more_than_one_grid(nmpc_mod, layout):
+    """alore_nmpc_rti_many in groups mode, 53 slots of a ragged batch (B not a multiple of the problems per wavefront),
+    automatic mapping.  strided: the slots of one arena in order -> ONE grid over all 53 (constant member strides).
+    scattered: the same slots in a shuffled order -> descriptor tables of at most 24, three grids.  Either way the bits of
+    slot-by-slot launches with the mapping pinned; canary slots around them stay intact."""
+    import ctypes as C
     import torch
-    B, N, slots = 203, 20, 55
+    from alore_legged_manipulator_amd._lib import Batch
+    B, N, slots = 212, 20, 55      # 212 = 13.25 wavefronts of 16 problems; a multiple of 4 keeps every slot 16-byte aligned
     eng = nmpc_mod.BatchedNmpc(B, N, slots=slots)
     rng = np.random.default_rng(0)
     seeds = rng.integers(0, 1 << 30, slots)
@@ -622,9 +626,20 @@ def test_groups_of_batches_ragged_and_more_than_one_grid(nmpc_mod):
         for s in (0, slots - 1):
             t[s].fill_(777 if t.dtype == torch.int32 else 12345.0)
     snap = {k: eng.ts[k].clone() for k in eng.ts}
-    eng.rti_range(1, slots - 2)
+    if layout == "strided":
+        eng.rti_range(1, slots - 2)
+        n_last = slots - 2
+    else:
+        order = rng.permutation(np.arange(1, slots - 1))
+        arr = (Batch * (slots - 2))(*[eng._batches[int(i)] for i in order])
+        eng._check(eng.lib.alore_nmpc_rti_many(eng.h, arr, slots - 2, B, 1, eng._stream()))
+        n_last = 17                              # 53 = 18 + 18 + 17: launch_info describes the last grid
     torch.cuda.synchronize()
     info = eng.launch_info()
+    # the mapping packs for the problems of ONE grid: all 53 x 212 (4 lanes per problem) or 18 x 212 (16 lanes)
+    assert info["lanes_per_problem"] == ((BLOCK | 4) if layout == "strided" else (BLOCK | 16)), info
+    per_wave = 64 // (info["lanes_per_problem"] & 0xff)
+    assert info["grid"] == n_last * ((B + per_wave - 1) // per_wave), info
     for k, t in eng.ts.items():
         want = 777 if t.dtype == torch.int32 else 12345.0
         for s in (0, slots - 1):
