@@ -56,6 +56,7 @@ struct alore_nmpc_solver {
     size_t stage_up_cap = 0, stage_down_cap = 0;
     // alore_nmpc_rti_many: launches of independent batches in flight at once (side streams forked from the caller's)
     int overlap = 16;
+    bool auto_pg = false; // warm_start_steps was left to the library: 6 for a launch on its own, 3 inside a grid of many batches
     int many_mode = 0; // alore_nmpc_rti_many: 0 = groups of batches per grid, 1 = one launch per batch on forked streams
     hipStream_t side[31] = {};
     hipEvent_t fork_ev = nullptr, join_ev[31] = {};
@@ -166,7 +167,8 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     if (!h) return ALORE_NMPC_E_NOMEM;
     h->cfg = *cfg;
     if (h->cfg.max_as_iter <= 0) h->cfg.max_as_iter = 128;
-    if (h->cfg.warm_start_steps < 0) h->cfg.warm_start_steps = 6; // swept on MI355X at N = 20 and 50 (tools/dbg/bb.sh, bb2.sh)
+    h->auto_pg = h->cfg.warm_start_steps < 0;
+    if (h->auto_pg) h->cfg.warm_start_steps = 6; // swept on MI355X at N = 20 and 50 (tools/dbg/bb.sh, bb2.sh)
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)prop.sharedMemPerBlock : 64 * 1024;
     if (prop.maxSharedMemoryPerMultiProcessor > (size_t)h->lds_limit)
@@ -549,6 +551,10 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti_many: horizon does not fit the stage-block kernel");
     nmpc::RtiParams p;
     fill_params(h, batches, B, n_sqp, g, &p);
+    // a launch on its own lasts as long as its slowest wavefront, so the prediction runs until (nearly) no problem needs a
+    // second sweep (6 .. 9 steps); when the chip is full of wavefronts the 2 % of problems that get one with 3 .. 4 steps cost
+    // less than the steps saved (profiles/r04_block_kernel_experiments.txt)
+    if (h->auto_pg && (long)B * count >= 16384) p.pg_steps = 3;
     nmpc::RtiGroup grp;
     grp.count = count;
     grp.blocks_per_batch = g.grid;

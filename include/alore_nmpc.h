@@ -69,7 +69,8 @@ typedef struct {
                               registers, sweeps lane by lane; horizons up to 64, L = 32 up to 32).  alore_nmpc_get_launch_info reports
                               the choice in the same encoding. */
     int warm_start_steps;  /* projected-gradient steps used to predict the working set of a QP whose
-                              first solve hit bounds (<0: default 6; 0: off).  Affects only the number
+                              first solve hit bounds (<0: default -- 6, or 3 for the launches of alore_nmpc_rti_many
+                              that fill the chip; 0: off).  Affects only the number
                               of working-set iterations, never the solution. */
 } alore_nmpc_config;
 
