@@ -254,6 +254,16 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
     const int gw = (p.shared & ALORE_NMPC_SHARED_W) ? 0 : ge; // whose copy of W this group reads
     const int top = (N - 1) / S;        // lane that owns stage N - 1 (and the terminal node)
 
+    // Staggered start.  A grid of several residencies (alore_nmpc_rti_many) begins with every SIMD loading at once: 1024
+    // wavefronts x 67 KB is a 14 us burst during which nothing computes, and wavefronts that start together finish together,
+    // so the next residency bursts again (20 batches: five rounds of 35 us against 25 us per round in a long run whose
+    // wavefronts have drifted apart).  The wavefronts of the FIRST residency therefore start spread over the time HBM needs
+    // to feed them -- they would have waited for their data that long anyway -- and the rounds never line up.
+    if (grp.stagger_x1024 > 0 && (int)blockIdx.x < grp.stagger_blocks) {
+        const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = ((unsigned long long)blockIdx.x * (unsigned)grp.stagger_x1024) >> 10;
+        while (__builtin_amdgcn_s_memrealtime() - ts < wait) __builtin_amdgcn_s_sleep(2);
+    }
     long long t0 = 0, t1 = 0, t4 = 0, t5 = 0;
     if (STAMP) t0 = __builtin_amdgcn_s_memtime();
 
@@ -1048,6 +1058,8 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
     grp.count = 1;
     grp.blocks_per_batch = g.grid;
     grp.strided = 0;
+    grp.stagger_blocks = 0;
+    grp.stagger_x1024 = 0;
     grp.b[0] = p.b;
     return launch_rti_block_group(p, grp, g, s);
 }

@@ -559,7 +559,21 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
     grp.count = count;
     grp.blocks_per_batch = g.grid;
     grp.strided = stride ? 1 : 0;
-    grp.pad_ = 0;
+    // staggered start of the first residency (see the kernel): one wavefront per SIMD at this kernel's register count, spread
+    // over the time HBM needs for their inputs at ~5 TB/s; only for grids of at least two residencies
+    grp.stagger_blocks = 0;
+    grp.stagger_x1024 = 0;
+    {
+        const long resident = 4L * h->n_cu;
+        static const char* env_ns = getenv("ALORE_NMPC_STAGGER_NS"); // diagnostic: total spread in ns (0 = off)
+        const double bytes_per_block = 4.0 * (51.0 * h->cfg.N + 28.0) * g.G;
+        double spread_ns = resident * bytes_per_block / 5.0e3; // bytes / (5e12 B/s) in ns
+        if (env_ns) spread_ns = atof(env_ns);
+        if ((long)g.grid * count >= 2 * resident && spread_ns > 0.0) {
+            grp.stagger_blocks = (int)resident;
+            grp.stagger_x1024 = (int)(spread_ns / 10.0 / resident * 1024.0 + 0.5); // ticks of 10 ns per block, x 1024
+        }
+    }
     for (int m = 0; m < 15; ++m) grp.stride[m] = stride ? stride[m] : 0;
     const int n_tab = stride ? 1 : count;
     for (int i = 0; i < n_tab; ++i) grp.b[i] = batches[i];

@@ -29,9 +29,10 @@ constexpr int GROUP_MAX = 24;
 struct RtiGroup {
     int count;            // batches in this launch
     int blocks_per_batch; // workgroups per batch: block -> batch by division
+    int stagger_blocks;   // the first stagger_blocks workgroups (one full residency of the chip) delay their start by
+    int stagger_x1024;    // blockIdx * stagger_x1024 / 1024 ticks of the 100 MHz real-time counter (0: no stagger), see the kernel
     int strided;          // 1: batch i = b[0] with every member pointer advanced by i * stride[member] bytes (any count);
                           // 0: batch i = b[i] (count <= GROUP_MAX)
-    int pad_;
     long long stride[15]; // bytes, in the member order of alore_nmpc_batch
     alore_nmpc_batch b[GROUP_MAX];
 };

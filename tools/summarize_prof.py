@@ -24,6 +24,13 @@ def from_rocpd(db, lines):
         else:
             other += tot
     lines.append(f"(all non-nmpc kernels: torch fills/copies of the bench setup),,{other},,,")
+    # the RTI kernel serves a whole group of batches per launch (alore_nmpc_rti_many): per launch geometry, so that the grid of
+    # the timed region (K batches) can be told from warm-up / steady-state / spot-check launches of the same kernel
+    lines.append("# nmpc::rti_* per launch geometry: name,grid_x,calls,avg_ns,min_ns,max_ns")
+    for name, gx, n, avg, mn, mx in c.execute(
+            "select name, grid_x, count(*), avg(end-start), min(end-start), max(end-start) from kernels where name like '%nmpc::rti_%' "
+            "group by name, grid_x order by name, grid_x"):
+        lines.append(f"{name},{gx},{n},{avg:.1f},{mn},{mx}")
     lines.append("# launch geometry / resources per nmpc kernel")
     for r in c.execute("select distinct name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
                        "from kernels"):
