@@ -33,16 +33,18 @@ class ResultGatherer:
     finished and returns the gathered tensors of the LAST submit (shape
     [world, *local_shape])."""
 
-    def __init__(self, dist, world: int):
+    def __init__(self, dist, world: int, depth: int = 1):
         self.dist = dist
         self.world = world
+        self.depth = max(1, depth)   # output buffers per tensor, used in turn: with 2 the previous gather stays readable while the next lands
+        self._turn = 0
         self._pending: List = []
         self._last: Optional[Dict[str, object]] = None
         self._out_cache: Dict[Tuple, object] = {}
 
     def _out_like(self, name: str, t):
         import torch
-        key = (name, tuple(t.shape), t.dtype, str(t.device))
+        key = (name, tuple(t.shape), t.dtype, str(t.device), self._turn % self.depth)
         out = self._out_cache.get(key)
         if out is None:
             out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
@@ -60,6 +62,7 @@ class ResultGatherer:
                 w = self.dist.all_gather_into_tensor(out.view(-1), t.view(-1), async_op=True)
                 self._pending.append(w)
             gathered[name] = out
+        self._turn += 1
         self._last = gathered
 
     def wait(self) -> Optional[Dict[str, object]]:
@@ -111,22 +114,35 @@ class HostHooks:
         return [float(v) for v in t]
 
 
-def timed_pass(eng, batch, mode: str, K: int, warmup: int, gather_every: int, gatherer, hooks, world: int):
+def timed_pass(eng, batch, mode: str, K: int, warmup: int, gather_every: int, gatherer, hooks, world: int, conv_iters: int = 15):
     """W untimed + K timed steps of `eng` (anything with load(batch, slot=None), rti(1, slot=i) and per-slot result
     tensors eng.ts[name][slot]) with the result exchange `mode`:
       full -- the trajectories (x, u, status, kkt) of EVERY timed batch are all-gathered to every rank, in buckets of
               `gather_every` steps issued asynchronously and all completed inside the timed region (eager launches:
               collectives sit between the solves);
       last -- only the last batch's trajectories are exchanged (the K launches may replay as one graph);
-      none -- results stay sharded.
+      none -- results stay sharded;
+      converged -- the north star's unit: every step solves its batch to convergence (`conv_iters` real-time iterations inside
+              one launch, the cold start of MpcWrapper::solve + its update() calls) and the converged trajectories (x, u,
+              status, kkt) are all-gathered to every rank, one collective per tensor per step, issued asynchronously right
+              behind the solve so that it runs under the next step's solve, all completed inside the timed region.
     Returns (elapsed seconds, device milliseconds, graph used): both times are the MAXIMUM over the ranks, measured
     between two barriers.  bench.py calls this with the GPU hooks; tests/dist_worker.py with HostHooks under gloo."""
     import time
     do_gather = world > 1 and mode == "full"
     gather_last = world > 1 and mode == "last"
+    converged = mode == "converged"
     ge = max(1, gather_every)
 
     def run_steps(first, count):
+        if converged:
+            for i in range(first, first + count):
+                eng.rti(conv_iters, slot=i)
+                if gatherer is not None:
+                    gatherer.submit({k: eng.ts[k][i] for k in ("x", "u", "status", "kkt")})
+            if gatherer is not None:
+                gatherer.wait()
+            return
         if not do_gather and count > 0 and hasattr(eng, "rti_range"):
             eng.rti_range(first, count)  # no collective between the solves: the launches go out from one library call
             return
@@ -143,7 +159,7 @@ def timed_pass(eng, batch, mode: str, K: int, warmup: int, gather_every: int, ga
     run_steps(0, warmup)
     hooks.barrier()
     replay = None
-    if not do_gather and K > 0:  # never with collectives between the solves
+    if not do_gather and not converged and K > 0:  # never with collectives between the solves
         replay = hooks.capture(lambda: run_steps(warmup, K))
     timer = hooks.device_timer()
     hooks.barrier()

@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--many-mode", choices=("groups", "streams"), default="groups",
                     help="how alore_nmpc_rti_many keeps the steps in flight: one grid over all of them (default) or one launch per "
                          "batch on forked streams")
+    ap.add_argument("--no-converged", action="store_true", help="skip the converged-solve + all-gather pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
@@ -475,6 +476,34 @@ def main():
         steady = {"steps": long_steps, "value": float(B) * long_steps / el_l, "ms_per_step": el_l / long_steps * 1e3,
                   "kernel_ms_avg": dms_l / long_steps, "hip_graph": g_l,
                   "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_l / long_steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # The north star's unit beside the headline: every step solves its batch to CONVERGENCE (15 real-time iterations in
+    # one launch) and all-gathers the converged trajectories (x, u, status, kkt) to every rank with RCCL, the collective of
+    # step i running under the solve of step i + 1.  Same pass at every world size (world = 1: the gather is a local copy),
+    # so a scaling run compares like with like; `value` of the line keeps the sharded real-time-iteration unit at every N.
+    conv = None
+    if a.steps > 0 and not a.no_converged:
+        try:
+            Kc = min(a.steps, 50)
+            cg = ResultGatherer(dist, world, depth=2)
+            el_c, dms_c, _ = shard_mod.timed_pass(eng, batch, "converged", Kc, min(a.warmup, 5), ge, cg, hooks, world, conv_iters=15)
+            last = cg.wait()
+            slot_last = min(a.warmup, 5) + Kc - 1
+            mine_ok = bool(torch.equal(last["x"][rank], eng.ts["x"][slot_last]) and torch.equal(last["status"][rank], eng.ts["status"][slot_last]))
+            flags = hooks.max_over_ranks([0.0 if mine_ok else 1.0])
+            per_rank_bytes = 4 * B * ((N + 1) * 3 + N * 2 + 2)
+            conv = {"metric": "converged NMPC solves/s with every rank holding every trajectory", "value": float(B) * world * Kc / el_c,
+                    "unit": "solves/s", "steps": Kc, "ms_per_step": el_c / Kc * 1e3, "kernel_ms_avg": dms_c / Kc,
+                    "real_time_iterations_per_solve": 15,
+                    "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1,
+                    "gathered_status_sum": int(last["status"].sum().item()), "gathered_problems": int(last["status"].numel()),
+                    "every_rank_holds_its_own_slab_in_the_gather": flags[0] == 0.0,
+                    "all_gather_bytes_in_per_rank_per_step": per_rank_bytes * (world - 1),
+                    "what": "per step: one launch of 15 real-time iterations (MpcWrapper::solve cold start to convergence), then x, u, status, kkt "
+                            "all-gathered to every rank (RCCL, asynchronous, overlapped with the next step's launch); all collectives complete "
+                            "inside the timed region"}
+        except Exception as e:  # pragma: no cover
+            conv = {"error": f"{type(e).__name__}: {e}"}
+
     exchange = None
     if world > 1 and a.gather != "none":
         # secondary figures: they must never cost the primary one (a rank that fails here would hang the others in the
@@ -580,6 +609,8 @@ def main():
             if not spot["ok"]:  # a fast kernel whose results differ from the reference's is not measured
                 result["value"] = None
                 result["error"] = f"parity spot check failed: worst relative error {spot['worst_rel']:.3e} > {spot['tolerance']}"
+        if conv is not None:
+            result["converged_all_gather"] = conv
         if exchange:
             result["result_exchange"] = exchange
         if steady is not None:
@@ -841,7 +872,10 @@ def main():
             dr = np.stack([np.repeat(vv[:, None], T, 1), np.repeat(ww[:, None], T, 1)], 2)
             st0 = rng.uniform(-0.1, 0.1, (B, 3))
             lt.set_refs(xr, dr)
-            t_a = time.perf_counter(); g0 = lt.get_cmd(st0, n_relin=5, reset=True); t_cold = time.perf_counter() - t_a
+            g0 = lt.get_cmd(st0, n_relin=5, reset=True)       # untimed: first launch of the kernel + the sweep counts of a cold start
+            # a control tick returns the command column and the status (16 B per robot): cold = freshly constructed controller
+            # (reset: no previous output, free working set), warm = the tick after
+            t_a = time.perf_counter(); lt.tick(st0, n_relin=5, reset=True); t_cold = time.perf_counter() - t_a
             t_a = time.perf_counter()
             for i in range(10):
                 cmd_w, st_w = lt.tick(st0, n_relin=5)     # commands + status only (16 B per robot over the bus)

@@ -61,8 +61,9 @@ class OracleEngine:
             pr = problem(self.batch, b)
             pr["x"] = self.ts["x"][slot, b].numpy().reshape(-1).copy(); pr["u"] = self.ts["u"][slot, b].numpy().reshape(-1).copy()
             orc.reset(); orc.initialize_solver(); orc.load(pr)
-            orc.preparation_step()
-            self.ts["status"][slot, b] = orc.feedback_step()
+            for it in range(n):   # n real-time iterations, as alore_nmpc_rti(n_sqp = n)
+                orc.preparation_step()
+                self.ts["status"][slot, b] = orc.feedback_step()
             self.ts["x"][slot, b] = torch.from_numpy(orc.v["x"].reshape(self.N + 1, 3))
             self.ts["u"][slot, b] = torch.from_numpy(orc.v["u"].reshape(self.N, 2))
             self.ts["kkt"][slot, b] = orc.get_kkt()
@@ -96,6 +97,22 @@ def bench_pass_bookkeeping(rank, world):
     el2, dms2, _ = timed_pass(eng, batch, "last", K, W, ge, g, hooks, world)
     checks["last: one submit"] = submits == [(B, N + 1, 3)] and eng.launches == list(range(W + K))
     checks["last: slab"] = torch.equal(g.wait()["x"][rank], eng.ts["x"][W + K - 1])
+    # the north star's unit: every step converged (here 2 iterations) and gathered to every rank, the previous gather still
+    # readable while the next one lands (two output buffers in turn)
+    submits.clear(); eng.launches.clear()
+    g2 = ResultGatherer(dist, world, depth=2)
+    seen = []
+    orig2 = g2.submit
+    g2.submit = lambda t: (seen.append({k: v.clone() for k, v in t.items()}), orig2(t))[1]
+    el3, dms3, graph3 = timed_pass(eng, batch, "converged", K, W, ge, g2, hooks, world, conv_iters=2)
+    lastc = g2.wait()
+    checks["converged: one gather per step"] = len(seen) == W + K and eng.launches == list(range(W + K)) and not graph3
+    checks["converged: own slab"] = torch.equal(lastc["x"][rank], eng.ts["x"][W + K - 1]) and torch.equal(lastc["kkt"][rank], eng.ts["kkt"][W + K - 1])
+    e3 = OracleEngine(B, N, 1); e3.load(other); e3.rti(2, 0)
+    checks["converged: peer slab"] = torch.equal(lastc["x"][1 - rank], e3.ts["x"][0]) and torch.equal(lastc["u"][1 - rank], e3.ts["u"][0])
+    checks["converged: every problem of every rank"] = tuple(lastc["status"].shape) == (world, B) and int(lastc["status"].sum()) == 0
+    e1 = OracleEngine(B, N, 1); e1.load(batch); e1.rti(1, 0)
+    checks["converged: two iterations differ from one"] = not torch.equal(e1.ts["u"][0], eng.ts["u"][W + K - 1])
     # secondary pass that fails on every rank before any collective: caught, the primary figure stands
     class Boom(OracleEngine):
         def load(self, batch, slot=None):
