@@ -78,6 +78,7 @@ def _bind(L):
     L.alore_backend_build_esdf.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                            C.c_double, C.c_double, C.c_double, DP]
     L.alore_backend_predicted_state.argtypes = [C.c_void_p, C.c_int, C.c_double, DP, DP, DP, DP, DP, DP, C.POINTER(C.c_int)]
+    L.alore_backend_path_points.argtypes = [C.c_void_p, C.c_int, C.c_int, DP, DP, C.POINTER(C.c_int)]
     L.alore_backend_set_problems.argtypes = [C.c_void_p, C.c_int, C.POINTER(FlatTrajC), C.c_void_p]
     L.alore_backend_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.alore_backend_results.argtypes = [C.c_void_p, C.c_int, C.POINTER(StatusC), DP, DP, DP, C.c_void_p]
@@ -160,6 +161,14 @@ class BatchedMSPlanner:
         self._check(self.L.alore_backend_predicted_state(self.h, n, float(resolution), _dp(st), _dp(t), _dp(sx), _dp(xyt), _dp(vaj), _dp(oaj),
                                                          fwd.ctypes.data_as(C.POINTER(C.c_int))))
         return {"xytheta": xyt, "vaj": vaj, "oaj": oaj, "forward": fwd.astype(bool)}
+
+    def path_points(self, panels_per_piece: int = 3, count: int | None = None):
+        """MSPlanner::mincoPointPub for the plans of the last launch: list of (points [n][2], yaw [n_pieces panels]) per plan"""
+        n = int(count or self.count)
+        per = self.P * (panels_per_piece + 1)
+        xy = np.zeros((n, per, 2)); yaw = np.zeros((n, self.P * panels_per_piece)); npts = np.zeros(n, np.int32)
+        self._check(self.L.alore_backend_path_points(self.h, n, int(panels_per_piece), _dp(xy), _dp(yaw), npts.ctypes.data_as(C.POINTER(C.c_int))))
+        return [(xy[b, :npts[b]].copy(), yaw[b, :(npts[b] // (panels_per_piece + 1)) * panels_per_piece].copy()) for b in range(n)]
 
     def set_free_map(self, half: float = 40.0, res: float = 0.1, value: float = 100.0):
         n = int(round(2 * half / res))

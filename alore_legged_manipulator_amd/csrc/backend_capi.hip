@@ -256,6 +256,33 @@ int alore_backend_predicted_state(alore_backend_handle h, int count, double reso
     return ALORE_BE_OK;
 }
 
+int alore_backend_path_points(alore_backend_handle h, int count, int panels_per_piece, double* xy, double* yaw, int* n_points)
+{
+    if (!h || count < 1 || count > h->B || panels_per_piece < 1 || !xy || !n_points)
+        return fail(h, ALORE_BE_E_INVALID, "path_points: bad argument");
+    if (!h->timed || count > h->count) return fail(h, ALORE_BE_E_INVALID, "path_points: no finished plan for these slots (alore_backend_plan first)");
+    BE_TRY(h, hipSetDevice(h->device));
+    const size_t n = count, per = (size_t)h->P * (panels_per_piece + 1);
+    double *d_xy = nullptr, *d_yaw = nullptr;
+    int* d_n = nullptr;
+    hipError_t e = hipMalloc((void**)&d_xy, sizeof(double) * n * per * 2);
+    if (e == hipSuccess) e = hipMemset(d_xy, 0, sizeof(double) * n * per * 2);
+    if (e == hipSuccess && yaw) e = hipMalloc((void**)&d_yaw, sizeof(double) * n * h->P * panels_per_piece);
+    if (e == hipSuccess && yaw) e = hipMemset(d_yaw, 0, sizeof(double) * n * h->P * panels_per_piece);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_n, sizeof(int) * n);
+    if (e == hipSuccess) {
+        backend::PathArgs g{count, h->P, panels_per_piece, h->d_M, h->r_ok, h->r_T, h->r_coef, h->d_sxyt, h->cfg.icr_xv, h->cfg.standard_diff != 0,
+                            d_xy, d_yaw, d_n};
+        e = backend::path_points(g, nullptr);
+    }
+    if (e == hipSuccess) e = hipMemcpy(xy, d_xy, sizeof(double) * n * per * 2, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && yaw) e = hipMemcpy(yaw, d_yaw, sizeof(double) * n * h->P * panels_per_piece, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(n_points, d_n, sizeof(int) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_xy); (void)hipFree(d_yaw); (void)hipFree(d_n);
+    if (e != hipSuccess) return fail(h, ALORE_BE_E_HIP, "path_points", e);
+    return ALORE_BE_OK;
+}
+
 int alore_backend_set_problems(alore_backend_handle h, int count, const alore_flat_traj* pr, void* stream)
 {
     if (!h || count < 1 || count > h->B || !pr) return fail(h, ALORE_BE_E_INVALID, "set_problems: bad argument");

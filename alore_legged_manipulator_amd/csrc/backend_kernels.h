@@ -84,6 +84,20 @@ struct PredictArgs {
     int* forward_out;
 };
 hipError_t predicted_state(const PredictArgs& g, hipStream_t s);
+// MSPlanner::mincoPointPub on the plans of the last launch (esdf_build.hip)
+struct PathArgs {
+    int count, P, res;
+    const int* n_pieces;
+    const int* ok;                 // [B] or null: plans the optimiser rejected have no path
+    const double *T, *coef;        // ResultStore
+    const double* plan_start_xyt;  // [B][3]
+    double xv;
+    bool standard_diff;
+    double* xy_out;                // [B][P (res + 1)][2]
+    double* yaw_out;               // [B][P res] or null
+    int* n_out;                    // [B] points written
+};
+hipError_t path_points(const PathArgs& g, hipStream_t s);
 
 // esdf_build.hip: SDFmap::updateESDF2d on the device
 hipError_t esdf_fill_max(double* p, size_t n, hipStream_t s);

@@ -237,6 +237,59 @@ __global__ void predicted_state_kernel(PredictArgs g)
 }
 } // namespace
 
+// ---- MSPlanner::mincoPointPub (optimizer.cpp:1714-1826): the marker points of every plan -------------------------------
+// One thread per plan: per piece `res` Simpson panels of the planar velocity in the reference's order of additions (start
+// term, 4 x mid term, end term), accumulated from the plan's start position; the last point of a piece is written twice.
+namespace {
+__global__ void path_points_kernel(PathArgs g)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.count) return;
+    const int M = g.n_pieces[b], res = g.res;
+    double* xy = g.xy_out + (size_t)b * g.P * (res + 1) * 2;
+    double* yaw = g.yaw_out ? g.yaw_out + (size_t)b * g.P * res : nullptr;
+    if (M < 1 || (g.ok && !g.ok[b])) { g.n_out[b] = 0; return; } // a slot without a plan has no path
+    const double* T = g.T + (size_t)b * g.P;
+    const double* coef = g.coef + (size_t)b * g.P * 12;
+    double px = g.plan_start_xyt[(size_t)b * 3], py = g.plan_start_xyt[(size_t)b * 3 + 1], sumT = 0.0;
+    int n = 0;
+    for (int i = 0; i < M; ++i) {
+        const double step = T[i] / res, halfstep = step / 2.0, C = T[i] / res / 6.0;
+        double s1 = 0.0, ax = 0.0, ay = 0.0; // the panel being filled
+        for (int j = 0; j <= 2 * res; ++j) {
+            double p[2], v[2], sy, cy, fx, fy;
+            plan_eval(T, coef, M, s1 + sumT, p, v, nullptr, nullptr);
+            s1 += halfstep;
+            sincos(p[0], &sy, &cy);
+            if ((j & 1) == 0) {
+                if (g.standard_diff) { fx = C * v[1] * cy; fy = C * v[1] * sy; }
+                else { fx = C * (v[1] * cy + v[0] * g.xv * sy); fy = C * (v[1] * sy - v[0] * g.xv * cy); }
+                if (j != 0) { // end term of panel j / 2 - 1: the panel is complete
+                    ax += fx; ay += fy;
+                    px += ax; py += ay;
+                    xy[2 * n] = px; xy[2 * n + 1] = py; ++n;
+                    if (yaw) yaw[i * res + j / 2 - 1] = p[0];
+                    if (j == 2 * res) { xy[2 * n] = px; xy[2 * n + 1] = py; ++n; }
+                }
+                ax = fx; ay = fy; // start term of panel j / 2 (0 + fx in the reference)
+            } else {
+                if (g.standard_diff) { fx = 4.0 * C * v[1] * cy; fy = 4.0 * C * v[1] * sy; }
+                else { fx = 4 * C * (v[1] * cy + v[0] * g.xv * sy); fy = 4 * C * (v[1] * sy - v[0] * g.xv * cy); }
+                ax += fx; ay += fy;
+            }
+        }
+        sumT += T[i];
+    }
+    g.n_out[b] = n;
+}
+} // namespace
+
+hipError_t path_points(const PathArgs& g, hipStream_t s)
+{
+    path_points_kernel<<<(g.count + 63) / 64, 64, 0, s>>>(g);
+    return hipGetLastError();
+}
+
 hipError_t predicted_state(const PredictArgs& g, hipStream_t s)
 {
     predicted_state_kernel<<<(g.count + 63) / 64, 64, 0, s>>>(g);

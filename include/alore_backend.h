@@ -152,6 +152,15 @@ int alore_backend_last_plan_ms(alore_backend_handle h, float *ms);
 int alore_backend_predicted_state(alore_backend_handle h, int count, double resolution, const double *start_time, const double *time,
                                   const double *start_xytheta, double *xytheta, double *vaj, double *oaj, int *forward);
 
+/* MSPlanner::mincoPointPub (optimizer.cpp:1714-1826) on the plans of the last alore_backend_plan: the optimised path as the
+ * marker points the reference publishes for the ALORE FSM to follow -- per piece `panels_per_piece` Simpson panels of the
+ * planar velocity ((int)(sparseResolution * 0.4) in the reference), accumulated from the plan's start position, the last
+ * point of every piece twice.  HOST pointers: xy [count][max_pieces (panels_per_piece + 1)][2] (z = 0.15 in the marker),
+ * yaw [count][max_pieces panels_per_piece] or NULL (the heading at the end of every panel: the reference computes it and
+ * does not publish it), n_points [count] (n_pieces (panels_per_piece + 1); 0 for a slot whose plan the optimiser rejected).
+ * Synchronises. */
+int alore_backend_path_points(alore_backend_handle h, int count, int panels_per_piece, double *xy, double *yaw, int *n_points);
+
 #ifdef __cplusplus
 }
 #endif

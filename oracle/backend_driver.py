@@ -120,6 +120,21 @@ def predicted_state(T, coef, step, time, start_time=0.0, start_xytheta=(0.0, 0.0
     return xyt, vaj, oaj, bool(fwd)
 
 
+def path_points(T, coef, res, start_xy=(0.0, 0.0), standard_diff=True, xv=0.0):
+    """MSPlanner::mincoPointPub on a plan: (points [M (res + 1)][2], yaw [M res])"""
+    if not os.path.exists(SO):
+        build()
+    L = C.CDLL(SO)
+    L.be_path_points.restype = C.c_int
+    L.be_path_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    T = np.ascontiguousarray(T, np.float64); coef = np.ascontiguousarray(coef, np.float64)
+    M = len(T)
+    xy = np.zeros((M * (res + 1), 2)); yaw = np.zeros(M * res); s0 = np.array(start_xy, np.float64)
+    n = L.be_path_points(T.ctypes.data, coef.ctypes.data, M, 1 if standard_diff else 0, xv, int(res), s0.ctypes.data, xy.ctypes.data, yaw.ctypes.data)
+    assert n == M * (res + 1)
+    return xy, yaw
+
+
 class BackendOracle:
     def __init__(self):
         if not os.path.exists(SO):

@@ -945,3 +945,47 @@ int be_predicted_state(const double *T, const double *coef, int M, int standard_
     traj_eval(T, coef, M, start_time, ps, 0, 0, 0);
     return pe[1] - ps[1] > 0.0 ? 1 : 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* MSPlanner::mincoPointPub (optimizer.cpp:1714-1826): the optimised trajectory as the marker points the ALORE FSM      */
+/* follows.  Per piece, `res` Simpson panels of the planar velocity (the same even / odd node walk and the same order of  */
+/* additions as the reference: start term, 4 x mid term, end term), accumulated from the start position; the last point  */
+/* of every piece is pushed twice.  res = (int)(sparseResolution_ * 0.4).  xy [M (res + 1)][2], yaw [M res] (the         */
+/* reference fills `Yaw` and does not publish it) or NULL.  Returns the number of points.                                */
+/* ------------------------------------------------------------------------------------------------------------------ */
+int be_path_points(const double *T, const double *coef, int M, int standard_diff, double xv, int res, const double start_xy[2],
+                   double *xy, double *yaw)
+{
+    double sumT = 0.0, px = start_xy[0], py = start_xy[1];
+    int i, j, n = 0;
+    double *ix = (double *)calloc((size_t)(res > 0 ? res : 1), sizeof(double)), *iy = (double *)calloc((size_t)(res > 0 ? res : 1), sizeof(double));
+    for (i = 0; i < M; ++i) {
+        const double step = T[i] / res, halfstep = step / 2.0, C = T[i] / res / 6.0;
+        double s1 = 0.0;
+        for (j = 0; j < res; ++j) ix[j] = iy[j] = 0.0;
+        for (j = 0; j <= 2 * res; ++j) {
+            double p[2], v[2], fx, fy, cy, sy;
+            traj_eval(T, coef, M, s1 + sumT, p, v, 0, 0);
+            s1 += halfstep;
+            cy = cos(p[0]); sy = sin(p[0]);
+            if (j % 2 == 0) {
+                if (standard_diff) { fx = C * v[1] * cy; fy = C * v[1] * sy; }
+                else { fx = C * (v[1] * cy + v[0] * xv * sy); fy = C * (v[1] * sy - v[0] * xv * cy); }
+                if (j != 0) { ix[j / 2 - 1] += fx; iy[j / 2 - 1] += fy; if (yaw) yaw[i * res + j / 2 - 1] = p[0]; }
+                if (j != 2 * res) { ix[j / 2] += fx; iy[j / 2] += fy; }
+            } else {
+                if (standard_diff) { fx = 4.0 * C * v[1] * cy; fy = 4.0 * C * v[1] * sy; }
+                else { fx = 4 * C * (v[1] * cy + v[0] * xv * sy); fy = 4 * C * (v[1] * sy - v[0] * xv * cy); }
+                ix[j / 2] += fx; iy[j / 2] += fy;
+            }
+        }
+        for (j = 0; j < res; ++j) {
+            px += ix[j]; py += iy[j];
+            xy[2 * n] = px; xy[2 * n + 1] = py; ++n;
+            if (j == res - 1) { xy[2 * n] = px; xy[2 * n + 1] = py; ++n; }
+        }
+        sumT += T[i];
+    }
+    free(ix); free(iy);
+    return n;
+}

@@ -122,4 +122,8 @@ int be_lbfgs_run(const be_config *c, const be_map *map, const be_problem *p, int
 #ifdef __cplusplus
 }
 #endif
+/* MSPlanner::mincoPointPub (optimizer.cpp:1714-1826): the marker points of an optimised trajectory; returns their number */
+int be_path_points(const double *T, const double *coef, int M, int standard_diff, double xv, int res, const double start_xy[2],
+                   double *xy, double *yaw);
+
 #endif

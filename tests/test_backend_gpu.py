@@ -250,6 +250,28 @@ def test_esdf_built_on_the_device_is_bit_identical_to_the_oracle(orc):
     assert res2["ok"][0] == 1 and res2["min_dist"][0] > orc.cfg.final_min_safe_dis
 
 
+def test_path_points_match_the_oracle(orc):
+    """alore_backend_path_points (MSPlanner::mincoPointPub: what the ALORE FSM follows) on the GPU's own plans against the
+    oracle's restatement fed with the same coefficients: the same Simpson panels in the same order of additions, 1e-10;
+    a plan the optimiser rejected has no points."""
+    from oracle.backend_driver import path_points
+    fts = monte_carlo_goals(24, seed=9)
+    pl = planner_for(free_grid(), len(fts))
+    res = pl.minco_plan(fts)
+    for panels in (3, 8):
+        got = pl.path_points(panels)
+        for b, ft in enumerate(fts):
+            M = res["n_pieces"][b]
+            xy, yaw = got[b]
+            if not res["ok"][b]:
+                assert xy.shape[0] == 0
+                continue
+            T, coef = res["T"][b, :M], res["coef"][b, :6 * M].reshape(-1)
+            exy, eyaw = path_points(T, coef, panels, ft.start_xytheta[:2])
+            assert xy.shape == exy.shape and np.max(np.abs(xy - exy)) < 1e-10 and np.max(np.abs(yaw - eyaw)) < 1e-10
+            assert np.hypot(*(xy[-1] - np.array(ft.final_xytheta[:2]))) < 0.05      # the path ends at the goal
+
+
 def test_predicted_state_matches_the_oracle(orc):
     """alore_backend_predicted_state (MSPlanner::get_the_predicted_state / _and_path) on the GPU's own plans against the
     oracle's restatement fed with the same coefficients: same Simpson steps in the same order, 1e-10."""

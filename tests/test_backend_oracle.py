@@ -260,6 +260,42 @@ def test_simpson_positions_against_quadrature(orc):
         orc.cfg.standard_diff = 1
 
 
+def test_path_points_against_quadrature_and_the_predicted_state(orc):
+    """be_path_points (MSPlanner::mincoPointPub): the marker points are the integral of the planar velocity -- SciPy
+    quadrature per panel, both ICR models -- every piece ends with a doubled point, and the last point is what
+    be_predicted_state reaches at the end of the plan when it integrates with the same panel width."""
+    from oracle.backend_driver import path_points, predicted_state
+    for standard, xv in ((True, 0.0), (False, 0.2)):
+        ft = straight_goal((0.3, -0.2, 0.5), (4.0, 3.0, -0.7))
+        x = orc.x0(ft)
+        M = ft.pieces
+        tau = x[2 * (M - 1) + 1:]
+        T = np.where(tau > 0, (0.5 * tau + 1) * tau + 1, 1 / ((0.5 * tau - 1) * tau + 1))
+        tail = ft.final_state.copy(); tail[1, 0] = x[2 * (M - 1)]
+        coef = orc.spline(T, x[:2 * (M - 1)].reshape(-1, 2), ft.start_state, tail).reshape(M, 6, 2)
+        res = 3
+        xy, yaw = path_points(T, coef.reshape(-1), res, ft.start_xytheta[:2], standard_diff=standard, xv=xv)
+        assert xy.shape == (M * (res + 1), 2) and yaw.shape == (M * res,)
+        pos = np.array(ft.start_xytheta[:2], dtype=float)
+        k = 0
+        for i in range(M):
+            fx = lambda t: poly_derivs(coef[i], t, 1)[1] * np.cos(poly_derivs(coef[i], t, 0)[0]) + poly_derivs(coef[i], t, 1)[0] * xv * np.sin(poly_derivs(coef[i], t, 0)[0])
+            fy = lambda t: poly_derivs(coef[i], t, 1)[1] * np.sin(poly_derivs(coef[i], t, 0)[0]) - poly_derivs(coef[i], t, 1)[0] * xv * np.cos(poly_derivs(coef[i], t, 0)[0])
+            for j in range(1, res + 1):
+                t = T[i] * j / res
+                ex = pos + np.array([quad(fx, 0, t, epsabs=1e-12)[0], quad(fy, 0, t, epsabs=1e-12)[0]])
+                assert np.max(np.abs(xy[k] - ex)) < 5e-4, (i, j)                       # Simpson, panels of ~0.2 s
+                assert abs(yaw[i * res + j - 1] - poly_derivs(coef[i], t, 0)[0]) < 1e-12
+                k += 1
+            assert np.array_equal(xy[k], xy[k - 1])                                    # the doubled end point of the piece
+            k += 1
+            pos = pos + np.array([quad(fx, 0, T[i], epsabs=1e-12)[0], quad(fy, 0, T[i], epsabs=1e-12)[0]])
+        # equal pieces: one panel width for the whole plan, which get_the_predicted_state then walks as well
+        if np.allclose(T, T[0]):
+            xyt, _, _, _ = predicted_state(T, coef.reshape(-1), T[0] / res, float(T.sum()), start_xytheta=ft.start_xytheta, standard_diff=standard, xv=xv)
+            assert np.max(np.abs(xyt[:2] - xy[-1])) < 1e-9
+
+
 def test_time_map_and_quirks(orc):
     ft = straight_goal((0, 0, 0), (4, 0, 0))
     grid = EsdfGrid.free(half=12.0)
