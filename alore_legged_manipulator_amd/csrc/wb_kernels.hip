@@ -405,6 +405,11 @@ struct RicArgs {
     float mu = 0.f;      // friction coefficient of the pyramid
     const unsigned char* stance = nullptr; // [B][N][4] 1 = foot in contact at that stage; null = every foot, every stage
     const float* pen = nullptr;            // [B][N][PEN] contact-consistency penalty written by the stage kernel (StageArgs::pen)
+    // refinement pass (alore_wb_set_refinement): the same LQ problem with the float64 residuals of a first solution as its
+    // right-hand sides -- `vec` then holds [defect residual | stage gradient at the first solution | - | input gradient] as
+    // they are (no weights applied, no penalty gradient added), resN the terminal gradient, the initial state step is zero
+    int refine = 0;
+    const float* resN = nullptr;           // [B][48]
 };
 
 // 44.2 KB: three workgroups per CU (the register budget of the kernel asks for no more).  P A, Qxx, the gains K0 / R / K
@@ -547,7 +552,10 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     const double* ur = g.uref + (size_t)b * N * NU;
     // terminal cost
     for (int i = tid; i < 48 * 48; i += RIC_THREADS) { const int r = i / 48, c = i % 48; S.P[r * LDX + c] = (r == c) ? (float)QNd[r] : 0.f; }
-    if (tid < 48) { S.p[tid] = (float)(QNd[tid] * (xb[(size_t)N * NX + tid] - xr[(size_t)N * NX + tid])); S.wq[tid] = (float)Qd[tid]; }
+    if (tid < 48) {
+        S.p[tid] = g.refine ? g.resN[(size_t)b * NX + tid] : (float)(QNd[tid] * (xb[(size_t)N * NX + tid] - xr[(size_t)N * NX + tid]));
+        S.wq[tid] = (float)Qd[tid];
+    }
     else if (tid >= 64 && tid < 96) S.wr[tid - 64] = (tid - 64) < NU ? (float)Rd[tid - 64] : 1.f; // identity on the 2 padding inputs
     __syncthreads();
 
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         const float4* Bg_ = reinterpret_cast<const float4*>(g.B32 + ((size_t)b * N + (kk)) * NX * NUP);      \
         pb0 = Bg_[ib0]; pb1 = Bg_[ib1];                                                                      \
         pvec = g.vec[((size_t)b * N + (kk)) * VEC + vi];                                                     \
-        if (PENALTY && tid >= 72 && tid < 96) ppen = g.pen[((size_t)b * N + (kk)) * PEN + 288 + tid - 72];     \
+        if (PENALTY && !g.refine && tid >= 72 && tid < 96) ppen = g.pen[((size_t)b * N + (kk)) * PEN + 288 + tid - 72]; \
     }
 #define RIC_PUT4(base, ld, per_row, idx, v)                                                                  \
     { float* dst_ = (base) + ((idx) / (per_row)) * (ld) + 4 * ((idx) % (per_row)); dst_[0] = (v).x; dst_[1] = (v).y; dst_[2] = (v).z; dst_[3] = (v).w; }
@@ -585,9 +593,9 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         if (tid + RIC_THREADS < 48 * 8) RIC_PUT4(S.B, LDU, 8, ib1, pb1)                                      \
         /* d | gx = Q (x - xref) | current input (for the torque limits; dxn is free during the backward sweep) | gu = R (u - uref) */ \
         if (tid < 48) S.d[tid] = pvec;                                                                       \
-        else if (tid < 96) S.gx[tid - 48] = S.wq[tid - 48] * pvec + ppen; /* + rho J_c' (J_c v) on the velocities */ \
+        else if (tid < 96) S.gx[tid - 48] = g.refine ? pvec : S.wq[tid - 48] * pvec + ppen; /* + rho J_c' (J_c v) on the velocities */ \
         else if (tid < 128) S.dxn[tid - 96] = pvec;                                                          \
-        else if (tid < 160) S.gu[tid - 128] = S.wr[tid - 128] * pvec;                                        \
+        else if (tid < 160) S.gu[tid - 128] = g.refine ? pvec : S.wr[tid - 128] * pvec;                      \
     }
     RIC_REQUEST_A(N - 1)
     RIC_REQUEST_B(N - 1)
@@ -882,7 +890,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     // ---- forward sweep
     double* dxb = g.dx + (size_t)b * (N + 1) * NX;
     double* dub = g.du + (size_t)b * N * NU;
-    if (tid < 48) { S.dxk[tid] = (float)(g.x0[(size_t)b * NX + tid] - xb[tid]); dxb[tid] = S.dxk[tid]; }
+    if (tid < 48) { S.dxk[tid] = g.refine ? 0.f : (float)(g.x0[(size_t)b * NX + tid] - xb[tid]); dxb[tid] = S.dxk[tid]; }
     __syncthreads();
     // row r of a product on the four lanes of quad r (thread 4 r + part): each lane reads a contiguous quarter of the
     // matrix row with 16-byte loads and the quad adds up over DPP -- 4 x fewer dependent loads per lane than one lane
@@ -908,7 +916,8 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         an[0] = ar_[0]; an[1] = ar_[1]; an[2] = ar_[2];                                                      \
         bn[0] = br_[0]; bn[1] = br_[1];                                                                      \
         kffn = g.kff[((size_t)b * N + (kk)) * 32 + krow];                                                    \
-        nxn = g.next[((size_t)b * N + (kk)) * NX + arow]; xnn = xb[(size_t)((kk) + 1) * NX + arow];          \
+        if (g.refine) { nxn = (double)g.vec[((size_t)b * N + (kk)) * VEC + arow]; xnn = 0.0; }               \
+        else { nxn = g.next[((size_t)b * N + (kk)) * NX + arow]; xnn = xb[(size_t)((kk) + 1) * NX + arow]; } \
     }
     RIC_FWD_REQUEST(0)
     float* dxc = S.dxk;  // dx_k
@@ -992,6 +1001,87 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     }
 }
 
+// ---- iterative refinement of the LQ step (alore_wb_set_refinement) ------------------------------------------------------
+// The float32 sweep loses digits where the stage Hessian is stiff (rho J_c' J_c of 1e3 next to velocity weights of 1).  One
+// step of iterative refinement: the residuals of the LQ optimality system at the float32 solution (dx, du) are formed in
+// float64 -- defect residual A dx_k + B du_k + d_k - dx_{k+1}, stage gradients gx_k + Q dx_k (+ rho J_c' J_c on the
+// velocities), gu_k + R du_k, terminal gradient -- and the SAME float32 sweep solves the same problem with these residuals as
+// right-hand sides (RicArgs::refine); the correction it returns carries the relative error of the first solution, so the sum
+// is accurate to its square.  One workgroup per (problem, stage), thread = row.
+__global__ __launch_bounds__(64) void residual_kernel(const float* A32, const float* B32, const double* next, const double* x, const double* u,
+                                                      const double* xref, const double* uref, const double* w, const float* pen,
+                                                      const double* dx, const double* du, int N, float* res, float* resN)
+{
+    const int item = blockIdx.x, b = item / N, k = item % N, t = threadIdx.x;
+    const double* dxk = dx + ((size_t)b * (N + 1) + k) * NX;
+    const double* duk = du + ((size_t)b * N + k) * NU;
+    float* out = res + (size_t)item * VEC;
+    if (t < NX) {
+        const float* Ar = A32 + ((size_t)item * NX + t) * NX;
+        const float* Br = B32 + ((size_t)item * NX + t) * NUP;
+        double acc = next[(size_t)item * NX + t] - x[((size_t)b * (N + 1) + k + 1) * NX + t];
+        for (int j = 0; j < NX; ++j) acc += (double)Ar[j] * dxk[j];
+        for (int j = 0; j < NU; ++j) acc += (double)Br[j] * duk[j];
+        acc -= dx[((size_t)b * (N + 1) + k + 1) * NX + t];
+        out[t] = (float)acc;
+        // stage gradient at the first solution
+        double gx = w[t] * (x[((size_t)b * (N + 1) + k) * NX + t] - xref[((size_t)b * (N + 1) + k) * NX + t] + dxk[t]);
+        if (pen && t >= NQ) {
+            const float* J = pen + (size_t)item * PEN; // sqrt(rho) J_c [12][24], then rho J_c' (J_c v) [24]
+            double h = (double)J[288 + t - NQ];
+            for (int r = 0; r < 12; ++r) {
+                double jv = 0.0;
+                for (int c = 0; c < NV; ++c) jv += (double)J[r * 24 + c] * dxk[NQ + c];
+                h += (double)J[r * 24 + t - NQ] * jv;
+            }
+            gx += h;
+        }
+        out[48 + t] = (float)gx;
+        if (k == N - 1) {
+            const double xe = x[((size_t)b * (N + 1) + N) * NX + t] - xref[((size_t)b * (N + 1) + N) * NX + t] + dx[((size_t)b * (N + 1) + N) * NX + t];
+            resN[(size_t)b * NX + t] = (float)(w[NX + NU + t] * xe);
+        }
+    }
+    if (t < 32) {
+        out[96 + t] = 0.f;
+        out[128 + t] = t < NU ? (float)(w[NX + t] * (u[((size_t)b * N + k) * NU + t] - uref[((size_t)b * N + k) * NU + t] + duk[t])) : 0.f;
+    }
+}
+
+// dx <- dx + ex, du <- du + eu, then what the Riccati kernel does with a finished step: refuse a step that is not finite,
+// add it to the iterate, clip the applied torques to the URDF effort limits
+__global__ __launch_bounds__(256) void refine_apply_kernel(double* dx, double* du, const double* ex, const double* eu, double* x, double* u, int N,
+                                                           int apply, int* status)
+{
+    __shared__ int bad_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double* dxb = dx + (size_t)b * (N + 1) * NX;
+    double* dub = du + (size_t)b * N * NU;
+    const double* exb = ex + (size_t)b * (N + 1) * NX;
+    const double* eub = eu + (size_t)b * N * NU;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int i = tid; i < (N + 1) * NX; i += 256) { const double v = dxb[i] + exb[i]; dxb[i] = v; bad |= !isfinite(v); }
+    for (int i = tid; i < N * NU; i += 256) { const double v = dub[i] + eub[i]; dub[i] = v; bad |= !isfinite(v); }
+    if (bad) bad_s = 1;
+    __syncthreads();
+    const bool failed = bad_s != 0 || (status && status[b] != 0);
+    __syncthreads();
+    if (tid == 0 && status) status[b] = failed ? 1 : 0;
+    if (apply && !failed) {
+        double* xw = x + (size_t)b * (N + 1) * NX;
+        double* uw = u + (size_t)b * N * NU;
+        for (int i = tid; i < (N + 1) * NX; i += 256) xw[i] += dxb[i];
+        for (int i = tid; i < N * NU; i += 256) {
+            const int j = i % NU;
+            double val = uw[i] + dub[i];
+            if (j < b2z1::NJ) { const double lim = b2z1::EFFORT[j]; val = val > lim ? lim : (val < -lim ? -lim : val); }
+            uw[i] = val;
+        }
+    }
+}
+
 // one lane per evaluation point (alore_wb_aba): the articulated-body algorithm of wb_aba.h
 __global__ __launch_bounds__(64) void aba_kernel(int n, const double* q, const double* v, const double* u, double grav, double* acc)
 {
@@ -1036,6 +1126,9 @@ struct alore_wb_solver {
     unsigned char* d_stance = nullptr; // [max_problems][N][4], null = all stance
     float* d_pen = nullptr;            // [max_problems][N][PEN], allocated by alore_wb_set_contact_penalty
     double rho = 0.0;
+    int refine = 0;                    // alore_wb_set_refinement
+    float *d_res = nullptr, *d_resN = nullptr; // [B][N][VEC], [B][48] residuals of the refinement pass
+    double *d_ex = nullptr, *d_eu = nullptr;   // its correction
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_lin = -1.f, ms_ric = -1.f;
     bool timed = false;
@@ -1143,7 +1236,7 @@ int alore_wb_destroy(alore_wb_handle h)
             std::fprintf(stderr, "\n");
         }
     }
-    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance, h->d_pen};
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance, h->d_pen, h->d_res, h->d_resN, h->d_ex, h->d_eu};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -1246,6 +1339,20 @@ int alore_wb_set_contact_penalty(alore_wb_handle h, double rho)
         if (zalloc(&h->d_pen, (size_t)h->cfg.max_problems * h->cfg.horizon * wb::PEN) != hipSuccess) return fail(h, ALORE_WB_E_NOMEM, "set_contact_penalty: device memory");
     }
     h->rho = rho;
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_refinement(alore_wb_handle h, int enable)
+{
+    if (!h || enable < 0 || enable > 4) return fail(h, ALORE_WB_E_INVALID, "set_refinement: 0 .. 4 steps");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    if (enable && !h->d_res) {
+        const size_t B = h->cfg.max_problems, N = h->cfg.horizon;
+        if (zalloc(&h->d_res, B * N * wb::VEC) != hipSuccess || zalloc(&h->d_resN, B * wb::NX) != hipSuccess ||
+            zalloc(&h->d_ex, B * (N + 1) * wb::NX) != hipSuccess || zalloc(&h->d_eu, B * N * wb::NU) != hipSuccess)
+            return fail(h, ALORE_WB_E_NOMEM, "set_refinement: device memory");
+    }
+    h->refine = enable;
     return ALORE_WB_OK;
 }
 
@@ -1371,11 +1478,23 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
         if (pen) wb::stage_kernel<true><<<(unsigned)n, 64, 0, s>>>(g);
         else wb::stage_kernel<false><<<(unsigned)n, 64, 0, s>>>(g);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
-        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec,
+        // one step of iterative refinement (alore_wb_set_refinement) where nothing is clamped inside the sweep: the float32
+        // solution is not applied, its float64 residuals go through the same sweep, the sum is applied
+        const bool refine = h->refine && !h->limits && !h->cones && h->d_res;
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, refine ? 0 : 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec,
                        h->cones, h->mu, h->d_stance};
         if (pen) r.pen = h->d_pen;
         if (pen) wb::riccati_kernel<true><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         else wb::riccati_kernel<false><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
+        for (int rs = 0; refine && rs < h->refine; ++rs) {
+            wb::residual_kernel<<<(unsigned)n, 64, 0, s>>>(h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_xref, h->d_uref, h->d_w, pen ? h->d_pen : nullptr,
+                                                           h->d_dx, h->d_du, N, h->d_res, h->d_resN);
+            wb::RicArgs c = r;
+            c.vec = h->d_res; c.resN = h->d_resN; c.refine = 1; c.dx = h->d_ex; c.du = h->d_eu; c.apply = 0; c.status = nullptr;
+            if (pen) wb::riccati_kernel<true><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(c);
+            else wb::riccati_kernel<false><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(c);
+            wb::refine_apply_kernel<<<B, 256, 0, s>>>(h->d_dx, h->d_du, h->d_ex, h->d_eu, h->d_x, h->d_u, N, rs == h->refine - 1 ? 1 : 0, h->d_status);
+        }
         if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
     }
     WB_TRY(h, hipGetLastError());

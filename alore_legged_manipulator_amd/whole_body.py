@@ -39,6 +39,7 @@ def _bind(L):
         "alore_wb_set_contact_constraints": (C.c_int, [H, C.c_int, C.c_double]),
         "alore_wb_set_contact_schedule": (C.c_int, [H, C.c_int, C.c_void_p]),
         "alore_wb_set_contact_penalty": (C.c_int, [H, C.c_double]),
+        "alore_wb_set_refinement": (C.c_int, [H, C.c_int]),
         "alore_wb_set_problem": (C.c_int, [H, C.c_int, DP, DP, DP]),
         "alore_wb_set_x0": (C.c_int, [H, C.c_int, DP]),
         "alore_wb_shift_iterate": (C.c_int, [H, C.c_int, C.c_void_p]),
@@ -134,6 +135,10 @@ class BatchedWholeBody:
     def set_contact_constraints(self, enable: bool, mu: float = 0.7):
         """friction pyramid + unilateral normal force of the stance feet, zero force of the swing feet, inside the sweep"""
         self._check(self.L.alore_wb_set_contact_constraints(self.h, 1 if enable else 0, float(mu)))
+
+    def set_refinement(self, steps=1):
+        """steps of iterative refinement of the LQ solution with float64 residuals (alore_wb_set_refinement; True = 1)"""
+        self._check(self.L.alore_wb_set_refinement(self.h, int(steps)))
 
     def set_contact_penalty(self, rho: float):
         """1/2 rho |J_c(q_k) v_k|^2 over the stance feet in the stage cost (alore_wb_set_contact_penalty; 0 = off)"""

@@ -116,6 +116,14 @@ int alore_wb_set_contact_schedule(alore_wb_handle h, int B, const unsigned char 
  * only.  The violation |J_c v| of the iterate shrinks like 1 / rho; rho of 1e3 .. 1e4 keeps it below a millimetre per second
  * on the test motions without hurting the conditioning of the float32 sweep. */
 int alore_wb_set_contact_penalty(alore_wb_handle h, double rho);
+/* `steps` (0 .. 4, default 0 = off) steps of iterative refinement of the LQ solution.  The Riccati sweep runs in float32 on the matrix cores
+ * and loses digits where the stage Hessian is stiff -- a contact penalty of rho = 2000 next to velocity weights of 1 leaves
+ * 1.5e-3 of relative error in the step.  With refinement the residuals of the LQ optimality system at that solution are
+ * formed in float64 (defect residuals, stage and terminal gradients, the penalty Hessian included) and go through the same
+ * float32 sweep as right-hand sides; the sum of the solutions is applied (every step multiplies the error by the one-pass error, at one more
+ * Riccati sweep).  Acts only while nothing is clamped inside the sweep (alore_wb_set_torque_limits(h, 0), no contact
+ * constraints): a clamped sweep would have to be repeated with its clamp set held, which is not built. */
+int alore_wb_set_refinement(alore_wb_handle h, int steps);
 /* n_iter real-time iterations (linearise + Riccati + step) for B problems; asynchronous on `stream`.
  * Stream contract of this header: only alore_wb_rti and alore_wb_shift_iterate enqueue on the caller's stream (which
  * may be a non-blocking one).  Every entry point that moves data between host and device (set_problem, set_x0,
