@@ -1001,6 +1001,133 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     }
 }
 
+// ---- hard contact rows (alore_wb_set_contact_rows) ------------------------------------------------------------------------
+// Stance feet do not move: J_c(q_k) v_{k+1} = 0 for every foot in contact at stage k, as EQUALITY rows of the LQ problem
+// (velocity level: with the semi-implicit Euler step this is J_c qdd + J_c v / dt = 0, the acceleration row with its
+// stabilisation term).  In the linearised dynamics the row reads
+//     J_c [A dx + B du + next]_v = 0,     [.]_v = the 24 velocity components,
+// and its block with respect to the 12 foot forces, G = J_c (dt M^-1 J_c') -- the velocity rows of the force columns of B --
+// is symmetric positive definite: the rows are solved for the foot forces,
+//     df = F_x dx + F_tau dtau + f0,      [F_x | F_tau | f0] = -G^-1 [J_c A_v | J_c B_v,tau | J_c next_v],
+// and the forces leave the problem (the null space of the rows is parametrised by the joint torques): A <- A + B_f F_x,
+// B_tau <- B_tau + B_f F_tau, B_f <- 0, next <- next + B_f f0.  The Riccati kernel then sweeps an ordinary LQ problem in
+// (dx, dtau) -- the foot forces carry no cost of their own in this mode, they are what the contacts need -- and the forces
+// follow from the solved dx, dtau afterwards.  A foot in the air (contact schedule) has the row f = 0 instead.
+// One wavefront per (problem, stage), float64; G^-1 by Gauss-Jordan on the 12 x 79 augmented block in LDS.
+constexpr int FCOL = 68; // floats per force row of the stored map: F_x (48) | F_tau (18) | f0 | pad
+__global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32, double* next, float* vec, const float* pen, const unsigned char* stance,
+                                                          const double* u, int N, float* Fg)
+{
+    constexpr int MC = 80; // G (12) | J A_v (48) | J B_v,tau (18) | J next_v (1) | pad
+    __shared__ double Mx[12 * MC];
+    __shared__ double Jl[12 * NV];
+    __shared__ double Bf[NX * 12];
+    __shared__ double colp[12];
+    const int item = blockIdx.x, lane = threadIdx.x;
+    float* A = A32 + (size_t)item * NX * NX;
+    float* Bm = B32 + (size_t)item * NX * NUP;
+    double* nx = next + (size_t)item * NX;
+    const float* J = pen + (size_t)item * PEN; // written with rho = 1: J_c itself, rows of swing feet zero
+    const unsigned char* st = stance ? stance + (size_t)item * 4 : nullptr;
+    for (int e = lane; e < 12 * NV; e += 64) Jl[e] = (double)J[e];
+    for (int e = lane; e < NX * 12; e += 64) Bf[e] = (double)Bm[(e / 12) * NUP + b2z1::NJ + e % 12];
+    __syncthreads();
+    for (int col = lane; col < 79; col += 64) {
+        for (int r = 0; r < 12; ++r) {
+            const bool in_contact = !st || st[r / 3];
+            double acc = 0.0;
+            if (in_contact) {
+                if (col < 12) { for (int c = 0; c < NV; ++c) acc += Jl[r * NV + c] * Bf[(NQ + c) * 12 + col]; }
+                else if (col < 60) { for (int c = 0; c < NV; ++c) acc += Jl[r * NV + c] * (double)A[(NQ + c) * NX + col - 12]; }
+                else if (col < 78) { for (int c = 0; c < NV; ++c) acc += Jl[r * NV + c] * (double)Bm[(NQ + c) * NUP + col - 60]; }
+                else { for (int c = 0; c < NV; ++c) acc += Jl[r * NV + c] * nx[NQ + c]; }
+            } else { // foot in the air: the row  df_r = -f_r  (no force)
+                if (col < 12) acc = (col == r) ? 1.0 : 0.0;
+                else if (col == 78) acc = u[(size_t)item * NU + b2z1::NJ + r];
+            }
+            Mx[r * MC + col] = acc;
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < 12; ++p) { // Gauss-Jordan without pivoting: G is symmetric positive definite
+        if (lane < 12) colp[lane] = Mx[lane * MC + p];
+        __syncthreads();
+        const double inv = 1.0 / colp[p];
+        for (int col = lane; col < 79; col += 64) {
+            const double pv = Mx[p * MC + col] * inv;
+            for (int r = 0; r < 12; ++r) Mx[r * MC + col] = (r == p) ? pv : Mx[r * MC + col] - colp[r] * pv;
+        }
+        __syncthreads();
+    }
+    // F = -G^-1 [ ... ]: columns 12 .. 78 of the reduced block
+    float* F = Fg + (size_t)item * 12 * FCOL;
+    for (int e = lane; e < 12 * FCOL; e += 64) {
+        const int r = e / FCOL, c = e % FCOL;
+        F[e] = c < 67 ? (float)(-Mx[r * MC + 12 + c]) : 0.f;
+    }
+    // the forces leave the dynamics
+    for (int e = lane; e < NX * NX; e += 64) {
+        const int i = e / NX, j = e % NX;
+        double acc = 0.0;
+        for (int q = 0; q < 12; ++q) acc -= Bf[i * 12 + q] * Mx[q * MC + 12 + j];
+        A[e] = (float)((double)A[e] + acc);
+    }
+    for (int e = lane; e < NX * b2z1::NJ; e += 64) {
+        const int i = e / b2z1::NJ, t = e % b2z1::NJ;
+        double acc = 0.0;
+        for (int q = 0; q < 12; ++q) acc -= Bf[i * 12 + q] * Mx[q * MC + 60 + t];
+        Bm[i * NUP + t] = (float)((double)Bm[i * NUP + t] + acc);
+    }
+    if (lane < NX) {
+        double acc = 0.0;
+        for (int q = 0; q < 12; ++q) acc -= Bf[lane * 12 + q] * Mx[q * MC + 78];
+        nx[lane] += acc;
+        vec[(size_t)item * VEC + lane] = (float)((double)vec[(size_t)item * VEC + lane] + acc);
+    }
+    __syncthreads();
+    for (int e = lane; e < NX * 12; e += 64) Bm[(e / 12) * NUP + b2z1::NJ + e % 12] = 0.f;
+}
+
+// the foot forces of the solved step, df = F_x dx + F_tau dtau + f0, then what the Riccati kernel does with a finished step
+__global__ __launch_bounds__(256) void contact_rows_apply_kernel(const float* Fg, const double* dx, double* du, double* x, double* u, int N, int apply,
+                                                                 int* status, const unsigned char* stance)
+{
+    __shared__ int bad_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* dxb = dx + (size_t)b * (N + 1) * NX;
+    double* dub = du + (size_t)b * N * NU;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int e = tid; e < N * 12; e += 256) {
+        const int k = e / 12, q = e % 12;
+        const float* F = Fg + (((size_t)b * N + k) * 12 + q) * FCOL;
+        double acc = (double)F[66];
+        for (int j = 0; j < NX; ++j) acc += (double)F[j] * dxb[(size_t)k * NX + j];
+        for (int t = 0; t < b2z1::NJ; ++t) acc += (double)F[48 + t] * dub[(size_t)k * NU + t];
+        // a foot in the air: exactly -f (its row of the map holds f rounded to float32)
+        if (stance && !stance[((size_t)b * N + k) * 4 + q / 3]) acc = -u[((size_t)b * N + k) * NU + b2z1::NJ + q];
+        dub[(size_t)k * NU + b2z1::NJ + q] = acc;
+        bad |= !isfinite(acc);
+    }
+    if (bad) bad_s = 1;
+    __syncthreads();
+    const bool failed = bad_s != 0 || (status && status[b] != 0);
+    __syncthreads();
+    if (tid == 0 && status) status[b] = failed ? 1 : 0;
+    if (apply && !failed) {
+        double* xw = x + (size_t)b * (N + 1) * NX;
+        double* uw = u + (size_t)b * N * NU;
+        for (int i = tid; i < (N + 1) * NX; i += 256) xw[i] += dxb[i];
+        for (int i = tid; i < N * NU; i += 256) {
+            const int j = i % NU;
+            double val = uw[i] + dub[i];
+            if (j < b2z1::NJ) { const double lim = b2z1::EFFORT[j]; val = val > lim ? lim : (val < -lim ? -lim : val); }
+            uw[i] = val;
+        }
+    }
+}
+
 // ---- iterative refinement of the LQ step (alore_wb_set_refinement) ------------------------------------------------------
 // The float32 sweep loses digits where the stage Hessian is stiff (rho J_c' J_c of 1e3 next to velocity weights of 1).  One
 // step of iterative refinement: the residuals of the LQ optimality system at the float32 solution (dx, du) are formed in
@@ -1126,6 +1253,8 @@ struct alore_wb_solver {
     unsigned char* d_stance = nullptr; // [max_problems][N][4], null = all stance
     float* d_pen = nullptr;            // [max_problems][N][PEN], allocated by alore_wb_set_contact_penalty
     double rho = 0.0;
+    int rows = 0;                      // alore_wb_set_contact_rows
+    float* d_F = nullptr;              // [B][N][12][FCOL] the foot forces as a map of (dx, dtau)
     int refine = 0;                    // alore_wb_set_refinement
     float *d_res = nullptr, *d_resN = nullptr; // [B][N][VEC], [B][48] residuals of the refinement pass
     double *d_ex = nullptr, *d_eu = nullptr;   // its correction
@@ -1236,7 +1365,7 @@ int alore_wb_destroy(alore_wb_handle h)
             std::fprintf(stderr, "\n");
         }
     }
-    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance, h->d_pen, h->d_res, h->d_resN, h->d_ex, h->d_eu};
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance, h->d_pen, h->d_res, h->d_resN, h->d_ex, h->d_eu, h->d_F};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -1339,6 +1468,17 @@ int alore_wb_set_contact_penalty(alore_wb_handle h, double rho)
         if (zalloc(&h->d_pen, (size_t)h->cfg.max_problems * h->cfg.horizon * wb::PEN) != hipSuccess) return fail(h, ALORE_WB_E_NOMEM, "set_contact_penalty: device memory");
     }
     h->rho = rho;
+    return ALORE_WB_OK;
+}
+
+int alore_wb_set_contact_rows(alore_wb_handle h, int enable)
+{
+    if (!h) return ALORE_WB_E_INVALID;
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->cfg.max_problems * h->cfg.horizon;
+    if (enable && !h->d_pen && zalloc(&h->d_pen, n * wb::PEN) != hipSuccess) return fail(h, ALORE_WB_E_NOMEM, "set_contact_rows: device memory");
+    if (enable && !h->d_F && zalloc(&h->d_F, n * 12 * wb::FCOL) != hipSuccess) return fail(h, ALORE_WB_E_NOMEM, "set_contact_rows: device memory");
+    h->rows = enable ? 1 : 0;
     return ALORE_WB_OK;
 }
 
@@ -1473,19 +1613,23 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
         const bool last = it == n_iter - 1;
         if (last) WB_TRY(h, hipEventRecord(h->ev[0], s));
         wb::StageArgs g{h->d_x, h->d_u, N, (int)n, h->cfg.dt, h->d_A, h->d_B, h->d_next, nullptr, nullptr, nullptr, nullptr, h->d_stamps, h->d_xref, h->d_uref, h->d_vec};
-        const bool pen = h->rho > 0.0 && h->d_pen;
+        const bool rows = h->rows && h->d_pen && h->d_F;   // hard contact rows: the stage kernel writes J_c (rho = 1), no penalty
+        const bool pen = !rows && h->rho > 0.0 && h->d_pen;
         if (pen) { g.pen = h->d_pen; g.rho = h->rho; g.stance = h->d_stance; }
-        if (pen) wb::stage_kernel<true><<<(unsigned)n, 64, 0, s>>>(g);
+        if (rows) { g.pen = h->d_pen; g.rho = 1.0; g.stance = h->d_stance; }
+        if (pen || rows) wb::stage_kernel<true><<<(unsigned)n, 64, 0, s>>>(g);
         else wb::stage_kernel<false><<<(unsigned)n, 64, 0, s>>>(g);
+        if (rows) wb::contact_rows_kernel<<<(unsigned)n, 64, 0, s>>>(h->d_A, h->d_B, h->d_next, h->d_vec, h->d_pen, h->d_stance, h->d_u, N, h->d_F);
         if (last) WB_TRY(h, hipEventRecord(h->ev[1], s));
         // one step of iterative refinement (alore_wb_set_refinement) where nothing is clamped inside the sweep: the float32
         // solution is not applied, its float64 residuals go through the same sweep, the sum is applied
-        const bool refine = h->refine && !h->limits && !h->cones && h->d_res;
-        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, refine ? 0 : 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec,
-                       h->cones, h->mu, h->d_stance};
+        const bool refine = h->refine && !h->limits && !h->cones && !rows && h->d_res;
+        wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, (refine || rows) ? 0 : 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec,
+                       rows ? 0 : h->cones, h->mu, h->d_stance};
         if (pen) r.pen = h->d_pen;
         if (pen) wb::riccati_kernel<true><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         else wb::riccati_kernel<false><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
+        if (rows) wb::contact_rows_apply_kernel<<<B, 256, 0, s>>>(h->d_F, h->d_dx, h->d_du, h->d_x, h->d_u, N, 1, h->d_status, h->d_stance);
         for (int rs = 0; refine && rs < h->refine; ++rs) {
             wb::residual_kernel<<<(unsigned)n, 64, 0, s>>>(h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_xref, h->d_uref, h->d_w, pen ? h->d_pen : nullptr,
                                                            h->d_dx, h->d_du, N, h->d_res, h->d_resN);

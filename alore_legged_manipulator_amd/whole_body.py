@@ -40,6 +40,7 @@ def _bind(L):
         "alore_wb_set_contact_schedule": (C.c_int, [H, C.c_int, C.c_void_p]),
         "alore_wb_set_contact_penalty": (C.c_int, [H, C.c_double]),
         "alore_wb_set_refinement": (C.c_int, [H, C.c_int]),
+        "alore_wb_set_contact_rows": (C.c_int, [H, C.c_int]),
         "alore_wb_set_problem": (C.c_int, [H, C.c_int, DP, DP, DP]),
         "alore_wb_set_x0": (C.c_int, [H, C.c_int, DP]),
         "alore_wb_shift_iterate": (C.c_int, [H, C.c_int, C.c_void_p]),
@@ -135,6 +136,10 @@ class BatchedWholeBody:
     def set_contact_constraints(self, enable: bool, mu: float = 0.7):
         """friction pyramid + unilateral normal force of the stance feet, zero force of the swing feet, inside the sweep"""
         self._check(self.L.alore_wb_set_contact_constraints(self.h, 1 if enable else 0, float(mu)))
+
+    def set_contact_rows(self, enable: bool = True):
+        """hard contact rows J_c(q_k) v_{k+1} = 0 of the stance feet, solved for the foot forces (alore_wb_set_contact_rows)"""
+        self._check(self.L.alore_wb_set_contact_rows(self.h, 1 if enable else 0))
 
     def set_refinement(self, steps=1):
         """steps of iterative refinement of the LQ solution with float64 residuals (alore_wb_set_refinement; True = 1)"""

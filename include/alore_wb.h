@@ -103,8 +103,8 @@ int alore_wb_linearize(alore_wb_handle h, int B, double *A, double *Bm, double *
  * are clamped -- the tangential bounds from the projected normal force of the same stage --, the free inputs are
  * re-solved against the clamped ones, the gain rows of clamped inputs are zero; the applied forces satisfy the
  * constraints exactly.  Off by default (enable = 0: forces are free inputs, as in round 2).  The kinematic side -- stance
- * feet do not move -- is alore_wb_set_contact_penalty below (velocity level, as a penalty on J_c v); hard equality rows
- * J_c qdd + Jdot_c qd = 0 are not modelled. */
+ * feet do not move -- is alore_wb_set_contact_penalty below (velocity level, as a penalty on J_c v) or, as hard equality
+ * rows, alore_wb_set_contact_rows. */
 int alore_wb_set_contact_constraints(alore_wb_handle h, int enable, double mu);
 int alore_wb_set_contact_schedule(alore_wb_handle h, int B, const unsigned char *stance);
 /* Contact consistency of the stance feet through the contact Jacobian J_c(q) (12 x 24: world-frame velocity of the four foot
@@ -116,6 +116,19 @@ int alore_wb_set_contact_schedule(alore_wb_handle h, int B, const unsigned char 
  * only.  The violation |J_c v| of the iterate shrinks like 1 / rho; rho of 1e3 .. 1e4 keeps it below a millimetre per second
  * on the test motions without hurting the conditioning of the float32 sweep. */
 int alore_wb_set_contact_penalty(alore_wb_handle h, double rho);
+/* Hard contact rows (default off): a foot in contact at stage k (contact schedule) does not move at the end of that step,
+ *     J_c(q_k) v_{k+1} = 0
+ * as EQUALITY rows of the LQ problem of every real-time iteration -- the velocity-level form of J_c qdd + Jdot_c qd = 0 under
+ * the semi-implicit Euler step (J_c qdd + J_c v / dt = 0: the acceleration row with its stabilisation term), J_c evaluated at
+ * the current iterate by the linearisation kernel.  The block of the rows with respect to the 12 foot forces,
+ * J_c (dt M^-1 J_c'), is symmetric positive definite, so the rows are solved for the forces: df = F_x dx + F_tau dtau + f0,
+ * the forces leave the dynamics (A + B_f F_x, B_tau + B_f F_tau: the null space of the rows, parametrised by the joint
+ * torques), the Riccati sweep solves an ordinary LQ problem in (dx, dtau) and the forces follow from its solution.  In this
+ * mode the foot forces are what the contacts need: their entries of R and uref are not used; a foot in the air carries f = 0.
+ * Replaces the contact penalty (its rho is ignored while the rows are on) and the force constraints of
+ * alore_wb_set_contact_constraints (unilateral / friction limits on the eliminated forces are not enforced); torque limits
+ * keep working.  oracle/wb_oracle.py: solve_lq_contact_rows is the float64 KKT restatement (tests/test_wb_gpu.py). */
+int alore_wb_set_contact_rows(alore_wb_handle h, int enable);
 /* `steps` (0 .. 4, default 0 = off) steps of iterative refinement of the LQ solution.  The Riccati sweep runs in float32 on the matrix cores
  * and loses digits where the stage Hessian is stiff -- a contact penalty of rho = 2000 next to velocity weights of 1 leaves
  * 1.5e-3 of relative error in the step.  With refinement the residuals of the LQ optimality system at that solution are

@@ -315,6 +315,57 @@ def solve_lq(A, B, d, Q, R, QN, gx, gu, gN, dx0):
     return dx, du
 
 
+def solve_lq_contact_rows(A, B, d, Q, R, QN, gx, gu, gN, dx0, J, v_next, u_f, stance=None):
+    """The LQ problem of one real-time iteration with HARD contact rows (include/alore_wb.h: alore_wb_set_contact_rows), as one
+    dense float64 KKT system: besides the dynamics rows of solve_lq, for every stage k and foot i
+        in contact:  J_k[3 i : 3 i + 3] (v_next_k + [A_k dx_k + B_k du_k]_v) = 0     (the foot point is at rest after the step)
+        in the air:  du_k[18 + 3 i : 18 + 3 i + 3] = -u_f_k[3 i : 3 i + 3]            (it carries no force)
+    and the foot forces carry no cost of their own (their entries of R and gu are dropped): they are what the contacts need.
+    J: N contact Jacobians [12][nv]; v_next: N vectors [nv] (velocity part of f(x_k, u_k)); u_f: N current foot forces [12];
+    stance: [N][4] or None (all in contact).  Returns dx (N + 1, nx), du (N, nu)."""
+    N = len(A); nx, nu = B[0].shape
+    nv = nx // 2
+    nz = (N + 1) * nx + N * nu
+    H = np.zeros((nz, nz)); g = np.zeros(nz)
+    ox = lambda k: k * (nx + nu)
+    ou = lambda k: k * (nx + nu) + nx
+    Rt = np.array(R, float).copy(); Rt[18:30, :] = 0.0; Rt[:, 18:30] = 0.0
+    for k in range(N):
+        H[ox(k):ox(k) + nx, ox(k):ox(k) + nx] = _stage_Q(Q, k)
+        H[ou(k):ou(k) + nu, ou(k):ou(k) + nu] = Rt
+        g[ox(k):ox(k) + nx] = gx[k]
+        gk = np.array(gu[k], float).copy(); gk[18:30] = 0.0
+        g[ou(k):ou(k) + nu] = gk
+    H[ox(N):ox(N) + nx, ox(N):ox(N) + nx] = QN
+    g[ox(N):ox(N) + nx] = gN
+    ne = (N + 1) * nx + N * 12
+    C = np.zeros((ne, nz)); c = np.zeros(ne)
+    C[:nx, :nx] = np.eye(nx); c[:nx] = dx0
+    for k in range(N):
+        r = (k + 1) * nx
+        C[r:r + nx, ox(k):ox(k) + nx] = -A[k]
+        C[r:r + nx, ou(k):ou(k) + nu] = -B[k]
+        C[r:r + nx, ox(k + 1):ox(k + 1) + nx] = np.eye(nx)
+        c[r:r + nx] = d[k]
+        r2 = (N + 1) * nx + 12 * k
+        for i in range(4):
+            rows = slice(r2 + 3 * i, r2 + 3 * i + 3)
+            if stance is None or stance[k][i]:
+                Ji = J[k][3 * i:3 * i + 3]
+                C[rows, ox(k):ox(k) + nx] = Ji @ A[k][nv:, :]
+                C[rows, ou(k):ou(k) + nu] = Ji @ B[k][nv:, :]
+                c[rows] = -Ji @ v_next[k]
+            else:
+                C[rows, ou(k) + 18 + 3 * i:ou(k) + 18 + 3 * i + 3] = np.eye(3)
+                c[rows] = -np.asarray(u_f[k])[3 * i:3 * i + 3]
+    K = np.block([[H, C.T], [C, np.zeros((ne, ne))]])
+    sol = np.linalg.solve(K, np.concatenate([-g, c]))
+    z = sol[:nz]
+    dx = np.array([z[ox(k):ox(k) + nx] for k in range(N + 1)])
+    du = np.array([z[ou(k):ou(k) + nu] for k in range(N)])
+    return dx, du
+
+
 def contact_penalty(model, x_k, rho, stance_k=None):
     """Gauss-Newton terms of the contact-consistency penalty 1/2 rho |J_c(q_k) v_k|^2 over the stance feet of one stage
     (include/alore_wb.h: alore_wb_set_contact_penalty): (Qadd [48][48], gadd [48]) to add to the stage Hessian / gradient."""

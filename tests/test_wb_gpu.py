@@ -477,6 +477,63 @@ def test_contact_penalty_step_matches_the_float64_restatement(model):
         assert worst < tol
 
 
+def test_contact_rows_match_the_float64_kkt_solve_and_hold_the_feet(model):
+    """alore_wb_set_contact_rows: J_c(q_k) v_{k+1} = 0 for the stance feet as equality rows, solved for the foot forces (the
+    forces leave the dynamics, the sweep runs on (dx, dtau), the forces follow).  The step of the kernels against the float64
+    dense KKT system with the same rows built from the ORACLE's contact Jacobian (oracle/wb_oracle.py:
+    solve_lq_contact_rows), 1e-4; the linearised foot-point velocities after the step vanish; a swing foot carries no force and
+    is free to move; repeated iterations settle with the stance feet at rest."""
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    from oracle.wb_oracle import solve_lq_contact_rows
+    B, N, dt = 3, 20, 0.01
+    x0, xref, uref, xi, ui = make_problems(model, B, N, seed=41, spread=0.5)
+    stance = np.ones((B, N, 4), np.uint8)
+    stance[:, 6:, 1] = 0
+    Q, R, QN = weights()
+    eng = BatchedWholeBody(B, N, dt)
+    eng.set_weights(Q, R, QN)
+    eng.set_torque_limits(False)
+    eng.set_contact_rows(True)
+    eng.set_contact_schedule(stance)
+    eng.set_problem(x0, xref, uref)
+    eng.set_iterate(xi, ui)
+    eng._lin = eng.linearize()
+    eng.rti(1)
+    assert (eng.status() == 0).all()
+    dx, du = eng.last_step()
+    x1, u1 = eng.get_iterate()
+    worst, rest = 0.0, 0.0
+    for b in range(B):
+        A, Bm, d, Qd, Rd, QNd, gx, gu, gN, dx0 = _lq_inputs(model, eng, xi, ui, x0, xref, uref, Q, R, QN, b, N)
+        J = [model.contact_jacobian(xi[b, k, :24]) for k in range(N)]
+        vn = [eng._lin[2][b, k, 24:] for k in range(N)]
+        rx, ru = solve_lq_contact_rows(A, Bm, d, Qd, Rd, QNd, gx, gu, gN, dx0, J, vn, [ui[b, k, 18:30] for k in range(N)], stance[b])
+        worst = max(worst, np.max(np.abs(dx[b] - rx)) / np.max(np.abs(rx)), np.max(np.abs(du[b] - ru)) / np.max(np.abs(ru)))
+        for k in range(N):
+            w = J[k] @ (vn[k] + (A[k] @ dx[b, k] + Bm[k] @ du[b, k])[24:])
+            w = w * np.repeat(stance[b, k].astype(float), 3)
+            rest = max(rest, np.max(np.abs(w)))
+        # without the rows the step is somewhere else: the rows do bind
+        from oracle.wb_oracle import solve_lq
+        fx, fu = solve_lq(A, Bm, d, Qd, Rd, QNd, gx, gu, gN, dx0)
+        assert np.max(np.abs(fx - rx)) > 100 * np.max(np.abs(dx[b] - rx))
+    print(f"contact rows: worst rel dev of the LQ step from the float64 KKT solve {worst:.2e}; linearised stance-foot speed after the step {rest:.2e} m/s")
+    assert worst < 1e-4 and rest < 1e-5
+    assert np.all(u1[:, 6:, 18 + 3:18 + 6] == 0.0)                 # the swing foot carries no force
+    for _ in range(4):
+        eng.rti(1)
+    assert (eng.status() == 0).all()
+    x5, _ = eng.get_iterate()
+    dxl, _ = eng.last_step()
+    assert np.max(np.abs(dxl)) < 1e-2
+    # the rows are J_c(q_k) v_{k+1} = 0: the Jacobian of stage k on the velocity the step ends with
+    held = np.array([max(np.max(np.abs((model.contact_jacobian(x5[b, k, :24]) @ x5[b, k + 1, 24:]) * np.repeat(stance[b, k].astype(float), 3)))
+                         for k in range(N)) for b in range(B)])
+    same_stage = np.array([_stance_foot_speed(model, x5[b], np.vstack([np.ones((1, 4)), stance[b]]))[1:].max() for b in range(B)])
+    print(f"settled iterate: |J_c(q_k) v_k+1| of the stance feet (max over stages) {held}; with the Jacobian of the same stage {same_stage}")
+    assert np.all(held < 1e-4) and np.all(same_stage < 5e-3)
+
+
 def test_contact_penalty_keeps_the_stance_feet_still(model):
     """Started with random joint rates, the posture cost alone lets the stance feet slide while the robot settles; with the
     penalty on J_c v the foot-point speeds of the returned trajectory drop by an order of magnitude (soft constraint:

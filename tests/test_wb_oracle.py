@@ -228,3 +228,63 @@ def test_contact_jacobian_is_the_velocity_of_the_foot_points(model):
     Jm = J.copy(); Jm[3:6] = 0.0
     assert np.allclose(Qa[24:, 24:], 50.0 * Jm.T @ Jm) and np.allclose(ga[24:], 50.0 * Jm.T @ (Jm @ v))
     assert not Qa[:24].any() and not Qa[:, :24].any() and not ga[:24].any()
+
+
+def test_contact_rows_restatement_is_the_limit_of_the_penalty_and_holds_the_rows():
+    """solve_lq_contact_rows (hard rows J (v_next + [A dx + B du]_v) = 0, solved with the forces free of cost) on a random LQ
+    problem of the whole-body shape (nx 48, nu 30): the rows and the dynamics hold to rounding, a swing foot's force step is
+    -f, and the solution is the limit rho -> infinity of the same problem with the penalty 1/2 rho |row|^2 and no force cost."""
+    from oracle.wb_oracle import solve_lq_contact_rows
+    rng = np.random.default_rng(9)
+    N, nx, nu, nv = 3, 48, 30, 24
+    A = [np.eye(nx) + 0.05 * rng.normal(size=(nx, nx)) for _ in range(N)]
+    B = [0.1 * rng.normal(size=(nx, nu)) for _ in range(N)]
+    d = [0.01 * rng.normal(size=nx) for _ in range(N)]
+    Q, R, QN = np.diag(rng.uniform(1, 2, nx)), np.diag(rng.uniform(0.1, 1, nu)), np.diag(rng.uniform(1, 2, nx))
+    gx = [rng.normal(size=nx) for _ in range(N)]; gu = [rng.normal(size=nu) for _ in range(N)]; gN = rng.normal(size=nx)
+    dx0 = 0.1 * rng.normal(size=nx)
+    J = [rng.normal(size=(12, nv)) for _ in range(N)]
+    vn = [0.1 * rng.normal(size=nv) for _ in range(N)]
+    uf = [rng.normal(size=12) for _ in range(N)]
+    stance = np.ones((N, 4), int); stance[1:, 2] = 0
+    dx, du = solve_lq_contact_rows(A, B, d, Q, R, QN, gx, gu, gN, dx0, J, vn, uf, stance)
+    assert np.allclose(dx[0], dx0)
+    for k in range(N):
+        assert np.allclose(dx[k + 1], A[k] @ dx[k] + B[k] @ du[k] + d[k], atol=1e-9)
+        row = J[k] @ (vn[k] + (A[k] @ dx[k] + B[k] @ du[k])[nv:])
+        for i in range(4):
+            if stance[k, i]:
+                assert np.max(np.abs(row[3 * i:3 * i + 3])) < 1e-9
+            else:
+                assert np.allclose(du[k][18 + 3 * i:21 + 3 * i], -uf[k][3 * i:3 * i + 3], atol=1e-10)
+    # the penalty limit: a dense KKT solve with rho (row)^2 in the cost, forces free of cost, swing forces fixed by a stiff term
+    def penalised(rho):
+        nz = (N + 1) * nx + N * nu
+        ox = lambda k: k * (nx + nu); ou = lambda k: k * (nx + nu) + nx
+        H = np.zeros((nz, nz)); g = np.zeros(nz)
+        Rt = R.copy(); Rt[18:, 18:] = 0.0
+        for k in range(N):
+            H[ox(k):ox(k) + nx, ox(k):ox(k) + nx] += Q; H[ou(k):ou(k) + nu, ou(k):ou(k) + nu] += Rt
+            g[ox(k):ox(k) + nx] += gx[k]; gk = gu[k].copy(); gk[18:] = 0.0; g[ou(k):ou(k) + nu] += gk
+            T = np.zeros((12, nz)); t0 = np.zeros(12)
+            for i in range(4):
+                rs = slice(3 * i, 3 * i + 3)
+                if stance[k, i]:
+                    T[rs, ox(k):ox(k) + nx] = J[k][rs] @ A[k][nv:]; T[rs, ou(k):ou(k) + nu] = J[k][rs] @ B[k][nv:]; t0[rs] = J[k][rs] @ vn[k]
+                else:
+                    T[rs, ou(k) + 18 + 3 * i:ou(k) + 21 + 3 * i] = np.eye(3); t0[rs] = uf[k][rs]
+            H += rho * T.T @ T; g += rho * T.T @ t0
+        H[ox(N):ox(N) + nx, ox(N):ox(N) + nx] += QN; g[ox(N):ox(N) + nx] += gN
+        ne = (N + 1) * nx
+        C = np.zeros((ne, nz)); c = np.zeros(ne)
+        C[:nx, :nx] = np.eye(nx); c[:nx] = dx0
+        for k in range(N):
+            r = (k + 1) * nx
+            C[r:r + nx, ox(k):ox(k) + nx] = -A[k]; C[r:r + nx, ou(k):ou(k) + nu] = -B[k]; C[r:r + nx, ox(k + 1):ox(k + 1) + nx] = np.eye(nx); c[r:r + nx] = d[k]
+        z = np.linalg.solve(np.block([[H, C.T], [C, np.zeros((ne, ne))]]), np.concatenate([-g, c]))[:nz]
+        return np.array([z[ox(k):ox(k) + nx] for k in range(N + 1)]), np.array([z[ou(k):ou(k) + nu] for k in range(N)])
+    e = []
+    for rho in (1e4, 1e6):
+        px, pu = penalised(rho)
+        e.append(max(np.max(np.abs(px - dx)), np.max(np.abs(pu - du))))
+    assert e[1] < 0.02 * e[0] and e[1] < 1e-3 * max(np.max(np.abs(dx)), np.max(np.abs(du)))
