@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
         const unsigned long long wait = ((unsigned long long)blockIdx.x * (unsigned)grp.stagger_x1024) >> 10;
         while (__builtin_amdgcn_s_memrealtime() - ts < wait) __builtin_amdgcn_s_sleep(2);
     }
-    long long t0 = 0, t1 = 0, t4 = 0, t5 = 0;
+    long long t0 = 0, t1 = 0, t4 = 0, t5 = 0, t_b = 0, t_f = 0, t_pg = 0;
     if (STAMP) t0 = __builtin_amdgcn_s_memtime();
 
     IrkConst K;
@@ -331,6 +331,31 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the DMA pieces have landed
     wave_sync();
 
+    // ---- diagonal weights (FULLN build): the reference's controller sets W = diag(Q, R), WN = diag(QN) (mpc_wrapper.cpp: setCosts),
+    //      and with literal zeros off the diagonal the Gauss-Newton blocks, the Hessian application of the prediction, the KKT
+    //      value and the objective lose a third of their multiply-adds.  Decided per wavefront from the data (every off-diagonal
+    //      entry of the W, WN of its problems is +-0), so the results are those of the general path; the rest of the kernel
+    //      exists twice, as the two instantiations of one generic lambda.
+    bool wdiag = false;
+    if constexpr (FULLN && !STAMP) {
+        unsigned nz = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float* Wk = lds + oW + gw * 25 * N + 25 * (j * S + s);
+#pragma unroll
+            for (int i = 0; i < 25; ++i)
+                if (i % 6 != 0) nz |= __float_as_uint(Wk[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            if (i % 4 != 0) nz |= __float_as_uint(WN[i]);
+        wdiag = __all((nz & 0x7fffffffu) == 0u);
+    }
+    auto body = [&](auto diagw_tag) {
+    constexpr bool DIAGW = decltype(diagw_tag)::value;
+    // the two instantiations begin with the same instructions; merged in front of the branch they would stay live through both
+    if constexpr (DIAGW) asm volatile("; diagonal weights" ::: "memory");
+    else asm volatile("; general weights" ::: "memory");
     // per-stage data of the S stages this lane owns (stage k = j * S + s; slots with k >= N are neutral)
     // Q, q, a, b carry one more element: the node after the lane's block (the next lane's first node, or the terminal
     // node, which also sits in its own slot when it falls inside the block) -- what the prediction's adjoint reads
@@ -353,7 +378,6 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
 
     int status = RET_OK, n_iter = 0;
     float kkt = 0.0f;
-    long long t_b = 0, t_f = 0, t_pg = 0;
 
     // ONCE: one real-time iteration per launch (the control tick): no loop, so the members that only feed the linearisation
     // (od, the raw bounds) are dead after phase A instead of live across the whole body
@@ -381,7 +405,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
             const float* Wk = lds + oW + gw * 25 * N + 25 * kc;
             float w[25];
 #pragma unroll
-            for (int i = 0; i < 25; ++i) w[i] = Wk[i];
+            for (int i = 0; i < 25; ++i) w[i] = (DIAGW && i % 6 != 0) ? 0.0f : Wk[i]; // diagonal path: literal zeros fold everything that follows
             const float e0 = x[s][0] - yk[0], e1 = x[s][1] - yk[1], e2 = x[s][2] - yk[2], e3 = u[s][0] - yk[3],
                         e4 = u[s][1] - yk[4];
             const float m = vs ? 1.0f : 0.0f;
@@ -404,10 +428,13 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
         }
         {
             const float e0 = xN[0] - yN[0], e1 = xN[1] - yN[1], e2 = xN[2] - yN[2];
-            QN[0] = WN[0]; QN[1] = WN[1]; QN[2] = WN[2]; QN[3] = WN[4]; QN[4] = WN[5]; QN[5] = WN[8];
-            qN[0] = WN[0] * e0 + WN[1] * e1 + WN[2] * e2;
-            qN[1] = WN[3] * e0 + WN[4] * e1 + WN[5] * e2;
-            qN[2] = WN[6] * e0 + WN[7] * e1 + WN[8] * e2;
+            float wn[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wn[i] = (DIAGW && i % 4 != 0) ? 0.0f : WN[i];
+            QN[0] = wn[0]; QN[1] = wn[1]; QN[2] = wn[2]; QN[3] = wn[4]; QN[4] = wn[5]; QN[5] = wn[8];
+            qN[0] = wn[0] * e0 + wn[1] * e1 + wn[2] * e2;
+            qN[1] = wn[3] * e0 + wn[4] * e1 + wn[5] * e2;
+            qN[2] = wn[6] * e0 + wn[7] * e1 + wn[8] * e2;
         }
         { // element [S]: first node of the next lane; the terminal node goes where node N falls
             Q00[S] = lane_next<L>(Q00[0]); Q01[S] = lane_next<L>(Q01[0]); Q02[S] = lane_next<L>(Q02[0]); Q11[S] = lane_next<L>(Q11[0]);
@@ -947,8 +974,12 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
             float acc = 0.0f;
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
-                const float tt = e[0] * Wk[c] + e[1] * Wk[5 + c] + e[2] * Wk[10 + c] + e[3] * Wk[15 + c] + e[4] * Wk[20 + c];
-                acc += e[c] * tt;
+                if constexpr (DIAGW) {
+                    acc += e[c] * (e[c] * Wk[6 * c]);
+                } else {
+                    const float tt = e[0] * Wk[c] + e[1] * Wk[5 + c] + e[2] * Wk[10 + c] + e[3] * Wk[15 + c] + e[4] * Wk[20 + c];
+                    acc += e[c] * tt;
+                }
             }
             part += (k < N) ? acc : 0.0f;
         }
@@ -998,6 +1029,13 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
         pb.n_iter[prob] = n_iter;
         if (DIAG && pb.kkt) pb.kkt[prob] = kkt;
         if (DIAG && pb.obj) pb.obj[prob] = obj;
+    }
+    };
+    if constexpr (FULLN && !STAMP) {
+        if (wdiag) body(std::true_type{});
+        else body(std::false_type{});
+    } else {
+        body(std::false_type{});
     }
     if (STAMP && lane == 0 && p.stamps) {
         long long* o = p.stamps + (size_t)blockIdx.x * 8;

@@ -788,3 +788,27 @@ def test_input_column_is_the_column_of_the_downloaded_inputs(nmpc_mod):
         assert np.array_equal(cmd, full["u"][:, node, :]) and np.array_equal(st, full["status"])
     with pytest.raises(Exception):
         eng.input_column(N)
+
+
+@pytest.mark.gpu
+def test_diagonal_weight_path_agrees_with_the_general_path(nmpc_mod):
+    """The N = 20 build of the (4, 5) mapping runs a wavefront whose W, WN are diagonal (the reference's controller sets
+    W = diag(Q, R)) through an instantiation with literal zeros off the diagonal.  A denormal-sized off-diagonal entry in ONE
+    problem sends that problem's wavefront (16 problems) down the general path: the results of all of them must agree with
+    the diagonal path to float32 rounding, and the other wavefronts must not notice (bit-equal)."""
+    B, N = 512, 20
+    batch = make_batch(B, N, seed=12, fast_tail=0.3)
+    eng = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=BLOCK | 4)
+    eng.load(batch); eng.rti(1); a = eng.fetch()
+    tweaked = {k: v.copy() for k, v in batch.items()}
+    tweaked["W"][37, 3, 0, 1] = 1e-38; tweaked["W"][37, 3, 1, 0] = 1e-38
+    e2 = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=BLOCK | 4)
+    e2.load(tweaked); e2.rti(1); b = e2.fetch()
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    wave = np.arange(32, 48)                      # the wavefront of problem 37
+    rest = np.setdiff1d(np.arange(B), wave)
+    for k in ("x", "u", "dual", "kkt", "obj"):
+        assert np.array_equal(a[k][rest], b[k][rest]), k
+        d = np.max(np.abs(a[k][wave].astype(np.float64) - b[k][wave])) / max(1.0, float(np.max(np.abs(a[k][wave]))))
+        assert d < 2e-6, (k, d)
+    assert np.array_equal(a["n_iter"], b["n_iter"])
