@@ -210,6 +210,98 @@ __device__ __forceinline__ void g_store(float* g, const float* l, int total, int
     if (lane < rem) g[n4 * 4 + lane] = l[n4 * 4 + lane];
 }
 
+// ---- packed float32 (v_pk_fma_f32 / v_pk_mul_f32, gfx90a+: two multiply-adds per issue slot of a wavefront) ------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f bc2(float a) { v2f r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// nmpc_core.h: riccati_step with the products over the two inputs paired -- P B, B' P B, B' P A and B' s go row by row over
+// (input 0, input 1), the rank-one updates of the cost-to-go over pairs of its six entries.  Same algebra, the sums associate
+// differently in places (results agree with the scalar step to float32 rounding).  B0 = (B00, B01), B1 = (B10, B11),
+// B2 = (B20, -B20), Rd = (R00, R11), r = (r0, r1); the rest as in StageQP.
+struct StagePk {
+    v2f B0, B1, B2, Rd, r;
+    float R01, a, b, d0, d1, d2;
+    Sym3 Q;
+    float q0, q1, q2;
+    int st0, st1;
+    float v0, v1;
+};
+__device__ __forceinline__ bool riccati_step_pk(const StagePk& s, Value& V, Policy& pol)
+{
+    const Sym3 P = V.P;
+    const float s0 = P.m00 * s.d0 + P.m01 * s.d1 + P.m02 * s.d2 + V.p0;
+    const float s1 = P.m01 * s.d0 + P.m11 * s.d1 + P.m12 * s.d2 + V.p1;
+    const float s2 = P.m02 * s.d0 + P.m12 * s.d1 + P.m22 * s.d2 + V.p2;
+    // rows of P B over the two inputs
+    const v2f PB0 = pfma(bc2(P.m00), s.B0, pfma(bc2(P.m01), s.B1, bc2(P.m02) * s.B2));
+    const v2f PB1 = pfma(bc2(P.m01), s.B0, pfma(bc2(P.m11), s.B1, bc2(P.m12) * s.B2));
+    const v2f PB2 = pfma(bc2(P.m02), s.B0, pfma(bc2(P.m12), s.B1, bc2(P.m22) * s.B2));
+    const v2f Hd = pfma(s.B0, PB0, pfma(s.B1, PB1, pfma(s.B2, PB2, s.Rd)));  // (H00, H11)
+    const float H01 = s.R01 + s.B0.x * PB0.y + s.B1.x * PB1.y + s.B2.x * PB2.y;
+    const v2f G2 = pfma(bc2(s.a), PB0, pfma(bc2(s.b), PB1, PB2));              // (G02, G12)
+    const v2f hu = pfma(s.B0, bc2(s0), pfma(s.B1, bc2(s1), pfma(s.B2, bc2(s2), s.r)));
+    float G00 = PB0.x, G01 = PB1.x, G02 = G2.x;
+    const float G10 = PB0.y, G11 = PB1.y, G12 = G2.y;
+    float hu0 = hu.x;
+    const float hu1 = hu.y, H00 = Hd.x, H11 = Hd.y;
+    // ---- eliminate input 1
+    const bool free1 = (s.st1 == ST_FREE);
+    const bool bad1 = free1 && !(H11 > 0.0f);
+    const float inv11 = pivot_rcp(H11);
+    const float w1 = free1 ? inv11 : 0.0f;
+    const float z1 = free1 ? -hu1 * inv11 : s.v1;
+    const float t1 = w1 * H01;
+    const float g1s = free1 ? -w1 : 1.0f;
+    pol.c10 = g1s * G10; pol.c11 = g1s * G11; pol.c12 = g1s * G12; pol.e1 = g1s * H01;
+    pol.f1 = free1 ? z1 : hu1 + H11 * s.v1;
+    const float H00r = H00 - t1 * H01;
+    G00 -= t1 * G10; G01 -= t1 * G11; G02 -= t1 * G12;
+    hu0 += H01 * z1;
+    // ---- eliminate input 0
+    const bool free0 = (s.st0 == ST_FREE);
+    const bool bad0 = free0 && !(H00r > 0.0f);
+    const float inv00 = pivot_rcp(H00r);
+    const float w0 = free0 ? inv00 : 0.0f;
+    const float z0 = free0 ? -hu0 * inv00 : s.v0;
+    const float g0s = free0 ? -w0 : 1.0f;
+    pol.c00 = g0s * G00; pol.c01 = g0s * G01; pol.c02 = g0s * G02;
+    pol.f0 = free0 ? z0 : hu0 + H00r * s.v0;
+    // ---- Hxx = Q + A' P A, hx = q + A' s, then the two inputs out
+    const float m02 = s.a * P.m00 + s.b * P.m01 + P.m02;
+    const float m12 = s.a * P.m01 + s.b * P.m11 + P.m12;
+    const float m22 = s.a * P.m02 + s.b * P.m12 + P.m22;
+    v2f Xa = mk2(s.Q.m00 + P.m00, s.Q.m01 + P.m01);                                  // (m00, m01)
+    v2f Xb = mk2(s.Q.m02 + m02, s.Q.m12 + m12);                                      // (m02, m12)
+    v2f Xc = mk2(s.Q.m11 + P.m11, s.Q.m22 + (s.a * m02 + s.b * m12 + m22));          // (m11, m22)
+    v2f hxa = mk2(s.q0 + s0, s.q1 + s1);
+    float hx2 = s.q2 + (s.a * s0 + s.b * s1 + s2);
+    {
+        const v2f Ga = mk2(G10, G11), Gb = mk2(G11, G12);
+        const v2f wga = bc2(w1) * Ga;                  // (w1 G10, w1 G11)
+        const float wg12 = w1 * G12;
+        Xa = pfma(-bc2(wga.x), Ga, Xa);
+        Xb = pfma(-wga, bc2(G12), Xb);
+        Xc = pfma(-mk2(wga.y, wg12), Gb, Xc);
+        hxa = pfma(Ga, bc2(z1), hxa);
+        hx2 += G12 * z1;
+    }
+    {
+        const v2f Ga = mk2(G00, G01), Gb = mk2(G01, G02);
+        const v2f wga = bc2(w0) * Ga;
+        const float wg02 = w0 * G02;
+        Xa = pfma(-bc2(wga.x), Ga, Xa);
+        Xb = pfma(-wga, bc2(G02), Xb);
+        Xc = pfma(-mk2(wga.y, wg02), Gb, Xc);
+        hxa = pfma(Ga, bc2(z0), hxa);
+        hx2 += G02 * z0;
+    }
+    V.P.m00 = Xa.x; V.P.m01 = Xa.y; V.P.m02 = Xb.x; V.P.m12 = Xb.y; V.P.m11 = Xc.x; V.P.m22 = Xc.y;
+    V.p0 = hxa.x; V.p1 = hxa.y; V.p2 = hx2;
+    return !(bad0 || bad1);
+}
+
 } // namespace
 
 // LDS floats of one wavefront: W and y of its 64 / L problems, each area padded to whole 256-float DMA pieces
@@ -359,9 +451,13 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
     // per-stage data of the S stages this lane owns (stage k = j * S + s; slots with k >= N are neutral)
     // Q, q, a, b carry one more element: the node after the lane's block (the next lane's first node, or the terminal
     // node, which also sits in its own slot when it falls inside the block) -- what the prediction's adjoint reads
-    float B00[S], B01[S], B10[S], B11[S], B20[S], sa[S + 1], sb[S + 1], d0[S], d1[S], d2[S];
+    // the input map, the input weights and gradients live as PAIRS over the two inputs (even-aligned register pairs): the
+    // backward step multiplies them with packed float32 instructions (v_pk_fma_f32: both inputs in one issue slot)
+    v2f BP0[S], BP1[S], BP2[S]; // rows of B: (B00, B01), (B10, B11), (B20, -B20)
+    v2f RD[S], RP[S];           // (R00, R11), (r0, r1)
+    float R01[S];
+    float sa[S + 1], sb[S + 1], d0[S], d1[S], d2[S];
     float Q00[S + 1], Q01[S + 1], Q02[S + 1], Q11[S + 1], Q12[S + 1], Q22[S + 1], q0[S + 1], q1[S + 1], q2[S + 1];
-    float R00[S], R01[S], R11[S], r0[S], r1[S];
     float lb0[S], ub0[S], lb1[S], ub1[S];
     int st0[S], st1[S];
     float c00[S], c01[S], c02[S], pf0[S], c10[S], c11[S], c12[S], pe1[S], pf1[S];
@@ -412,11 +508,11 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
             q0[s] = m * (w[0] * e0 + w[1] * e1 + w[2] * e2 + w[3] * e3 + w[4] * e4);
             q1[s] = m * (w[5] * e0 + w[6] * e1 + w[7] * e2 + w[8] * e3 + w[9] * e4);
             q2[s] = m * (w[10] * e0 + w[11] * e1 + w[12] * e2 + w[13] * e3 + w[14] * e4);
-            r0[s] = m * (w[15] * e0 + w[16] * e1 + w[17] * e2 + w[18] * e3 + w[19] * e4);
-            r1[s] = m * (w[20] * e0 + w[21] * e1 + w[22] * e2 + w[23] * e3 + w[24] * e4);
+            RP[s].x = m * (w[15] * e0 + w[16] * e1 + w[17] * e2 + w[18] * e3 + w[19] * e4);
+            RP[s].y = m * (w[20] * e0 + w[21] * e1 + w[22] * e2 + w[23] * e3 + w[24] * e4);
             Q00[s] = m * w[0]; Q01[s] = m * w[1]; Q02[s] = m * w[2]; Q11[s] = m * w[6]; Q12[s] = m * w[7]; Q22[s] = m * w[12];
-            R00[s] = vs ? w[18] : 1.0f; R01[s] = m * w[19]; R11[s] = vs ? w[24] : 1.0f;
-            B00[s] = m * lin.B00; B01[s] = m * lin.B01; B10[s] = m * lin.B10; B11[s] = m * lin.B11; B20[s] = m * lin.B20;
+            RD[s].x = vs ? w[18] : 1.0f; R01[s] = m * w[19]; RD[s].y = vs ? w[24] : 1.0f;
+            BP0[s].x = m * lin.B00; BP0[s].y = m * lin.B01; BP1[s].x = m * lin.B10; BP1[s].y = m * lin.B11; BP2[s].x = m * lin.B20; BP2[s].y = -(m * lin.B20);
             sa[s] = m * lin.a; sb[s] = m * lin.b;
             d0[s] = m * (lin.phi0 - xn[0]); d1[s] = m * (lin.phi1 - xn[1]); d2[s] = m * (lin.phi2 - xn[2]);
             const float l0 = m * (lbv[s][0] - u[s][0]), l1 = m * (lbv[s][1] - u[s][1]);
@@ -471,7 +567,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                 float X0[S], X1[S], X2[S], in2[S];
                 float acc = 0.0f;
 #pragma unroll
-                for (int s = 0; s < S; ++s) { acc += B20[s] * (v0[s] - v1[s]) + d2[s]; X2[s] = acc; }
+                for (int s = 0; s < S; ++s) { acc += BP2[s].x * (v0[s] - v1[s]) + d2[s]; X2[s] = acc; }
                 const float ex2 = gprefix<L>(acc, j) - acc + Dx2; // psi entering the block
 #pragma unroll
                 for (int s = 0; s < S; ++s) { in2[s] = (s == 0) ? ex2 : X2[(s > 0) ? s - 1 : 0] + ex2; }
@@ -480,8 +576,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                 float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    a0 += sa[s] * in2[s] + B00[s] * v0[s] + B01[s] * v1[s] + d0[s]; X0[s] = a0;
-                    a1 += sb[s] * in2[s] + B10[s] * v0[s] + B11[s] * v1[s] + d1[s]; X1[s] = a1;
+                    a0 += sa[s] * in2[s] + BP0[s].x * v0[s] + BP0[s].y * v1[s] + d0[s]; X0[s] = a0;
+                    a1 += sb[s] * in2[s] + BP1[s].x * v0[s] + BP1[s].y * v1[s] + d1[s]; X1[s] = a1;
                 }
                 const float ex0 = gprefix<L>(a0, j) - a0 + Dx0, ex1 = gprefix<L>(a1, j) - a1 + Dx1;
                 float y0[S], y1[S], y2[S];
@@ -517,8 +613,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     const float Lps = Lp[s] + es2;
-                    g0[s] = R00[s] * v0[s] + R01[s] * v1[s] + r0[s] + B00[s] * Lx[s] + B10[s] * Ly[s] + B20[s] * Lps;
-                    g1[s] = R01[s] * v0[s] + R11[s] * v1[s] + r1[s] + B01[s] * Lx[s] + B11[s] * Ly[s] - B20[s] * Lps;
+                    g0[s] = RD[s].x * v0[s] + R01[s] * v1[s] + RP[s].x + BP0[s].x * Lx[s] + BP1[s].x * Ly[s] + BP2[s].x * Lps;
+                    g1[s] = R01[s] * v0[s] + RD[s].y * v1[s] + RP[s].y + BP0[s].y * Lx[s] + BP1[s].y * Ly[s] - BP2[s].x * Lps;
                 }
             };
             float is0[S], is1[S], w0[S], w1[S];
@@ -529,11 +625,11 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const bool in = j * S + s < N;
-                is0[s] = in ? rcp_f(fmaxf(R00[s], 1e-20f)) : 0.0f;
-                is1[s] = in ? rcp_f(fmaxf(R11[s], 1e-20f)) : 0.0f;
+                is0[s] = in ? rcp_f(fmaxf(RD[s].x, 1e-20f)) : 0.0f;
+                is1[s] = in ? rcp_f(fmaxf(RD[s].y, 1e-20f)) : 0.0f;
                 const float j0 = -is0[s] * g0[s], j1 = -is1[s] * g1[s];
                 hits |= (j0 < lb0[s]) | (j0 > ub0[s]) | (j1 < lb1[s]) | (j1 > ub1[s]);
-                badw |= in ? ((!(R00[s] > 0.0f)) | (!(R11[s] > 0.0f))) : 0;
+                badw |= in ? ((!(RD[s].x > 0.0f)) | (!(RD[s].y > 0.0f))) : 0;
                 w0[s] = clampf(j0, lb0[s], ub0[s]); w1[s] = clampf(j1, lb1[s], ub1[s]);
             }
             const bool run = cold && gany<L>(hits != 0, gbase) && !gany<L>(badw != 0, gbase);
@@ -556,7 +652,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         const float e0 = w0[s] - pu0[s], e1 = w1[s] - pu1[s];
-                        num += R00[s] * e0 * e0 + R11[s] * e1 * e1;
+                        num += RD[s].x * e0 * e0 + RD[s].y * e1 * e1;
                         den += e0 * (g0[s] - pg0[s]) + e1 * (g1[s] - pg1[s]);
                     }
                     num = gtotal<L>(num, j, lane);
@@ -619,13 +715,13 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                             g12 = f1 ? c12[s] + pe1[s] * g02 : 0.0f;
                 const float h1 = f1 ? pe1[s] * h0 + pf1[s] : b1;
                 const float gd0 = g00 - g10, gd1 = g01 - g11, gd2 = g02 - g12;
-                const float a00 = 1.0f + B00[s] * g00 + B01[s] * g10, a01 = B00[s] * g01 + B01[s] * g11,
-                            a02 = sa[s] + B00[s] * g02 + B01[s] * g12;
-                const float a10 = B10[s] * g00 + B11[s] * g10, a11 = 1.0f + B10[s] * g01 + B11[s] * g11,
-                            a12 = sb[s] + B10[s] * g02 + B11[s] * g12;
-                const float a20 = B20[s] * gd0, a21 = B20[s] * gd1, a22 = 1.0f + B20[s] * gd2;
-                const float cc0 = B00[s] * h0 + B01[s] * h1 + d0[s], cc1 = B10[s] * h0 + B11[s] * h1 + d1[s],
-                            cc2 = B20[s] * (h0 - h1) + d2[s];
+                const float a00 = 1.0f + BP0[s].x * g00 + BP0[s].y * g10, a01 = BP0[s].x * g01 + BP0[s].y * g11,
+                            a02 = sa[s] + BP0[s].x * g02 + BP0[s].y * g12;
+                const float a10 = BP1[s].x * g00 + BP1[s].y * g10, a11 = 1.0f + BP1[s].x * g01 + BP1[s].y * g11,
+                            a12 = sb[s] + BP1[s].x * g02 + BP1[s].y * g12;
+                const float a20 = BP2[s].x * gd0, a21 = BP2[s].x * gd1, a22 = 1.0f + BP2[s].x * gd2;
+                const float cc0 = BP0[s].x * h0 + BP0[s].y * h1 + d0[s], cc1 = BP1[s].x * h0 + BP1[s].y * h1 + d1[s],
+                            cc2 = BP2[s].x * (h0 - h1) + d2[s];
                 if (s == 0) {
                     m00 = a00; m01 = a01; m02 = a02; m10 = a10; m11 = a11; m12 = a12; m20 = a20; m21 = a21; m22 = a22;
                     k0 = cc0; k1 = cc1; k2 = cc2;
@@ -688,17 +784,17 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
 #pragma unroll
             for (int s = S - 1; s >= 0; --s) {
                 if (FULL || t * S + s < N) { // wavefront-uniform: the stage of lane t exists
-                    StageQP q;
-                    q.a = sa[s]; q.b = sb[s]; q.B00 = B00[s]; q.B01 = B01[s]; q.B10 = B10[s]; q.B11 = B11[s]; q.B20 = B20[s];
+                    StagePk q;
+                    q.a = sa[s]; q.b = sb[s]; q.B0 = BP0[s]; q.B1 = BP1[s]; q.B2 = BP2[s];
                     q.d0 = d0[s]; q.d1 = d1[s]; q.d2 = d2[s];
                     q.Q.m00 = Q00[s]; q.Q.m01 = Q01[s]; q.Q.m02 = Q02[s]; q.Q.m11 = Q11[s]; q.Q.m12 = Q12[s]; q.Q.m22 = Q22[s];
                     q.q0 = q0[s]; q.q1 = q1[s]; q.q2 = q2[s];
-                    q.R00 = R00[s]; q.R01 = R01[s]; q.R11 = R11[s]; q.r0 = r0[s]; q.r1 = r1[s];
+                    q.Rd = RD[s]; q.R01 = R01[s]; q.r = RP[s];
                     q.st0 = st0[s]; q.st1 = st1[s];
                     q.v0 = (st0[s] == ST_UPPER) ? ub0[s] : lb0[s];
                     q.v1 = (st1[s] == ST_UPPER) ? ub1[s] : lb1[s];
                     Policy pol;
-                    ok &= riccati_step(q, val, pol, true) ? 1 : 0;
+                    ok &= riccati_step_pk(q, val, pol) ? 1 : 0;
                     c00[s] = mine ? pol.c00 : c00[s]; c01[s] = mine ? pol.c01 : c01[s]; c02[s] = mine ? pol.c02 : c02[s];
                     pf0[s] = mine ? pol.f0 : pf0[s];
                     c10[s] = mine ? pol.c10 : c10[s]; c11[s] = mine ? pol.c11 : c11[s]; c12[s] = mine ? pol.c12 : c12[s];
@@ -773,9 +869,9 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                         du0[s] = o.du0; du1[s] = o.du1; mu0[s] = o.mu0; mu1[s] = o.mu1;
                         dxs[s][0] = e0; dxs[s][1] = e1; dxs[s][2] = e2;
                     }
-                    const float n0 = e0 + sa[s] * e2 + B00[s] * o.du0 + B01[s] * o.du1 + d0[s];
-                    const float n1 = e1 + sb[s] * e2 + B10[s] * o.du0 + B11[s] * o.du1 + d1[s];
-                    const float n2 = e2 + B20[s] * (o.du0 - o.du1) + d2[s];
+                    const float n0 = e0 + sa[s] * e2 + BP0[s].x * o.du0 + BP0[s].y * o.du1 + d0[s];
+                    const float n1 = e1 + sb[s] * e2 + BP1[s].x * o.du0 + BP1[s].y * o.du1 + d1[s];
+                    const float n2 = e2 + BP2[s].x * (o.du0 - o.du1) + d2[s];
                     e0 = n0; e1 = n1; e2 = n2;
                 }
                 if (active) { dxo[0] = e0; dxo[1] = e1; dxo[2] = e2; }
@@ -838,9 +934,9 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                                 du0[s] = o.du0; du1[s] = o.du1; mu0[s] = o.mu0; mu1[s] = o.mu1;
                                 dxs[s][0] = e0; dxs[s][1] = e1; dxs[s][2] = e2;
                             }
-                            const float n0 = e0 + sa[s] * e2 + B00[s] * o.du0 + B01[s] * o.du1 + d0[s];
-                            const float n1 = e1 + sb[s] * e2 + B10[s] * o.du0 + B11[s] * o.du1 + d1[s];
-                            const float n2 = e2 + B20[s] * (o.du0 - o.du1) + d2[s];
+                            const float n0 = e0 + sa[s] * e2 + BP0[s].x * o.du0 + BP0[s].y * o.du1 + d0[s];
+                            const float n1 = e1 + sb[s] * e2 + BP1[s].x * o.du0 + BP1[s].y * o.du1 + d1[s];
+                            const float n2 = e2 + BP2[s].x * (o.du0 - o.du1) + d2[s];
                             e0 = n0; e1 = n1; e2 = n2;
                         }
                         if (todo == 1) { dxo[0] = e0; dxo[1] = e1; dxo[2] = e2; }
@@ -938,7 +1034,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                                  (Q01[s] * b0 + Q11[s] * b1 + Q12[s] * b2 + q1[s]) * e1 +
                                  (Q02[s] * b0 + Q12[s] * b1 + Q22[s] * b2 + q2[s]) * e2;
                 gd += (k > 0 && k < N) ? tq : 0.0f;
-                gd += r0[s] * du0[s] + r1[s] * du1[s];
+                gd += RP[s].x * du0[s] + RP[s].y * du1[s];
                 comp += (mu0[s] > 1e-12f) ? fabsf(lb0[s] * mu0[s]) : ((mu0[s] < -1e-12f) ? fabsf(ub0[s] * mu0[s]) : 0.0f);
                 comp += (mu1[s] > 1e-12f) ? fabsf(lb1[s] * mu1[s]) : ((mu1[s] < -1e-12f) ? fabsf(ub1[s] * mu1[s]) : 0.0f);
             }

@@ -69,7 +69,8 @@ def check(path):
                 elif depth > 0:
                     body.append(ln)
             need = 150 if "ILi16ELi2E" in k else 75   # two stage steps / one
-            if sum(1 for ln in body if re.search(r"\bv_(fma|fmac|mul|add)_f32", ln)) <= need:
+            # multiply-adds inside the window (a packed instruction counts for its two)
+            if sum((2 if "v_pk_" in ln else 1) for ln in body if re.search(r"\bv_(pk_)?(fma|fmac|mul|add)_f32", ln)) <= need:
                 findings.append(f"{k}: the Riccati steps are not inside the masked window?")
             bad = [ln.strip() for ln in body if BAD.search(ln)]
             if bad:
