@@ -216,37 +216,46 @@ __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; 
 __device__ __forceinline__ v2f bc2(float a) { v2f r; r.x = a; r.y = a; return r; }
 __device__ __forceinline__ v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-// nmpc_core.h: riccati_step with the products over the two inputs paired -- P B, B' P B, B' P A and B' s go row by row over
-// (input 0, input 1), the rank-one updates of the cost-to-go over pairs of its six entries.  Same algebra, the sums associate
-// differently in places (results agree with the scalar step to float32 rounding).  B0 = (B00, B01), B1 = (B10, B11),
-// B2 = (B20, -B20), Rd = (R00, R11), r = (r0, r1); the rest as in StageQP.
+// lane-local transposes of register pairs (v_pk_mov_b32: low half of the result from src0, high half from src1, each taken
+// from the half op_sel names; tools/micro/pk_mov_check.hip prints them)
+__device__ __forceinline__ v2f hi_hi(v2f a, v2f b) { v2f r; asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2f lo_lo(v2f a, v2f b) { v2f r; asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2f hi_lo(v2f a, v2f b) { v2f r; asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// nmpc_core.h: riccati_step on register pairs.  The cost-to-go travels as Pa = (P00, P01), Pb = (P02, P12), Pc = (P11, P22),
+// pa = (p0, p1), p2; the stage as B0 = (B00, B01), B1 = (B10, B11), B2 = (B20, -B20), Rd = (R00, R11), r = (r0, r1),
+// QA = (Q00, Q01), QB = (Q02, Q12), QC = (Q11, Q22), qa = (q0, q1).  P d, P B, B' P B, B' P A, B' s, A' P A and the rank-one
+// updates run as packed multiply-adds over the two inputs / over pairs of entries; the handful of lane-local transposes are
+// single v_pk_mov_b32.  Same algebra as the scalar step, sums associate differently in places (float32 rounding).
+struct ValuePk {
+    v2f Pa, Pb, Pc, pa;
+    float p2;
+};
 struct StagePk {
-    v2f B0, B1, B2, Rd, r;
-    float R01, a, b, d0, d1, d2;
-    Sym3 Q;
-    float q0, q1, q2;
+    v2f B0, B1, B2, Rd, r, QA, QB, QC, qa;
+    float R01, a, b, d0, d1, d2, q2;
     int st0, st1;
     float v0, v1;
 };
-__device__ __forceinline__ bool riccati_step_pk(const StagePk& s, Value& V, Policy& pol)
+__device__ __forceinline__ bool riccati_step_pk(const StagePk& s, ValuePk& V, Policy& pol)
 {
-    const Sym3 P = V.P;
-    const float s0 = P.m00 * s.d0 + P.m01 * s.d1 + P.m02 * s.d2 + V.p0;
-    const float s1 = P.m01 * s.d0 + P.m11 * s.d1 + P.m12 * s.d2 + V.p1;
-    const float s2 = P.m02 * s.d0 + P.m12 * s.d1 + P.m22 * s.d2 + V.p2;
+    const v2f Pa = V.Pa, Pb = V.Pb, Pc = V.Pc;
+    const v2f Pd = hi_lo(Pa, Pc); // (P01, P11)
+    // s = P d + p
+    const v2f s01 = pfma(Pa, bc2(s.d0), pfma(Pd, bc2(s.d1), pfma(Pb, bc2(s.d2), V.pa)));
+    const float s2 = Pb.x * s.d0 + Pb.y * s.d1 + Pc.y * s.d2 + V.p2;
     // rows of P B over the two inputs
-    const v2f PB0 = pfma(bc2(P.m00), s.B0, pfma(bc2(P.m01), s.B1, bc2(P.m02) * s.B2));
-    const v2f PB1 = pfma(bc2(P.m01), s.B0, pfma(bc2(P.m11), s.B1, bc2(P.m12) * s.B2));
-    const v2f PB2 = pfma(bc2(P.m02), s.B0, pfma(bc2(P.m12), s.B1, bc2(P.m22) * s.B2));
+    const v2f PB0 = pfma(bc2(Pa.x), s.B0, pfma(bc2(Pa.y), s.B1, bc2(Pb.x) * s.B2));
+    const v2f PB1 = pfma(bc2(Pa.y), s.B0, pfma(bc2(Pc.x), s.B1, bc2(Pb.y) * s.B2));
+    const v2f PB2 = pfma(bc2(Pb.x), s.B0, pfma(bc2(Pb.y), s.B1, bc2(Pc.y) * s.B2));
     const v2f Hd = pfma(s.B0, PB0, pfma(s.B1, PB1, pfma(s.B2, PB2, s.Rd)));  // (H00, H11)
     const float H01 = s.R01 + s.B0.x * PB0.y + s.B1.x * PB1.y + s.B2.x * PB2.y;
-    const v2f G2 = pfma(bc2(s.a), PB0, pfma(bc2(s.b), PB1, PB2));              // (G02, G12)
-    const v2f hu = pfma(s.B0, bc2(s0), pfma(s.B1, bc2(s1), pfma(s.B2, bc2(s2), s.r)));
-    float G00 = PB0.x, G01 = PB1.x, G02 = G2.x;
-    const float G10 = PB0.y, G11 = PB1.y, G12 = G2.y;
-    float hu0 = hu.x;
-    const float hu1 = hu.y, H00 = Hd.x, H11 = Hd.y;
+    const v2f G2 = pfma(bc2(s.a), PB0, pfma(bc2(s.b), PB1, PB2));            // (G02, G12)
+    const v2f hu = pfma(s.B0, bc2(s01.x), pfma(s.B1, bc2(s01.y), pfma(s.B2, bc2(s2), s.r)));
+    const v2f G1 = hi_hi(PB0, PB1);                                            // (G10, G11)
+    v2f G0 = lo_lo(PB0, PB1);                                                  // (G00, G01)
     // ---- eliminate input 1
+    const float H11 = Hd.y, hu1 = hu.y;
     const bool free1 = (s.st1 == ST_FREE);
     const bool bad1 = free1 && !(H11 > 0.0f);
     const float inv11 = pivot_rcp(H11);
@@ -254,11 +263,13 @@ __device__ __forceinline__ bool riccati_step_pk(const StagePk& s, Value& V, Poli
     const float z1 = free1 ? -hu1 * inv11 : s.v1;
     const float t1 = w1 * H01;
     const float g1s = free1 ? -w1 : 1.0f;
-    pol.c10 = g1s * G10; pol.c11 = g1s * G11; pol.c12 = g1s * G12; pol.e1 = g1s * H01;
+    const v2f c1 = bc2(g1s) * G1;
+    pol.c10 = c1.x; pol.c11 = c1.y; pol.c12 = g1s * G2.y; pol.e1 = g1s * H01;
     pol.f1 = free1 ? z1 : hu1 + H11 * s.v1;
-    const float H00r = H00 - t1 * H01;
-    G00 -= t1 * G10; G01 -= t1 * G11; G02 -= t1 * G12;
-    hu0 += H01 * z1;
+    const float H00r = Hd.x - t1 * H01;
+    G0 = pfma(-bc2(t1), G1, G0);                       // reduced (G00, G01)
+    const v2f G2r = pfma(-bc2(t1), bc2(G2.y), G2);     // .x = reduced G02
+    const float hu0 = hu.x + H01 * z1;
     // ---- eliminate input 0
     const bool free0 = (s.st0 == ST_FREE);
     const bool bad0 = free0 && !(H00r > 0.0f);
@@ -266,39 +277,36 @@ __device__ __forceinline__ bool riccati_step_pk(const StagePk& s, Value& V, Poli
     const float w0 = free0 ? inv00 : 0.0f;
     const float z0 = free0 ? -hu0 * inv00 : s.v0;
     const float g0s = free0 ? -w0 : 1.0f;
-    pol.c00 = g0s * G00; pol.c01 = g0s * G01; pol.c02 = g0s * G02;
+    const v2f c0 = bc2(g0s) * G0;
+    pol.c00 = c0.x; pol.c01 = c0.y; pol.c02 = g0s * G2r.x;
     pol.f0 = free0 ? z0 : hu0 + H00r * s.v0;
-    // ---- Hxx = Q + A' P A, hx = q + A' s, then the two inputs out
-    const float m02 = s.a * P.m00 + s.b * P.m01 + P.m02;
-    const float m12 = s.a * P.m01 + s.b * P.m11 + P.m12;
-    const float m22 = s.a * P.m02 + s.b * P.m12 + P.m22;
-    v2f Xa = mk2(s.Q.m00 + P.m00, s.Q.m01 + P.m01);                                  // (m00, m01)
-    v2f Xb = mk2(s.Q.m02 + m02, s.Q.m12 + m12);                                      // (m02, m12)
-    v2f Xc = mk2(s.Q.m11 + P.m11, s.Q.m22 + (s.a * m02 + s.b * m12 + m22));          // (m11, m22)
-    v2f hxa = mk2(s.q0 + s0, s.q1 + s1);
-    float hx2 = s.q2 + (s.a * s0 + s.b * s1 + s2);
-    {
-        const v2f Ga = mk2(G10, G11), Gb = mk2(G11, G12);
-        const v2f wga = bc2(w1) * Ga;                  // (w1 G10, w1 G11)
-        const float wg12 = w1 * G12;
-        Xa = pfma(-bc2(wga.x), Ga, Xa);
-        Xb = pfma(-wga, bc2(G12), Xb);
-        Xc = pfma(-mk2(wga.y, wg12), Gb, Xc);
-        hxa = pfma(Ga, bc2(z1), hxa);
-        hx2 += G12 * z1;
+    // ---- Hxx = Q + A' P A, hx = q + A' s
+    const v2f mb = pfma(bc2(s.a), Pa, pfma(bc2(s.b), Pd, Pb));  // (P A)(0..1, 2): a P00 + b P01 + P02, a P01 + b P11 + P12
+    v2f Xa = s.QA + Pa;
+    v2f Xb = s.QB + mb;
+    v2f Xc = s.QC + Pc;
+    Xc.y += s.a * mb.x + s.b * mb.y + s.a * Pb.x + s.b * Pb.y;  // + a (PA)02 + b (PA)12 + (a P02 + b P12): the rest of (A' P A)22
+    v2f hxa = s.qa + s01;
+    float hx2 = s.q2 + (s.a * s01.x + s.b * s01.y + s2);
+    { // input 1 out:  Hxx -= w1 G1' G1,  hx += G1' z1   (G1 = (G10, G11, G12))
+        const v2f Gb = hi_hi(PB1, G2);                 // (G11, G12)
+        const v2f wga = bc2(w1) * G1, wgb = bc2(w1) * Gb;
+        Xa = pfma(-bc2(wga.x), G1, Xa);
+        Xb = pfma(-wga, bc2(G2.y), Xb);
+        Xc = pfma(-wgb, Gb, Xc);
+        hxa = pfma(G1, bc2(z1), hxa);
+        hx2 += G2.y * z1;
     }
-    {
-        const v2f Ga = mk2(G00, G01), Gb = mk2(G01, G02);
-        const v2f wga = bc2(w0) * Ga;
-        const float wg02 = w0 * G02;
-        Xa = pfma(-bc2(wga.x), Ga, Xa);
-        Xb = pfma(-wga, bc2(G02), Xb);
-        Xc = pfma(-mk2(wga.y, wg02), Gb, Xc);
-        hxa = pfma(Ga, bc2(z0), hxa);
-        hx2 += G02 * z0;
+    { // input 0 out (the reduced row)
+        const v2f Gb = hi_lo(G0, G2r);                 // (G01, G02)
+        const v2f wga = bc2(w0) * G0, wgb = bc2(w0) * Gb;
+        Xa = pfma(-bc2(wga.x), G0, Xa);
+        Xb = pfma(-wga, bc2(G2r.x), Xb);
+        Xc = pfma(-wgb, Gb, Xc);
+        hxa = pfma(G0, bc2(z0), hxa);
+        hx2 += G2r.x * z0;
     }
-    V.P.m00 = Xa.x; V.P.m01 = Xa.y; V.P.m02 = Xb.x; V.P.m12 = Xb.y; V.P.m11 = Xc.x; V.P.m22 = Xc.y;
-    V.p0 = hxa.x; V.p1 = hxa.y; V.p2 = hx2;
+    V.Pa = Xa; V.Pb = Xb; V.Pc = Xc; V.pa = hxa; V.p2 = hx2;
     return !(bad0 || bad1);
 }
 
@@ -457,7 +465,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
     v2f RD[S], RP[S];           // (R00, R11), (r0, r1)
     float R01[S];
     float sa[S + 1], sb[S + 1], d0[S], d1[S], d2[S];
-    float Q00[S + 1], Q01[S + 1], Q02[S + 1], Q11[S + 1], Q12[S + 1], Q22[S + 1], q0[S + 1], q1[S + 1], q2[S + 1];
+    v2f QA[S + 1], QB[S + 1], QC[S + 1], qA[S + 1]; // (Q00, Q01), (Q02, Q12), (Q11, Q22), (q0, q1): the pairs the backward step adds up
+    float q2[S + 1];
     float lb0[S], ub0[S], lb1[S], ub1[S];
     int st0[S], st1[S];
     float c00[S], c01[S], c02[S], pf0[S], c10[S], c11[S], c12[S], pe1[S], pf1[S];
@@ -505,12 +514,12 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
             const float e0 = x[s][0] - yk[0], e1 = x[s][1] - yk[1], e2 = x[s][2] - yk[2], e3 = u[s][0] - yk[3],
                         e4 = u[s][1] - yk[4];
             const float m = vs ? 1.0f : 0.0f;
-            q0[s] = m * (w[0] * e0 + w[1] * e1 + w[2] * e2 + w[3] * e3 + w[4] * e4);
-            q1[s] = m * (w[5] * e0 + w[6] * e1 + w[7] * e2 + w[8] * e3 + w[9] * e4);
+            qA[s].x = m * (w[0] * e0 + w[1] * e1 + w[2] * e2 + w[3] * e3 + w[4] * e4);
+            qA[s].y = m * (w[5] * e0 + w[6] * e1 + w[7] * e2 + w[8] * e3 + w[9] * e4);
             q2[s] = m * (w[10] * e0 + w[11] * e1 + w[12] * e2 + w[13] * e3 + w[14] * e4);
             RP[s].x = m * (w[15] * e0 + w[16] * e1 + w[17] * e2 + w[18] * e3 + w[19] * e4);
             RP[s].y = m * (w[20] * e0 + w[21] * e1 + w[22] * e2 + w[23] * e3 + w[24] * e4);
-            Q00[s] = m * w[0]; Q01[s] = m * w[1]; Q02[s] = m * w[2]; Q11[s] = m * w[6]; Q12[s] = m * w[7]; Q22[s] = m * w[12];
+            QA[s].x = m * w[0]; QA[s].y = m * w[1]; QB[s].x = m * w[2]; QC[s].x = m * w[6]; QB[s].y = m * w[7]; QC[s].y = m * w[12];
             RD[s].x = vs ? w[18] : 1.0f; R01[s] = m * w[19]; RD[s].y = vs ? w[24] : 1.0f;
             BP0[s].x = m * lin.B00; BP0[s].y = m * lin.B01; BP1[s].x = m * lin.B10; BP1[s].y = m * lin.B11; BP2[s].x = m * lin.B20; BP2[s].y = -(m * lin.B20);
             sa[s] = m * lin.a; sb[s] = m * lin.b;
@@ -533,15 +542,15 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
             qN[2] = wn[6] * e0 + wn[7] * e1 + wn[8] * e2;
         }
         { // element [S]: first node of the next lane; the terminal node goes where node N falls
-            Q00[S] = lane_next<L>(Q00[0]); Q01[S] = lane_next<L>(Q01[0]); Q02[S] = lane_next<L>(Q02[0]); Q11[S] = lane_next<L>(Q11[0]);
-            Q12[S] = lane_next<L>(Q12[0]); Q22[S] = lane_next<L>(Q22[0]); q0[S] = lane_next<L>(q0[0]); q1[S] = lane_next<L>(q1[0]);
+            QA[S].x = lane_next<L>(QA[0].x); QA[S].y = lane_next<L>(QA[0].y); QB[S].x = lane_next<L>(QB[0].x); QC[S].x = lane_next<L>(QC[0].x);
+            QB[S].y = lane_next<L>(QB[0].y); QC[S].y = lane_next<L>(QC[0].y); qA[S].x = lane_next<L>(qA[0].x); qA[S].y = lane_next<L>(qA[0].y);
             q2[S] = lane_next<L>(q2[0]); sa[S] = lane_next<L>(sa[0]); sb[S] = lane_next<L>(sb[0]);
-            if (j == L - 1) { Q00[S] = Q01[S] = Q02[S] = Q11[S] = Q12[S] = Q22[S] = q0[S] = q1[S] = q2[S] = sa[S] = sb[S] = 0.0f; }
+            if (j == L - 1) { QA[S].x = QA[S].y = QB[S].x = QC[S].x = QB[S].y = QC[S].y = qA[S].x = qA[S].y = q2[S] = sa[S] = sb[S] = 0.0f; }
 #pragma unroll
             for (int s = 0; s <= S; ++s) {
                 if (j * S + s == N) {
-                    Q00[s] = QN[0]; Q01[s] = QN[1]; Q02[s] = QN[2]; Q11[s] = QN[3]; Q12[s] = QN[4]; Q22[s] = QN[5];
-                    q0[s] = qN[0]; q1[s] = qN[1]; q2[s] = qN[2]; sa[s] = 0.0f; sb[s] = 0.0f;
+                    QA[s].x = QN[0]; QA[s].y = QN[1]; QB[s].x = QN[2]; QC[s].x = QN[3]; QB[s].y = QN[4]; QC[s].y = QN[5];
+                    qA[s].x = qN[0]; qA[s].y = qN[1]; q2[s] = qN[2]; sa[s] = 0.0f; sb[s] = 0.0f;
                 }
             }
         }
@@ -584,9 +593,9 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     const float X0s = X0[s] + ex0, X1s = X1[s] + ex1;
-                    y0[s] = Q00[s + 1] * X0s + Q01[s + 1] * X1s + Q02[s + 1] * X2[s] + q0[s + 1];
-                    y1[s] = Q01[s + 1] * X0s + Q11[s + 1] * X1s + Q12[s + 1] * X2[s] + q1[s + 1];
-                    y2[s] = Q02[s + 1] * X0s + Q12[s + 1] * X1s + Q22[s + 1] * X2[s] + q2[s + 1];
+                    y0[s] = QA[s + 1].x * X0s + QA[s + 1].y * X1s + QB[s + 1].x * X2[s] + qA[s + 1].x;
+                    y1[s] = QA[s + 1].y * X0s + QC[s + 1].x * X1s + QB[s + 1].y * X2[s] + qA[s + 1].y;
+                    y2[s] = QB[s + 1].x * X0s + QB[s + 1].y * X1s + QC[s + 1].y * X2[s] + q2[s + 1];
                 }
                 // adjoint at node k + 1: suffix sums
                 float Lx[S], Ly[S], Lp[S];
@@ -777,9 +786,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
         // ltv_mpc.hip).  `t` is wavefront-uniform, so the slots past the horizon are skipped with a uniform branch.
         auto backward_block = [&](int t, bool mine, auto full_tag) -> int {
             constexpr bool FULL = decltype(full_tag)::value; // every slot of lane t is a stage: one basic block
-            Value val;
-            val.P.m00 = V[0]; val.P.m01 = V[1]; val.P.m02 = V[2]; val.P.m11 = V[3]; val.P.m12 = V[4]; val.P.m22 = V[5];
-            val.p0 = V[6]; val.p1 = V[7]; val.p2 = V[8];
+            ValuePk val; // V = P00 P01 P02 P11 P12 P22 p0 p1 p2
+            val.Pa = mk2(V[0], V[1]); val.Pb = mk2(V[2], V[4]); val.Pc = mk2(V[3], V[5]); val.pa = mk2(V[6], V[7]); val.p2 = V[8];
             int ok = 1;
 #pragma unroll
             for (int s = S - 1; s >= 0; --s) {
@@ -787,8 +795,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                     StagePk q;
                     q.a = sa[s]; q.b = sb[s]; q.B0 = BP0[s]; q.B1 = BP1[s]; q.B2 = BP2[s];
                     q.d0 = d0[s]; q.d1 = d1[s]; q.d2 = d2[s];
-                    q.Q.m00 = Q00[s]; q.Q.m01 = Q01[s]; q.Q.m02 = Q02[s]; q.Q.m11 = Q11[s]; q.Q.m12 = Q12[s]; q.Q.m22 = Q22[s];
-                    q.q0 = q0[s]; q.q1 = q1[s]; q.q2 = q2[s];
+                    q.QA = QA[s]; q.QB = QB[s]; q.QC = QC[s]; q.qa = qA[s]; q.q2 = q2[s];
                     q.Rd = RD[s]; q.R01 = R01[s]; q.r = RP[s];
                     q.st0 = st0[s]; q.st1 = st1[s];
                     q.v0 = (st0[s] == ST_UPPER) ? ub0[s] : lb0[s];
@@ -801,8 +808,8 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                     pe1[s] = mine ? pol.e1 : pe1[s]; pf1[s] = mine ? pol.f1 : pf1[s];
                 }
             }
-            V[0] = val.P.m00; V[1] = val.P.m01; V[2] = val.P.m02; V[3] = val.P.m11; V[4] = val.P.m12; V[5] = val.P.m22;
-            V[6] = val.p0; V[7] = val.p1; V[8] = val.p2;
+            V[0] = val.Pa.x; V[1] = val.Pa.y; V[2] = val.Pb.x; V[3] = val.Pc.x; V[4] = val.Pb.y; V[5] = val.Pc.y;
+            V[6] = val.pa.x; V[7] = val.pa.y; V[8] = val.p2;
             return ok;
         };
         // backward sweep of the groups flagged `act`, each from the lane that owns its highest stale stage `from`
@@ -1030,9 +1037,9 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
                 // carries QN for the prediction: it is added below)
                 const float b0 = sbs[s][0], b1 = sbs[s][1], b2 = sbs[s][2];
                 const float e0 = dxs[s][0] - b0, e1 = dxs[s][1] - b1, e2 = dxs[s][2] - b2;
-                const float tq = (Q00[s] * b0 + Q01[s] * b1 + Q02[s] * b2 + q0[s]) * e0 +
-                                 (Q01[s] * b0 + Q11[s] * b1 + Q12[s] * b2 + q1[s]) * e1 +
-                                 (Q02[s] * b0 + Q12[s] * b1 + Q22[s] * b2 + q2[s]) * e2;
+                const float tq = (QA[s].x * b0 + QA[s].y * b1 + QB[s].x * b2 + qA[s].x) * e0 +
+                                 (QA[s].y * b0 + QC[s].x * b1 + QB[s].y * b2 + qA[s].y) * e1 +
+                                 (QB[s].x * b0 + QB[s].y * b1 + QC[s].y * b2 + q2[s]) * e2;
                 gd += (k > 0 && k < N) ? tq : 0.0f;
                 gd += RP[s].x * du0[s] + RP[s].y * du1[s];
                 comp += (mu0[s] > 1e-12f) ? fabsf(lb0[s] * mu0[s]) : ((mu0[s] < -1e-12f) ? fabsf(ub0[s] * mu0[s]) : 0.0f);
