@@ -57,6 +57,8 @@ struct alore_nmpc_solver {
     // alore_nmpc_rti_many: launches of independent batches in flight at once (side streams forked from the caller's)
     int overlap = 16;
     bool auto_pg = false; // warm_start_steps was left to the library: 6 for a launch on its own, 3 inside a grid of many batches
+    unsigned long long indep_sig = 0; // signature of the last descriptor set that passed the independence check of alore_nmpc_rti_many
+    bool indep_valid = false;
     int many_mode = 0; // alore_nmpc_rti_many: 0 = groups of batches per grid, 1 = one launch per batch on forked streams
     hipStream_t side[31] = {};
     hipEvent_t fork_ev = nullptr, join_ev[31] = {};
@@ -630,7 +632,20 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     if (const char* e = std::getenv("ALORE_NMPC_OVERLAP")) ways = std::atoi(e);
     ways = ways < 1 ? 1 : (ways > 32 ? 32 : ways);
     if (ways > count) ways = count;
-    if (ways > 1 && (h->timing || h->stamps || !batches_independent(h, batches, count, B))) ways = 1;
+    if (ways > 1 && (h->timing || h->stamps)) ways = 1;
+    if (ways > 1) {
+        // the independence check (a sort of 15 x count address ranges) is remembered for the descriptor set it passed on: a host
+        // that steps the same slots every tick pays for it once (FNV-1a over the descriptors, B and the shared-member mask)
+        unsigned long long sig = 1469598103934665603ull;
+        auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
+        const unsigned long long* words = reinterpret_cast<const unsigned long long*>(batches);
+        for (size_t i = 0; i < (size_t)count * (sizeof(alore_nmpc_batch) / 8); ++i) mix(words[i]);
+        mix((unsigned long long)B); mix((unsigned long long)count); mix((unsigned long long)h->shared);
+        if (!(h->indep_valid && h->indep_sig == sig)) {
+            if (batches_independent(h, batches, count, B)) { h->indep_sig = sig; h->indep_valid = true; }
+            else ways = 1;
+        }
+    }
     if (ways == 1) {
         for (int i = 0; i < count; ++i) {
             const int rc = rti_one(h, batches + i, B, n_sqp, stream, 0);
