@@ -867,6 +867,22 @@ def main():
             wbe.rti(1); torch.cuda.synchronize(dev)
             lin3_ms, ric3_ms = wbe.last_times()
             con_ok = bool((wbe.status() == 0).all())
+            # hard contact rows (the forces eliminated by the rows, then the sweep) and the refined penalty step (round 4)
+            wbe.set_contact_constraints(False)
+            wbe.set_contact_penalty(0.0)
+            wbe.set_contact_rows(True)
+            wbe.set_iterate(xiw, uiw)
+            wbe.rti(1); torch.cuda.synchronize(dev)
+            lin4_ms, ric4_ms = wbe.last_times()
+            rows_ok = bool((wbe.status() == 0).all())
+            wbe.set_contact_rows(False)
+            wbe.set_torque_limits(False)
+            wbe.set_contact_penalty(2000.0)
+            wbe.set_refinement(1)
+            wbe.set_iterate(xiw, uiw)
+            wbe.rti(1); torch.cuda.synchronize(dev)
+            lin5_ms, ric5_ms = wbe.last_times()
+            ref_ok = bool((wbe.status() == 0).all())
             extras["whole_body_b2z1"] = {"problems": Bw, "horizon": N, "ms_linearize": lin_ms, "ms_riccati": ric_ms,
                                          "ms_wall_one_rti": (t_b - t_a) * 1e3, "solves_per_s": Bw / ((lin_ms + ric_ms) * 1e-3),
                                          "mfma_f32_TFLOPs_riccati": Bw * mfma_flops / (ric_ms * 1e-3) / 1e12,
@@ -874,6 +890,10 @@ def main():
                                          "stages_with_a_saturated_torque_frac": sat,
                                          "second_iteration": {"ms_linearize": lin2_ms, "ms_riccati": ric2_ms,
                                                               "solves_per_s": Bw / ((lin2_ms + ric2_ms) * 1e-3)},
+                                         "with_hard_contact_rows": {"ms_linearize_and_row_elimination": lin4_ms, "ms_riccati_and_forces": ric4_ms,
+                                                                    "solves_per_s": Bw / ((lin4_ms + ric4_ms) * 1e-3), "all_steps_applied": rows_ok},
+                                         "penalty_2000_with_one_refinement_step": {"ms_linearize": lin5_ms, "ms_riccati_twice_and_residuals": ric5_ms,
+                                                                                   "solves_per_s": Bw / ((lin5_ms + ric5_ms) * 1e-3), "all_steps_applied": ref_ok},
                                          "with_contact_constraints_and_penalty": {"ms_linearize": lin3_ms, "ms_riccati": ric3_ms,
                                                                                   "solves_per_s": Bw / ((lin3_ms + ric3_ms) * 1e-3), "all_steps_applied": con_ok},
                                          "first_step_max": float(np.max(np.abs(dxw))), "finite": bool(np.isfinite(dxw).all() and np.isfinite(duw).all())}
