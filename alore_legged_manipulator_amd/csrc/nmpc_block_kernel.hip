@@ -1098,6 +1098,28 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
         }
         obj = 0.5f * gtotal<L>(part, j, lane);
     }
+    // problems the caller masked out (alore_nmpc_set_problem_mask: idle robots of a fleet) go back exactly as they came: their
+    // lanes ran along on whatever the members hold (results of a group never reach another group), now they fetch the
+    // iterate and the dual again and write nothing else
+    const bool skip = valid && p.mask != nullptr && p.mask[prob] == 0;
+    if (__any(skip)) {
+        typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        const float* gx = pb.x + (size_t)prob * nx;
+        const float* gu = pb.u + (size_t)prob * nu;
+        const float* gdl = pb.dual + (size_t)prob * nu;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int k = j * S + s;
+            const f3u vx = *reinterpret_cast<const f3u*>(gx + 3 * min(k, N));
+            const f2u vu = *reinterpret_cast<const f2u*>(gu + 2 * min(k, N - 1)), vd = *reinterpret_cast<const f2u*>(gdl + 2 * min(k, N - 1));
+            x[s][0] = skip ? vx.x : x[s][0]; x[s][1] = skip ? vx.y : x[s][1]; x[s][2] = skip ? vx.z : x[s][2];
+            u[s][0] = skip ? vu.x : u[s][0]; u[s][1] = skip ? vu.y : u[s][1];
+            mu0[s] = skip ? vd.x : mu0[s]; mu1[s] = skip ? vd.y : mu1[s];
+        }
+        const f3u vn = *reinterpret_cast<const f3u*>(gx + 3 * N);
+        xN[0] = skip ? vn.x : xN[0]; xN[1] = skip ? vn.y : xN[1]; xN[2] = skip ? vn.z : xN[2];
+    }
     wave_sync(); // W / y are dead from here: their area becomes the output staging buffer
     if (valid) {
 #pragma unroll
@@ -1127,7 +1149,7 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
         g_store<UU>(pb.u + (size_t)prob0 * nu, lds + oU, np_ * nu, lane);
         g_store<UU>(pb.dual + (size_t)prob0 * nu, lds + oDL, np_ * nu, lane);
     }
-    if (valid && j == 0) {
+    if (valid && !skip && j == 0) {
         pb.status[prob] = status;
         pb.n_iter[prob] = n_iter;
         if (DIAG && pb.kkt) pb.kkt[prob] = kkt;

@@ -48,6 +48,7 @@ struct alore_nmpc_solver {
     size_t panels_cap = 0;
     size_t inc_doubles = 0;
     unsigned shared = 0;          // see alore_nmpc_set_shared_members
+    const unsigned char* mask = nullptr; // see alore_nmpc_set_problem_mask
     const float* lin_x = nullptr; // see alore_nmpc_set_linearization_point
     const float* lin_u = nullptr;
     // pinned staging for alore_nmpc_batch_upload / _download from pageable host memory
@@ -440,6 +441,7 @@ void fill_params(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_
     p->stamps = nullptr;
     p->lin_x = h->lin_x;
     p->lin_u = h->lin_u;
+    p->mask = nullptr;
 }
 
 // one launch for one batch; B_in_flight = problems of all launches that run concurrently with it (0: only this one)
@@ -453,8 +455,11 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
                            nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight);
     if (!use_block && !nmpc::rti_geometry(B, h->cfg.N, (lp & 0x100) ? 0 : lp, h->lds_limit, h->n_cu, &g, forced_wpb))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: horizon does not fit the LDS layout");
+    if (h->mask && !use_block)
+        return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: a problem mask needs the stage-block kernel (horizon <= 64, aligned members, no forced wavefront mapping)");
     nmpc::RtiParams p;
     fill_params(h, dev, B, n_sqp, g, &p);
+    p.mask = h->mask;
     hipStream_t s = (hipStream_t)stream;
     if (h->stamps) {
         const size_t need = (size_t)g.grid * g.wpb * 8; // one record per wavefront
@@ -722,6 +727,13 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
         if (rc == ALORE_NMPC_OK && e2 != hipSuccess) rc = fail(h, ALORE_NMPC_E_HIP, "rti_many: join", e2);
     }
     return rc;
+}
+
+int alore_nmpc_set_problem_mask(alore_nmpc_handle h, const unsigned char* mask)
+{
+    if (!h) return ALORE_NMPC_E_INVALID;
+    h->mask = mask;
+    return ALORE_NMPC_OK;
 }
 
 int alore_nmpc_set_many_mode(alore_nmpc_handle h, int mode)

@@ -22,6 +22,7 @@ struct RtiParams {
     const float* lin_u; // optional [B][N*2]
     long long* stamps; // diagnostic builds only: per-block phase cycle counts (8 per block), else null
     unsigned shared; // ALORE_NMPC_SHARED_* bits: members that are ONE copy for the whole batch (problem stride 0)
+    const unsigned char* mask; // optional [B]: 0 = the problem is left exactly as it is (alore_nmpc_set_problem_mask), else null
 };
 
 // up to GROUP_MAX independent batches served by one grid of the stage-block kernel (by value in the kernel arguments: 24 x 120 B of the 4 KB they hold)

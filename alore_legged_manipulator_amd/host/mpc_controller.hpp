@@ -86,6 +86,7 @@ public:
     ~BatchedMpcWrapper()
     {
         if (h_) {
+            if (d_mask_) (void)hipFree(d_mask_);
             alore_nmpc_batch_free(h_, &dev_);
             alore_nmpc_destroy(h_);
         }
@@ -185,6 +186,17 @@ public:
     {
         check(alore_nmpc_refs_sample(h_, &dev_, B, now, est, icr, 1, nullptr, nullptr));
         pending_goal_ = at_goal;
+    }
+
+    // which robots the next update() solves (1) and which it leaves exactly as they are (0): alore_nmpc_set_problem_mask.
+    // The reference's CmdCallback returns early for a robot without odometry / trajectory, at its goal or stopped
+    // (mpc.cpp:176-203): its solver state stays what its last real solve left.  nullptr: all.
+    void setSolveMask(const unsigned char* solving)
+    {
+        if (!solving) { check(alore_nmpc_set_problem_mask(h_, nullptr)); return; }
+        if (!d_mask_ && hipMalloc((void**)&d_mask_, (size_t)B) != hipSuccess) throw std::runtime_error("hipMalloc (problem mask)");
+        if (hipMemcpyAsync(d_mask_, solving, (size_t)B, hipMemcpyHostToDevice, nullptr) != hipSuccess) throw std::runtime_error("hipMemcpyAsync (problem mask)");
+        check(alore_nmpc_set_problem_mask(h_, d_mask_));
     }
 
     // mpc_wrapper.cpp:279-373 for all robots at once: states = B x 3
@@ -297,6 +309,7 @@ private:
     bool acado_is_prepared_ = false, dirty_costs_ = true, dirty_iterate_ = true, device_refs_ = false;
     mutable bool x_stale_ = false; // x_ lags the device copy (downloaded on demand)
     int* pending_goal_ = nullptr;
+    unsigned char* d_mask_ = nullptr; // device copy of the solve mask of the tick (setSolveMask)
     const double dt_;
 };
 
@@ -305,7 +318,6 @@ private:
 struct RobotNode {
     bool has_odom = false, receive_traj_ = false, at_goal = false;
     bool solve_from_scratch_ = true;          // mpc.cpp:317-320: the first solve of THIS robot resets its iterate
-    bool idle_ticks_ = false;                 // the batch was ticked while this robot was idle: its iterate is stale
     bool pending = false;                     // new_traj_.if_get_traj_
     double new_traj_start_time_ = 0.0, start_time = -1.0, traj_duration = 0.0, new_duration_ = 0.0;
     Polynome msg_, new_msg_;
@@ -410,18 +422,17 @@ public:
             return;
         }
         mpc_wrapper_.sampleDeviceRefs(now, est.data(), icr.data(), goal.data()); // goal: valid after update()
-        // mpc.cpp:317-320, per robot: x <- est replicated, u <- 0 on its first solve.  The batch launch below also
-        // advances the iterates of idle robots (no odometry / no trajectory / at goal / stopped) against stale
-        // references, which the reference's CmdCallback never does (it returns early): such an iterate is discarded
-        // when the robot starts solving again -- a cold start, never a warm start from something the reference
-        // would not have computed (and a non-finite idle solve cannot leak into the next trajectory).
+        // mpc.cpp:317-320, per robot: x <- est replicated, u <- 0 on its FIRST solve only.  Idle robots (no odometry / no
+        // trajectory / at goal / stopped) sit the launch out (problem mask): their iterate and multipliers stay what their last
+        // real solve left, and they warm-start from them when they move again -- as the reference's node does, whose
+        // CmdCallback returns early for them.
         for (int b = 0; b < B; ++b) {
-            if (solving[b] && (robots[b].solve_from_scratch_ || robots[b].idle_ticks_)) {
+            if (solving[b] && robots[b].solve_from_scratch_) {
                 mpc_wrapper_.resetIterate(b, &est[(size_t)b * 3]);
                 robots[b].solve_from_scratch_ = false;
             }
-            robots[b].idle_ticks_ = !solving[b];
         }
+        mpc_wrapper_.setSolveMask(reinterpret_cast<const unsigned char*>(solving.data()));
         mpc_wrapper_.update(est.data(), false, node); // only column `node` of the inputs crosses the bus with the tick
         mpc_wrapper_.prepare(); // the reference's preparation thread (mpc.cpp:336, 394-403)
         for (int b = 0; b < B; ++b) {

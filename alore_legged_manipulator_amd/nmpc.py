@@ -130,6 +130,17 @@ class BatchedNmpc:
         """launches of independent slots kept in flight at once by rti_range (alore_nmpc_set_launch_overlap; 1 = in order)"""
         self._check(self.lib.alore_nmpc_set_launch_overlap(self.h, int(ways)))
 
+    def set_problem_mask(self, mask) -> None:
+        """mask [B] (1 = solve, 0 = leave the problem exactly as it is) for the following rti() calls, None = all
+        (alore_nmpc_set_problem_mask); kept on the device by this object"""
+        if mask is None:
+            self._mask = None
+            self._check(self.lib.alore_nmpc_set_problem_mask(self.h, None))
+            return
+        m = self.torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=self.device).reshape(self.B).contiguous()
+        self._mask = m
+        self._check(self.lib.alore_nmpc_set_problem_mask(self.h, C.c_void_p(m.data_ptr())))
+
     def set_many_mode(self, mode: str) -> None:
         """how rti_range keeps independent slots in flight (alore_nmpc_set_many_mode): "groups" -- up to 24 slots per grid,
         the default -- or "streams" -- one launch per slot on forked streams"""

@@ -171,6 +171,16 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch *batches, in
 int alore_nmpc_set_many_mode(alore_nmpc_handle h, int mode); /* 0 = groups (default), 1 = streams */
 int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
 
+/* Problems that sit a tick out.  mask: DEVICE pointer [B] (kept by the handle until reset with NULL), 1 = solve, 0 = the
+ * problem is left exactly as it is by the following alore_nmpc_rti calls -- x, u, dual, status, n_iter, kkt, obj unchanged,
+ * whatever its references hold (they may be stale or non-finite; nothing of it reaches the other problems).  This is how a
+ * fleet controller keeps the reference's per-robot semantics inside one launch: MpcController::CmdCallback returns early for
+ * a robot without odometry / trajectory, at its goal or stopped (mpc.cpp:176-203) and its solver state stays what the last
+ * real solve left, so that the robot warm-starts from it when it moves again (mpc.cpp:317-320 resets only once).  Applies to
+ * alore_nmpc_rti on the stage-block kernel (ALORE_NMPC_E_UNSUPPORTED with the wavefront mapping); alore_nmpc_rti_many
+ * ignores it. */
+int alore_nmpc_set_problem_mask(alore_nmpc_handle h, const unsigned char *mask);
+
 /* ACADO split semantics.  The reference prepares (linearises, evaluates h(x,u)) in
  * acado_preparationStep() and solves/expands in acado_feedbackStep(); a caller may change
  * acadoVariables.x/u in between (MpcWrapper::solve does, mpc_wrapper.cpp:267-275), in which case the

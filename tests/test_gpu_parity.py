@@ -812,3 +812,41 @@ def test_diagonal_weight_path_agrees_with_the_general_path(nmpc_mod):
         d = np.max(np.abs(a[k][wave].astype(np.float64) - b[k][wave])) / max(1.0, float(np.max(np.abs(a[k][wave]))))
         assert d < 2e-6, (k, d)
     assert np.array_equal(a["n_iter"], b["n_iter"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,lanes,n_sqp", [(20, 0, 1), (20, BLOCK | 4, 1), (20, BLOCK | 16, 2), (31, BLOCK | 16, 1), (7, BLOCK | 8, 1)])
+def test_masked_problems_are_left_exactly_as_they_are(nmpc_mod, N, lanes, n_sqp):
+    """alore_nmpc_set_problem_mask: the problems with mask 0 (idle robots of a fleet) keep every member bit for bit -- x, u, dual,
+    status, n_iter, kkt, obj -- even when their references are NaN, and the others return the bits of a launch without a mask."""
+    B = 131
+    batch = make_batch(B, N, seed=21, fast_tail=0.4)
+    ref = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=lanes)
+    ref.load(batch); ref.rti(n_sqp); want = ref.fetch()
+    mask = np.ones(B, np.uint8); mask[[0, 5, 17, 64, 65, 130]] = 0
+    broken = {k: v.copy() for k, v in batch.items()}
+    broken["y"][5] = np.nan; broken["x0"][64] = np.inf            # stale / non-finite references of idle robots
+    eng = nmpc_mod.BatchedNmpc(B, N, lanes_per_problem=lanes)
+    eng.load(broken)
+    for k in ("status", "n_iter"):
+        eng.ts[k][0].fill_(-7)
+    for k in ("kkt", "obj"):
+        eng.ts[k][0].fill_(123.5)
+    before = eng.fetch()
+    eng.set_problem_mask(mask)
+    eng.rti(n_sqp)
+    got = eng.fetch()
+    on, off = mask == 1, mask == 0
+    for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj"):
+        assert np.array_equal(got[k][off], before[k][off], equal_nan=True), k
+        assert np.array_equal(got[k][on], want[k][on]), k
+    eng.set_problem_mask(None)
+    eng.load(batch); eng.rti(n_sqp)
+    again = eng.fetch()
+    for k in ("x", "u", "dual", "status"):
+        assert np.array_equal(again[k], want[k]), k
+    # the wavefront mapping has no mask
+    w = nmpc_mod.BatchedNmpc(8, 20, lanes_per_problem=32)
+    w.load(make_batch(8, 20)); w.set_problem_mask(np.ones(8, np.uint8))
+    with pytest.raises(Exception):
+        w.rti(1)

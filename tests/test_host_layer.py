@@ -223,6 +223,34 @@ def test_cold_start_is_per_robot_and_emergency_stop_forgets_the_trajectory():
     assert late.tick_full(0.17)[0].wheel_published
 
 
+def test_a_robot_that_was_idle_warm_starts_from_its_last_solve():
+    """The reference resets the iterate once (solve_from_scratch_, mpc.cpp:317-320) and warm-starts ever after: a robot that
+    reached its goal (or was stopped) and gets a new trajectory continues from the iterate and multipliers its LAST solve left,
+    however many ticks the rest of the fleet ran in between (idle robots sit the batch launch out: alore_nmpc_set_problem_mask).
+    A fleet of three, of which robot 1 pauses, against a lone controller with robot 1's history and no fleet around it."""
+    from alore_legged_manipulator_amd.host import BatchedMpcController
+    B, N, dt = 3, 20, 0.01
+    m1 = arc_polynome(1.2, 0.6, 0.2, [0.5, 0.5, 0.5], xv=0.1, t0=0.0)
+    m2 = arc_polynome(0.8, -0.4, 0.2, [0.6, 0.6], xv=0.1, t0=0.30)
+    od = (0.05, -0.1, 0.25)
+    fleet, lone = BatchedMpcController(B, N, dt), BatchedMpcController(1, N, dt)
+    for r in list(fleet.robots) + [lone.robots[0]]:
+        r.traj(as_host_msg(m1)); r.odom(*od); r.icr(-0.3, 0.3, 0.1)
+    for t in (0.10, 0.11, 0.12):
+        a, b = fleet.tick(t), lone.tick(t)
+        assert np.array_equal(a[1], b[0])
+    fleet.robots[1].emergency_stop(); lone.robots[0].emergency_stop()
+    for t in (0.13, 0.14, 0.15, 0.16, 0.17):            # the fleet keeps ticking, robot 1 idles; the lone controller has nothing to solve
+        cmd = fleet.tick_full(t)
+        assert not cmd[1].wheel_published and cmd[0].wheel_published and cmd[2].wheel_published
+    fleet.robots[1].traj(as_host_msg(m2)); lone.robots[0].traj(as_host_msg(m2))
+    for t in (0.31, 0.32, 0.33):
+        a, b = fleet.tick(t), lone.tick(t)
+        assert np.array_equal(a[1], b[0]), (t, a[1], b[0])
+    (sf, uf, stf), (sl, ul, stl) = fleet.prediction(1), lone.prediction(0)
+    assert stf == 0 and stl == 0 and np.array_equal(sf, sl) and np.array_equal(uf, ul)
+
+
 def test_open_loop_replay_without_mpc():
     """if_mpc = false (mpc.cpp:211-234): the planned flat velocities and accelerations at t_cur are republished."""
     from alore_legged_manipulator_amd.host import BatchedMpcController, default_params
