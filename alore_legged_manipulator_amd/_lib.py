@@ -84,6 +84,8 @@ SYMBOLS = (
     ("alore_nmpc_set_launch_overlap", C.c_int, [C.c_void_p, C.c_int]),
     ("alore_nmpc_set_many_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("alore_nmpc_set_problem_mask", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_condense", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("alore_nmpc_dense_qp", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("alore_nmpc_input_column", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
     ("alore_nmpc_linearize", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.POINTER(LinOut), C.c_void_p]),
     ("alore_nmpc_forward_simulate", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_void_p]),

@@ -19,6 +19,8 @@ alore_nmpc_handle g_h = nullptr;
 alore_nmpc_batch g_dev{};
 float *g_lin_x = nullptr, *g_lin_u = nullptr; // device copies of the prepared iterate
 float *g_d = nullptr, *g_gx = nullptr, *g_gu = nullptr;
+float *g_H = nullptr, *g_g = nullptr, *g_lb = nullptr, *g_ub = nullptr, *g_qx = nullptr, *g_qy = nullptr; // the condensed QP on the device
+int* g_qst = nullptr; // [2]: status, factorisations
 int g_device = 0;
 int g_nwsr = 0;
 float g_kkt = 0.0f, g_obj = 0.0f;
@@ -43,6 +45,10 @@ bool ensure()
     if (hipMalloc((void**)&g_d, sizeof(float) * 3 * N) != hipSuccess) return false;
     if (hipMalloc((void**)&g_gx, sizeof(float) * 9 * N) != hipSuccess) return false;
     if (hipMalloc((void**)&g_gu, sizeof(float) * 6 * N) != hipSuccess) return false;
+    if (hipMalloc((void**)&g_H, sizeof(float) * ACADO_QP_NV * ACADO_QP_NV) != hipSuccess) return false;
+    if (hipMalloc((void**)&g_g, sizeof(float) * ACADO_QP_NV * 5) != hipSuccess) return false; // g | lb | ub | x | y
+    g_lb = g_g + ACADO_QP_NV; g_ub = g_lb + ACADO_QP_NV; g_qx = g_ub + ACADO_QP_NV; g_qy = g_qx + ACADO_QP_NV;
+    if (hipMalloc((void**)&g_qst, sizeof(int) * 2) != hipSuccess) return false;
     return true;
 }
 
@@ -55,6 +61,14 @@ void upload_variables(const ACADOvariables& v, bool iterate, bool dual)
     if (dual) host.dual = acadoWorkspace.y;
     alore_nmpc_batch_upload(g_h, &g_dev, &host, 1, nullptr);
 }
+// the condensed QP of the batch on the device -> acadoWorkspace.H, g (what condensePrep / condenseFdb leave there)
+void condense_to_workspace(bool with_g)
+{
+    alore_nmpc_dense_qp_data q{g_H, g_g, g_lb, g_ub};
+    if (!ok(alore_nmpc_condense(g_h, &g_dev, 1, &q, nullptr))) return;
+    (void)hipMemcpyAsync(acadoWorkspace.H, g_H, sizeof(float) * ACADO_QP_NV * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr);
+    if (with_g) (void)hipMemcpyAsync(acadoWorkspace.g, g_g, sizeof(float) * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr);
+}
 } // namespace
 
 extern "C" {
@@ -66,6 +80,7 @@ void alore_acado_shutdown(void)
     if (!g_h) return;
     alore_nmpc_batch_free(g_h, &g_dev);
     (void)hipFree(g_lin_x); (void)hipFree(g_lin_u); (void)hipFree(g_d); (void)hipFree(g_gx); (void)hipFree(g_gu);
+    (void)hipFree(g_H); (void)hipFree(g_g); (void)hipFree(g_qst);
     alore_nmpc_destroy(g_h);
     g_h = nullptr;
     g_have_prep = false;
@@ -105,6 +120,7 @@ int acado_preparationStep(void)
     (void)hipMemcpyAsync(acadoWorkspace.d, g_d, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, nullptr);
     (void)hipMemcpyAsync(acadoWorkspace.evGx, g_gx, sizeof(float) * 9 * N, hipMemcpyDeviceToHost, nullptr);
     (void)hipMemcpyAsync(acadoWorkspace.evGu, g_gu, sizeof(float) * 6 * N, hipMemcpyDeviceToHost, nullptr);
+    condense_to_workspace(false); // acado_condensePrep: the Hessian of the condensed QP belongs to the preparation
     (void)hipStreamSynchronize(nullptr);
     return 0;
 }
@@ -129,6 +145,7 @@ int acado_feedbackStep(void)
         acadoWorkspace.lb[i] = acadoVariables.lbValues[i] - acadoVariables.u[i];
         acadoWorkspace.ub[i] = acadoVariables.ubValues[i] - acadoVariables.u[i];
     }
+    condense_to_workspace(true); // acado_condenseFdb: gradient of the condensed QP for the measured state (H again: same linearisation)
     const int rc = alore_nmpc_rti(g_h, &g_dev, 1, 1, nullptr);
     alore_nmpc_set_linearization_point(g_h, nullptr, nullptr);
     int status = 0;
@@ -230,13 +247,33 @@ void acado_diffs(const real_t* in, real_t* out)
     out[14] = -inv;
 }
 
-int acado_solve(void) { return 29; } // the dense condensed QP is never formed (RET_INIT_FAILED)
+// CG/acado_qpoases_interface.cpp:39-60: qpOASES' QProblemB on acadoWorkspace.H / g / lb / ub, primal into acadoWorkspace.x, dual
+// into acadoWorkspace.y (whose previous content seeds the working set).  Here: the dense working-set solver of
+// nmpc_dense.hip on the same arrays, as the caller left them.
+int acado_solve(void)
+{
+    if (!ensure()) return 29;
+    (void)hipMemcpyAsync(g_H, acadoWorkspace.H, sizeof(float) * ACADO_QP_NV * ACADO_QP_NV, hipMemcpyHostToDevice, nullptr);
+    (void)hipMemcpyAsync(g_g, acadoWorkspace.g, sizeof(float) * ACADO_QP_NV, hipMemcpyHostToDevice, nullptr);
+    (void)hipMemcpyAsync(g_lb, acadoWorkspace.lb, sizeof(float) * ACADO_QP_NV, hipMemcpyHostToDevice, nullptr);
+    (void)hipMemcpyAsync(g_ub, acadoWorkspace.ub, sizeof(float) * ACADO_QP_NV, hipMemcpyHostToDevice, nullptr);
+    (void)hipMemcpyAsync(g_qy, acadoWorkspace.y, sizeof(float) * ACADO_QP_NV, hipMemcpyHostToDevice, nullptr);
+    alore_nmpc_dense_qp_data q{g_H, g_g, g_lb, g_ub};
+    if (!ok(alore_nmpc_dense_qp(g_h, 1, ACADO_QP_NV, &q, g_qx, g_qy, g_qst, g_qst + 1, nullptr))) return 29;
+    int st[2] = {29, 0};
+    (void)hipMemcpyAsync(acadoWorkspace.x, g_qx, sizeof(float) * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr);
+    (void)hipMemcpyAsync(acadoWorkspace.y, g_qy, sizeof(float) * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr);
+    (void)hipMemcpyAsync(st, g_qst, sizeof(st), hipMemcpyDeviceToHost, nullptr);
+    (void)hipStreamSynchronize(nullptr);
+    g_nwsr = st[1];
+    return st[0];
+}
 
 const char* acado_getErrorString(int error)
 {
     switch (error) {
     case 0: return "Successful return";
-    case 29: return "Initialisation failed (no GPU engine / dense QP interface not provided)";
+    case 29: return "Initialisation failed (no GPU engine)";
     case 31: return "Initialisation failed: Hessian not positive definite";
     case 33: return "Initial QP could not be solved due to infeasibility";
     case 58: return "Maximum number of working set recalculations performed";

@@ -760,6 +760,27 @@ int alore_nmpc_linearize(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B
     return ALORE_NMPC_OK;
 }
 
+int alore_nmpc_condense(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, const alore_nmpc_dense_qp_data* out, void* stream)
+{
+    if (!h || !dev || !out || B <= 0 || !out->H || !out->g || !out->lb || !out->ub || !dev->x || !dev->u || !dev->od || !dev->y || !dev->yN ||
+        !dev->W || !dev->WN || !dev->x0 || !dev->lbValues || !dev->ubValues)
+        return fail(h, ALORE_NMPC_E_INVALID, "condense: bad argument");
+    if (h->cfg.N > 64) return fail(h, ALORE_NMPC_E_UNSUPPORTED, "condense: horizons up to 64 (the E blocks of a problem live in LDS)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, nmpc::launch_condense(*dev, h->lin_x, h->lin_u, B, h->cfg.N, h->cfg.dt, h->shared, out->H, out->g, out->lb, out->ub, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_dense_qp(alore_nmpc_handle h, int B, int n, const alore_nmpc_dense_qp_data* qp, float* x, float* y, int* status, int* n_iter,
+                        void* stream)
+{
+    if (!h || !qp || B <= 0 || n < 1 || n > 128 || !qp->H || !qp->g || !qp->lb || !qp->ub || !x || !y || !status || !n_iter)
+        return fail(h, ALORE_NMPC_E_INVALID, "dense_qp: bad argument (n <= 128)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, nmpc::launch_dense_qp(B, n, qp->H, qp->g, qp->lb, qp->ub, x, y, status, n_iter, h->cfg.max_as_iter, (hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
 int alore_nmpc_forward_simulate(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, void* stream)
 {
     if (!h || !dev || B <= 0 || !dev->x || !dev->u || !dev->od)

@@ -62,6 +62,12 @@ bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, L
 hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
 hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const LaunchGeom& g, hipStream_t s);
 
+// nmpc_dense.hip: the condensed QP of the reference's dense interface (acadoWorkspace.H / g / lb / ub, acado_solve)
+hipError_t launch_condense(const alore_nmpc_batch& b, const float* lin_x, const float* lin_u, int B, int N, float dt, unsigned shared, float* H,
+                           float* g, float* lb, float* ub, hipStream_t s);
+hipError_t launch_dense_qp(int B, int n, const float* H, const float* g, const float* lb, const float* ub, float* x, float* y, int* status,
+                           int* n_iter, int max_iter, hipStream_t s);
+
 hipError_t launch_linearize(const alore_nmpc_batch& b, int B, int N, float dt, const alore_nmpc_lin_out& o,
                             hipStream_t s);
 hipError_t launch_forward_simulate(const alore_nmpc_batch& b, int B, int N, float dt, hipStream_t s);

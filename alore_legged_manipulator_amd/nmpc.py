@@ -130,6 +130,32 @@ class BatchedNmpc:
         """launches of independent slots kept in flight at once by rti_range (alore_nmpc_set_launch_overlap; 1 = in order)"""
         self._check(self.lib.alore_nmpc_set_launch_overlap(self.h, int(ways)))
 
+    def condense(self, slot: int = 0) -> dict:
+        """The condensed QP of the batch as it stands (alore_nmpc_condense: acadoWorkspace.H / g / lb / ub of the reference):
+        H (B, 2N, 2N), g, lb, ub (B, 2N), device tensors."""
+        torch = self.torch
+        n = 2 * self.N
+        out = {"H": torch.empty((self.B, n, n), dtype=torch.float32, device=self.device)}
+        for k in ("g", "lb", "ub"):
+            out[k] = torch.empty((self.B, n), dtype=torch.float32, device=self.device)
+        qp = (C.c_void_p * 4)(out["H"].data_ptr(), out["g"].data_ptr(), out["lb"].data_ptr(), out["ub"].data_ptr())
+        self._check(self.lib.alore_nmpc_condense(self.h, C.addressof(self._batches[slot]), self.B, C.addressof(qp), self._stream()))
+        return out
+
+    def dense_qp(self, H, g, lb, ub, y0=None):
+        """acado_solve() for a batch of dense box QPs (alore_nmpc_dense_qp): min 1/2 x'Hx + g'x, lb <= x <= ub; device tensors
+        H (B, n, n), g / lb / ub (B, n); returns x, y (multipliers, > 0 lower / < 0 upper), status, n_iter."""
+        torch = self.torch
+        Bq, n = g.shape
+        x = torch.empty_like(g)
+        y = torch.zeros_like(g) if y0 is None else y0.clone().contiguous()
+        st = torch.empty(Bq, dtype=torch.int32, device=g.device); ni = torch.empty(Bq, dtype=torch.int32, device=g.device)
+        H, g, lb, ub = (t.contiguous() for t in (H, g, lb, ub))
+        qp = (C.c_void_p * 4)(H.data_ptr(), g.data_ptr(), lb.data_ptr(), ub.data_ptr())
+        self._check(self.lib.alore_nmpc_dense_qp(self.h, Bq, n, C.addressof(qp), x.data_ptr(), y.data_ptr(), st.data_ptr(), ni.data_ptr(),
+                                                 self._stream()))
+        return x, y, st, ni
+
     def set_problem_mask(self, mask) -> None:
         """mask [B] (1 = solve, 0 = leave the problem exactly as it is) for the following rti() calls, None = all
         (alore_nmpc_set_problem_mask); kept on the device by this object"""

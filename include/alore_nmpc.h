@@ -195,6 +195,25 @@ int alore_nmpc_set_linearization_point(alore_nmpc_handle h, const float *x_lin, 
 int alore_nmpc_linearize(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, const alore_nmpc_lin_out *out,
                          void *stream);
 
+/* ---- the condensed (dense) QP, for callers of the reference's dense interface ---------------------------------------
+ * The engine never condenses -- alore_nmpc_rti solves the stage-wise QP.  The reference does, and exposes the result:
+ * acado_preparationStep / acado_feedbackStep leave the 2N x 2N Hessian H, the gradient g and the bounds lb, ub of the step
+ * in acadoWorkspace (acado_solver.c:327-363 condensePrep, :365-891 condenseFdb; acado_common.h:170-257) and acado_solve()
+ * (acado_qpoases_interface.cpp:39-60) runs qpOASES' QProblemB on exactly those arrays.
+ * alore_nmpc_condense forms them on the GPU for B problems from the batch as it stands (linearised at the iterate, or at
+ * the point of alore_nmpc_set_linearization_point): H [B][2N][2N] row-major (variable 2 i + c = input c of stage i),
+ * g, lb, ub [B][2N], DEVICE pointers, horizons up to 64; it does not touch the batch.
+ * alore_nmpc_dense_qp solves  min 1/2 x' H x + g' x,  lb <= x <= ub  for B dense symmetric positive definite problems of order
+ * n <= 128 (one workgroup each: working-set iteration on a Cholesky factorisation in LDS; y [B][n] in: the previous dual, its
+ * signs seed the working set like QProblemB does; out: the multipliers, > 0 at a lower bound, < 0 at an upper one; status
+ * 0 / 31 / 33 / 58 as alore_nmpc_batch.status; n_iter = factorisations, the role of nWSR). */
+typedef struct {
+    float *H, *g, *lb, *ub;
+} alore_nmpc_dense_qp_data;
+int alore_nmpc_condense(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, const alore_nmpc_dense_qp_data *out, void *stream);
+int alore_nmpc_dense_qp(alore_nmpc_handle h, int B, int n, const alore_nmpc_dense_qp_data *qp, float *x, float *y, int *status, int *n_iter,
+                        void *stream);
+
 /* replaces acado_initializeNodesByForwardSimulation() (acado_solver.c:1292-1312):
  * x[k+1] <- phi(x[k], u[k]) for k = 0..N-1 */
 int alore_nmpc_forward_simulate(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, void *stream);

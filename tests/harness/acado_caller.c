@@ -26,6 +26,8 @@ ACC(ws_x, acadoWorkspace.x)
 ACC(ws_y, acadoWorkspace.y)
 ACC(ws_lb, acadoWorkspace.lb)
 ACC(ws_ub, acadoWorkspace.ub)
+ACC(ws_H, acadoWorkspace.H)
+ACC(ws_g, acadoWorkspace.g)
 int caller_sizeof_variables(void) { return (int)sizeof(ACADOvariables); }
 int caller_sizeof_workspace(void) { return (int)sizeof(ACADOworkspace); }
 void caller_reset(void)

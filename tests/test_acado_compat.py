@@ -46,8 +46,8 @@ class Compat:
         self.L = C.CDLL(CALLER_SO, mode=C.RTLD_GLOBAL)
         self.S = C.CDLL(os.path.join(PKG, "libalore_acado_compat.so"), mode=C.RTLD_GLOBAL)
         sizes = {"x": 153, "u": 100, "od": 153, "y": 250, "yN": 3, "W": 1250, "WN": 9, "x0": 3, "lbValues": 100,
-                 "ubValues": 100, "d": 150, "evGx": 450, "evGu": 300, "dx": 100, "dual": 100, "lb": 100, "ub": 100}
-        names = {"d": "ws_d", "evGx": "ws_evGx", "evGu": "ws_evGu", "dx": "ws_x", "dual": "ws_y", "lb": "ws_lb", "ub": "ws_ub"}
+                 "ubValues": 100, "d": 150, "evGx": 450, "evGu": 300, "dx": 100, "dual": 100, "lb": 100, "ub": 100, "H": 10000, "g": 100}
+        names = {"d": "ws_d", "evGx": "ws_evGx", "evGu": "ws_evGu", "dx": "ws_x", "dual": "ws_y", "lb": "ws_lb", "ub": "ws_ub", "H": "ws_H", "g": "ws_g"}
         self.v = {}
         for k, n in sizes.items():
             fn = getattr(self.L, "caller_" + names.get(k, k))
@@ -63,6 +63,7 @@ class Compat:
     def feedback_step(self): return self.S.acado_feedbackStep()
     def get_kkt(self): return float(self.S.acado_getKKT())
     def get_nwsr(self): return int(self.S.acado_getNWSR())
+    def solve(self): return int(self.S.acado_solve())
 
 
 def wrapper_sequence(s, p, ticks):
@@ -117,3 +118,44 @@ def test_wrapper_call_sequence_matches_reference_semantics():
     comp.preparation_step()
     assert np.max(np.abs(comp.v["d"] - orc.v["d"])) < 5e-6
     assert np.max(np.abs(comp.v["evGu"] - orc.v["evGu"])) < 5e-6
+
+
+@pytest.mark.gpu
+def test_acado_solve_and_the_condensed_workspace_members():
+    """acadoWorkspace.H / g after acado_preparationStep + acado_feedbackStep are the condensed QP the reference leaves there
+    (CG/acado_solver.c:327-891; compared with the oracle, bit-exact with the reference at N = 50, and with the compiled reference
+    itself where it is present), and acado_solve() (CG/acado_qpoases_interface.cpp:39-60) solves the QP that is in the
+    workspace: called again after the feedback step it returns the step the feedback step took; with a changed gradient it
+    returns the minimiser of the changed QP (checked in float64)."""
+    from scipy.optimize import lsq_linear
+    N = 50
+    batch = make_batch(3, N, seed=91, fast_tail=0.5)
+    comp = Compat()
+    orc = Oracle(N)
+    ref = RefAcado() if ref_available() else None
+    for b in range(3):
+        p = problem(batch, b)
+        for s in (comp, orc, ref):
+            if s is None:
+                continue
+            s.reset(); s.initialize_solver()
+            for k in ("x", "u", "od", "y", "yN", "W", "WN", "x0"):
+                s.v[k][:] = p[k]
+            assert s.preparation_step() == 0 and s.feedback_step() == 0
+        H, g = orc.v["H"].reshape(100, 100), orc.v["g"]
+        assert np.max(np.abs(comp.v["H"].reshape(100, 100) - H)) < 1e-5 * np.max(np.abs(H))
+        assert np.max(np.abs(comp.v["g"] - g)) < 1e-5 * max(1.0, np.max(np.abs(g)))
+        if ref is not None:
+            assert np.max(np.abs(comp.v["H"] - ref.v["H"])) < 1e-5 * np.max(np.abs(ref.v["H"]))
+            assert np.max(np.abs(comp.v["g"] - ref.v["g"])) < 1e-5 * max(1.0, np.max(np.abs(ref.v["g"])))
+        step = comp.v["dx"].copy()
+        assert comp.solve() == 0 and comp.get_nwsr() >= 1
+        assert np.max(np.abs(comp.v["dx"] - step)) < 1e-4 * max(1.0, np.max(np.abs(step)))
+        # a QP the caller changed: the minimiser of what is in the workspace
+        comp.v["g"][:] = comp.v["g"] * 0.5 + 0.3
+        Hc = comp.v["H"].reshape(100, 100).astype(np.float64); Hc = 0.5 * (Hc + Hc.T)
+        Lc = np.linalg.cholesky(Hc)
+        tr = lsq_linear(Lc.T, -np.linalg.solve(Lc, comp.v["g"].astype(np.float64)), bounds=(comp.v["lb"].astype(np.float64), comp.v["ub"].astype(np.float64)),
+                        method="bvls", tol=1e-15, max_iter=2000).x
+        assert comp.solve() == 0
+        assert np.max(np.abs(comp.v["dx"] - tr)) < 1e-4 * max(1.0, np.max(np.abs(tr)))

@@ -850,3 +850,45 @@ def test_masked_problems_are_left_exactly_as_they_are(nmpc_mod, N, lanes, n_sqp)
     w.load(make_batch(8, 20)); w.set_problem_mask(np.ones(8, np.uint8))
     with pytest.raises(Exception):
         w.rti(1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [20, 50, 7])
+def test_condensed_qp_matches_the_oracle_and_its_dense_solve_matches_the_stage_wise_one(nmpc_mod, N):
+    """alore_nmpc_condense: H, g, lb, ub of the condensed QP (what acado_condensePrep / condenseFdb leave in acadoWorkspace)
+    against the oracle's (bit-exact with the reference at N = 50) on a non-trivial iterate; alore_nmpc_dense_qp (the role of
+    acado_solve) on those arrays against the float64 minimiser and against the step of the stage-wise real-time iteration."""
+    import torch
+    B = 24
+    batch = make_batch(B, N, seed=4, fast_tail=0.5)
+    eng = nmpc_mod.BatchedNmpc(B, N)
+    eng.load(batch)
+    eng.rti(1)                                   # a non-trivial iterate and dual
+    mid = eng.fetch()
+    qp = eng.condense()
+    Hd, gd, lbd, ubd = (qp[k].cpu().numpy() for k in ("H", "g", "lb", "ub"))
+    y0 = eng.ts["dual"][0].clone()
+    x, y, st, ni = eng.dense_qp(qp["H"], qp["g"], qp["lb"], qp["ub"], y0=y0)
+    eng.rti(1)
+    out = eng.fetch()
+    n = 2 * N
+    x, y, st = x.cpu().numpy().reshape(B, n), y.cpu().numpy().reshape(B, n), st.cpu().numpy()
+    assert (st == 0).all() and (out["status"] == 0).all()
+    orc = Oracle(N)
+    for b in range(0, B, 3):
+        p = dict(problem(batch, b))
+        p["x"] = mid["x"][b].reshape(-1); p["u"] = mid["u"][b].reshape(-1); p["dual"] = mid["dual"][b].reshape(-1)
+        orc.reset(); orc.initialize_solver(); orc.load(p); orc.preparation_step()
+        assert orc.feedback_step() == 0
+        H, g = orc.v["H"].reshape(n, n), orc.v["g"]
+        assert np.max(np.abs(Hd[b] - H)) < 1e-5 * np.max(np.abs(H)), (b, "H")
+        assert np.max(np.abs(gd[b] - g)) < 1e-5 * max(1.0, np.max(np.abs(g))), (b, "g")
+        assert np.array_equal(lbd[b], orc.v["lb"]) and np.array_equal(ubd[b], orc.v["ub"])
+        truth = exact_box_qp(H, g, orc.v["lb"], orc.v["ub"])
+        scale = max(1.0, float(np.max(np.abs(orc.v["u"]))))
+        assert np.max(np.abs(x[b] - truth)) / scale < 1e-4, (b, np.max(np.abs(x[b] - truth)))
+        # the stage-wise iteration took the same step (clipped into the box, like the expansion does)
+        du = out["u"][b].reshape(-1) - mid["u"][b].reshape(-1)
+        assert np.max(np.abs(du - np.clip(x[b], lbd[b], ubd[b]))) / scale < 1e-4, b
+        act = np.abs(y[b]) > 1e-6
+        assert np.all(np.where(y[b][act] > 0, np.abs(x[b][act] - lbd[b][act]), np.abs(x[b][act] - ubd[b][act])) < 1e-5)
