@@ -66,7 +66,7 @@ void free_all(alore_backend_handle h)
         long long st[64];
         if (hipMemcpy(st, h->d_stamps, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {
             std::fprintf(stderr, "[alore_backend stamps] workgroup 0, cycles per phase of eval_cost (slot 0 also holds the time outside it):");
-            for (int i = 0; i < 20; ++i) std::fprintf(stderr, " %lld", st[i]);
+            for (int i = 0; i < 44; ++i) std::fprintf(stderr, " %lld", st[i]);
             std::fprintf(stderr, "\n");
         }
         (void)hipFree(h->d_stamps);

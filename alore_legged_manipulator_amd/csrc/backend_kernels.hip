@@ -26,12 +26,26 @@ namespace backend {
 
 namespace {
 
-// diagnostic phase stamps: workgroup 0 adds the cycles since its previous stamp to slot i
+// Address spaces are spelled out.  Inside the (noinline) device functions below a plain pointer is a generic one: the
+// compiler then reaches LDS through flat instructions and looks the base of the dynamic LDS block up in a table at every
+// access site, and reads the parameter block with vector loads.  With typed pointers the same accesses are ds_* instructions
+// on a base handed down from the kernel, scalar loads of the (read-only) parameter block and global_* loads / stores.
+#define LDSQ __attribute__((address_space(3)))
+#define GLBQ __attribute__((address_space(1)))
+#define CSTQ __attribute__((address_space(4)))
+typedef const CSTQ Params CParams;
+typedef const CSTQ Config CConfig;
+typedef const CSTQ MapView CMapView;
+typedef const CSTQ LbfgsParam CLbfgsParam;
+
+// diagnostic phase stamps: workgroup 0 adds the cycles since its previous stamp to slot i (global stores: a pending FLAT
+// access would make every later wait on the vector-memory counter a wait for everything)
 #define BE_STAMP(i)                                                                              \
     if (gp->stamps && blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+        GLBQ long long* st_ = (GLBQ long long*)gp->stamps;                                       \
         const long long now_ = (long long)__builtin_readcyclecounter();                          \
-        gp->stamps[i] += now_ - gp->stamps[63];                                                  \
-        gp->stamps[63] = now_;                                                                   \
+        st_[i] += now_ - st_[63];                                                                \
+        st_[63] = now_;                                                                          \
     }
 
 constexpr int NS = 17; // Simpson nodes per piece (sparseResolution 8)
@@ -99,6 +113,25 @@ __device__ __forceinline__ double uni(double v) // value known to be wave-unifor
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Arguments of the (noinline) device functions below arrive in vector registers and count as divergent: every loop bound,
+// branch and address formed from them would run on the vector unit under EXEC masks, with conservative waits at the block
+// boundaries.  They are wave-uniform by construction -- the functions move them to scalar registers first.
+template <class T>
+__device__ __forceinline__ T* uni_ptr(T* q)
+{
+    const unsigned long long b = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ LbfgsParam uni(const LbfgsParam& q)
+{
+    LbfgsParam r;
+    r.mem_size = uni(q.mem_size); r.past = uni(q.past); r.max_iterations = uni(q.max_iterations); r.max_linesearch = uni(q.max_linesearch);
+    r.g_epsilon = uni(q.g_epsilon); r.delta = uni(q.delta); r.min_step = uni(q.min_step); r.max_step = uni(q.max_step);
+    r.f_dec_coeff = uni(q.f_dec_coeff); r.s_curv_coeff = uni(q.s_curv_coeff); r.cautious_factor = uni(q.cautious_factor);
+    r.machine_prec = uni(q.machine_prec);
+    return r;
+}
 
 __device__ __forceinline__ void smoothed_l1(double eps, double x, double& f, double& df)
 {
@@ -121,7 +154,7 @@ __device__ __forceinline__ double dt_dtau(double v)
 }
 
 // SDFmap::getDistWithGradBilinear(pos, grad, mindis) (sdf_map.cpp:796-834) and (pos) (:836-861, want_grad = false)
-__device__ __forceinline__ double esdf(const MapView& m, double x, double y, bool want_grad, double mindis, double& gx, double& gy)
+__device__ __forceinline__ double esdf(CMapView& m, double x, double y, bool want_grad, double mindis, double& gx, double& gy)
 {
     gx = 0.0; gy = 0.0;
     if (x < m.x_lo || y < m.y_lo || x > m.x_hi || y > m.y_hi) return 1e10;
@@ -131,7 +164,7 @@ __device__ __forceinline__ double esdf(const MapView& m, double x, double y, boo
     iy = min(max(iy, 0), m.ny - 1);
     if (ix >= m.nx - 1 || iy >= m.ny - 1) return 1e10;
     const double fx = (x - ((ix + 0.5) * m.res + m.x_lo)) * inv, fy = (y - ((iy + 0.5) * m.res + m.y_lo)) * inv;
-    const double* c = m.dist + (size_t)ix * m.ny + iy;
+    const GLBQ double* c = (const GLBQ double*)m.dist + (size_t)ix * m.ny + iy;
     const double v00 = c[0], v01 = c[1], v10 = c[m.ny], v11 = c[m.ny + 1];
     const double lo = (1 - fx) * v00 + fx * v10, hi = (1 - fx) * v01 + fx * v11;
     const double dist = (1 - fy) * lo + fy * hi;
@@ -166,13 +199,22 @@ struct Lds {
     double nodeT[P * NS];
     double posx[RES * P + 1], posy[RES * P + 1];      // pose at the Simpson panel ends
     double x[3 * P], g[3 * P], d[3 * P], xp[3 * P], gp[3 * P];
-    double ys[MEM_MAX], alpha[MEM_MAX];
+    double alpha[MEM_MAX];
     double pf[16];
 };
 
 extern __shared__ __align__(16) unsigned char lds_raw[];
+// the kernel takes the offset of the dynamic LDS block (the low half of its generic address) and hands it down
+// (through an empty asm: as a constant expression the address would be propagated into the callees, which would go back to
+// the table lookup)
+__device__ __forceinline__ unsigned lds_base_of_kernel()
+{
+    unsigned b = (unsigned)(unsigned long long)lds_raw;
+    asm volatile("; dynamic LDS block at %0" : "+s"(b));
+    return b;
+}
 template <int P>
-__device__ __forceinline__ Lds<P>& lds() { return *reinterpret_cast<Lds<P>*>(lds_raw); }
+__device__ __forceinline__ LDSQ Lds<P>& lds(unsigned base) { return *(LDSQ Lds<P>*)(unsigned long)base; }
 
 // Knot system by parallel cyclic reduction: equation k (interior knot k = lane + 1) is
 //   L_k y_{k-1} + D_k y_k + U_k y_{k+1} = r_k,   L_k = U_{k-1}',   2 x 2 blocks (csrc/minco_spline.h: knot_diag, knot_upper).
@@ -234,7 +276,7 @@ __device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk)
 
 // rhs / solution: y[d][lane][0..1] in LDS for d = 0, 1 (the caller's layout); all 64 lanes must call
 template <int P>
-__device__ __forceinline__ void knot_pcr(int M, const double* T, double (*y0)[2], double (*y1)[2])
+__device__ __forceinline__ void knot_pcr(int M, const LDSQ double* T, LDSQ double (*y0)[2], LDSQ double (*y1)[2])
 {
     constexpr bool DPP = P <= 16; // all knots (<= 15) in one DPP row
     const int e = threadIdx.x, nk = M - 1;
@@ -264,12 +306,13 @@ __device__ __forceinline__ void knot_pcr(int M, const double* T, double (*y0)[2]
 // One cost callback.  x in L.x, gradient to L.g.  Returns the cost (wave-uniform).  *skipped is set when the
 // reference's norm guard fires (cost 0, gradient untouched).
 template <int P>
-__device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__ gp, bool* skipped)
+__device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsigned lds_in)
 {
-    const Params& prm = *gp;
-    const Config& c = prm.cfg;
-    Lds<P>& L = lds<P>();
-    EvalCtx& e = L.e;
+    CParams* gp = (CParams*)uni_ptr(gp_in);
+    CParams& prm = *gp;
+    CConfig& c = prm.cfg;
+    LDSQ Lds<P>& L = lds<P>(uni((int)lds_in));
+    LDSQ EvalCtx& e = L.e;
     const int lane = threadIdx.x, M = uni(e.M), n = uni(e.n), NN = M * NS;
     const double xvI = c.standard_diff ? 0.0 : c.icr_xv;
     __syncthreads();
@@ -278,8 +321,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     // ---- norm guard (optimizer.cpp:635-636: `inf` is the macro 1 >> 30 = 0)
     double part = 0.0;
     for (int v = lane; v < n; v += 64) part += L.x[v] * L.x[v];
-    if (sqrt(uni(wave_sum(part))) > 1e4) { *skipped = true; return 0.0; }
-    *skipped = false;
+    if (sqrt(uni(wave_sum(part))) > 1e4) return 0.0; // cost 0, gradient untouched
 
     // ---- durations, knot positions
     double tpart = 0.0;
@@ -359,7 +401,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     for (int node = lane; node < NN; node += 64) {
         const int i = node / NS, j = node - i * NS;
         const double T = L.T[i], step = T / RES, t = j * (step / 2.0);
-        const double* ci = L.coef + 12 * i;
+        const LDSQ double* ci = L.coef + 12 * i;
         double sg[2], d1[2], d2[2], d3[2];
         for (int d = 0; d < 2; ++d) {
             const double c0 = ci[d], c1 = ci[2 + d], c2 = ci[4 + d], c3 = ci[6 + d], c4 = ci[8 + d], c5 = ci[10 + d];
@@ -408,7 +450,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
                          (gb[1][0] += ws * c.w_cen_acc * df * (2 * d1[0] * d1[1] * d1[1]),
                           gb[1][1] += ws * c.w_cen_acc * df * (2 * d1[0] * d1[0] * d1[1])));
         }
-        double* E = L.E + node * 6;
+        LDSQ double* E = L.E + node * 6;
         E[0] = gb[0][0]; E[1] = gb[0][1]; E[2] = gb[1][0]; E[3] = gb[1][1]; E[4] = gb[2][0]; E[5] = gb[2][1];
         L.nodeT[node] = gT;
     }
@@ -453,7 +495,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
             const int i = en / (RES + 1), je = en - i * (RES + 1), j = 2 * je, node = i * NS + j;
             const double T = L.T[i], step = T / RES, alpha = (double)je / RES, omg = (j == 0 || j == NS - 1) ? 0.5 : 1.0, ws = omg * step;
             const double px = L.posx[RES * i + je], py = L.posy[RES * i + je], cy = L.cy[node], sy = L.sy[node];
-            const double* ci = L.coef + 12 * i;
+            const LDSQ double* ci = L.coef + 12 * i;
             const double t = j * (step / 2.0);
             const double d1th = (((5.0 * ci[10] * t + 4.0 * ci[8]) * t + 3.0 * ci[6]) * t + 2.0 * ci[4]) * t + ci[2];
             double gpx = 0.0, gpy = 0.0, gb0 = 0.0, gT = 0.0;
@@ -479,8 +521,9 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
             L.nodeT[node] += gT;
         }
     } else { // way-point attraction at the end of every piece
+        const GLBQ double* way = (const GLBQ double*)e.positions;
         for (int i = lane; i < M; i += 64) {
-            const double ex = L.posx[RES * (i + 1)] - e.positions[2 * i], ey = L.posy[RES * (i + 1)] - e.positions[2 * i + 1];
+            const double ex = L.posx[RES * (i + 1)] - way[2 * i], ey = L.posy[RES * (i + 1)] - way[2 * i + 1];
             cost_part += c.p_bigpath * (ex * ex + ey * ey);
             L.fx[i * NS + NS - 1] = c.p_bigpath * 2.0 * ex;
             L.fy[i * NS + NS - 1] = c.p_bigpath * 2.0 * ey;
@@ -516,7 +559,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         const double T = L.T[i], step = T / RES, t = j * (step / 2.0), cint = T / (RES * 6), ialpha = (double)j / (2 * RES);
         const double sw = (j == 0 || j == NS - 1) ? 1.0 : ((j & 1) ? 4.0 : 2.0);
         const double cx = L.fx[node] * sw, cyy = L.fy[node] * sw, cy = L.cy[node], sy = L.sy[node];
-        const double* ci = L.coef + 12 * i;
+        const LDSQ double* ci = L.coef + 12 * i;
         double d1[2], d2[2];
         for (int d = 0; d < 2; ++d) {
             const double c1 = ci[2 + d], c2 = ci[4 + d], c3 = ci[6 + d], c4 = ci[8 + d], c5 = ci[10 + d];
@@ -526,7 +569,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
         const double fxv = d1[1] * cy + d1[0] * xvI * sy, fyv = d1[1] * sy - d1[0] * xvI * cy;
         // d(dx)/d(theta coefficients) = b0 (-s' sin + th' xv cos) + b1 xv sin ; d(dy)/.. = b0 (s' cos - th' xv sin) - b1 xv cos
         // (the reference's sign of the th' xv sin term, optimizer.cpp:822; exact would be +)
-        double* E = L.E + node * 6;
+        LDSQ double* E = L.E + node * 6;
         E[0] += cint * ((-d1[1] * sy + d1[0] * xvI * cy) * cx + (d1[1] * cy - d1[0] * xvI * sy) * cyy);
         E[2] += cint * xvI * (sy * cx - cy * cyy);
         E[3] += cint * (cy * cx + sy * cyy);
@@ -537,27 +580,28 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* __restrict__
     __syncthreads();
     BE_STAMP(11)
     // ---- node terms -> coefficient gradient: lane = (piece, power, dim); time gradient: lane = piece
-    for (int t = lane; t < 12 * M; t += 64) {
-        const int i = t / 12, r = t - i * 12, q = r >> 1, d = r & 1;
+    // One lane per (piece, dimension) carries the six accumulators of its powers: the running powers 1, t, t^2, ... of a node
+    // are formed once (the same products in the same order as a power loop per exponent) and serve all six, the three node
+    // terms are read once -- a fifth of the instructions of one lane per (piece, power, dimension), in one round.
+    for (int t = lane; t < 2 * M; t += 64) {
+        const int i = t >> 1, d = t & 1;
         const double half = L.T[i] / (2 * RES);
-        double acc = 0.0;
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int j = 0; j < NS; ++j) {
-            const double* E = L.E + (i * NS + j) * 6;
-            const double tt = j * half;
-            // t^(q-2), t^(q-1), t^q from the running powers 1, t, t^2, ... (same products in the same order as a
-            // power loop per exponent, without its data-dependent trip count)
-            double pw = 1.0, pm2 = 0.0, pm1 = 0.0, pq = 1.0;
+            const LDSQ double* E = L.E + (i * NS + j) * 6;
+            const double tt = j * half, E0 = E[d], E1 = E[2 + d], E2 = E[4 + d];
+            double pw[6];
+            pw[0] = 1.0;
 #pragma unroll
-            for (int k = 0; k <= 5; ++k) {
-                if (k == q - 2) pm2 = pw;
-                if (k == q - 1) pm1 = pw;
-                if (k == q) pq = pw;
-                pw *= tt;
+            for (int k = 1; k <= 5; ++k) pw[k] = pw[k - 1] * tt;
+#pragma unroll
+            for (int q = 0; q <= 5; ++q) {
+                const double p0 = pw[q], p1 = q >= 1 ? q * pw[q >= 1 ? q - 1 : 0] : 0.0, p2 = q >= 2 ? q * (q - 1) * pw[q >= 2 ? q - 2 : 0] : 0.0;
+                acc[q] += p0 * E0 + p1 * E1 + p2 * E2;
             }
-            const double p0 = pq, p1 = q >= 1 ? q * pm1 : 0.0, p2 = q >= 2 ? q * (q - 1) * pm2 : 0.0;
-            acc += p0 * E[d] + p1 * E[2 + d] + p2 * E[4 + d];
         }
-        L.gdC[t] += acc; // gdC index (6 i + q) * 2 + d = 12 i + r
+#pragma unroll
+        for (int q = 0; q <= 5; ++q) L.gdC[(6 * i + q) * 2 + d] += acc[q];
     }
     for (int i = lane; i < M; i += 64) {
         double acc = 0.0;
@@ -647,25 +691,77 @@ enum { LB_CONVERGENCE = 0, LB_STOP = 1, LBE_INVALID_FUNCVAL = -1012, LBE_MINIMUM
        LBE_INCREASEGRADIENT = -1005 };
 
 template <int P>
-__device__ double vdot(const double* a, const double* b, int n)
+__device__ double vdot(const LDSQ double* a, const LDSQ double* b, int n)
 {
     double s = 0.0;
     for (int v = threadIdx.x; v < n; v += 64) s += a[v] * b[v];
     return uni(wave_sum(s));
 }
 template <int P>
-__device__ double vmaxabs(const double* a, int n)
+__device__ double vmaxabs(const LDSQ double* a, int n)
 {
     double s = 0.0;
     for (int v = threadIdx.x; v < n; v += 64) s = fmax(s, fabs(a[v]));
     return uni(wave_max(s));
 }
 
+// a / b with r = 1 / b (correctly rounded) known in advance: two Newton corrections of a * r through exact residuals
+// (Markstein's division: the result is the correctly rounded quotient) -- five dependent multiply-adds on the chain of the
+// two-loop recursion instead of the ~12 dependent instructions of the division macro (v_div_scale, v_rcp_f64, ...).
+__device__ __forceinline__ double div_by_known(double a, double b, double r)
+{
+    const double q0 = a * r;
+    const double q1 = fma(fma(-b, q0, a), r, q0);
+    return fma(fma(-b, q1, a), r, q1);
+}
+
+// CH (s, y) pairs of the L-BFGS history in registers, as loaded: lane v holds entries v, v + 64, ... (clamped to the slab's
+// last slot, nstride - 1, where y's and its reciprocal ride: lane 63 of the last round has them).  Pairs first, first + dir,
+// ... (mod m).  EVERY load is issued whatever the number of pairs wanted and n are, and nothing here looks at a loaded value:
+// with loads under conditions the compiler cannot count the outstanding ones and waits for all of them -- the next chunk's
+// included -- before the first use; the consumer masks (pair_values).
+template <int NVL, int CH>
+struct PairChunk {
+    double s[CH][NVL], y[CH][NVL];
+};
+template <int NVL, int CH>
+__device__ __forceinline__ void load_pairs(PairChunk<NVL, CH>& c, const GLBQ double* hist, int nstride, int m, int first, int dir, int lane)
+{
+#pragma unroll
+    for (int cidx = 0; cidx < CH; ++cidx) {
+        int jj = first + dir * cidx;
+        if (m >= CH) { jj += jj < 0 ? m : 0; jj -= jj >= m ? m : 0; }
+        else jj = ((jj % m) + m) % m;
+        const GLBQ double* sj = hist + (size_t)jj * 2 * nstride;
+#pragma unroll
+        for (int r = 0; r < NVL; ++r) {
+            const int at = min(lane + 64 * r, nstride - 1);
+            c.s[cidx][r] = sj[at];
+            c.y[cidx][r] = sj[nstride + at];
+        }
+    }
+}
+// pair cidx of a chunk: the vectors with the lanes beyond n zeroed, y's and 1 / y's
+template <int NVL, int CH>
+__device__ __forceinline__ void pair_values(const PairChunk<NVL, CH>& c, int cidx, int n, int lane, double (&sv)[NVL], double (&yv)[NVL], double& ys,
+                                            double& rys)
+{
+#pragma unroll
+    for (int r = 0; r < NVL; ++r) {
+        const bool in = lane + 64 * r < n;
+        sv[r] = in ? c.s[cidx][r] : 0.0;
+        yv[r] = in ? c.y[cidx][r] : 0.0;
+    }
+    ys = lane63(c.s[cidx][NVL - 1]);
+    rys = lane63(c.y[cidx][NVL - 1]);
+}
+
 // line_search_lewisoverton: x, g in L.x / L.g; s = L.d; xp, gp in L.xp / L.gp
 template <int P>
-__device__ int line_search(const Params* __restrict__ gp, const LbfgsParam& pr, double& f, double& stp, double stpmin, double stpmax)
+__device__ __forceinline__ int line_search(const Params* gp, unsigned lbase, const LbfgsParam& pr, double& f, double& stp, double stpmin,
+                                           double stpmax)
 {
-    Lds<P>& L = lds<P>();
+    LDSQ Lds<P>& L = lds<P>(lbase);
     const int n = uni(L.e.n), lane = threadIdx.x;
     int count = 0;
     bool brackt = false, touched = false;
@@ -677,8 +773,7 @@ __device__ int line_search(const Params* __restrict__ gp, const LbfgsParam& pr, 
     for (;;) {
         for (int v = lane; v < n; v += 64) L.x[v] = L.xp[v] + stp * L.d[v];
         __syncthreads();
-        bool skipped;
-        f = eval_cost<P>(gp, &skipped);
+        f = uni(eval_cost<P>(gp, lbase)); // a function's return value arrives in vector registers
         ++count;
         if (isinf(f) || isnan(f)) return LBE_INVALID_FUNCVAL;
         if (pr.past > 0 && fabs(finit - f) / (fabs(finit) + 1.0) < pr.delta / pr.past) return count;
@@ -704,14 +799,18 @@ __device__ int line_search(const Params* __restrict__ gp, const LbfgsParam& pr, 
 
 // lbfgs_optimize.  hist: [mem][2][nstride] doubles of this problem.  iter_cap > 0 limits the iterations.
 template <int P>
-__device__ __attribute__((noinline)) int lbfgs(const Params* __restrict__ gp, const LbfgsParam pr, double* hist, int nstride, int iter_cap,
-                                               double& f_out, int& k_out)
+__device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds_in, const LbfgsParam pr_in, double* hist_in, int nstride_in,
+                                               int iter_cap_in, double& f_out, int& k_out)
 {
-    Lds<P>& L = lds<P>();
+    const Params* gp = uni_ptr(gp_in);
+    const unsigned lbase = uni((int)lds_in);
+    const LbfgsParam pr = uni(pr_in);
+    GLBQ double* hist = (GLBQ double*)uni_ptr(hist_in);
+    const int nstride = uni(nstride_in), iter_cap = uni(iter_cap_in);
+    LDSQ Lds<P>& L = lds<P>(lbase);
     const int n = uni(L.e.n), lane = threadIdx.x, m = pr.mem_size;
     int ret, k = 1, end = 0, bound = 0;
-    bool skipped;
-    double fx = eval_cost<P>(gp, &skipped);
+    double fx = uni(eval_cost<P>(gp, lbase));
     if (lane == 0) L.pf[0] = fx;
     for (int v = lane; v < n; v += 64) L.d[v] = -L.g[v];
     __syncthreads();
@@ -723,7 +822,7 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* __restrict__ gp, co
         for (;;) {
             for (int v = lane; v < n; v += 64) { L.xp[v] = L.x[v]; L.gp[v] = L.g[v]; }
             __syncthreads();
-            const int ls = line_search<P>(gp, pr, fx, step, pr.min_step, pr.max_step);
+            const int ls = line_search<P>(gp, lbase, pr, fx, step, pr.min_step, pr.max_step);
             if (ls < 0) {
                 for (int v = lane; v < n; v += 64) { L.x[v] = L.xp[v]; L.g[v] = L.gp[v]; }
                 __syncthreads();
@@ -744,8 +843,8 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* __restrict__ gp, co
             }
             if ((pr.max_iterations != 0 && pr.max_iterations <= k) || (iter_cap > 0 && iter_cap <= k)) { ret = LBE_MAXIMUMITERATION; break; }
             ++k;
-            double* sk = hist + (size_t)end * 2 * nstride;
-            double* yk = sk + nstride;
+            GLBQ double* sk = hist + (size_t)end * 2 * nstride;
+            GLBQ double* yk = sk + nstride;
             double pys = 0.0, pyy = 0.0, pss = 0.0, pgg = 0.0;
             for (int v = lane; v < n; v += 64) {
                 const double s = L.x[v] - L.xp[v], y = L.g[v] - L.gp[v];
@@ -756,84 +855,108 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* __restrict__ gp, co
             }
             const double ys = uni(wave_sum(pys)), yy = uni(wave_sum(pyy));
             const double cau = uni(wave_sum(pss)) * sqrt(uni(wave_sum(pgg))) * pr.cautious_factor;
-            if (lane == 0) L.ys[end] = ys;
+            // y's and its reciprocal ride in the last slot of the pair's s / y slabs (n <= nstride - 1: the slot is free) and
+            // come back with the chunk loads of the recursion
+            if (lane == 0) { sk[nstride - 1] = ys; yk[nstride - 1] = 1.0 / ys; }
             __syncthreads();
+            BE_STAMP(20)
             if (ys > cau) {
                 ++bound;
                 if (bound > m) bound = m;
                 end = (end + 1) % m;
                 // Two-loop recursion (lbfgs.hpp:704-735).  d stays in registers (NVL values per lane); the (s, y)
-                // pairs come from HBM in chunks of CH pairs whose 2 * CH * NVL loads are all in flight together --
-                // one memory latency per chunk instead of two per pair.  Same operations in the same order as the
-                // pair-at-a-time form: results are bit-identical.
+                // pairs come from HBM in chunks of CH pairs whose loads are all in flight together, and the loads of
+                // the NEXT chunk are issued before the current one is worked on (two register buffers): the memory
+                // latency of a chunk hides under the dependent chain of the one before it.  Same operations in the
+                // same order as the pair-at-a-time form.
                 constexpr int NVL = (3 * P + 63) / 64, CH = 8;
+                typedef PairChunk<NVL, CH> Chunk;
                 double dreg[NVL];
 #pragma unroll
                 for (int r = 0; r < NVL; ++r) dreg[r] = (lane + 64 * r < n) ? L.d[lane + 64 * r] : 0.0;
-                int j = end;
-                for (int i0 = 0; i0 < bound; i0 += CH) {
-                    const int cnt = min(CH, bound - i0);
-                    double sv[CH][NVL], yv[CH][NVL];
-#pragma unroll
-                    for (int cidx = 0; cidx < CH; ++cidx) {
-                        const int jj = (j + 2 * m - 1 - cidx) % m;
-                        const double* sj = hist + (size_t)jj * 2 * nstride;
-#pragma unroll
-                        for (int r = 0; r < NVL; ++r) {
-                            const bool in = cidx < cnt && lane + 64 * r < n;
-                            sv[cidx][r] = in ? sj[lane + 64 * r] : 0.0;
-                            yv[cidx][r] = in ? sj[nstride + lane + 64 * r] : 0.0;
-                        }
-                    }
+                auto wrap = [m](int v) { while (v < 0) v += m; while (v >= m) v -= m; return v; };
+                int j = end, left = bound;
+                // first loop: pairs j - 1, j - 2, ... (newest first)
+                auto first_loop = [&](const Chunk& c, int cnt) {
 #pragma unroll
                     for (int cidx = 0; cidx < CH; ++cidx) {
                         if (cidx < cnt) {
-                            j = (j + m - 1) % m;
+                            j = (j == 0 ? m : j) - 1;
+                            double sv[NVL], yv[NVL], ysj, rysj;
+                            pair_values(c, cidx, n, lane, sv, yv, ysj, rysj);
                             double p = 0.0;
 #pragma unroll
-                            for (int r = 0; r < NVL; ++r) p += sv[cidx][r] * dreg[r];
-                            const double a = uni(wave_sum(p)) / L.ys[j];
+                            for (int r = 0; r < NVL; ++r) p += sv[r] * dreg[r];
+                            const double a = div_by_known(uni(wave_sum(p)), ysj, rysj);
                             if (lane == 0) L.alpha[j] = a;
 #pragma unroll
-                            for (int r = 0; r < NVL; ++r) dreg[r] += (-a) * yv[cidx][r];
+                            for (int r = 0; r < NVL; ++r) dreg[r] += (-a) * yv[r];
                         }
+                    }
+                };
+                {
+                    Chunk A, B;
+                    int cntA = min(CH, left), cntB;
+                    load_pairs(A, hist, nstride, m, wrap(j - 1), -1, lane);
+                    for (;;) {
+                        left -= cntA;
+                        cntB = min(CH, left);
+                        load_pairs(B, hist, nstride, m, wrap(j - 1 - cntA), -1, lane);
+                        first_loop(A, cntA);
+                        if (cntB == 0) break;
+                        left -= cntB;
+                        cntA = min(CH, left);
+                        load_pairs(A, hist, nstride, m, wrap(j - 1 - cntB), -1, lane);
+                        first_loop(B, cntB);
+                        if (cntA == 0) break;
                     }
                 }
                 const double sc = ys / yy;
 #pragma unroll
                 for (int r = 0; r < NVL; ++r) dreg[r] *= sc;
                 __syncthreads(); // alpha[] written by lane 0 is read back below
-                for (int i0 = 0; i0 < bound; i0 += CH) {
-                    const int cnt = min(CH, bound - i0);
-                    double sv[CH][NVL], yv[CH][NVL];
-#pragma unroll
-                    for (int cidx = 0; cidx < CH; ++cidx) {
-                        const int jj = (j + cidx) % m;
-                        const double* sj = hist + (size_t)jj * 2 * nstride;
-#pragma unroll
-                        for (int r = 0; r < NVL; ++r) {
-                            const bool in = cidx < cnt && lane + 64 * r < n;
-                            sv[cidx][r] = in ? sj[lane + 64 * r] : 0.0;
-                            yv[cidx][r] = in ? sj[nstride + lane + 64 * r] : 0.0;
-                        }
-                    }
+                BE_STAMP(21)
+                if (gp->stamps && blockIdx.x == 0 && threadIdx.x == 0) { GLBQ long long* st_ = (GLBQ long long*)gp->stamps; st_[40] += 1; st_[41] += bound; }
+                // second loop: pairs j, j + 1, ... (oldest first)
+                auto second_loop = [&](const Chunk& c, int cnt) {
 #pragma unroll
                     for (int cidx = 0; cidx < CH; ++cidx) {
                         if (cidx < cnt) {
+                            double sv[NVL], yv[NVL], ysj, rysj;
+                            pair_values(c, cidx, n, lane, sv, yv, ysj, rysj);
                             double p = 0.0;
 #pragma unroll
-                            for (int r = 0; r < NVL; ++r) p += yv[cidx][r] * dreg[r];
-                            const double beta = uni(wave_sum(p)) / L.ys[j];
+                            for (int r = 0; r < NVL; ++r) p += yv[r] * dreg[r];
+                            const double beta = div_by_known(uni(wave_sum(p)), ysj, rysj);
                             const double a = L.alpha[j];
 #pragma unroll
-                            for (int r = 0; r < NVL; ++r) dreg[r] += (a - beta) * sv[cidx][r];
-                            j = (j + 1) % m;
+                            for (int r = 0; r < NVL; ++r) dreg[r] += (a - beta) * sv[r];
+                            j = (j + 1 == m) ? 0 : j + 1;
                         }
+                    }
+                };
+                {
+                    Chunk A, B;
+                    left = bound;
+                    int cntA = min(CH, left), cntB;
+                    load_pairs(A, hist, nstride, m, j, 1, lane);
+                    for (;;) {
+                        left -= cntA;
+                        cntB = min(CH, left);
+                        load_pairs(B, hist, nstride, m, wrap(j + cntA), 1, lane);
+                        second_loop(A, cntA);
+                        if (cntB == 0) break;
+                        left -= cntB;
+                        cntA = min(CH, left);
+                        load_pairs(A, hist, nstride, m, wrap(j + cntB), 1, lane);
+                        second_loop(B, cntB);
+                        if (cntA == 0) break;
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < NVL; ++r)
                     if (lane + 64 * r < n) L.d[lane + 64 * r] = dreg[r];
+                BE_STAMP(22)
             }
             __syncthreads();
             step = 1.0;
@@ -846,12 +969,13 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* __restrict__ gp, co
 
 // final collision check (optimizer.cpp:474-571): 16 Simpson panels per piece, ESDF at the panel ends
 template <int P>
-__device__ __attribute__((noinline)) bool final_collision(const Params* __restrict__ gp, double& min_dist)
+__device__ __attribute__((noinline)) bool final_collision(const Params* gp_in, unsigned lds_in, double& min_dist)
 {
-    const Params& prm = *gp;
-    const Config& c = prm.cfg;
-    Lds<P>& L = lds<P>();
-    const EvalCtx& e = L.e;
+    CParams* gp = (CParams*)uni_ptr(gp_in);
+    CParams& prm = *gp;
+    CConfig& c = prm.cfg;
+    LDSQ Lds<P>& L = lds<P>(uni((int)lds_in));
+    const LDSQ EvalCtx& e = L.e;
     const int lane = threadIdx.x, M = uni(e.M), R = c.final_check_num, NP = R * M;
     const double xvI = c.standard_diff ? 0.0 : c.icr_xv;
     double carry_x = e.start_xy[0], carry_y = e.start_xy[1], mind = 1.79769313486231570815e+308;
@@ -862,7 +986,7 @@ __device__ __attribute__((noinline)) bool final_collision(const Params* __restri
         if (p < NP) {
             const int i = p / R, q = p - i * R;
             const double T = L.T[i], half = T / R / 2.0, cint = T / R / 6.0;
-            const double* ci = L.coef + 12 * i;
+            const LDSQ double* ci = L.coef + 12 * i;
             for (int s = 0; s < 3; ++s) {
                 const double t = (2 * q + s) * half;
                 double sg, d1[2];
@@ -903,10 +1027,10 @@ __device__ __attribute__((noinline)) bool final_collision(const Params* __restri
 }
 
 template <int P>
-__device__ void load_problem(const Params& prm, int b)
+__device__ void load_problem(const Params& prm, unsigned lbase, int b)
 {
-    Lds<P>& L = lds<P>();
-    EvalCtx& e = L.e;
+    LDSQ Lds<P>& L = lds<P>(lbase);
+    LDSQ EvalCtx& e = L.e;
     const ProblemStore& s = prm.prob;
     if (threadIdx.x == 0) {
         e.M = s.M[b];
@@ -924,18 +1048,20 @@ __device__ void load_problem(const Params& prm, int b)
 
 } // namespace
 
+// LDS admits four workgroups per CU (one wavefront per SIMD): the register file of a SIMD belongs to one wavefront
 template <int P>
-__global__ __launch_bounds__(64) void backend_kernel(const Params* __restrict__ gp)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void backend_kernel(const Params* __restrict__ gp)
 {
     if (gp->stamps && blockIdx.x == 0 && threadIdx.x == 0) gp->stamps[63] = (long long)__builtin_readcyclecounter();
     const Params& prm = *gp;
-    Lds<P>& L = lds<P>();
-    EvalCtx& e = L.e;
+    const unsigned lbase = lds_base_of_kernel();
+    LDSQ Lds<P>& L = lds<P>(lbase);
+    LDSQ EvalCtx& e = L.e;
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= prm.count) return;
     const int b = prm.order ? prm.order[blockIdx.x] : (int)blockIdx.x;
     const Config& c = prm.cfg;
-    load_problem<P>(prm, b);
+    load_problem<P>(prm, lbase, b);
     const int M = uni(e.M), n = uni(e.n), nstride = 3 * prm.prob.P;
     double* hist = prm.hist + (size_t)b * MEM_MAX * 2 * nstride;
     const bool cut = prm.prob.if_cut[b] != 0;
@@ -956,12 +1082,11 @@ __global__ __launch_bounds__(64) void backend_kernel(const Params* __restrict__ 
         double cost;
         int ret = 0, iters = 0;
         if (prm.mode == MODE_EVAL) {
-            bool skipped;
-            cost = eval_cost<P>(gp, &skipped);
+            cost = uni(eval_cost<P>(gp, lbase));
         } else {
             LbfgsParam pr = prm.stage == 1 ? c.path_lbfgs : c.lbfgs;
             if (prm.stage == 1 && fabs(e.tail[1][0]) < c.shot_path_horizon) pr.past = c.shot_path_past;
-            ret = lbfgs<P>(gp, pr, hist, nstride, prm.max_iter, cost, iters);
+            ret = uni(lbfgs<P>(gp, lbase, pr, hist, nstride, prm.max_iter, cost, iters));
         }
         __syncthreads();
         for (int v = lane; v < n; v += 64) {
@@ -1017,14 +1142,14 @@ __global__ __launch_bounds__(64) void backend_kernel(const Params* __restrict__ 
         LbfgsParam pp = c.path_lbfgs;
         if (fabs(tail_s0) < c.shot_path_horizon) pp.past = c.shot_path_past;
         int iters;
-        path_ret = lbfgs<P>(gp, pp, hist, nstride, 0, cost, iters);
+        path_ret = uni(lbfgs<P>(gp, lbase, pp, hist, nstride, 0, cost, iters));
         // stage 2: augmented-Lagrangian loop
         __syncthreads();
         if (lane == 0) e.stage = 2;
         __syncthreads();
         alm_rounds = 0;
         for (;;) {
-            lb_ret = lbfgs<P>(gp, c.lbfgs, hist, nstride, 0, cost, iters);
+            lb_ret = uni(lbfgs<P>(gp, lbase, c.lbfgs, hist, nstride, 0, cost, iters));
             ++alm_rounds;
             __syncthreads();
             const double ex = uni(e.xy_err[0]), ey = uni(e.xy_err[1]);
@@ -1043,12 +1168,9 @@ __global__ __launch_bounds__(64) void backend_kernel(const Params* __restrict__ 
         ++attempts;
         // final trajectory: setParameters(finalInnerpoints, finalpieceTime) -- one more pass leaves T and the
         // coefficients of the final x in LDS (its cost and gradient are not used)
-        {
-            bool skipped;
-            (void)eval_cost<P>(gp, &skipped);
-        }
+        (void)eval_cost<P>(gp, lbase);
         __syncthreads();
-        collision = final_collision<P>(gp, min_dist);
+        collision = uni((int)final_collision<P>(gp, lbase, min_dist)) != 0;
         if (!collision) break;
         tw *= 0.75;
     }
