@@ -19,6 +19,8 @@
 // Control flow is wave-uniform by construction (every decision is taken on a butterfly-reduced value).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "backend_kernels.h"
 #include "minco_spline.h"
 
@@ -66,14 +68,25 @@ __device__ __forceinline__ double lane63(double v)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// The total only: the value of lane 63 of the scan below, computed by the same additions in the same order -- but nothing
+// else has to be right, so the moves need no `old` operand (row shifts fill with zeros through bound_ctrl, the broadcasts go
+// to every row they reach: what lands in lanes that do not feed lane 63 is never looked at): three instructions per level
+// instead of six.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_nofill(double x)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-    v += dpp_f64<0x111, 0xF>(0.0, v); // row_shr:1   (lanes without a source keep `old` = 0)
-    v += dpp_f64<0x112, 0xF>(0.0, v); // row_shr:2
-    v += dpp_f64<0x114, 0xF>(0.0, v); // row_shr:4
-    v += dpp_f64<0x118, 0xF>(0.0, v); // row_shr:8
-    v += dpp_f64<0x142, 0xA>(0.0, v); // row_bcast15 into rows 1 and 3
-    v += dpp_f64<0x143, 0xC>(0.0, v); // row_bcast31 into rows 2 and 3
+    v += dpp_f64_nofill<0x111>(v); // row_shr:1
+    v += dpp_f64_nofill<0x112>(v); // row_shr:2
+    v += dpp_f64_nofill<0x114>(v); // row_shr:4
+    v += dpp_f64_nofill<0x118>(v); // row_shr:8: lanes 15, 31, 47, 63 hold their rows' sums
+    v += dpp_f64_nofill<0x142>(v); // row_bcast15: lane 31 = rows 0 + 1, lane 63 = rows 2 + 3
+    v += dpp_f64_nofill<0x143>(v); // row_bcast31: lane 63 += lane 31
     return lane63(v);
 }
 // inclusive prefix sum over the 64 lanes (the scan wave_sum reads its total from), and the suffix sum: lanes reversed
@@ -877,10 +890,11 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
                 auto wrap = [m](int v) { while (v < 0) v += m; while (v >= m) v -= m; return v; };
                 int j = end, left = bound;
                 // first loop: pairs j - 1, j - 2, ... (newest first)
-                auto first_loop = [&](const Chunk& c, int cnt) {
+                // (a whole chunk runs as straight-line code: the preparation of a pair overlaps the chain of the one before)
+                auto first_loop = [&](const Chunk& c, int cnt, auto full) {
 #pragma unroll
                     for (int cidx = 0; cidx < CH; ++cidx) {
-                        if (cidx < cnt) {
+                        if (decltype(full)::value || cidx < cnt) {
                             j = (j == 0 ? m : j) - 1;
                             double sv[NVL], yv[NVL], ysj, rysj;
                             pair_values(c, cidx, n, lane, sv, yv, ysj, rysj);
@@ -888,7 +902,7 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
 #pragma unroll
                             for (int r = 0; r < NVL; ++r) p += sv[r] * dreg[r];
                             const double a = div_by_known(uni(wave_sum(p)), ysj, rysj);
-                            if (lane == 0) L.alpha[j] = a;
+                            L.alpha[j] = a; // every lane, the same value
 #pragma unroll
                             for (int r = 0; r < NVL; ++r) dreg[r] += (-a) * yv[r];
                         }
@@ -902,12 +916,12 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
                         left -= cntA;
                         cntB = min(CH, left);
                         load_pairs(B, hist, nstride, m, wrap(j - 1 - cntA), -1, lane);
-                        first_loop(A, cntA);
+                        if (cntA == CH) first_loop(A, cntA, std::true_type{}); else first_loop(A, cntA, std::false_type{});
                         if (cntB == 0) break;
                         left -= cntB;
                         cntA = min(CH, left);
                         load_pairs(A, hist, nstride, m, wrap(j - 1 - cntB), -1, lane);
-                        first_loop(B, cntB);
+                        if (cntB == CH) first_loop(B, cntB, std::true_type{}); else first_loop(B, cntB, std::false_type{});
                         if (cntA == 0) break;
                     }
                 }
@@ -918,10 +932,10 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
                 BE_STAMP(21)
                 if (gp->stamps && blockIdx.x == 0 && threadIdx.x == 0) { GLBQ long long* st_ = (GLBQ long long*)gp->stamps; st_[40] += 1; st_[41] += bound; }
                 // second loop: pairs j, j + 1, ... (oldest first)
-                auto second_loop = [&](const Chunk& c, int cnt) {
+                auto second_loop = [&](const Chunk& c, int cnt, auto full) {
 #pragma unroll
                     for (int cidx = 0; cidx < CH; ++cidx) {
-                        if (cidx < cnt) {
+                        if (decltype(full)::value || cidx < cnt) {
                             double sv[NVL], yv[NVL], ysj, rysj;
                             pair_values(c, cidx, n, lane, sv, yv, ysj, rysj);
                             double p = 0.0;
@@ -944,12 +958,12 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
                         left -= cntA;
                         cntB = min(CH, left);
                         load_pairs(B, hist, nstride, m, wrap(j + cntA), 1, lane);
-                        second_loop(A, cntA);
+                        if (cntA == CH) second_loop(A, cntA, std::true_type{}); else second_loop(A, cntA, std::false_type{});
                         if (cntB == 0) break;
                         left -= cntB;
                         cntA = min(CH, left);
                         load_pairs(A, hist, nstride, m, wrap(j + cntB), 1, lane);
-                        second_loop(B, cntB);
+                        if (cntB == CH) second_loop(B, cntB, std::true_type{}); else second_loop(B, cntB, std::false_type{});
                         if (cntA == 0) break;
                     }
                 }
