@@ -54,6 +54,15 @@ struct Quad7 { // symmetric 7 x 7 form H and vector h in w = (xi0..4, u0, u1); o
 
 __device__ __forceinline__ double& W(const Dev& d, int j, int f, int b) { return d.ws[((size_t)j * NF + f) * d.stride + b]; }
 
+// 1 if the float64 at p is NaN or Inf, by its exponent bits (this file is built without NaN / Inf semantics: no floating-point
+// test would survive).  A plain 32-bit load of the high word; the empty asm keeps the optimiser from reasoning about the value.
+__device__ __forceinline__ unsigned nf_bits(const double* p)
+{
+    unsigned hi = reinterpret_cast<const unsigned*>(p)[1];
+    asm volatile("" : "+v"(hi));
+    return ((hi >> 20) & 0x7ffu) == 0x7ffu ? 1u : 0u;
+}
+
 __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -78,11 +87,11 @@ __global__ __launch_bounds__(64) void get_cmd_kernel(Dev d)
     const double x0 = d.now[(size_t)b * 3], y0 = d.now[(size_t)b * 3 + 1], th0 = d.now[(size_t)b * 3 + 2];
     int sweeps = 0, status = 0;
     { // this file is built without NaN / Inf semantics: a robot with a non-finite input is not solved at all (bit tests)
-        bool bad = false;
-        for (int i = 0; i < 3; ++i) bad = bad || non_finite_at(d.now + (size_t)b * 3 + i);
-        for (int i = 0; i < 3 * T; ++i) bad = bad || non_finite_at(xr + i);
-        for (int i = 0; i < 2 * T; ++i) bad = bad || non_finite_at(dr + i) || non_finite_at(out + i);
-        for (int i = 0; i < 2 * dl; ++i) bad = bad || non_finite_at(bf + i);
+        unsigned bad = 0u;
+        for (int i = 0; i < 3; ++i) bad |= nf_bits(d.now + (size_t)b * 3 + i);
+        for (int i = 0; i < 3 * T; ++i) bad |= nf_bits(xr + i);
+        for (int i = 0; i < 2 * T; ++i) bad |= nf_bits(dr + i) | nf_bits(out + i);
+        for (int i = 0; i < 2 * dl; ++i) bad |= nf_bits(bf + i);
         if (bad) {
             d.sweeps[b] = 0;
             d.status[b] = STATUS_NON_FINITE;
@@ -479,17 +488,18 @@ __global__ __launch_bounds__(64) void get_cmd_lanes_kernel(Dev d)
     // its wavefront mates, it gets status 2 and a zero command, and its stored output / working set / delay buffer stay.
     bool poisoned;
     {
-        bool bad = (j < 3) && non_finite_at(d.now + (size_t)b * 3 + j);
+        // (plain loads of the high words, all in flight together, made opaque to the optimiser: a volatile load per value is a
+        // system-scope access of its own, and behind short-circuit ORs thirteen of them ran one after the other -- ~20 us)
+        unsigned bad = (j < 3) ? nf_bits(d.now + (size_t)b * 3 + j) : 0u;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int kc = min(j * S + s, K - 1);
-            bad = bad || non_finite_at(xrg + (dl + kc) * 3) || non_finite_at(xrg + (dl + kc) * 3 + 1) || non_finite_at(xrg + (dl + kc) * 3 + 2) ||
-                  non_finite_at(drg + (dl + kc) * 2);
-            if (!d.reset) bad = bad || non_finite_at(out + 2 * (dl + kc)) || non_finite_at(out + 2 * (dl + kc) + 1);
+            bad |= nf_bits(xrg + (dl + kc) * 3) | nf_bits(xrg + (dl + kc) * 3 + 1) | nf_bits(xrg + (dl + kc) * 3 + 2) | nf_bits(drg + (dl + kc) * 2);
+            if (!d.reset) bad |= nf_bits(out + 2 * (dl + kc)) | nf_bits(out + 2 * (dl + kc) + 1);
         }
         if (!d.reset)
-            for (int i = j; i < 2 * dl; i += 16) bad = bad || non_finite_at(out + i) || non_finite_at(bf + i);
-        poisoned = ((__ballot(bad) >> (lane & ~15)) & 0xffffull) != 0ull;
+            for (int i = j; i < 2 * dl; i += 16) bad |= nf_bits(out + i) | nf_bits(bf + i);
+        poisoned = ((__ballot(bad != 0u) >> (lane & ~15)) & 0xffffull) != 0ull;
         if (poisoned) {
 #pragma unroll
             for (int s = 0; s < S; ++s) { ua[s] = uw[s] = 0.0; xr[s][0] = xr[s][1] = xr[s][2] = 0.0; dr0[s] = 0.0; st[s][0] = st[s][1] = FREE; }
