@@ -190,7 +190,7 @@ __device__ __forceinline__ double esdf(CMapView& m, double x, double y, bool wan
 // everything a cost evaluation needs besides x; lives in LDS (wave-uniform, written by lane 0 + barrier or by
 // all lanes with the same value)
 struct EvalCtx {
-    int M, n, stage, evals;
+    int M, n, stage, evals, prob;
     double lam[2], rho[2], safe_dis, time_weight;
     const double* positions; // [M][2] way-points + final (stage 1)
     double head[2][3], tail[2][3], start_xy[2], final_xy[2];
@@ -769,6 +769,83 @@ __device__ __forceinline__ void pair_values(const PairChunk<NVL, CH>& c, int cid
     rys = lane63(c.y[cidx][NVL - 1]);
 }
 
+
+// ---- two-loop recursion on aligned chunks of 8 pairs with their cross products at hand ------------------------------------
+// The pair-at-a-time recursion is one chain: every pair pays a wavefront sum, a division and an update before the next may
+// start (~260 cycles for a lone wavefront, tools/micro/wave_sum_f64.hip), and a plan with 50 pairs in its history walks it a
+// hundred times per iteration.  Inside an aligned chunk of 8 slots the chain shortens to scalar work when the cross products
+// G[k][l] = s_k . y_l (k < l) are known -- and they are properties of the history, computed once when pair l arrives:
+//   first loop  (l descending):  a_l = (s_l . q_top - sum_{j > l} a_j G[l][j]) / y's_l,        q -= a_l y_l
+//   second loop (l ascending):   b_l = (y_l . r_base + sum_{j < l} (a_j - b_j) G[j][l]) / y's_l,  r += (a_l - b_l) s_l
+// (q_top / r_base: the vector as the chunk finds it).  The 8 products of a chunk against that vector are independent and are
+// summed TOGETHER (sum8: a transposing butterfly, 64 instructions for 8 wavefront sums instead of 8 x 19); the recurrence runs
+// lane-parallel (lane k carries row k of G and its running numerator: a step is the division in every lane, one v_readlane
+// for the pair whose turn it is, one multiply-add on the numerators and one on the vector).  Same algebra as lbfgs.hpp:704-735,
+// sums associate differently (float64 rounding).  Used while the history has not wrapped (slots 0 .. bound - 1, which is every
+// iteration of a run of up to mem_size iterations); after that the pair-at-a-time form below takes over.
+__device__ __forceinline__ double xor4_f64(double x)
+{
+    const int xl = __double2loint(x), xh = __double2hiint(x);
+    int lo = __builtin_amdgcn_update_dpp(0, xl, 0x104, 0xF, 0x5, false); // row_shl:4 into banks 0, 2: lane i <- i + 4
+    int hi = __builtin_amdgcn_update_dpp(0, xh, 0x104, 0xF, 0x5, false);
+    lo = __builtin_amdgcn_update_dpp(lo, xl, 0x114, 0xF, 0xA, false);   // row_shr:4 into banks 1, 3: lane i <- i - 4
+    hi = __builtin_amdgcn_update_dpp(hi, xh, 0x114, 0xF, 0xA, false);
+    return __hiloint2double(hi, lo);
+}
+// sums over the wavefront of 8 vectors at once: lane i returns the total of v[i & 7]
+__device__ __forceinline__ double sum8(const double (&v)[8], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    double w[4], x[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { // lanes i, i ^ 1: the even lane keeps vector 2 i, the odd one vector 2 i + 1
+        const double keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+        w[i] = keep + dpp_f64_nofill<0xB1>(send); // quad_perm [1, 0, 3, 2]
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = b1 ? w[2 * i + 1] : w[2 * i], send = b1 ? w[2 * i] : w[2 * i + 1];
+        x[i] = keep + dpp_f64_nofill<0x4E>(send); // quad_perm [2, 3, 0, 1]
+    }
+    const double keep = b2 ? x[1] : x[0], send = b2 ? x[0] : x[1];
+    double y = keep + xor4_f64(send);   // lane i: vector i & 7, summed over its group of 8 lanes
+    y += dpp_f64_nofill<0x128>(y);      // row_ror:8: over the row of 16
+    { // rows 0 + 2 and 1 + 3, then even + odd (v_permlane32_swap / v_permlane16_swap, gfx950)
+        const auto l32 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(y), (unsigned)__double2loint(y), false, false);
+        const auto h32 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(y), (unsigned)__double2hiint(y), false, false);
+        y = __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);
+        const auto l16 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(y), (unsigned)__double2loint(y), false, false);
+        const auto h16 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(y), (unsigned)__double2hiint(y), false, false);
+        y = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);
+    }
+    return y;
+}
+__device__ __forceinline__ double lane_of(double v, int l) // wave-uniform l
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// one aligned chunk in registers: lane v holds entry v of the 8 s and y vectors (slots 8 c .. 8 c + 7; entries beyond n are
+// zeros / y's: finite, and they meet zeros of the other factor), lane k (mod 8) row k of G (first loop) or of its transpose
+// (second loop) and y's, 1 / y's of slot 8 c + k
+struct GramChunk {
+    double s[8], y[8], g[8], ys, rys;
+};
+__device__ __forceinline__ void load_gram_chunk(GramChunk& c, const GLBQ double* hist, const GLBQ double* gram, int nstride, int chunk, int goff, int lane)
+{
+    const int at = min(lane, nstride - 1), k = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const GLBQ double* sj = hist + (size_t)(8 * chunk + i) * 2 * nstride;
+        c.s[i] = sj[at];
+        c.y[i] = sj[nstride + at];
+    }
+    const GLBQ double* row = gram + goff + chunk * 64 + k * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.g[i] = row[i];
+    c.ys = gram[GRAM_YS + 8 * chunk + k];
+    c.rys = gram[GRAM_RYS + 8 * chunk + k];
+}
+
 // line_search_lewisoverton: x, g in L.x / L.g; s = L.d; xp, gp in L.xp / L.gp
 template <int P>
 __device__ __forceinline__ int line_search(const Params* gp, unsigned lbase, const LbfgsParam& pr, double& f, double& stp, double stpmin,
@@ -870,13 +947,104 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
             const double cau = uni(wave_sum(pss)) * sqrt(uni(wave_sum(pgg))) * pr.cautious_factor;
             // y's and its reciprocal ride in the last slot of the pair's s / y slabs (n <= nstride - 1: the slot is free) and
             // come back with the chunk loads of the recursion
-            if (lane == 0) { sk[nstride - 1] = ys; yk[nstride - 1] = 1.0 / ys; }
+            // (the slots between n and the last one are zeroed: the chunked recursion multiplies whole slabs)
+            for (int v = n + lane; v < nstride - 1; v += 64) { sk[v] = 0.0; yk[v] = 0.0; }
+            if (lane == 0) {
+                const double rys = 1.0 / ys;
+                sk[nstride - 1] = ys; yk[nstride - 1] = rys;
+                if (gp->gram) {
+                    GLBQ double* gram = (GLBQ double*)gp->gram + (size_t)L.e.prob * GRAM_DOUBLES;
+                    gram[GRAM_YS + end] = ys; gram[GRAM_RYS + end] = rys;
+                }
+            }
             __syncthreads();
             BE_STAMP(20)
             if (ys > cau) {
+                const int slot_new = end;
                 ++bound;
                 if (bound > m) bound = m;
                 end = (end + 1) % m;
+                bool chunked = false;
+                if constexpr (3 * P <= 64) chunked = (end != 0 && bound == end); // the history sits in slots 0 .. bound - 1
+                if (chunked) {
+                    GLBQ double* gram = (GLBQ double*)gp->gram + (size_t)uni(L.e.prob) * GRAM_DOUBLES;
+                    const int top = (bound - 1) >> 3, hi_top = (bound - 1) & 7, pnew = slot_new & 7;
+                    double dq = (lane < n) ? L.d[lane] : 0.0;
+                    const double ynew = (lane < n) ? L.g[lane] - L.gp[lane] : 0.0;
+                    GramChunk A, B;
+                    // first loop, chunks top .. 0; the newest pair's column of G is formed on the way (its chunk is the first)
+                    auto first = [&](GramChunk& c, int ch, auto full) {
+                        constexpr bool FULL = decltype(full)::value;
+                        double pr8[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pr8[i] = c.s[i] * dq;
+                        double D = sum8(pr8, lane);
+                        if (!FULL) { // the top chunk: column pnew of G = s_k . y_new, k < pnew (lane k), stored and patched into the rows at hand
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) pr8[i] = c.s[i] * ynew;
+                            const double col = sum8(pr8, lane);
+                            const int k = lane & 7;
+                            if (lane < pnew) {
+                                gram[GRAM_G + ch * 64 + k * 8 + pnew] = col;
+                                gram[GRAM_GT + ch * 64 + pnew * 8 + k] = col;
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) c.g[i] = (i == pnew) ? (k < pnew ? col : 0.0) : c.g[i];
+                        }
+#pragma unroll
+                        for (int l = 7; l >= 0; --l) {
+                            if (FULL || l <= hi_top) {
+                                const double a = lane_of(div_by_known(D, c.ys, c.rys), l);
+                                D = fma(-a, c.g[l], D);
+                                dq = fma(-a, c.y[l], dq);
+                            }
+                        }
+                        const double afin = div_by_known(D, c.ys, c.rys); // lane k: a of slot 8 ch + k (rows of G are zero up to the diagonal)
+                        if (lane < 8) L.alpha[8 * ch + lane] = afin;
+                        dq = (lane < n) ? dq : 0.0;
+                    };
+                    load_gram_chunk(A, hist, gram, nstride, top, GRAM_G, lane);
+                    for (int ch = top;; ch -= 2) {
+                        load_gram_chunk(B, hist, gram, nstride, max(ch - 1, 0), GRAM_G, lane);
+                        if (ch == top) first(A, ch, std::false_type{}); else first(A, ch, std::true_type{});
+                        if (ch == 0) break;
+                        load_gram_chunk(A, hist, gram, nstride, max(ch - 2, 0), GRAM_G, lane);
+                        first(B, ch - 1, std::true_type{});
+                        if (ch == 1) break;
+                    }
+                    dq *= ys / yy;
+                    __syncthreads(); // alpha[] and the new column of the transpose are read back below
+                    BE_STAMP(21)
+                    if (gp->stamps && blockIdx.x == 0 && threadIdx.x == 0) { GLBQ long long* st_ = (GLBQ long long*)gp->stamps; st_[40] += 1; st_[41] += bound; }
+                    auto second = [&](GramChunk& c, int ch, auto full) {
+                        constexpr bool FULL = decltype(full)::value;
+                        double pr8[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) pr8[i] = c.y[i] * dq;
+                        double E = sum8(pr8, lane);
+                        const double al = L.alpha[8 * ch + (lane & 7)];
+#pragma unroll
+                        for (int l = 0; l < 8; ++l) {
+                            if (FULL || l <= hi_top) {
+                                const double cf = lane_of(al - div_by_known(E, c.ys, c.rys), l);
+                                E = fma(cf, c.g[l], E);
+                                dq = fma(cf, c.s[l], dq);
+                            }
+                        }
+                        dq = (lane < n) ? dq : 0.0;
+                    };
+                    load_gram_chunk(A, hist, gram, nstride, 0, GRAM_GT, lane);
+                    for (int ch = 0;; ch += 2) {
+                        load_gram_chunk(B, hist, gram, nstride, min(ch + 1, top), GRAM_GT, lane);
+                        if (ch == top) second(A, ch, std::false_type{}); else second(A, ch, std::true_type{});
+                        if (ch == top) break;
+                        load_gram_chunk(A, hist, gram, nstride, min(ch + 2, top), GRAM_GT, lane);
+                        if (ch + 1 == top) second(B, ch + 1, std::false_type{}); else second(B, ch + 1, std::true_type{});
+                        if (ch + 1 == top) break;
+                    }
+                    if (lane < n) L.d[lane] = dq;
+                    BE_STAMP(22)
+                } else {
                 // Two-loop recursion (lbfgs.hpp:704-735).  d stays in registers (NVL values per lane); the (s, y)
                 // pairs come from HBM in chunks of CH pairs whose loads are all in flight together, and the loads of
                 // the NEXT chunk are issued before the current one is worked on (two register buffers): the memory
@@ -971,6 +1139,7 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
                 for (int r = 0; r < NVL; ++r)
                     if (lane + 64 * r < n) L.d[lane + 64 * r] = dreg[r];
                 BE_STAMP(22)
+                }
             }
             __syncthreads();
             step = 1.0;
@@ -1048,6 +1217,7 @@ __device__ void load_problem(const Params& prm, unsigned lbase, int b)
     const ProblemStore& s = prm.prob;
     if (threadIdx.x == 0) {
         e.M = s.M[b];
+        e.prob = b;
         e.n = 3 * e.M - 1;
         for (int d = 0; d < 2; ++d)
             for (int k = 0; k < 3; ++k) { e.head[d][k] = s.head[(size_t)b * 6 + d * 3 + k]; e.tail[d][k] = s.tail[(size_t)b * 6 + d * 3 + k]; }
