@@ -106,6 +106,36 @@ def test_lbfgs_iterations_track_the_oracle(orc, stage, iters):
         assert np.max(np.abs(out["x"][b] - ref["x"])) <= 1e-6, b
 
 
+@pytest.mark.parametrize("mem,iters", [(5, 25), (8, 30), (12, 25)])
+def test_lbfgs_with_a_short_history_tracks_the_oracle(orc, mem, iters):
+    """mem_size smaller than the run: the history wraps.  The kernel runs the two-loop recursion on aligned chunks with stored
+    cross products while the history sits in slots 0 .. bound - 1 and pair by pair once it has wrapped; both forms, and the
+    iteration at which one hands over to the other, against the oracle's plain recursion (lbfgs.hpp:704-735)."""
+    from alore_legged_manipulator_amd.backend import default_config
+    grid = free_grid()
+    fts = monte_carlo_goals(12, seed=78)
+    xs = [orc.x0(ft) for ft in fts]
+    cfg = default_config()
+    cfg.lbfgs.mem_size = mem
+    cfg.path_lbfgs.mem_size = mem
+    keep = (orc.cfg.lbfgs.mem_size, orc.cfg.path_lbfgs.mem_size)
+    orc.cfg.lbfgs.mem_size = mem
+    orc.cfg.path_lbfgs.mem_size = mem
+    try:
+        pl = planner_for(grid, len(fts), cfg=cfg)
+        pl.set_problems(fts)
+        out = pl.lbfgs(2, xs, max_iter=iters)
+        wrapped = 0
+        for b, ft in enumerate(fts):
+            ref = orc.lbfgs_run(grid, ft, 2, xs[b], lam=(0.0, 0.0), rho=(1e4, 1e4), max_iter=iters)
+            assert out["ret"][b] == ref["ret"] and out["iters"][b] == ref["iters"] and out["evals"][b] == ref["evals"], b
+            assert np.max(np.abs(out["x"][b] - ref["x"])) <= 1e-6, b
+            wrapped += int(ref["iters"] > mem + 2)
+        assert wrapped >= len(fts) // 2   # the runs are long enough to wrap
+    finally:
+        orc.cfg.lbfgs.mem_size, orc.cfg.path_lbfgs.mem_size = keep
+
+
 def test_minco_plan_matches_oracle_on_monte_carlo_goals(orc):
     """Whole plans.  The reference's optimiser is chaotic in the last digits of its inputs: L-BFGS with a loose
     stopping rule (relative cost decrease < 5e-4 over 3 iterations) ends on a different iteration when an input
