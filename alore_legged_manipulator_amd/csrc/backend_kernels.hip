@@ -214,6 +214,8 @@ struct Lds {
     double x[3 * P], g[3 * P], d[3 * P], xp[3 * P], gp[3 * P];
     double alpha[MEM_MAX];
     double pf[16];
+    // elimination factors of the knot system of this evaluation (knot_pcr): per step and knot alpha, gamma (2 x 2 each), then D^-1
+    double pcr_f[P <= 16 ? 4 : 5][P <= 16 ? 16 : 32][8], pcr_d[P <= 16 ? 16 : 32][4];
 };
 
 extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -261,7 +263,7 @@ template <int S, bool DPP> __device__ __forceinline__ B2 lane_down(const B2& m) 
 struct PcrState { B2 Lk, Dk, Uk; double r0, r1, r2, r3; };
 
 template <int S, bool DPP>
-__device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk)
+__device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk, LDSQ double* fac)
 {
     const B2 Lm = lane_up<S, DPP>(q.Lk), Dm = lane_up<S, DPP>(q.Dk), Um = lane_up<S, DPP>(q.Uk);
     const double m0 = lane_up<S, DPP>(q.r0), m1 = lane_up<S, DPP>(q.r1), m2 = lane_up<S, DPP>(q.r2), m3 = lane_up<S, DPP>(q.r3);
@@ -271,6 +273,7 @@ __device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk)
     B2 al{0, 0, 0, 0}, ga{0, 0, 0, 0};
     if (hm) { const B2 t = mul(q.Lk, inv2(Dm)); al = {-t.a, -t.b, -t.c, -t.d}; }
     if (hp) { const B2 t = mul(q.Uk, inv2(Dp)); ga = {-t.a, -t.b, -t.c, -t.d}; }
+    fac[0] = al.a; fac[1] = al.b; fac[2] = al.c; fac[3] = al.d; fac[4] = ga.a; fac[5] = ga.b; fac[6] = ga.c; fac[7] = ga.d;
     if (hm) {
         const B2 t = mul(al, Um);
         q.Dk = {q.Dk.a + t.a, q.Dk.b + t.b, q.Dk.c + t.c, q.Dk.d + t.d};
@@ -287,13 +290,46 @@ __device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk)
     } else q.Uk = {0, 0, 0, 0};
 }
 
-// rhs / solution: y[d][lane][0..1] in LDS for d = 0, 1 (the caller's layout); all 64 lanes must call
-template <int P>
-__device__ __forceinline__ void knot_pcr(int M, const LDSQ double* T, LDSQ double (*y0)[2], LDSQ double (*y1)[2])
+// the same elimination on right-hand sides only, with the factors a factorising call left in LDS (the knot matrix of an
+// evaluation serves twice: spline, then its adjoint): a step is 16 shifted values + 16 multiply-adds instead of two 2 x 2
+// inverses and four block products
+template <int S, bool DPP>
+__device__ __forceinline__ void pcr_replay(double (&r)[4], const LDSQ double* fac)
+{
+    const double m0 = lane_up<S, DPP>(r[0]), m1 = lane_up<S, DPP>(r[1]), m2 = lane_up<S, DPP>(r[2]), m3 = lane_up<S, DPP>(r[3]);
+    const double p0 = lane_down<S, DPP>(r[0]), p1 = lane_down<S, DPP>(r[1]), p2 = lane_down<S, DPP>(r[2]), p3 = lane_down<S, DPP>(r[3]);
+    const B2 al{fac[0], fac[1], fac[2], fac[3]}, ga{fac[4], fac[5], fac[6], fac[7]}; // zeros where a neighbour is missing
+    r[0] += al.a * m0 + al.b * m1; r[1] += al.c * m0 + al.d * m1;
+    r[2] += al.a * m2 + al.b * m3; r[3] += al.c * m2 + al.d * m3;
+    r[0] += ga.a * p0 + ga.b * p1; r[1] += ga.c * p0 + ga.d * p1;
+    r[2] += ga.a * p2 + ga.b * p3; r[3] += ga.c * p2 + ga.d * p3;
+}
+
+// rhs / solution: y[d][lane][0..1] in LDS for d = 0, 1 (the caller's layout); all 64 lanes must call.  REPLAY = false
+// factorises (and leaves the factors in L.pcr_f / L.pcr_d), REPLAY = true solves with the factors of the last factorising call.
+template <int P, bool REPLAY>
+__device__ __forceinline__ void knot_pcr(LDSQ Lds<P>& L, int M, const LDSQ double* T, LDSQ double (*y0)[2], LDSQ double (*y1)[2])
 {
     constexpr bool DPP = P <= 16; // all knots (<= 15) in one DPP row
+    constexpr int PL = P <= 16 ? 16 : 32;
     const int e = threadIdx.x, nk = M - 1;
     const bool act = e < nk;
+    const int el = act ? e : PL - 1; // slot PL - 1 is never a knot: the idle lanes keep zero factors there (finite operands for them)
+    if constexpr (REPLAY) {
+        double r[4] = {0.0, 0.0, 0.0, 0.0};
+        if (act) { r[0] = y0[e][0]; r[1] = y0[e][1]; r[2] = y1[e][0]; r[3] = y1[e][1]; }
+        if (1 < nk) pcr_replay<1, DPP>(r, L.pcr_f[0][el]);
+        if (2 < nk) pcr_replay<2, DPP>(r, L.pcr_f[1][el]);
+        if (4 < nk) pcr_replay<4, DPP>(r, L.pcr_f[2][el]);
+        if (8 < nk) pcr_replay<8, DPP>(r, L.pcr_f[3][el]);
+        if constexpr (P > 16) { if (16 < nk) pcr_replay<16, false>(r, L.pcr_f[4][el]); }
+        if (act) {
+            const B2 di{L.pcr_d[el][0], L.pcr_d[el][1], L.pcr_d[el][2], L.pcr_d[el][3]};
+            y0[e][0] = di.a * r[0] + di.b * r[1]; y0[e][1] = di.c * r[0] + di.d * r[1];
+            y1[e][0] = di.a * r[2] + di.b * r[3]; y1[e][1] = di.c * r[2] + di.d * r[3];
+        }
+        return;
+    }
     PcrState q{{0, 0, 0, 0}, {1, 0, 0, 1}, {0, 0, 0, 0}, 0.0, 0.0, 0.0, 0.0};
     if (act) {
         const int k = e + 1;
@@ -304,13 +340,16 @@ __device__ __forceinline__ void knot_pcr(int M, const LDSQ double* T, LDSQ doubl
         if (k < M - 1) { const minco::Mat2 u = minco::knot_upper(r); q.Uk = {u.a, u.b, u.c, u.d}; }
         q.r0 = y0[e][0]; q.r1 = y0[e][1]; q.r2 = y1[e][0]; q.r3 = y1[e][1];
     }
-    if (1 < nk) pcr_step<1, DPP>(q, act, e, nk);
-    if (2 < nk) pcr_step<2, DPP>(q, act, e, nk);
-    if (4 < nk) pcr_step<4, DPP>(q, act, e, nk);
-    if (8 < nk) pcr_step<8, DPP>(q, act, e, nk);
-    if constexpr (P > 16) { if (16 < nk) pcr_step<16, false>(q, act, e, nk); }
+    LDSQ double* f0 = L.pcr_f[0][el];
+    const int fstep = PL * 8;
+    if (1 < nk) pcr_step<1, DPP>(q, act, e, nk, f0);
+    if (2 < nk) pcr_step<2, DPP>(q, act, e, nk, f0 + fstep);
+    if (4 < nk) pcr_step<4, DPP>(q, act, e, nk, f0 + 2 * fstep);
+    if (8 < nk) pcr_step<8, DPP>(q, act, e, nk, f0 + 3 * fstep);
+    if constexpr (P > 16) { if (16 < nk) pcr_step<16, false>(q, act, e, nk, f0 + 4 * fstep); }
     if (act) {
         const B2 di = inv2(q.Dk);
+        L.pcr_d[el][0] = di.a; L.pcr_d[el][1] = di.b; L.pcr_d[el][2] = di.c; L.pcr_d[el][3] = di.d;
         y0[e][0] = di.a * q.r0 + di.b * q.r1; y0[e][1] = di.c * q.r0 + di.d * q.r1;
         y1[e][0] = di.a * q.r2 + di.b * q.r3; y1[e][1] = di.c * q.r2 + di.d * q.r3;
     }
@@ -377,7 +416,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     }
     __syncthreads();
     BE_STAMP(2)
-    knot_pcr<P>(M, L.T, L.y[0], L.y[1]);
+    knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1]);
     __syncthreads();
     if (lane < 2)
         for (int k = 1; k < M; ++k) { L.kv[lane][k] = L.y[lane][k - 1][0]; L.ka[lane][k] = L.y[lane][k - 1][1]; }
@@ -650,7 +689,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     }
     __syncthreads();
     BE_STAMP(15)
-    knot_pcr<P>(M, L.T, L.y[0], L.y[1]); // K is symmetric: the same system
+    knot_pcr<P, true>(L, M, L.T, L.y[0], L.y[1]); // K is symmetric: the same system, its factors are in LDS
     __syncthreads();
     BE_STAMP(16)
     // way-point and tail gradients: lane = (knot 1..M, dim)
@@ -1384,6 +1423,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int k = 0; k < 3; ++k) r.tail[(size_t)b * 6 + d * 3 + k] = (d == 1 && k == 0) ? L.x[2 * (M - 1)] : e.tail[d][k];
     }
 }
+
+// four workgroups of the 16-piece build share a CU's 160 KB (one wavefront per SIMD): 40400 B today
+static_assert(sizeof(Lds<16>) <= 160 * 1024 / 4, "Lds<16> must leave room for four workgroups per CU");
 
 size_t lds_bytes(int P)
 {

@@ -917,12 +917,19 @@ def main():
             # a control tick returns the command column and the status (16 B per robot): cold = freshly constructed controller
             # (reset: no previous output, free working set), warm = the tick after
             t_a = time.perf_counter(); lt.tick(st0, n_relin=5, reset=True); t_cold = time.perf_counter() - t_a
+            # the ten ticks after a reset still settle their working sets (kernel 0.40, 0.22, 0.20, ... 0.16 ms: profiles/r04_c_ltv_*);
+            # warm = the ticks after those, what a running controller pays
             t_a = time.perf_counter()
             for i in range(10):
                 cmd_w, st_w = lt.tick(st0, n_relin=5)     # commands + status only (16 B per robot over the bus)
-            t_warm = (time.perf_counter() - t_a) / 10
+            t_settle = (time.perf_counter() - t_a) / 10
+            t_a = time.perf_counter()
+            for i in range(20):
+                cmd_w, st_w = lt.tick(st0, n_relin=5)
+            t_warm = (time.perf_counter() - t_a) / 20
             g1 = lt.get_cmd(st0, n_relin=5)
             extras["ltv_mpc"] = {"robots": B, "relinearisations": 5, "cold_ms": t_cold * 1e3, "warm_ms": t_warm * 1e3,
+                                 "first_ten_ticks_after_reset_ms": t_settle * 1e3,
                                  "robot_ticks_per_s_warm": B / t_warm, "sweeps_last_qp_cold_mean": float(g0["sweeps"].mean()),
                                  "sweeps_last_qp_warm_mean": float(g1["sweeps"].mean()), "unsettled": int((g1["status"] != 0).sum())}
             if not a.no_cpu_baseline:
