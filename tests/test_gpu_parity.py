@@ -892,3 +892,63 @@ def test_condensed_qp_matches_the_oracle_and_its_dense_solve_matches_the_stage_w
         assert np.max(np.abs(du - np.clip(x[b], lbd[b], ubd[b]))) / scale < 1e-4, b
         act = np.abs(y[b]) > 1e-6
         assert np.all(np.where(y[b][act] > 0, np.abs(x[b][act] - lbd[b][act]), np.abs(x[b][act] - ubd[b][act])) < 1e-5)
+
+
+@pytest.mark.gpu
+def test_dense_box_qp_edge_cases(nmpc_mod):
+    """alore_nmpc_dense_qp (the role of acado_solve / QProblemB, QPO/SRC/QProblemB.cpp:315-506) at the edges: orders 1 and 128,
+    most variables at a bound, a warm start from the true dual (one factorisation), a wrong warm start (recovers), and the
+    reference's failure codes: inconsistent bounds 33 (RET_INIT_FAILED_INFEASIBILITY), a Hessian that is not positive
+    definite 31 (RET_INIT_FAILED_CHOLESKY), an iteration cap that is too small 58 (RET_MAX_NWSR_REACHED).  Problems of a launch do not
+    see each other: the failing ones sit between healthy ones."""
+    import torch
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+
+    def spd(n, cond=50.0):
+        q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        return (q * np.geomspace(1.0, cond, n)) @ q.T
+
+    eng = nmpc_mod.BatchedNmpc(4, 20)
+    for n in (1, 2, 40, 128):
+        B = 6
+        H = np.stack([spd(n) for _ in range(B)]).astype(np.float32)
+        g = rng.normal(size=(B, n)).astype(np.float32) * 3.0
+        lb = -np.abs(rng.normal(size=(B, n))).astype(np.float32) * 0.3
+        ub = np.abs(rng.normal(size=(B, n))).astype(np.float32) * 0.3
+        g[1] *= 100.0                      # most variables of problem 1 end at a bound
+        lb[3, 0], ub[3, 0] = 1.0, -1.0     # problem 3: inconsistent bounds
+        H[4] = -H[4]                       # problem 4: not positive definite
+        t = [torch.from_numpy(a).to(dev) for a in (H, g, lb, ub)]
+        x, y, st, ni = eng.dense_qp(*t)
+        x, y, st, ni = x.cpu().numpy(), y.cpu().numpy(), st.cpu().numpy(), ni.cpu().numpy()
+        assert st[3] == 33 and st[4] == 31, (n, st)
+        for b in (0, 1, 2, 5):
+            assert st[b] == 0, (n, b, st)
+            truth = exact_box_qp(H[b], g[b], lb[b], ub[b])
+            assert np.max(np.abs(x[b] - truth)) < 1e-4 * max(1.0, np.max(np.abs(truth))), (n, b)
+            assert np.all(x[b] >= lb[b] - 1e-6) and np.all(x[b] <= ub[b] + 1e-6)
+            grad = H[b].astype(np.float64) @ x[b] + g[b]
+            free = y[b] == 0.0
+            assert np.max(np.abs(grad[free]), initial=0.0) < 2e-3 * max(1.0, np.max(np.abs(g[b]))), (n, b)   # stationarity on the free set
+            assert np.all(y[b][~free] * (x[b][~free] - 0.5 * (lb[b][~free] + ub[b][~free])) <= 0.0)          # > 0 at lower, < 0 at upper
+        assert np.mean((x[1] == lb[1]) | (x[1] == ub[1])) > 0.5            # problem 1 sits mostly on its bounds
+        # warm start from the dual just returned: the working set reproduces itself in one factorisation
+        x2, y2, st2, ni2 = eng.dense_qp(*t, y0=torch.from_numpy(y).to(dev))
+        ok = [0, 1, 2, 5]
+        assert (st2.cpu().numpy()[ok] == 0).all() and (ni2.cpu().numpy()[ok] == 1).all(), (n, ni2)
+        assert np.max(np.abs(x2.cpu().numpy()[ok] - x[ok])) < 1e-5
+        # warm start from the opposite working set: still the same minimiser
+        x3, _, st3, _ = eng.dense_qp(*t, y0=torch.from_numpy(-y - 1.0).to(dev))
+        assert (st3.cpu().numpy()[ok] == 0).all()
+        assert np.max(np.abs(x3.cpu().numpy()[ok] - x[ok])) < 1e-4 * max(1.0, np.max(np.abs(x[ok])))
+    # iteration cap: a cold start with active bounds needs more than one factorisation
+    capped = nmpc_mod.BatchedNmpc(4, 20, max_as_iter=1)
+    n = 40
+    H = np.stack([spd(n) for _ in range(3)]).astype(np.float32)
+    g = (rng.normal(size=(3, n)) * 5.0).astype(np.float32)
+    lb = np.full((3, n), -0.1, np.float32); ub = np.full((3, n), 0.1, np.float32)
+    g[1] = 0.0                             # problem 1: the unconstrained minimiser 0 is inside the box, one factorisation
+    _, _, st, ni = capped.dense_qp(*[torch.from_numpy(a).to(dev) for a in (H, g, lb, ub)])
+    st = st.cpu().numpy()
+    assert st[0] == 58 and st[2] == 58 and st[1] == 0, st
