@@ -52,6 +52,7 @@ typedef const CSTQ LbfgsParam CLbfgsParam;
 
 constexpr int NS = 17; // Simpson nodes per piece (sparseResolution 8)
 constexpr int RES = 8;
+static_assert(RES * 6 == 48, "div_res6 divides by the literal 48");
 
 // Wavefront reductions on the DPP data path (no LDS crossbar): inclusive scan inside each row of 16 lanes
 // (row_shr 1, 2, 4, 8), row totals passed on with row_bcast15 / row_bcast31, result read from lane 63 and returned
@@ -146,16 +147,29 @@ __device__ __forceinline__ LbfgsParam uni(const LbfgsParam& q)
     return r;
 }
 
-__device__ __forceinline__ void smoothed_l1(double eps, double x, double& f, double& df)
+// the two coefficients of the cubic branch depend on eps alone: formed once per evaluation (two float64 divisions that every
+// active penalty term used to repeat on its own chain)
+struct SmoothL1 {
+    double eps, f3, f4;
+    __device__ __forceinline__ explicit SmoothL1(double e) : eps(e), f3(1.0 / (e * e)), f4(-0.5 * (1.0 / (e * e)) / e) {}
+};
+__device__ __forceinline__ void smoothed_l1(const SmoothL1& k, double x, double& f, double& df)
 {
-    if (x < eps) {
-        const double f3 = 1.0 / (eps * eps), f4 = -0.5 * f3 / eps;
-        f = (f4 * x + f3) * x * x * x;
-        df = (4.0 * f4 * x + 3.0 * f3) * x * x;
+    if (x < k.eps) {
+        f = (k.f4 * x + k.f3) * x * x * x;
+        df = (4.0 * k.f4 * x + 3.0 * k.f3) * x * x;
     } else {
-        f = x - 0.5 * eps;
+        f = x - 0.5 * k.eps;
         df = 1.0;
     }
+}
+// x / (RES * 6), the Simpson weight of the reference, correctly rounded like the division it replaces (div_by_known)
+__device__ __forceinline__ double div_res6(double a)
+{
+    constexpr double b = 48.0, r = 1.0 / 48.0;
+    const double q0 = a * r;
+    const double q1 = fma(fma(-b, q0, a), r, q0);
+    return fma(fma(-b, q1, a), r, q1);
 }
 __device__ __forceinline__ double t_of_tau(double v) { return v > 0.0 ? ((0.5 * v + 1.0) * v + 1.0) : 1.0 / ((0.5 * v - 1.0) * v + 1.0); }
 __device__ __forceinline__ double tau_of_t(double t) { return t > 1.0 ? (sqrt(2.0 * t - 1.0) - 1.0) : (1.0 - sqrt(2.0 / t - 1.0)); }
@@ -167,11 +181,11 @@ __device__ __forceinline__ double dt_dtau(double v)
 }
 
 // SDFmap::getDistWithGradBilinear(pos, grad, mindis) (sdf_map.cpp:796-834) and (pos) (:836-861, want_grad = false)
-__device__ __forceinline__ double esdf(CMapView& m, double x, double y, bool want_grad, double mindis, double& gx, double& gy)
+// (inv = 1 / m.res, formed once by the caller: a float64 division on the chain of every query otherwise)
+__device__ __forceinline__ double esdf(CMapView& m, double inv, double x, double y, bool want_grad, double mindis, double& gx, double& gy)
 {
     gx = 0.0; gy = 0.0;
     if (x < m.x_lo || y < m.y_lo || x > m.x_hi || y > m.y_hi) return 1e10;
-    const double inv = 1.0 / m.res;
     int ix = (int)((x - m.x_lo) * inv - 0.5), iy = (int)((y - m.y_lo) * inv - 0.5);
     ix = min(max(ix, 0), m.nx - 1);
     iy = min(max(iy, 0), m.ny - 1);
@@ -200,7 +214,7 @@ struct EvalCtx {
 template <int P>
 struct Lds {
     EvalCtx e;
-    double T[P];
+    double T[P], iT[P]; // piece durations and their reciprocals
     double kp[2][P + 1], kv[2][P + 1], ka[2][P + 1]; // knot states per flat dimension
     double y[2][P][2];                                // knot system right-hand side / solution per dimension
     double coef[P * 12];                              // (6 i + q) * 2 + d
@@ -333,7 +347,7 @@ __device__ __forceinline__ void knot_pcr(LDSQ Lds<P>& L, int M, const LDSQ doubl
     PcrState q{{0, 0, 0, 0}, {1, 0, 0, 1}, {0, 0, 0, 0}, 0.0, 0.0, 0.0, 0.0};
     if (act) {
         const int k = e + 1;
-        const minco::InvT l(T[k - 1]), r(T[k]);
+        const minco::InvT l(T[k - 1], L.iT[k - 1]), r(T[k], L.iT[k]);
         const minco::Sym2 dg = minco::knot_diag(l, r);
         q.Dk = {dg.a, dg.b, dg.b, dg.c};
         if (k > 1) { const minco::Mat2 u = minco::knot_upper(l); q.Lk = {u.a, u.c, u.b, u.d}; } // U_{k-1}'
@@ -367,6 +381,8 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     LDSQ EvalCtx& e = L.e;
     const int lane = threadIdx.x, M = uni(e.M), n = uni(e.n), NN = M * NS;
     const double xvI = c.standard_diff ? 0.0 : c.icr_xv;
+    const SmoothL1 sl1(c.smooth_eps);
+    const double map_inv = 1.0 / prm.map.res;
     __syncthreads();
     BE_STAMP(0)
     if (lane == 0) ++e.evals;
@@ -380,6 +396,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     for (int i = lane; i < M; i += 64) {
         const double T = t_of_tau(L.x[2 * (M - 1) + 1 + i]);
         L.T[i] = T;
+        L.iT[i] = 1.0 / T;
         tpart += T;
     }
     const double sumT = uni(wave_sum(tpart));
@@ -398,7 +415,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     // ---- knot system: right-hand sides (lane = (knot, dim)), factorisation + solves (lanes 0, 1)
     for (int t = lane; t < 2 * (M - 1); t += 64) {
         const int k = 1 + (t >> 1), d = t & 1;
-        const minco::InvT l(L.T[k - 1]), r(L.T[k]);
+        const minco::InvT l(L.T[k - 1], L.iT[k - 1]), r(L.T[k], L.iT[k]);
         double rr[2];
         minco::knot_rhs(l, r, L.kp[d][k - 1], L.kp[d][k], L.kp[d][k + 1], rr);
         if (k == 1) {
@@ -426,7 +443,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     for (int t = lane; t < 2 * M; t += 64) {
         const int i = t >> 1, d = t & 1;
         const double T = L.T[i];
-        const minco::InvT q(T);
+        const minco::InvT q(T, L.iT[i]);
         double cc[6];
         minco::hermite(T, q, L.kp[d][i], L.kv[d][i], L.ka[d][i], L.kp[d][i + 1], L.kv[d][i + 1], L.ka[d][i + 1], cc, nullptr);
         for (int k = 0; k < 6; ++k) L.coef[(6 * i + k) * 2 + d] = cc[k];
@@ -474,7 +491,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
             double f, df, v;
 #define PENALISE(viol, weight, dviol_dt, apply)                           \
     if ((v = (viol)) > 0.0) {                                             \
-        smoothed_l1(c.smooth_eps, v, f, df);                              \
+        smoothed_l1(sl1, v, f, df);                                       \
         apply;                                                            \
         gT += omg * (weight) * (df * (dviol_dt) * step + f / RES);        \
         cost_part += ws * (weight) * f;                                   \
@@ -519,7 +536,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
             double ix = 0.0, iy = 0.0;
             if (p < NP) {
                 const int i = p / RES, q = p - i * RES, n0 = i * NS + 2 * q;
-                const double cint = L.T[i] / (RES * 6);
+                const double cint = div_res6(L.T[i]);
                 // the reference accumulates  cint f0 + 4 cint f1 + cint f2  into a zeroed sum, in this order
                 ix = cint * L.fx[n0]; ix += 4.0 * cint * L.fx[n0 + 1]; ix += cint * L.fx[n0 + 2];
                 iy = cint * L.fy[n0]; iy += 4.0 * cint * L.fy[n0 + 1]; iy += cint * L.fy[n0 + 2];
@@ -554,11 +571,11 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
             for (int q = 0; q < c.n_check; ++q) {
                 const double bx = c.check_pts[q][0], by = c.check_pts[q][1];
                 double gx, gy;
-                const double sd = esdf(prm.map, px + cy * bx - sy * by, py + sy * bx + cy * by, true, e.safe_dis, gx, gy);
+                const double sd = esdf(prm.map, map_inv, px + cy * bx - sy * by, py + sy * bx + cy * by, true, e.safe_dis, gx, gy);
                 const double viol = e.safe_dis - sd;
                 if (viol > 0.0) {
                     double f, df;
-                    smoothed_l1(c.smooth_eps, viol, f, df);
+                    smoothed_l1(sl1, viol, f, df);
                     const double rot = gx * (-sy * bx - cy * by) + gy * (cy * bx - sy * by);
                     gpx -= ws * c.w_collision * df * gx;
                     gpy -= ws * c.w_collision * df * gy;
@@ -608,7 +625,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     // ---- pass C: chain rule through the Simpson sums into the node terms
     for (int node = lane; node < NN; node += 64) {
         const int i = node / NS, j = node - i * NS;
-        const double T = L.T[i], step = T / RES, t = j * (step / 2.0), cint = T / (RES * 6), ialpha = (double)j / (2 * RES);
+        const double T = L.T[i], step = T / RES, t = j * (step / 2.0), cint = div_res6(T), ialpha = (double)j / (2 * RES);
         const double sw = (j == 0 || j == NS - 1) ? 1.0 : ((j & 1) ? 4.0 : 2.0);
         const double cx = L.fx[node] * sw, cyy = L.fy[node] * sw, cy = L.cy[node], sy = L.sy[node];
         const LDSQ double* ci = L.coef + 12 * i;
@@ -625,8 +642,8 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         E[0] += cint * ((-d1[1] * sy + d1[0] * xvI * cy) * cx + (d1[1] * cy - d1[0] * xvI * sy) * cyy);
         E[2] += cint * xvI * (sy * cx - cy * cyy);
         E[3] += cint * (cy * cx + sy * cyy);
-        const double XT = (d2[1] * cy - d1[1] * d1[0] * sy + d2[0] * xvI * sy + d1[0] * d1[0] * xvI * cy) * ialpha * cint + fxv / (RES * 6);
-        const double YT = (d2[1] * sy + d1[1] * d1[0] * cy - d2[0] * xvI * cy + d1[0] * d1[0] * xvI * sy) * ialpha * cint + fyv / (RES * 6);
+        const double XT = (d2[1] * cy - d1[1] * d1[0] * sy + d2[0] * xvI * sy + d1[0] * d1[0] * xvI * cy) * ialpha * cint + div_res6(fxv);
+        const double YT = (d2[1] * sy + d1[1] * d1[0] * cy - d2[0] * xvI * cy + d1[0] * d1[0] * xvI * sy) * ialpha * cint + div_res6(fyv);
         L.nodeT[node] += XT * cx + YT * cyy;
     }
     __syncthreads();
@@ -667,7 +684,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     // the start knot is written directly, the end knot goes through a staging slot (E is free by now)
     for (int t = lane; t < 2 * M; t += 64) {
         const int i = t >> 1, d = t & 1;
-        const minco::InvT q(L.T[i]);
+        const minco::InvT q(L.T[i], L.iT[i]);
         double G[6], g0[3], g1[3];
         for (int k = 0; k < 6; ++k) G[k] = L.gdC[(6 * i + k) * 2 + d];
         minco::hermite_adjoint(q, G, g0, g1);
@@ -698,15 +715,15 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         double val = L.gk[d][k][0];
         // - sum_k' mu_k' . dF_k'/dp_k ; dF_k'/dp: from knot k'+... (see minco_spline.h knot_rhs)
         if (k + 1 <= M - 1) { // F_{k+1} depends on p_k as its left neighbour: dF/dp = (360 l4, -60 l3), l = T_k
-            const minco::InvT l(L.T[k]);
+            const minco::InvT l(L.T[k], L.iT[k]);
             val -= L.y[d][k][0] * (360.0 * l.i4) + L.y[d][k][1] * (-60.0 * l.i3);
         }
         if (k <= M - 1) { // F_k on its own position: -(360 l4 - 360 r4... ) see below
-            const minco::InvT l(L.T[k - 1]), r(L.T[k]);
+            const minco::InvT l(L.T[k - 1], L.iT[k - 1]), r(L.T[k], L.iT[k]);
             val -= L.y[d][k - 1][0] * (-360.0 * l.i4 + 360.0 * r.i4) + L.y[d][k - 1][1] * (60.0 * l.i3 + 60.0 * r.i3);
         }
         if (k - 1 >= 1) { // F_{k-1} depends on p_k as its right neighbour: dF/dp = (-360 r4, -60 r3), r = T_{k-1}
-            const minco::InvT r(L.T[k - 1]);
+            const minco::InvT r(L.T[k - 1], L.iT[k - 1]);
             val -= L.y[d][k - 2][0] * (-360.0 * r.i4) + L.y[d][k - 2][1] * (-60.0 * r.i3);
         }
         if (k <= M - 1) L.g[2 * (k - 1) + d] = val;
@@ -716,7 +733,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     for (int t = lane; t < 2 * M; t += 64) {
         const int i = t >> 1, d = t & 1;
         const double T = L.T[i];
-        const minco::InvT q(T);
+        const minco::InvT q(T, L.iT[i]);
         double cc[6], dc[6], dE0[2], dE1[2];
         minco::hermite(T, q, L.kp[d][i], L.kv[d][i], L.ka[d][i], L.kp[d][i + 1], L.kv[d][i + 1], L.ka[d][i + 1], cc, dc);
         minco::piece_end_rows(T, cc, dc, dE0, dE1);
@@ -1199,7 +1216,7 @@ __device__ __attribute__((noinline)) bool final_collision(const Params* gp_in, u
     LDSQ Lds<P>& L = lds<P>(uni((int)lds_in));
     const LDSQ EvalCtx& e = L.e;
     const int lane = threadIdx.x, M = uni(e.M), R = c.final_check_num, NP = R * M;
-    const double xvI = c.standard_diff ? 0.0 : c.icr_xv;
+    const double xvI = c.standard_diff ? 0.0 : c.icr_xv, map_inv = 1.0 / prm.map.res;
     double carry_x = e.start_xy[0], carry_y = e.start_xy[1], mind = 1.79769313486231570815e+308;
     int first_hit = 0x7fffffff;
     for (int base = 0; base < NP; base += 64) {
@@ -1225,7 +1242,7 @@ __device__ __attribute__((noinline)) bool final_collision(const Params* gp_in, u
         ix = wave_prefix(ix); iy = wave_prefix(iy);
         if (p < NP) {
             double gx, gy;
-            const double sd = esdf(prm.map, carry_x + ix, carry_y + iy, false, 0.0, gx, gy);
+            const double sd = esdf(prm.map, map_inv, carry_x + ix, carry_y + iy, false, 0.0, gx, gy);
             if (sd < c.final_min_safe_dis && p < first_hit) first_hit = p;
             L.nodeT[lane] = sd; // staging for the ordered minimum below
         }

@@ -38,6 +38,11 @@ struct InvT {
     {
         i1 = 1.0 / T; i2 = i1 * i1; i3 = i2 * i1; i4 = i2 * i2; i5 = i4 * i1;
     }
+    // with 1 / T at hand (formed once per piece by the caller: the division heads a dependent chain wherever this is built)
+    MINCO_HD InvT(double, double inv)
+    {
+        i1 = inv; i2 = i1 * i1; i3 = i2 * i1; i4 = i2 * i2; i5 = i4 * i1;
+    }
 };
 
 // Quintic through (p0, v0, a0) at 0 and (p1, v1, a1) at T, ascending coefficients c[0..5];
