@@ -180,25 +180,44 @@ __device__ __forceinline__ double dt_dtau(double v)
     return (1.0 - v) / (den * den);
 }
 
-// SDFmap::getDistWithGradBilinear(pos, grad, mindis) (sdf_map.cpp:796-834) and (pos) (:836-861, want_grad = false)
+// SDFmap::getDistWithGradBilinear(pos, grad, mindis) (sdf_map.cpp:796-834) and (pos) (:836-861, want_grad = false), in two halves:
+// esdf_fetch finds the cell and issues the four loads, esdf_eval interpolates -- so that a caller can have the loads of several
+// queries in flight before it needs the first value (a query is one trip to L2 / HBM).
 // (inv = 1 / m.res, formed once by the caller: a float64 division on the chain of every query otherwise)
-__device__ __forceinline__ double esdf(CMapView& m, double inv, double x, double y, bool want_grad, double mindis, double& gx, double& gy)
+struct EsdfCell {
+    double v00, v01, v10, v11, fx, fy;
+    bool inside;
+};
+__device__ __forceinline__ EsdfCell esdf_fetch(CMapView& m, double inv, double x, double y)
 {
-    gx = 0.0; gy = 0.0;
-    if (x < m.x_lo || y < m.y_lo || x > m.x_hi || y > m.y_hi) return 1e10;
+    EsdfCell r{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, false};
+    if (x < m.x_lo || y < m.y_lo || x > m.x_hi || y > m.y_hi) return r;
     int ix = (int)((x - m.x_lo) * inv - 0.5), iy = (int)((y - m.y_lo) * inv - 0.5);
     ix = min(max(ix, 0), m.nx - 1);
     iy = min(max(iy, 0), m.ny - 1);
-    if (ix >= m.nx - 1 || iy >= m.ny - 1) return 1e10;
-    const double fx = (x - ((ix + 0.5) * m.res + m.x_lo)) * inv, fy = (y - ((iy + 0.5) * m.res + m.y_lo)) * inv;
+    if (ix >= m.nx - 1 || iy >= m.ny - 1) return r;
+    r.fx = (x - ((ix + 0.5) * m.res + m.x_lo)) * inv;
+    r.fy = (y - ((iy + 0.5) * m.res + m.y_lo)) * inv;
     const GLBQ double* c = (const GLBQ double*)m.dist + (size_t)ix * m.ny + iy;
-    const double v00 = c[0], v01 = c[1], v10 = c[m.ny], v11 = c[m.ny + 1];
+    r.v00 = c[0]; r.v01 = c[1]; r.v10 = c[m.ny]; r.v11 = c[m.ny + 1];
+    r.inside = true;
+    return r;
+}
+__device__ __forceinline__ double esdf_eval(const EsdfCell& q, double inv, bool want_grad, double mindis, double& gx, double& gy)
+{
+    gx = 0.0; gy = 0.0;
+    if (!q.inside) return 1e10;
+    const double fx = q.fx, fy = q.fy, v00 = q.v00, v01 = q.v01, v10 = q.v10, v11 = q.v11;
     const double lo = (1 - fx) * v00 + fx * v10, hi = (1 - fx) * v01 + fx * v11;
     const double dist = (1 - fy) * lo + fy * hi;
     if (!want_grad || dist > mindis) return dist;
     gy = (hi - lo) * inv;
     gx = ((1 - fy) * (v10 - v00) + fy * (v11 - v01)) * inv;
     return dist;
+}
+__device__ __forceinline__ double esdf(CMapView& m, double inv, double x, double y, bool want_grad, double mindis, double& gx, double& gy)
+{
+    return esdf_eval(esdf_fetch(m, inv, x, y), inv, want_grad, mindis, gx, gy);
 }
 
 // everything a cost evaluation needs besides x; lives in LDS (wave-uniform, written by lane 0 + barrier or by
@@ -568,10 +587,10 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
             const double t = j * (step / 2.0);
             const double d1th = (((5.0 * ci[10] * t + 4.0 * ci[8]) * t + 3.0 * ci[6]) * t + 2.0 * ci[4]) * t + ci[2];
             double gpx = 0.0, gpy = 0.0, gb0 = 0.0, gT = 0.0;
-            for (int q = 0; q < c.n_check; ++q) {
-                const double bx = c.check_pts[q][0], by = c.check_pts[q][1];
+            // two check points at a time: both queries' loads are in flight before the first is interpolated; accumulated in order
+            auto account = [&](const EsdfCell& cell, double bx, double by) {
                 double gx, gy;
-                const double sd = esdf(prm.map, map_inv, px + cy * bx - sy * by, py + sy * bx + cy * by, true, e.safe_dis, gx, gy);
+                const double sd = esdf_eval(cell, map_inv, true, e.safe_dis, gx, gy);
                 const double viol = e.safe_dis - sd;
                 if (viol > 0.0) {
                     double f, df;
@@ -583,6 +602,16 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
                     gT += omg * c.w_collision * (df * (-alpha * d1th * rot) * step + f / RES);
                     cost_part += ws * c.w_collision * f;
                 }
+            };
+            const int nq = c.n_check;
+            for (int q = 0; q < nq; q += 2) {
+                const bool two = q + 1 < nq;
+                const double bx0 = c.check_pts[q][0], by0 = c.check_pts[q][1];
+                const double bx1 = c.check_pts[two ? q + 1 : q][0], by1 = c.check_pts[two ? q + 1 : q][1];
+                const EsdfCell c0 = esdf_fetch(prm.map, map_inv, px + cy * bx0 - sy * by0, py + sy * bx0 + cy * by0);
+                const EsdfCell c1 = esdf_fetch(prm.map, map_inv, px + cy * bx1 - sy * by1, py + sy * bx1 + cy * by1);
+                account(c0, bx0, by0);
+                if (two) account(c1, bx1, by1);
             }
             L.fx[node] = gpx;
             L.fy[node] = gpy;
