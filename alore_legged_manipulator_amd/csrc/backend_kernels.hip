@@ -454,8 +454,11 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     BE_STAMP(2)
     knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1]);
     __syncthreads();
-    if (lane < 2)
-        for (int k = 1; k < M; ++k) { L.kv[lane][k] = L.y[lane][k - 1][0]; L.ka[lane][k] = L.y[lane][k - 1][1]; }
+    for (int t = lane; t < 2 * (M - 1); t += 64) { // lane = (knot, dim): one round (was a walk over the knots on two lanes)
+        const int k = 1 + (t >> 1), d = t & 1;
+        L.kv[d][k] = L.y[d][k - 1][0];
+        L.ka[d][k] = L.y[d][k - 1][1];
+    }
     __syncthreads();
     // ---- coefficients, energy and its partial gradients: lane = (piece, dim)
     double epart = 0.0;
