@@ -992,6 +992,31 @@ def main():
             del e8
         except Exception as e:  # pragma: no cover
             extras["compact_io"] = {"error": f"{type(e).__name__}: {e}"}
+        # the reference's own route through the QP -- condense to the dense 2N x 2N problem, solve that (acado_condensePrep /
+        # condenseFdb + acado_solve) -- on the GPU (alore_nmpc_condense + alore_nmpc_dense_qp), beside the stage-wise solve
+        try:
+            e10 = BatchedNmpc(B, N, device=local_rank)
+            e10.load(batch)
+            qp = e10.condense()
+            xq, yq, stq, niq = e10.dense_qp(qp["H"], qp["g"], qp["lb"], qp["ub"])
+            torch.cuda.synchronize(dev)
+            ev_a.record()
+            for i in range(5):
+                qp = e10.condense()
+            ev_b.record(); torch.cuda.synchronize(dev)
+            ms_cond = ev_a.elapsed_time(ev_b) / 5
+            ev_a.record()
+            for i in range(5):
+                xq, yq, stq, niq = e10.dense_qp(qp["H"], qp["g"], qp["lb"], qp["ub"])
+            ev_b.record(); torch.cuda.synchronize(dev)
+            ms_qp = ev_a.elapsed_time(ev_b) / 5
+            extras["dense_route"] = {"batch": B, "order": 2 * N, "ms_condense": ms_cond, "ms_dense_qp": ms_qp,
+                                     "solves_per_s": B / ((ms_cond + ms_qp) * 1e-3), "factorisations_mean": float(niq.float().mean().item()),
+                                     "unsolved": int((stq != 0).sum().item()),
+                                     "note": "what the stage-wise kernel replaces: H alone is 4 (2N)^2 bytes per solve"}
+            del e10, qp
+        except Exception as e:  # pragma: no cover
+            extras["dense_route"] = {"error": f"{type(e).__name__}: {e}"}
         # the tick as the reference runs it: acado_getKKT / acado_getObjective are never called by its wrapper;
         # with NULL kkt / obj the kernel skips them (the headline computes them)
         try:
