@@ -643,13 +643,16 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         }
         double carry_x = 0.0, carry_y = 0.0;
         const int rounds = (NN + 63) / 64;
+        // the nodes of a round sit on the lanes in REVERSE order (lane l holds node 64 r + 63 - l): the suffix sum over the nodes is
+        // the prefix scan over the lanes -- the same additions in the same order as reversing the lanes around the scan, without
+        // the four LDS permutes per scan that the reversals were
         for (int r = rounds - 1; r >= 0; --r) {
-            const int node = r * 64 + lane;
+            const int node = r * 64 + 63 - lane;
             double vx = node < NN ? L.fx[node] : 0.0, vy = node < NN ? L.fy[node] : 0.0;
-            vx = wave_suffix(vx); vy = wave_suffix(vy);
+            vx = wave_prefix(vx); vy = wave_prefix(vy);
             if (node < NN) { L.fx[node] = vx + carry_x + add_x; L.fy[node] = vy + carry_y + add_y; }
-            carry_x += lane0(vx);
-            carry_y += lane0(vy);
+            carry_x += lane63(vx);
+            carry_y += lane63(vy);
         }
     }
     __syncthreads();
