@@ -1096,10 +1096,11 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
                     };
                     load_gram_chunk(A, hist, gram, nstride, top, GRAM_G, lane);
                     for (int ch = top;; ch -= 2) {
-                        load_gram_chunk(B, hist, gram, nstride, max(ch - 1, 0), GRAM_G, lane);
+                        // (past chunk 0 the next thing needed is chunk 0 again, with the rows of the transpose: the second loop's first chunk)
+                        load_gram_chunk(B, hist, gram, nstride, max(ch - 1, 0), ch >= 1 ? GRAM_G : GRAM_GT, lane);
                         if (ch == top) first(A, ch, std::false_type{}); else first(A, ch, std::true_type{});
                         if (ch == 0) break;
-                        load_gram_chunk(A, hist, gram, nstride, max(ch - 2, 0), GRAM_G, lane);
+                        load_gram_chunk(A, hist, gram, nstride, max(ch - 2, 0), ch >= 2 ? GRAM_G : GRAM_GT, lane);
                         first(B, ch - 1, std::true_type{});
                         if (ch == 1) break;
                     }
@@ -1124,7 +1125,10 @@ __device__ __attribute__((noinline)) int lbfgs(const Params* gp_in, unsigned lds
                         }
                         dq = (lane < n) ? dq : 0.0;
                     };
-                    load_gram_chunk(A, hist, gram, nstride, 0, GRAM_GT, lane);
+                    // chunk 0 with the transposed rows is in flight since the end of the first loop -- in B when top is even, in A when
+                    // it is odd -- unless chunk 0 is the top chunk itself, whose row of the transpose has just been written
+                    if (top == 0) load_gram_chunk(A, hist, gram, nstride, 0, GRAM_GT, lane);
+                    else if ((top & 1) == 0) A = B;
                     for (int ch = 0;; ch += 2) {
                         load_gram_chunk(B, hist, gram, nstride, min(ch + 1, top), GRAM_GT, lane);
                         if (ch == top) second(A, ch, std::false_type{}); else second(A, ch, std::true_type{});
