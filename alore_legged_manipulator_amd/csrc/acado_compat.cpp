@@ -5,6 +5,8 @@
 // at that moment (alore_nmpc_set_linearization_point), like acado_solver.c:1057-1077.
 #include "../../include/alore_acado_compat.h"
 
+#include <cstdlib>
+
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
@@ -62,8 +64,11 @@ void upload_variables(const ACADOvariables& v, bool iterate, bool dual)
     alore_nmpc_batch_upload(g_h, &g_dev, &host, 1, nullptr);
 }
 // the condensed QP of the batch on the device -> acadoWorkspace.H, g (what condensePrep / condenseFdb leave there)
+int g_dense = -1; // -1: not decided yet (environment), 0 / 1
 void condense_to_workspace(bool with_g)
 {
+    if (g_dense < 0) { const char* e = std::getenv("ALORE_ACADO_DENSE_WORKSPACE"); g_dense = (e && e[0] == '0') ? 0 : 1; }
+    if (!g_dense) return;
     alore_nmpc_dense_qp_data q{g_H, g_g, g_lb, g_ub};
     if (!ok(alore_nmpc_condense(g_h, &g_dev, 1, &q, nullptr))) return;
     (void)hipMemcpyAsync(acadoWorkspace.H, g_H, sizeof(float) * ACADO_QP_NV * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr);
@@ -74,6 +79,7 @@ void condense_to_workspace(bool with_g)
 extern "C" {
 
 void alore_acado_set_device(int device) { g_device = device; }
+void alore_acado_dense_workspace(int enable) { g_dense = enable ? 1 : 0; }
 
 void alore_acado_shutdown(void)
 {

@@ -103,6 +103,11 @@ const char *acado_getErrorString(int error);            /* :67 */
 /* not part of the reference ABI: choose the GPU (before acado_initializeSolver), release the engine */
 void alore_acado_set_device(int device);
 void alore_acado_shutdown(void);
+/* acado_preparationStep / acado_feedbackStep leave the condensed QP (acadoWorkspace.H, g) behind like the reference's do: one
+ * more launch and 4 (2N)^2 bytes over the bus per call.  A caller that never reads them (MpcWrapper does not) can switch that
+ * off: 0 = H / g are not refreshed (acado_solve() then works on whatever the caller puts there), 1 = refreshed (default; the
+ * environment variable ALORE_ACADO_DENSE_WORKSPACE=0 has the same effect as a call with 0). */
+void alore_acado_dense_workspace(int enable);
 
 #ifdef __cplusplus
 }
