@@ -180,6 +180,58 @@ struct Chain {
     }
 };
 
+// The four legs are one structure with four sets of constants (joint axes x, y, y at depths 0, 1, 2): ONE copy of the walk, run
+// four times over the model table (wave-uniform index: scalar loads), instead of four unrolled copies -- the stage kernel's time
+// is instruction fetch to a sixth (its RNEA alone was 55 KB against a 64 KB instruction cache shared by two CUs).
+static_assert(b2z1::AXIS[1] == 0 && b2z1::AXIS[2] == 1 && b2z1::AXIS[3] == 1 && b2z1::AXIS[4] == 0 && b2z1::AXIS[5] == 1 && b2z1::AXIS[6] == 1 &&
+                  b2z1::AXIS[7] == 0 && b2z1::AXIS[8] == 1 && b2z1::AXIS[9] == 1 && b2z1::AXIS[10] == 0 && b2z1::AXIS[11] == 1 && b2z1::AXIS[12] == 1,
+              "the legs share their joint axes");
+WB_FN V3 origin_rt(int I) { return {b2z1::ORIGIN[3 * I], b2z1::ORIGIN[3 * I + 1], b2z1::ORIGIN[3 * I + 2]}; }
+WB_FN void body_wrench_rt(int I, V3 w, V3 wd, V3 ac, V3& F, V3& N)
+{
+    const V3 c = {b2z1::COM[3 * I], b2z1::COM[3 * I + 1], b2z1::COM[3 * I + 2]};
+    const double xx = b2z1::INERTIA[6 * I], xy = b2z1::INERTIA[6 * I + 1], xz = b2z1::INERTIA[6 * I + 2];
+    const double yy = b2z1::INERTIA[6 * I + 3], yz = b2z1::INERTIA[6 * I + 4], zz = b2z1::INERTIA[6 * I + 5];
+    auto inertia = [&](V3 u) -> V3 { return {xx * u.x + xy * u.y + xz * u.z, xy * u.x + yy * u.y + yz * u.z, xz * u.x + yz * u.y + zz * u.z}; };
+    const V3 acom = ac + cross(wd, c) + cross(w, cross(w, c));
+    F = b2z1::MASS[I] * acom;
+    N = inertia(wd) + cross(w, inertia(w)) + cross(c, F);
+}
+template <int D>
+struct LegChain {
+    static WB_FN void walk(const Eval& e, int first, int foot, V3 w, V3 wd, V3 ac, V3 fe, const Sink& tau, V3& f_up, V3& n_up)
+    {
+        const int I = first + D;
+        constexpr int AX = D == 0 ? 0 : 1;
+        const V3 p = origin_rt(I);
+        double s, c;
+        e.SC(5 + I, &s, &c);
+        const double qd = e.V(5 + I), qdd = e.A(5 + I);
+        const V3 ax = unit<AX>();
+        const V3 wl = rotT<AX>(c, s, w);
+        const V3 aci = rotT<AX>(c, s, ac + cross(wd, p) + cross(w, cross(w, p)));
+        const V3 wdi = rotT<AX>(c, s, wd) + qdd * ax + qd * cross(wl, ax);
+        const V3 wi = wl + qd * ax;
+        const V3 fei = rotT<AX>(c, s, fe);
+        V3 F, N;
+        body_wrench_rt(I, wi, wdi, aci, F, N);
+        if (D + 1 < 3) {
+            V3 fc, nc;
+            LegChain<(D + 1 < 3 ? D + 1 : D)>::walk(e, first, foot, wi, wdi, aci, fei, tau, fc, nc);
+            F = F + fc;
+            N = N + nc;
+        } else {
+            const V3 r = {b2z1::FOOT_POINT[3 * foot], b2z1::FOOT_POINT[3 * foot + 1], b2z1::FOOT_POINT[3 * foot + 2]};
+            F = F - fei;
+            N = N - cross(r, fei);
+        }
+        tau.put(5 + I, comp<AX>(N));
+        const V3 fp = rot<AX>(c, s, F);
+        f_up = fp;
+        n_up = rot<AX>(c, s, N) + cross(p, fp);
+    }
+};
+
 // the 24 rows of RNEA at the evaluation point go to the sink
 WB_FN void rnea(const Eval& e, const Sink& tau)
 {
@@ -192,16 +244,15 @@ WB_FN void rnea(const Eval& e, const Sink& tau)
     body_wrench<0>(w0, wd0, ac0, F, N);
     V3 fc, nc;
     WB_FENCE
-#define WB_LEG(FIRST, K)                                                                                                 \
-    Chain<FIRST, 0, 3, K>::walk(e, w0, wd0, ac0, R.toBase({e.F(3 * K), e.F(3 * K + 1), e.F(3 * K + 2)}), tau, fc, nc);     \
-    F = F + fc;                                                                                                          \
-    N = N + nc;                                                                                                          \
-    WB_FENCE
-    WB_LEG(1, 0)
-    WB_LEG(4, 1)
-    WB_LEG(7, 2)
-    WB_LEG(10, 3)
-#undef WB_LEG
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int leg = 0; leg < 4; ++leg) {
+        LegChain<0>::walk(e, 1 + 3 * leg, leg, w0, wd0, ac0, R.toBase({e.F(3 * leg), e.F(3 * leg + 1), e.F(3 * leg + 2)}), tau, fc, nc);
+        F = F + fc;
+        N = N + nc;
+        WB_FENCE
+    }
     Chain<13, 0, 6, -1>::walk(e, w0, wd0, ac0, {0.0, 0.0, 0.0}, tau, fc, nc);
     F = F + fc;
     N = N + nc;
