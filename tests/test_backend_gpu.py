@@ -230,6 +230,22 @@ def test_long_paths_use_the_32_piece_kernel(orc):
     assert res["ok"][0] == 1 and np.hypot(*res["xy_err"][0]) < orc.cfg.tol
 
 
+def test_lbfgs_of_the_32_piece_kernel_tracks_the_oracle(orc):
+    """The 32-piece build keeps the pair-at-a-time two-loop recursion (two registers per vector): its iterates against the
+    oracle's, like test_lbfgs_iterations_track_the_oracle for the 16-piece build."""
+    grid = free_grid(40.0)
+    ft = waypoint_path([[-6.0, -4.0], [0.0, -1.0], [6.0, 4.0]], 0.0, 1.0)
+    assert 16 < ft.pieces <= 32
+    x0 = orc.x0(ft)
+    pl = planner_for(grid, 1, max_pieces=32)
+    pl.set_problems([ft])
+    for stage, iters in ((1, 4), (2, 20)):
+        out = pl.lbfgs(stage, [x0], max_iter=iters)
+        ref = orc.lbfgs_run(grid, ft, stage, x0, lam=(0.0, 0.0), rho=(1e4, 1e4), max_iter=iters)
+        assert out["ret"][0] == ref["ret"] and out["iters"][0] == ref["iters"] and out["evals"][0] == ref["evals"], stage
+        assert np.max(np.abs(out["x"][0] - ref["x"])) <= 1e-6, stage
+
+
 def test_too_many_pieces_is_refused():
     from alore_legged_manipulator_amd.backend import BackendError, BatchedMSPlanner
     grid = free_grid(40.0)
