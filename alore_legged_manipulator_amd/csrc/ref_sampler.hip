@@ -114,7 +114,6 @@ __global__ void ref_sample_smooth_kernel(RefStore s, alore_nmpc_batch b, int B, 
     double cur = 0.0;
     const bool have = in_range && ref_sample_node(s, b, N, dt, now, est, icr, at_goal, r, j, cur);
     const double th = est[(size_t)r * 3 + 2];
-    const int base = (threadIdx.x & 63) - j; // first lane of the group inside the wavefront
     double prev = th;                          // what this node is unwrapped against (lane 0: the measured heading)
     for (int i = 0; i <= N; ++i) {             // wavefront-uniform
         if (j == i) {
@@ -122,8 +121,11 @@ __global__ void ref_sample_smooth_kernel(RefStore s, alore_nmpc_batch b, int B, 
             while (dyaw >= M_PI / 2) { cur -= M_PI * 2; dyaw = cur - prev; }
             while (dyaw <= -M_PI / 2) { cur += M_PI * 2; dyaw = cur - prev; }
         }
-        const double c = __shfl(cur, base + i);
-        if (j == i + 1) prev = c;
+        // the value of the lane to the left (the only reader is lane i + 1 of the group): a wavefront shift on the DPP path
+        // (wave_shr:1 crosses the rows of 16) instead of an LDS permute and its latency in each of the N + 1 dependent steps
+        const int clo = __builtin_amdgcn_update_dpp(0, __double2loint(cur), 0x138, 0xF, 0xF, false);
+        const int chi = __builtin_amdgcn_update_dpp(0, __double2hiint(cur), 0x138, 0xF, 0xF, false);
+        if (j == i + 1) prev = __hiloint2double(chi, clo);
     }
     if (have) {
         if (j < N) const_cast<float*>(b.y)[((size_t)r * N + j) * 5 + 2] = (float)cur;
