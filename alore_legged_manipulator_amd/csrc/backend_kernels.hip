@@ -90,8 +90,8 @@ __device__ __forceinline__ double wave_sum(double v)
     v += dpp_f64_nofill<0x143>(v); // row_bcast31: lane 63 += lane 31
     return lane63(v);
 }
-// inclusive prefix sum over the 64 lanes (the scan wave_sum reads its total from), and the suffix sum: lanes reversed
-// (one LDS permute there and one back instead of six dependent ones), the same scan
+// inclusive prefix sum over the 64 lanes (the scan wave_sum reads its total from); suffix sums use it on lanes that hold
+// their items in reverse order (eval_cost: chain coefficients)
 __device__ __forceinline__ double wave_prefix(double v)
 {
     v += dpp_f64<0x111, 0xF>(0.0, v);
@@ -101,15 +101,6 @@ __device__ __forceinline__ double wave_prefix(double v)
     v += dpp_f64<0x142, 0xA>(0.0, v);
     v += dpp_f64<0x143, 0xC>(0.0, v);
     return v;
-}
-__device__ __forceinline__ double wave_suffix(double v)
-{
-    const int rev = 63 - (int)threadIdx.x;
-    return __shfl(wave_prefix(__shfl(v, rev)), rev);
-}
-__device__ __forceinline__ double lane0(double v)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
 }
 __device__ __forceinline__ double wave_max(double v)
 {
