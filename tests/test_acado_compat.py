@@ -159,3 +159,41 @@ def test_acado_solve_and_the_condensed_workspace_members():
                         method="bvls", tol=1e-15, max_iter=2000).x
         assert comp.solve() == 0
         assert np.max(np.abs(comp.v["dx"] - tr)) < 1e-4 * max(1.0, np.max(np.abs(tr)))
+
+
+@pytest.mark.gpu
+def test_dense_workspace_refresh_can_be_switched_off():
+    """alore_acado_dense_workspace(0): the preparation / feedback steps no longer touch acadoWorkspace.H / g (a caller like
+    MpcWrapper never reads them: one launch and 40 KB over the bus less per step); the tick itself is unchanged; switched on
+    again they are refreshed."""
+    N = 50
+    batch = make_batch(1, N, seed=17, fast_tail=0.5)
+    p = problem(batch, 0)
+    comp = Compat()
+    comp.S.alore_acado_dense_workspace.argtypes = [C.c_int]
+    comp.S.alore_acado_dense_workspace.restype = None
+
+    def tick():
+        comp.reset(); comp.initialize_solver()
+        for k in ("x", "u", "od", "y", "yN", "W", "WN", "x0"):
+            comp.v[k][:] = p[k]
+        assert comp.preparation_step() == 0 and comp.feedback_step() == 0
+        return comp.v["u"].copy(), comp.v["H"].copy(), comp.v["g"].copy()
+
+    u_on, H_on, g_on = tick()
+    assert np.max(np.abs(H_on)) > 0.0
+    comp.S.alore_acado_dense_workspace(0)
+    try:
+        comp.v["H"][:] = 7.0; comp.v["g"][:] = -3.0
+        # caller_reset() clears the structs: fill the markers after it, inside the sequence
+        comp.reset(); comp.initialize_solver()
+        for k in ("x", "u", "od", "y", "yN", "W", "WN", "x0"):
+            comp.v[k][:] = p[k]
+        comp.v["H"][:] = 7.0; comp.v["g"][:] = -3.0
+        assert comp.preparation_step() == 0 and comp.feedback_step() == 0
+        assert np.all(comp.v["H"] == 7.0) and np.all(comp.v["g"] == -3.0)
+        assert np.array_equal(comp.v["u"], u_on)
+    finally:
+        comp.S.alore_acado_dense_workspace(1)
+    u_again, H_again, g_again = tick()
+    assert np.array_equal(H_again, H_on) and np.array_equal(g_again, g_on) and np.array_equal(u_again, u_on)
