@@ -324,28 +324,60 @@ int block_lds_floats(int N, int L)
 // wavefront-uniform (scalar loads from the kernel-argument segment); a single batch is the group of one.
 // FULLN: the horizon is exactly L * S (N = 20 on (4, 5)): every slot of every lane is a stage, the horizon is a compile-time
 // constant and all the masking of neutral slots folds away (a twentieth of the instructions of the (4, 5) build).
-template <int L, int S, bool DIAG, bool STAMP, bool ONCE, bool FULLN = false>
-__global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const RtiGroup grp)
+// TRACE (diagnostic instantiation of the FULLN build, ALORE_NMPC_TRACE=<file>): every workgroup leaves the 100 MHz real-time
+// counter at its start, after the staggered wait, when its inputs have landed, at its last store and when the stores are
+// acknowledged, with the SIMD it ran on (tools/trace_timeline.py turns that into per-SIMD timelines of a grid).
+// PERSIST (grid builds): the grid is one workgroup per SIMD slot and every workgroup takes blocks of 64 / L problems ("items")
+// from a ticket counter in device memory until none is left -- the hardware deals the workgroups of a plain grid to the XCDs and
+// their shader engines in fixed shares, so the grid lasts as long as its slowest XCD (they differ by ~5 % in clock under this
+// load: profiles/r05_a_timeline_*.txt); with tickets a faster XCD takes more items.  The ticket of the next item is requested
+// when the current one starts, so its latency is never waited for.
+template <int L, int S, bool DIAG, bool STAMP, bool ONCE, bool FULLN = false, bool TRACE = false, bool PERSIST = false>
+__global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p_arg, const RtiGroup grp_arg)
 {
     extern __shared__ float4 lds_raw[];
     float* lds = reinterpret_cast<float*>(lds_raw);
     constexpr int G = 64 / L;
     constexpr int NMAX = L * S;
     constexpr bool MASKED = (L == 16 && S == 2) || (L == 32 && S == 1); // see backward_sweep
-    const int N = FULLN ? L * S : p.N;
-    const int lane = threadIdx.x;
+    const int N = FULLN ? L * S : p_arg.N;
+    int item = (int)blockIdx.x; // block of G problems this workgroup works on
+next_item:
+    int lane = threadIdx.x;
+    // the kernel arguments, read through the kernel-argument segment pointer (what `p_arg`, `grp_arg` are)
+    typedef const __attribute__((address_space(4))) char* karg_ptr;
+    karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    // persistent loop: everything derived from the lane number and from the kernel arguments would be hoisted out of the loop and
+    // kept live across the whole body (hundreds of bytes of scratch, a register full of spilled scalars); opaque to the
+    // optimiser they are recomputed / loaded again per item like in the plain grid
+    if constexpr (PERSIST) {
+        asm volatile("" : "+v"(lane));
+        asm volatile("" : "+s"(ka));
+    }
+    const auto& p = *reinterpret_cast<const __attribute__((address_space(4))) RtiParams*>(ka);
+    const auto& grp = *reinterpret_cast<const __attribute__((address_space(4))) RtiGroup*>(ka + ((sizeof(RtiParams) + 7) & ~(size_t)7));
+    (void)p_arg; (void)grp_arg;
     const int g = lane / L, j = lane % L;
     const int gbase = lane - j;
-    const int bi = (grp.count > 1) ? (int)blockIdx.x / grp.blocks_per_batch : 0;
+    int ticket = 0;
+    if constexpr (PERSIST) {
+        if (lane == 0) ticket = atomicAdd(grp.counter, 1);
+    }
+    const int bi = (grp.count > 1) ? item / grp.blocks_per_batch : 0;
     // the workgroup's batch: entry bi of the table, or (batches laid out at constant strides, any number of them) the first
     // batch with every member pointer advanced by bi strides -- wavefront-uniform either way
-    alore_nmpc_batch pb = grp.b[grp.strided ? 0 : bi];
-    if (grp.strided) {
+    alore_nmpc_batch pb;
+    {
         char** q = reinterpret_cast<char**>(&pb);
+        const auto* src = reinterpret_cast<char* const __attribute__((address_space(4)))*>(&grp.b[grp.strided ? 0 : bi]);
 #pragma unroll
-        for (int i = 0; i < 15; ++i) q[i] = q[i] ? q[i] + (long long)bi * grp.stride[i] : q[i];
+        for (int i = 0; i < 15; ++i) q[i] = src[i];
+        if (grp.strided) {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) q[i] = q[i] ? q[i] + (long long)bi * grp.stride[i] : q[i];
+        }
     }
-    const int prob0 = ((int)blockIdx.x - bi * grp.blocks_per_batch) * G;
+    const int prob0 = (item - bi * grp.blocks_per_batch) * G;
     const int np_ = min(G, p.B - prob0);
     const bool valid = g < np_;
     const int ge = valid ? g : np_ - 1; // padding groups shadow the last problem, never store
@@ -359,13 +391,23 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
     // so the next residency bursts again (20 batches: five rounds of 35 us against 25 us per round in a long run whose
     // wavefronts have drifted apart).  The wavefronts of the FIRST residency therefore start spread over the time HBM needs
     // to feed them -- they would have waited for their data that long anyway -- and the rounds never line up.
-    if (grp.stagger_x1024 > 0 && (int)blockIdx.x < grp.stagger_blocks) {
+    if constexpr (TRACE) {
+        if (grp.trace && threadIdx.x == 0) {
+            long long* o = grp.trace + (size_t)item * 8;
+            o[0] = (long long)__builtin_amdgcn_s_memrealtime();
+            o[5] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); // HW_ID, XCC_ID
+        }
+    }
+    if (grp.stagger_x1024 > 0 && item == (int)blockIdx.x && item < grp.stagger_blocks) {
         const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long wait = ((unsigned long long)blockIdx.x * (unsigned)grp.stagger_x1024) >> 10;
+        const unsigned long long wait = ((unsigned long long)item * (unsigned)grp.stagger_x1024) >> 10;
         while (__builtin_amdgcn_s_memrealtime() - ts < wait) __builtin_amdgcn_s_sleep(2);
     }
     long long t0 = 0, t1 = 0, t4 = 0, t5 = 0, t_b = 0, t_f = 0, t_pg = 0;
     if (STAMP) t0 = __builtin_amdgcn_s_memtime();
+    if constexpr (TRACE) {
+        if (grp.trace && threadIdx.x == 0) grp.trace[(size_t)item * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 
     IrkConst K;
     K.h = p.h; K.hh = p.hh; K.c1h = p.c1h; K.c2h = p.c2h;
@@ -430,6 +472,34 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
     }
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the DMA pieces have landed
     wave_sync();
+    if constexpr (PERSIST) ticket = __builtin_amdgcn_readfirstlane(ticket); // the ticket has come back with the loads: into a scalar register
+    if constexpr (TRACE) {
+        if (grp.trace && threadIdx.x == 0) grp.trace[(size_t)item * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+
+    // problems the caller masked out (alore_nmpc_set_problem_mask) run along on whatever their members hold and write nothing
+    // (see the end of the kernel).  Their references may be stale or non-finite: they are replaced by the iterate itself (zero
+    // tracking error), so that such a problem cannot keep its wavefront in the working-set loop up to max_as_iter.  Cold path.
+    if (p.mask != nullptr) {
+        const bool sit_out = valid && p.mask[prob] == 0;
+        if (__any(sit_out)) {
+            if (sit_out) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int k = j * S + s;
+                    if (k < N) {
+                        float* yk = lds + oY + ge * 5 * N + 5 * k;
+                        yk[0] = x[s][0]; yk[1] = x[s][1]; yk[2] = x[s][2]; yk[3] = u[s][0]; yk[4] = u[s][1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) yN[c] = sit_out ? xN[c] : yN[c];
+            const float f0 = gfirst<L>(x[0][0], lane), f1 = gfirst<L>(x[0][1], lane), f2 = gfirst<L>(x[0][2], lane);
+            x00 = sit_out ? f0 : x00; x01 = sit_out ? f1 : x01; x02 = sit_out ? f2 : x02; // ... and the state estimate by node 0
+            wave_sync();
+        }
+    }
 
     // ---- diagonal weights (FULLN build): the reference's controller sets W = diag(Q, R), WN = diag(QN) (mpc_wrapper.cpp: setCosts),
     //      and with literal zeros off the diagonal the Gauss-Newton blocks, the Hessian application of the prediction, the KKT
@@ -1155,12 +1225,41 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p, const 
         if (DIAG && pb.kkt) pb.kkt[prob] = kkt;
         if (DIAG && pb.obj) pb.obj[prob] = obj;
     }
+    if constexpr (TRACE) {
+        if (grp.trace) {
+            int worst = 0; // sweeps of the slowest problem of the wavefront
+            while (worst < 64 && __any(n_iter > worst)) ++worst;
+            const long long te = (long long)__builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the stores are acknowledged
+            if (threadIdx.x == 0) {
+                long long* o = grp.trace + (size_t)item * 8;
+                o[3] = te;
+                o[4] = (long long)__builtin_amdgcn_s_memrealtime();
+                o[6] = worst;
+                o[7] = DIAGW ? 1 : 0;
+            }
+        }
+    }
     };
     if constexpr (FULLN && !STAMP) {
         if (wdiag) body(std::true_type{});
         else body(std::false_type{});
     } else {
         body(std::false_type{});
+    }
+    if constexpr (PERSIST) {
+        item = (int)gridDim.x + ticket;
+        if (item < grp.blocks_per_batch * grp.count) {
+            wave_sync(); // the staging area has been read: the next item's W / y may land
+            goto next_item;
+        }
+        // the last workgroup out puts the counters back for the next launch
+        if (lane == 0) {
+            if (atomicAdd(grp.counter + 1, 1) == (int)gridDim.x - 1) {
+                grp.counter[0] = 0;
+                grp.counter[1] = 0;
+            }
+        }
     }
     if (STAMP && lane == 0 && p.stamps) {
         long long* o = p.stamps + (size_t)blockIdx.x * 8;
@@ -1223,6 +1322,9 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
     grp.strided = 0;
     grp.stagger_blocks = 0;
     grp.stagger_x1024 = 0;
+    grp.trace = nullptr;
+    grp.counter = nullptr;
+    grp.persist_blocks = 0;
     grp.b[0] = p.b;
     return launch_rti_block_group(p, grp, g, s);
 }
@@ -1257,19 +1359,32 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
         v = 25 + (diag ? 0 : 1);
         fn = diag ? (const void*)rti_block_kernel<4, 5, true, false, true, true> : (const void*)rti_block_kernel<4, 5, false, false, true, true>;
     }
+    const bool persist = grp.counter != nullptr;
+    if (persist) {
+        if (!(g.L == 4 && g.RS == 5 && p.N == 20 && once && !stamp)) return hipErrorInvalidValue;
+        v = 28 + (diag ? 0 : 1);
+        fn = diag ? (const void*)rti_block_kernel<4, 5, true, false, true, true, false, true> : (const void*)rti_block_kernel<4, 5, false, false, true, true, false, true>;
+    }
+    if (grp.trace) { // diagnostic: only the grid builds have an instrumented twin
+        if (!(g.L == 4 && g.RS == 5 && p.N == 20 && once && !stamp && diag)) return hipErrorInvalidValue;
+        v = persist ? 30 : 27;
+        fn = persist ? (const void*)rti_block_kernel<4, 5, true, false, true, true, true, true> : (const void*)rti_block_kernel<4, 5, true, false, true, true, true>;
+    }
     if (!fn) return hipErrorInvalidValue;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     dev &= 15;
-    static size_t configured[16][27] = {{0}};
+    static size_t configured[16][31] = {{0}};
     if (g.lds_bytes > configured[dev][v]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
         if (e != hipSuccess) return e;
         configured[dev][v] = g.lds_bytes;
     }
     void* args[] = {const_cast<RtiParams*>(&p), const_cast<RtiGroup*>(&grp)};
-    e = hipLaunchKernel(fn, dim3((unsigned)g.grid * (unsigned)grp.count), dim3(64), args, g.lds_bytes, s);
+    unsigned blocks = (unsigned)g.grid * (unsigned)grp.count;
+    if (persist && blocks > (unsigned)grp.persist_blocks) blocks = (unsigned)grp.persist_blocks;
+    e = hipLaunchKernel(fn, dim3(blocks), dim3(64), args, g.lds_bytes, s);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }

@@ -58,8 +58,11 @@ struct alore_nmpc_solver {
     // alore_nmpc_rti_many: launches of independent batches in flight at once (side streams forked from the caller's)
     int overlap = 16;
     bool auto_pg = false; // warm_start_steps was left to the library: 6 for a launch on its own, 3 inside a grid of many batches
-    unsigned long long indep_sig = 0; // signature of the last descriptor set that passed the independence check of alore_nmpc_rti_many
-    bool indep_valid = false;
+    // the last descriptor set that passed the independence check of alore_nmpc_rti_many, kept whole (with the B and the shared-member
+    // mask it was checked for): any contiguous run of it is independent too
+    std::vector<alore_nmpc_batch> indep_set;
+    int indep_B = 0;
+    unsigned indep_shared = 0;
     int many_mode = 0; // alore_nmpc_rti_many: 0 = groups of batches per grid, 1 = one launch per batch on forked streams
     hipStream_t side[31] = {};
     hipEvent_t fork_ev = nullptr, join_ev[31] = {};
@@ -67,6 +70,11 @@ struct alore_nmpc_solver {
     // diagnostic phase stamps (env ALORE_NMPC_STAMPS=1): per-phase cycle shares, printed at destroy
     bool stamps = false;
     long long* d_stamps = nullptr;
+    // ticket counters of the persistent grids (nmpc_block_kernel.hip: PERSIST): a ring of pairs, one pair per launch in turn, so
+    // that grids of this handle that overlap on different streams never share one; every pair is back at 0 when its grid ends
+    static constexpr int kTicketRing = 16;
+    int* d_tickets = nullptr;
+    unsigned ticket_turn = 0;
     size_t stamps_cap = 0;
     double stamp_sum[7] = {0, 0, 0, 0, 0, 0, 0};
     double stamp_max_total = 0;
@@ -200,6 +208,11 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
         (void)alore_nmpc_destroy(h);
         return ALORE_NMPC_E_HIP;
     }
+    if (hipMalloc((void**)&h->d_tickets, sizeof(int) * 2 * alore_nmpc_solver::kTicketRing) != hipSuccess ||
+        hipMemset(h->d_tickets, 0, sizeof(int) * 2 * alore_nmpc_solver::kTicketRing) != hipSuccess) {
+        (void)alore_nmpc_destroy(h);
+        return ALORE_NMPC_E_HIP;
+    }
     const char* st = std::getenv("ALORE_NMPC_STAMPS");
     h->stamps = st && st[0] == '1';
     *out = h;
@@ -223,6 +236,7 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
         std::fprintf(stderr, "\n");
     }
     if (h->d_stamps) (void)hipFree(h->d_stamps);
+    if (h->d_tickets) (void)hipFree(h->d_tickets);
     for (int w = 0; w < 31; ++w) {
         if (h->side[w]) (void)hipStreamDestroy(h->side[w]);
         if (h->join_ev[w]) (void)hipEventDestroy(h->join_ev[w]);
@@ -455,8 +469,6 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
                            nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight);
     if (!use_block && !nmpc::rti_geometry(B, h->cfg.N, (lp & 0x100) ? 0 : lp, h->lds_limit, h->n_cu, &g, forced_wpb))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: horizon does not fit the LDS layout");
-    if (h->mask && !use_block)
-        return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: a problem mask needs the stage-block kernel (horizon <= 64, aligned members, no forced wavefront mapping)");
     nmpc::RtiParams p;
     fill_params(h, dev, B, n_sqp, g, &p);
     p.mask = h->mask;
@@ -548,6 +560,23 @@ bool batches_independent(alore_nmpc_handle h, const alore_nmpc_batch* batches, i
     return true;
 }
 
+// Is (batches, count) a contiguous run of the descriptor set that last passed the check, for the same B and shared members?  The
+// descriptors are compared, not a digest of them.
+bool known_independent(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B)
+{
+    const size_t n = h->indep_set.size();
+    if (n == 0 || (size_t)count > n || h->indep_B != B || h->indep_shared != h->shared) return false;
+    for (size_t i0 = 0; i0 + (size_t)count <= n; ++i0)
+        if (h->indep_set[i0].x == batches[0].x && std::memcmp(&h->indep_set[i0], batches, (size_t)count * sizeof(alore_nmpc_batch)) == 0) return true;
+    return false;
+}
+void remember_independent(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B)
+{
+    h->indep_set.assign(batches, batches + count);
+    h->indep_B = B;
+    h->indep_shared = h->shared;
+}
+
 // `count` independent batches on the stage-block kernel as ONE grid (nmpc_block_kernel.hip: RtiGroup): by table
 // (count <= GROUP_MAX) or, with `stride`, by constant member strides (any count)
 int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B, int n_sqp, void* stream, int B_in_flight,
@@ -558,6 +587,7 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti_many: horizon does not fit the stage-block kernel");
     nmpc::RtiParams p;
     fill_params(h, batches, B, n_sqp, g, &p);
+    p.mask = h->mask; // problem b of EVERY batch of the call (alore_nmpc_set_problem_mask)
     // a launch on its own lasts as long as its slowest wavefront, so the prediction runs until (nearly) no problem needs a
     // second sweep (6 .. 9 steps); when the chip is full of wavefronts the 2 % of problems that get one with 3 .. 4 steps cost
     // less than the steps saved (profiles/r04_block_kernel_experiments.txt)
@@ -584,6 +614,47 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
     for (int m = 0; m < 15; ++m) grp.stride[m] = stride ? stride[m] : 0;
     const int n_tab = stride ? 1 : count;
     for (int i = 0; i < n_tab; ++i) grp.b[i] = batches[i];
+    // diagnostic (ALORE_NMPC_TRACE=<file>, never under a stream capture): the instrumented twin of the grid build leaves 8 words per
+    // workgroup (real-time counter at start / after the stagger / inputs landed / last store / stores acknowledged, HW_ID, sweeps,
+    // diagonal path); the launch is synchronous, one file <file>.<n> per traced grid (tools/trace_timeline.py)
+    // ALORE_NMPC_PERSIST=1 (measured alternative, off by default): grids of at least two residencies of the build that fills the
+    // (4, 5) mapping run persistent -- one workgroup per SIMD slot, blocks of problems taken by ticket (see the kernel).  It evens out
+    // the XCDs (the hardware deals a plain grid to them in fixed shares and they differ by ~5 % in speed: tail 3.6 -> 1.4 % of a
+    // 200-batch grid), but the loop around the body costs the register allocation more than that: profiles/r05_persistent_grid.txt
+    static const bool persist_on = getenv("ALORE_NMPC_PERSIST") && atoi(getenv("ALORE_NMPC_PERSIST")) == 1;
+    grp.counter = nullptr;
+    grp.persist_blocks = 0;
+    if (persist_on && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && (long)g.grid * count >= 2L * 4 * h->n_cu) {
+        grp.counter = h->d_tickets + 2 * (h->ticket_turn++ % alore_nmpc_solver::kTicketRing);
+        grp.persist_blocks = 4 * h->n_cu;
+    }
+    static const char* trace_path = getenv("ALORE_NMPC_TRACE");
+    grp.trace = nullptr;
+    if (trace_path && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && batches[0].kkt && batches[0].obj) {
+        const size_t words = (size_t)g.grid * count * 8;
+        long long* d_trace = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&d_trace, words * sizeof(long long)));
+        grp.trace = d_trace;
+        hipError_t e = hipMemsetAsync(d_trace, 0, words * sizeof(long long), (hipStream_t)stream);
+        if (e == hipSuccess) e = nmpc::launch_rti_block_group(p, grp, g, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        std::vector<long long> host(words);
+        if (e == hipSuccess) e = hipMemcpy(host.data(), d_trace, words * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(d_trace);
+        if (e != hipSuccess) return fail(h, ALORE_NMPC_E_HIP, "rti_many: traced launch", e);
+        static int trace_seq = 0; // one file per traced grid: <path>.<n>
+        const std::string fname = std::string(trace_path) + "." + std::to_string(trace_seq++);
+        if (FILE* f = std::fopen(fname.c_str(), "wb")) {
+            const long long hdr[8] = {0x4543415254LL /* "TRACE" */, (long long)g.grid * count, count, g.grid, grp.stagger_blocks, grp.stagger_x1024, p.pg_steps, 0};
+            std::fwrite(hdr, sizeof(long long), 8, f);
+            std::fwrite(host.data(), sizeof(long long), host.size(), f);
+            std::fclose(f);
+        }
+        h->last_geom = g;
+        h->last_geom.grid = g.grid * count;
+        h->have_geom = true;
+        return ALORE_NMPC_OK;
+    }
     HIP_TRY(h, nmpc::launch_rti_block_group(p, grp, g, (hipStream_t)stream));
     h->last_geom = g;
     h->last_geom.grid = g.grid * count;
@@ -640,14 +711,9 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     if (ways > 1 && (h->timing || h->stamps)) ways = 1;
     if (ways > 1) {
         // the independence check (a sort of 15 x count address ranges) is remembered for the descriptor set it passed on: a host
-        // that steps the same slots every tick pays for it once (FNV-1a over the descriptors, B and the shared-member mask)
-        unsigned long long sig = 1469598103934665603ull;
-        auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ull; };
-        const unsigned long long* words = reinterpret_cast<const unsigned long long*>(batches);
-        for (size_t i = 0; i < (size_t)count * (sizeof(alore_nmpc_batch) / 8); ++i) mix(words[i]);
-        mix((unsigned long long)B); mix((unsigned long long)count); mix((unsigned long long)h->shared);
-        if (!(h->indep_valid && h->indep_sig == sig)) {
-            if (batches_independent(h, batches, count, B)) { h->indep_sig = sig; h->indep_valid = true; }
+        // that steps the same slots every tick pays for it once (alore_nmpc_rti_many_prepare: before the first tick)
+        if (!known_independent(h, batches, count, B)) {
+            if (batches_independent(h, batches, count, B)) remember_independent(h, batches, count, B);
             else ways = 1;
         }
     }
@@ -727,6 +793,18 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
         if (rc == ALORE_NMPC_OK && e2 != hipSuccess) rc = fail(h, ALORE_NMPC_E_HIP, "rti_many: join", e2);
     }
     return rc;
+}
+
+int alore_nmpc_rti_many_prepare(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B)
+{
+    if (!h || !batches || count < 1 || B <= 0) return fail(h, ALORE_NMPC_E_INVALID, "rti_many_prepare: bad argument");
+    for (int i = 0; i < count; ++i)
+        if (!batch_complete(batches + i)) return fail(h, ALORE_NMPC_E_INVALID, "rti_many_prepare: batch has NULL members");
+    if (known_independent(h, batches, count, B)) return ALORE_NMPC_OK;
+    if (!batches_independent(h, batches, count, B))
+        return fail(h, ALORE_NMPC_E_INVALID, "rti_many_prepare: the batches overlap (alore_nmpc_rti_many would run them in order)");
+    remember_independent(h, batches, count, B);
+    return ALORE_NMPC_OK;
 }
 
 int alore_nmpc_set_problem_mask(alore_nmpc_handle h, const unsigned char* mask)

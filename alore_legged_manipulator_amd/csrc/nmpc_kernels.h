@@ -34,6 +34,9 @@ struct RtiGroup {
     int stagger_x1024;    // blockIdx * stagger_x1024 / 1024 ticks of the 100 MHz real-time counter (0: no stagger), see the kernel
     int strided;          // 1: batch i = b[0] with every member pointer advanced by i * stride[member] bytes (any count);
                           // 0: batch i = b[i] (count <= GROUP_MAX)
+    long long* trace;     // diagnostic (ALORE_NMPC_TRACE): 8 words per workgroup, see the kernel; else null
+    int* counter;         // persistent grid: [0] tickets handed out, [1] workgroups that have left (both 0 between launches); else null
+    int persist_blocks;   // persistent grid: workgroups launched (one per SIMD slot); items beyond them are taken by ticket
     long long stride[15]; // bytes, in the member order of alore_nmpc_batch
     alore_nmpc_batch b[GROUP_MAX];
 };

@@ -703,8 +703,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
             rec[2] = gdual[i];
         }
     }
-    const float x00 = p.b.x0[(size_t)prob * 3], x01 = p.b.x0[(size_t)prob * 3 + 1],
-                x02 = p.b.x0[(size_t)prob * 3 + 2];
+    float x00 = p.b.x0[(size_t)prob * 3], x01 = p.b.x0[(size_t)prob * 3 + 1], x02 = p.b.x0[(size_t)prob * 3 + 2];
     wave_sync();
     // WREG: W_j of this lane's stage from the folded pass-through area into registers, for the whole launch
     float wreg[25];
@@ -717,6 +716,30 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
         }
         wave_sync(); // the records are about to overwrite the pass-through area
     }
+
+    // problems the caller masked out (alore_nmpc_set_problem_mask: idle robots of a fleet) run along and store nothing.  Their
+    // references may be stale or non-finite: they are replaced by the iterate itself (zero tracking error), so that such a
+    // problem cannot keep its wavefront in the working-set loop up to max_as_iter
+    const bool sit_out = valid && p.mask != nullptr && p.mask[prob] == 0;
+    if (__any(sit_out)) {
+        if (sit_out) {
+            for (int k = j; k < N; k += L) {
+                const float4 xk = lds4(row + k * SR, S_X), uy = lds4(row + k * SR, S_UY);
+                float* yk = stg + SG.y + k * 5;
+                yk[0] = xk.x; yk[1] = xk.y; yk[2] = xk.z; yk[3] = uy.x; yk[4] = uy.y;
+            }
+            if (j == 0) {
+                const float4 xe = lds4(row + N * SR, S_X);
+                stg[SG.term + 9] = xe.x; stg[SG.term + 10] = xe.y; stg[SG.term + 11] = xe.z;
+            }
+        }
+        wave_sync();
+        if (sit_out) { // ... and the state estimate by node 0 of the iterate
+            const float4 xb = lds4(row, S_X);
+            x00 = xb.x; x01 = xb.y; x02 = xb.z;
+        }
+    }
+    const bool keep = valid && !sit_out;
 
     // row role of this lane inside its quad (backward sweep)
     const int rq = j & 3;
@@ -1149,7 +1172,7 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 }
                 part += acc;
             }
-            if (valid) {
+            if (keep) {
                 float* ou = p.b.u + (size_t)prob * N * 2;
                 float* od = p.b.dual + (size_t)prob * N * 2;
                 ou[k * 2] = uy.x; ou[k * 2 + 1] = uy.y;
@@ -1162,14 +1185,14 @@ __global__ __launch_bounds__(64 * WPB) void rti_kernel(const RtiParams p)
                 part += e0 * e0 * tn[0] + e1 * e1 * tn[4] + e2 * e2 * tn[8];
             }
         }
-        if (valid) {
+        if (keep) {
             float* ox = p.b.x + (size_t)prob * (N + 1) * 3;
             ox[k * 3] = xk.x; ox[k * 3 + 1] = xk.y; ox[k * 3 + 2] = xk.z;
         }
     }
     float obj = 0.0f;
     if (want_obj) obj = 0.5f * group_total<L>(part, j);
-    if (valid && writer) {
+    if (keep && writer) {
         p.b.status[prob] = status;
         p.b.n_iter[prob] = n_iter;
         if (want_kkt && p.b.kkt) p.b.kkt[prob] = kkt;

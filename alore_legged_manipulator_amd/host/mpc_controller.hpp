@@ -193,7 +193,12 @@ public:
     // (mpc.cpp:176-203): its solver state stays what its last real solve left.  nullptr: all.
     void setSolveMask(const unsigned char* solving)
     {
-        if (!solving) { check(alore_nmpc_set_problem_mask(h_, nullptr)); return; }
+        bool all = solving == nullptr; // every robot solves: no mask (no 4 KB copy per tick, and the launch reads nothing extra)
+        if (!all) {
+            all = true;
+            for (int b = 0; b < B && all; ++b) all = solving[b] != 0;
+        }
+        if (all) { check(alore_nmpc_set_problem_mask(h_, nullptr)); return; }
         if (!d_mask_ && hipMalloc((void**)&d_mask_, (size_t)B) != hipSuccess) throw std::runtime_error("hipMalloc (problem mask)");
         if (hipMemcpyAsync(d_mask_, solving, (size_t)B, hipMemcpyHostToDevice, nullptr) != hipSuccess) throw std::runtime_error("hipMemcpyAsync (problem mask)");
         check(alore_nmpc_set_problem_mask(h_, d_mask_));

@@ -182,6 +182,16 @@ class BatchedNmpc:
         self._check(self.lib.alore_nmpc_rti_many(self.h, C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch)),
                                                 int(count), self.B, int(n_sqp), self._stream()))
 
+    def prepare_range(self, first: int, count: int) -> None:
+        """the independence check of rti_range(first, count) ahead of time (alore_nmpc_rti_many_prepare): later calls on these
+        slots, or on any contiguous run of them, go straight to the launch"""
+        if first < 0 or count < 1 or first + count > self.slots:
+            raise ValueError(f"prepare_range: slots {first} .. {first + count - 1} outside 0 .. {self.slots - 1}")
+        if not hasattr(self, "_batch_array"):
+            self._batch_array = (Batch * self.slots)(*self._batches)
+        self._check(self.lib.alore_nmpc_rti_many_prepare(self.h, C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch)),
+                                                        int(count), self.B))
+
     def linearize(self) -> dict:
         torch = self.torch
         d = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.device)

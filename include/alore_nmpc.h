@@ -168,6 +168,11 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int 
  * of B): results of different mappings agree to float32 rounding; pin lanes_per_problem where the bits of a single
  * alore_nmpc_rti launch are wanted. */
 int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch *batches, int count, int B, int n_sqp, void *stream);
+/* The independence check of alore_nmpc_rti_many (one sort of 15 x count address ranges) ahead of time: validates the set and
+ * remembers it -- the descriptors themselves, with B and the shared-member mask -- so that alore_nmpc_rti_many calls on it, or
+ * on any contiguous run of it, go straight to the launch.  A host that steps the same slots every tick calls it once (a stream
+ * capture of the call has the same effect: the check runs at capture time).  ALORE_NMPC_E_INVALID: the batches overlap. */
+int alore_nmpc_rti_many_prepare(alore_nmpc_handle h, const alore_nmpc_batch *batches, int count, int B);
 int alore_nmpc_set_many_mode(alore_nmpc_handle h, int mode); /* 0 = groups (default), 1 = streams */
 int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
 
@@ -177,8 +182,9 @@ int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
  * fleet controller keeps the reference's per-robot semantics inside one launch: MpcController::CmdCallback returns early for
  * a robot without odometry / trajectory, at its goal or stopped (mpc.cpp:176-203) and its solver state stays what the last
  * real solve left, so that the robot warm-starts from it when it moves again (mpc.cpp:317-320 resets only once).  Applies to
- * alore_nmpc_rti on the stage-block kernel (ALORE_NMPC_E_UNSUPPORTED with the wavefront mapping); alore_nmpc_rti_many
- * ignores it. */
+ * alore_nmpc_rti with either kernel mapping and to alore_nmpc_rti_many in every mode, where mask[b] stands for problem b of
+ * EVERY batch of the call.  A masked problem still occupies its lanes; its references are replaced by its own iterate inside
+ * the kernel, so stale or non-finite references cannot hold its wavefront in the working-set loop. */
 int alore_nmpc_set_problem_mask(alore_nmpc_handle h, const unsigned char *mask);
 
 /* ACADO split semantics.  The reference prepares (linearises, evaluates h(x,u)) in

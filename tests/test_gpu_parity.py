@@ -815,7 +815,8 @@ def test_diagonal_weight_path_agrees_with_the_general_path(nmpc_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,lanes,n_sqp", [(20, 0, 1), (20, BLOCK | 4, 1), (20, BLOCK | 16, 2), (31, BLOCK | 16, 1), (7, BLOCK | 8, 1)])
+@pytest.mark.parametrize("N,lanes,n_sqp", [(20, 0, 1), (20, BLOCK | 4, 1), (20, BLOCK | 16, 2), (31, BLOCK | 16, 1), (7, BLOCK | 8, 1),
+                                           (20, 32, 1), (50, 64, 2), (20, 16, 1)])
 def test_masked_problems_are_left_exactly_as_they_are(nmpc_mod, N, lanes, n_sqp):
     """alore_nmpc_set_problem_mask: the problems with mask 0 (idle robots of a fleet) keep every member bit for bit -- x, u, dual,
     status, n_iter, kkt, obj -- even when their references are NaN, and the others return the bits of a launch without a mask."""
@@ -845,11 +846,42 @@ def test_masked_problems_are_left_exactly_as_they_are(nmpc_mod, N, lanes, n_sqp)
     again = eng.fetch()
     for k in ("x", "u", "dual", "status"):
         assert np.array_equal(again[k], want[k]), k
-    # the wavefront mapping has no mask
-    w = nmpc_mod.BatchedNmpc(8, 20, lanes_per_problem=32)
-    w.load(make_batch(8, 20)); w.set_problem_mask(np.ones(8, np.uint8))
-    with pytest.raises(Exception):
-        w.rti(1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,overlap", [("groups", 16), ("streams", 4), ("groups", 1)])
+def test_the_problem_mask_applies_to_every_batch_of_rti_many(nmpc_mod, mode, overlap):
+    """alore_nmpc_rti_many (rti_range) with a problem mask, in every mode -- one grid, forked streams, in order: problem b of EVERY
+    batch of the call sits out when mask[b] = 0 (bit-untouched members, NaN references harmless), the others return the bits
+    of a call without a mask."""
+    B, N, slots = 300, 20, 5
+    rng = np.random.default_rng(5)
+    mask = (rng.uniform(size=B) > 0.2).astype(np.uint8); mask[[0, 16, 299]] = 0
+    engs = []
+    for masked in (False, True):
+        eng = nmpc_mod.BatchedNmpc(B, N, slots=slots)
+        eng.set_launch_overlap(overlap); eng.set_many_mode(mode)
+        for s in range(slots):
+            b = make_batch(B, N, seed=40 + s, fast_tail=0.3)
+            if masked:
+                b["y"][16] = np.nan; b["yN"][299] = np.inf
+            eng.load(b, slot=s)
+        for k in ("status", "n_iter"):
+            eng.ts[k].fill_(-3)
+        for k in ("kkt", "obj"):
+            eng.ts[k].fill_(-1.25)
+        engs.append(eng)
+    ref, eng = engs
+    before = {k: eng.ts[k].cpu().numpy().copy() for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj")}
+    ref.rti_range(0, slots)
+    eng.set_problem_mask(mask)
+    eng.rti_range(0, slots)
+    on, off = mask == 1, mask == 0
+    for k in before:
+        want, got = ref.ts[k].cpu().numpy(), eng.ts[k].cpu().numpy()
+        assert np.array_equal(got[:, off], before[k][:, off], equal_nan=True), (mode, k)
+        assert np.array_equal(got[:, on], want[:, on]), (mode, k)
+    assert (ref.ts["status"].cpu().numpy() == 0).all()
 
 
 @pytest.mark.gpu
