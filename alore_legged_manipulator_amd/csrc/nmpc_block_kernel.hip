@@ -541,14 +541,19 @@ next_item:
     int st0[S], st1[S];
     float c00[S], c01[S], c02[S], pf0[S], c10[S], c11[S], c12[S], pe1[S], pf1[S];
     float du0[S], du1[S], dxs[S][3], sbs[S][3];
+    // FULLN: every slot of every lane is a stage, the first backward sweep (every lane runs its block, see backward_sweep) writes all
+    // policy records and the first forward sweep (every problem starts `changed`) all steps before anything reads them: no initial
+    // value is needed, and "no value" costs no instruction where 0 costs ninety moves into registers and AGPRs per wavefront
+    auto blank = [] { float v; if constexpr (FULLN) asm("" : "=v"(v)); else v = 0.0f; return v; };
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        du0[s] = du1[s] = 0.0f;
-        c00[s] = c01[s] = c02[s] = pf0[s] = c10[s] = c11[s] = c12[s] = pe1[s] = pf1[s] = 0.0f;
+        du0[s] = blank(); du1[s] = blank();
+        c00[s] = blank(); c01[s] = blank(); c02[s] = blank(); pf0[s] = blank(); c10[s] = blank(); c11[s] = blank(); c12[s] = blank();
+        pe1[s] = blank(); pf1[s] = blank();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dxs[s][c] = sbs[s][c] = 0.0f;
+        for (int c = 0; c < 3; ++c) { dxs[s][c] = blank(); sbs[s][c] = blank(); }
     }
-    float dxo[3] = {0.f, 0.f, 0.f}, sbo[3] = {0.f, 0.f, 0.f}; // state step / free response leaving the lane's block
+    float dxo[3] = {blank(), blank(), blank()}, sbo[3] = {blank(), blank(), blank()}; // state step / free response leaving the lane's block
     float QN[6], qN[3];                                       // terminal node (meaningful in lane `top`)
 
     int status = RET_OK, n_iter = 0;
@@ -642,7 +647,7 @@ next_item:
             const bool cold = !gany<L>(nonfree != 0, gbase);
             // gradient H du + g of the condensed QP at du
             float g0[S], g1[S];
-            auto apply = [&](const float (&v0)[S], const float (&v1)[S]) {
+            auto apply = [&](const float (&v0)[S], const float (&v1)[S], float (&g0)[S], float (&g1)[S]) {
                 float X0[S], X1[S], X2[S], in2[S];
                 float acc = 0.0f;
 #pragma unroll
@@ -700,7 +705,7 @@ next_item:
             int hits = 0, badw = 0;
 #pragma unroll
             for (int s = 0; s < S; ++s) { w0[s] = 0.0f; w1[s] = 0.0f; }
-            apply(w0, w1);
+            apply(w0, w1, g0, g1);
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const bool in = j * S + s < N;
@@ -713,26 +718,32 @@ next_item:
             }
             const bool run = cold && gany<L>(hits != 0, gbase) && !gany<L>(badw != 0, gbase);
             if (__any(run)) {
-                float pu0[S], pu1[S], pg0[S], pg1[S];
+                // Two buffers take turns as (iterate, gradient) of the current and of the previous step: a step reads both and writes the
+                // next iterate over the previous one, so nothing is copied from step to step.
+                // FULLN (the grid build, 3 .. 4 steps): plain steps, no bookkeeping.  Elsewhere a problem whose predicted set has
+                // not moved for two steps stops updating and the loop ends when all have (the fewest sweeps for a launch on its own).
+                float v0[S], v1[S], h0[S], h1[S]; // second buffer: starts as the previous point (0, gradient at 0)
                 int bits[S];
-                auto at_bounds = [&](int s) {
-                    return (w0[s] <= lb0[s] ? 1 : 0) | (w0[s] >= ub0[s] ? 2 : 0) | (w1[s] <= lb1[s] ? 4 : 0) | (w1[s] >= ub1[s] ? 8 : 0);
+                auto at_bounds = [&](float a0, float a1, int s) {
+                    return (a0 <= lb0[s] ? 1 : 0) | (a0 >= ub0[s] ? 2 : 0) | (a1 <= lb1[s] ? 4 : 0) | (a1 >= ub1[s] ? 8 : 0);
                 };
 #pragma unroll
-                for (int s = 0; s < S; ++s) { pu0[s] = 0.0f; pu1[s] = 0.0f; pg0[s] = g0[s]; pg1[s] = g1[s]; bits[s] = at_bounds(s); }
+                for (int s = 0; s < S; ++s) { v0[s] = 0.0f; v1[s] = 0.0f; h0[s] = g0[s]; h1[s] = g1[s]; bits[s] = FULLN ? 0 : at_bounds(w0[s], w1[s], s); }
                 float alpha = 1.0f;
                 const int max_steps = p.pg_steps + p.pg_steps / 2;
                 int still = 0;
                 bool frozen = !run;
-#pragma unroll 1
-                for (int t = 1; t < max_steps; ++t) {
-                    apply(w0, w1);
+                // one step: gradient at the current iterate (c*) into cg*, Barzilai-Borwein length from the differences to the previous point
+                // (q*, qg*), next iterate over q*; returns true when every problem of the wavefront has stopped
+                auto bb_step = [&](int t, const float (&c0)[S], const float (&c1)[S], float (&cg0)[S], float (&cg1)[S], float (&q0)[S], float (&q1)[S],
+                                   const float (&qg0)[S], const float (&qg1)[S]) -> bool {
+                    apply(c0, c1, cg0, cg1);
                     float num = 0.0f, den = 0.0f;
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        const float e0 = w0[s] - pu0[s], e1 = w1[s] - pu1[s];
+                        const float e0 = c0[s] - q0[s], e1 = c1[s] - q1[s];
                         num += RD[s].x * e0 * e0 + RD[s].y * e1 * e1;
-                        den += e0 * (g0[s] - pg0[s]) + e1 * (g1[s] - pg1[s]);
+                        den += e0 * (cg0[s] - qg0[s]) + e1 * (cg1[s] - qg1[s]);
                     }
                     num = gtotal<L>(num, j, lane);
                     den = gtotal<L>(den, j, lane);
@@ -740,27 +751,45 @@ next_item:
                     int moved = 0;
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        pu0[s] = w0[s]; pu1[s] = w1[s]; pg0[s] = g0[s]; pg1[s] = g1[s];
-                        const float n0 = __builtin_amdgcn_fmed3f(w0[s] - alpha * is0[s] * g0[s], lb0[s], ub0[s]);
-                        const float n1 = __builtin_amdgcn_fmed3f(w1[s] - alpha * is1[s] * g1[s], lb1[s], ub1[s]);
-                        w0[s] = frozen ? w0[s] : n0;
-                        w1[s] = frozen ? w1[s] : n1;
-                        const int nb = at_bounds(s);
-                        moved |= (j * S + s < N && nb != bits[s]) ? 1 : 0;
-                        bits[s] = nb;
+                        const float n0 = __builtin_amdgcn_fmed3f(c0[s] - alpha * is0[s] * cg0[s], lb0[s], ub0[s]);
+                        const float n1 = __builtin_amdgcn_fmed3f(c1[s] - alpha * is1[s] * cg1[s], lb1[s], ub1[s]);
+                        if constexpr (FULLN) { // a problem that does not take the prediction runs along: its result is not used
+                            q0[s] = n0; q1[s] = n1;
+                        } else {
+                            q0[s] = frozen ? c0[s] : n0;
+                            q1[s] = frozen ? c1[s] : n1;
+                            const int nb = at_bounds(q0[s], q1[s], s);
+                            moved |= (j * S + s < N && nb != bits[s]) ? 1 : 0;
+                            bits[s] = nb;
+                        }
                     }
+                    if constexpr (FULLN) return false;
                     still = gany<L>(moved != 0, gbase) ? 0 : still + 1;
                     frozen = frozen || (still >= 2 && t + 1 >= p.pg_steps);
-                    if (__all(frozen)) break;
-                }
+                    return __all(frozen);
+                };
+                auto take_set = [&](const float (&a0)[S], const float (&a1)[S]) {
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const bool set = run && (j * S + s < N);
-                    const int n0 = (ub0[s] - lb0[s] > BOUNDTOL) ? ((w0[s] <= lb0[s]) ? ST_LOWER : ((w0[s] >= ub0[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
-                    const int n1 = (ub1[s] - lb1[s] > BOUNDTOL) ? ((w1[s] <= lb1[s]) ? ST_LOWER : ((w1[s] >= ub1[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
-                    st0[s] = set ? n0 : st0[s];
-                    st1[s] = set ? n1 : st1[s];
+                    for (int s = 0; s < S; ++s) {
+                        const bool set = run && (j * S + s < N);
+                        const int n0 = (ub0[s] - lb0[s] > BOUNDTOL) ? ((a0[s] <= lb0[s]) ? ST_LOWER : ((a0[s] >= ub0[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
+                        const int n1 = (ub1[s] - lb1[s] > BOUNDTOL) ? ((a1[s] <= lb1[s]) ? ST_LOWER : ((a1[s] >= ub1[s]) ? ST_UPPER : ST_FREE)) : ST_LOWER;
+                        st0[s] = set ? n0 : st0[s];
+                        st1[s] = set ? n1 : st1[s];
+                    }
+                };
+                bool in_w = true; // the latest iterate is in (w0, w1), else in (v0, v1)
+#pragma unroll 1
+                for (int t = 1; t < max_steps; t += 2) {
+                    const bool done = bb_step(t, w0, w1, g0, g1, v0, v1, h0, h1);
+                    in_w = false;
+                    if (done || t + 1 >= max_steps) break;
+                    const bool done2 = bb_step(t + 1, v0, v1, h0, h1, w0, w1, g0, g1);
+                    in_w = true;
+                    if (done2) break;
                 }
+                if (in_w) take_set(w0, w1);
+                else take_set(v0, v1);
             }
             if (STAMP) t_pg = __builtin_amdgcn_s_memtime() - tp0;
         }
@@ -901,14 +930,30 @@ next_item:
                             pd_fail |= ok ? 0 : 1;
                         }
                     } else {
-                        if (__any(start)) {
+                        // EVERY lane runs its block from the cost-to-go that enters IT (Vin) and keeps what comes out: a lane whose turn
+                        // has been (j > t, or its group sits this sweep out, or starts below) reproduces its own records bit for bit
+                        // -- same instructions, same inputs -- and a lane whose turn is still to come writes records that its turn
+                        // replaces.  So the nine policy values of a stage need no select; only the entering cost-to-go of the lane
+                        // whose turn it is does (it takes what was handed down, unless its group starts the sweep here).
+                        // (Only where the horizon fills the mapping.  Elsewhere the lane that owns stage N - 1 skips its slots past the
+                        // horizon, one of which carries the terminal weights for the prediction: run again from Vin over all S slots
+                        // it would add them a second time.  There the records are committed by selects, on lane t's turn only.)
+                        if constexpr (FULLN) {
+                            const bool take = mine && !start;
 #pragma unroll
-                            for (int i = 0; i < 9; ++i) V[i] = start ? Vin[i] : V[i];
+                            for (int i = 0; i < 9; ++i) { Vin[i] = take ? V[i] : Vin[i]; V[i] = Vin[i]; }
+                            const int ok = backward_block(t, true, std::true_type{});
+                            pd_fail |= (mine && !ok) ? 1 : 0;
+                        } else {
+                            if (__any(start)) {
+#pragma unroll
+                                for (int i = 0; i < 9; ++i) V[i] = start ? Vin[i] : V[i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) Vin[i] = mine ? V[i] : Vin[i];
+                            const int ok = ((t + 1) * S <= N) ? backward_block(t, mine, std::true_type{}) : backward_block(t, mine, std::false_type{});
+                            pd_fail |= (mine && !ok) ? 1 : 0;
                         }
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) Vin[i] = mine ? V[i] : Vin[i];
-                        const int ok = ((t + 1) * S <= N) ? backward_block(t, mine, std::true_type{}) : backward_block(t, mine, std::false_type{});
-                        pd_fail |= (mine && !ok) ? 1 : 0;
                     }
 #pragma unroll
                     for (int i = 0; i < 9; ++i) V[i] = lane_next<L>(V[i]);
@@ -1172,6 +1217,33 @@ next_item:
     // lanes ran along on whatever the members hold (results of a group never reach another group), now they fetch the
     // iterate and the dual again and write nothing else
     const bool skip = valid && p.mask != nullptr && p.mask[prob] == 0;
+    // The grid build stores the iterate and the dual straight from the registers of the lane that owns the stage -- 12- and 8-byte
+    // pieces of a span the wavefront writes completely, like the loads of phase 0; L2 merges them into whole lines -- instead of
+    // transposing them through LDS into 16-byte pieces (76 LDS writes, 26 reads and their waits per wavefront)
+    constexpr bool DIRECT = FULLN;
+    if constexpr (DIRECT) {
+        if (valid && !skip) {
+            typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+            float* gx = pb.x + (size_t)prob * nx;
+            float* gu = pb.u + (size_t)prob * nu;
+            float* gdl = pb.dual + (size_t)prob * nu;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int k = j * S + s;
+                f3u vx; vx.x = x[s][0]; vx.y = x[s][1]; vx.z = x[s][2];
+                f2u vu; vu.x = u[s][0]; vu.y = u[s][1];
+                f2u vd; vd.x = mu0[s]; vd.y = mu1[s];
+                *reinterpret_cast<f3u*>(gx + 3 * k) = vx;
+                *reinterpret_cast<f2u*>(gu + 2 * k) = vu;
+                *reinterpret_cast<f2u*>(gdl + 2 * k) = vd;
+            }
+            if (j == top) {
+                f3u vn; vn.x = xN[0]; vn.y = xN[1]; vn.z = xN[2];
+                *reinterpret_cast<f3u*>(gx + 3 * N) = vn;
+            }
+        }
+    } else {
     if (__any(skip)) {
         typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
         typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -1218,6 +1290,7 @@ next_item:
         g_store<UX>(pb.x + (size_t)prob0 * nx, lds + oX, np_ * nx, lane);
         g_store<UU>(pb.u + (size_t)prob0 * nu, lds + oU, np_ * nu, lane);
         g_store<UU>(pb.dual + (size_t)prob0 * nu, lds + oDL, np_ * nu, lane);
+    }
     }
     if (valid && !skip && j == 0) {
         pb.status[prob] = status;
