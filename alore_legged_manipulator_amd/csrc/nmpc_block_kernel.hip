@@ -366,16 +366,16 @@ next_item:
     const int bi = (grp.count > 1) ? item / grp.blocks_per_batch : 0;
     // the workgroup's batch: entry bi of the table, or (batches laid out at constant strides, any number of them) the first
     // batch with every member pointer advanced by bi strides -- wavefront-uniform either way
+    // Straight-line scalar code: the fifteen pointers and strides come in a few wide scalar loads with ONE wait (a test per member
+    // made every load its own round trip: two dozen of them in a row, ~1 us before a wavefront issued its first load).  A member
+    // that is absent has stride 0 (the host sets it), so null stays null without a test.
     alore_nmpc_batch pb;
     {
         char** q = reinterpret_cast<char**>(&pb);
         const auto* src = reinterpret_cast<char* const __attribute__((address_space(4)))*>(&grp.b[grp.strided ? 0 : bi]);
+        const long long sbi = grp.strided ? (long long)bi : 0ll;
 #pragma unroll
-        for (int i = 0; i < 15; ++i) q[i] = src[i];
-        if (grp.strided) {
-#pragma unroll
-            for (int i = 0; i < 15; ++i) q[i] = q[i] ? q[i] + (long long)bi * grp.stride[i] : q[i];
-        }
+        for (int i = 0; i < 15; ++i) q[i] = src[i] + sbi * grp.stride[i];
     }
     const int prob0 = (item - bi * grp.blocks_per_batch) * G;
     const int np_ = min(G, p.B - prob0);
@@ -730,7 +730,7 @@ next_item:
 #pragma unroll
                 for (int s = 0; s < S; ++s) { v0[s] = 0.0f; v1[s] = 0.0f; h0[s] = g0[s]; h1[s] = g1[s]; bits[s] = FULLN ? 0 : at_bounds(w0[s], w1[s], s); }
                 float alpha = 1.0f;
-                const int max_steps = p.pg_steps + p.pg_steps / 2;
+                const int max_steps = FULLN ? p.pg_steps + 1 : p.pg_steps + p.pg_steps / 2; // FULLN: exactly pg_steps steps
                 int still = 0;
                 bool frozen = !run;
                 // one step: gradient at the current iterate (c*) into cg*, Barzilai-Borwein length from the differences to the previous point
@@ -1315,7 +1315,7 @@ next_item:
     }
     };
     if constexpr (FULLN && !STAMP) {
-        if (wdiag) body(std::true_type{});
+        if (__builtin_expect(wdiag, 1)) body(std::true_type{}); // block frequencies steer the register allocator: the copies go to the rare path
         else body(std::false_type{});
     } else {
         body(std::false_type{});

@@ -591,7 +591,7 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
     // a launch on its own lasts as long as its slowest wavefront, so the prediction runs until (nearly) no problem needs a
     // second sweep (6 .. 9 steps); when the chip is full of wavefronts the 2 % of problems that get one with 3 .. 4 steps cost
     // less than the steps saved (profiles/r04_block_kernel_experiments.txt)
-    if (h->auto_pg && (long)B * count >= 16384) p.pg_steps = 3;
+    if (h->auto_pg && (long)B * count >= 16384) p.pg_steps = 4; // round 5 (a prediction step costs 443 instructions, was 573): 2 / 3 / 4 / 5 / 6 steps: 5.97 / 5.61 / 5.50 / 5.72 / 6.20 us per batch
     nmpc::RtiGroup grp;
     grp.count = count;
     grp.blocks_per_batch = g.grid;
@@ -604,7 +604,9 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
         const long resident = 4L * h->n_cu;
         static const char* env_ns = getenv("ALORE_NMPC_STAGGER_NS"); // diagnostic: total spread in ns (0 = off)
         const double bytes_per_block = 4.0 * (51.0 * h->cfg.N + 28.0) * g.G;
-        double spread_ns = resident * bytes_per_block / 5.0e3; // bytes / (5e12 B/s) in ns
+        // bytes / (7.5e12 B/s) in ns: 9 us for 1024 wavefronts x 67 KB (round 5, profiles/r05_b_stagger_and_pg_sweep.txt: 6 .. 11 us are
+        // equally good, 0 costs 15 us per 20-batch grid, 14 and more 1 .. 3 us)
+        double spread_ns = resident * bytes_per_block / 7.5e3;
         if (env_ns) spread_ns = atof(env_ns);
         if ((long)g.grid * count >= 2 * resident && spread_ns > 0.0) {
             grp.stagger_blocks = (int)resident;

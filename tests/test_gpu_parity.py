@@ -579,9 +579,9 @@ def test_what_the_bench_times_is_pinned(nmpc_mod, mode):
     assert info["lanes_per_problem"] == (BLOCK | 4), info
     got = {k: eng.ts[k].clone() for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj")}
     assert (got["status"] == 0).all()
-    # inside a grid that fills the chip the library runs the working-set prediction with 3 steps instead of 6 (the solution does
+    # inside a grid that fills the chip the library runs the working-set prediction with 4 steps instead of 6 (the solution does
     # not depend on it, the iteration counts do): the slot-by-slot reference is given the same number
-    ref = nmpc_mod.BatchedNmpc(B, N, slots=slots, lanes_per_problem=info["lanes_per_problem"], warm_start_steps=3 if mode == "groups" else -1)
+    ref = nmpc_mod.BatchedNmpc(B, N, slots=slots, lanes_per_problem=info["lanes_per_problem"], warm_start_steps=4 if mode == "groups" else -1)
     for s in range(slots):
         ref.load(batches[s], slot=s)
     for s in range(slots):
