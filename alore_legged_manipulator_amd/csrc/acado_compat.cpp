@@ -65,14 +65,19 @@ void upload_variables(const ACADOvariables& v, bool iterate, bool dual)
 }
 // the condensed QP of the batch on the device -> acadoWorkspace.H, g (what condensePrep / condenseFdb leave there)
 int g_dense = -1; // -1: not decided yet (environment), 0 / 1
-void condense_to_workspace(bool with_g)
+// false: the condensed QP could not be formed -- acadoWorkspace.H / g would be stale, the step reports it (29, as for a lost device)
+bool condense_to_workspace(bool with_g)
 {
     if (g_dense < 0) { const char* e = std::getenv("ALORE_ACADO_DENSE_WORKSPACE"); g_dense = (e && e[0] == '0') ? 0 : 1; }
-    if (!g_dense) return;
+    if (!g_dense) return true;
     alore_nmpc_dense_qp_data q{g_H, g_g, g_lb, g_ub};
-    if (!ok(alore_nmpc_condense(g_h, &g_dev, 1, &q, nullptr))) return;
-    (void)hipMemcpyAsync(acadoWorkspace.H, g_H, sizeof(float) * ACADO_QP_NV * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr);
-    if (with_g) (void)hipMemcpyAsync(acadoWorkspace.g, g_g, sizeof(float) * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr);
+    if (!ok(alore_nmpc_condense(g_h, &g_dev, 1, &q, nullptr))) {
+        std::fprintf(stderr, "[alore_acado_compat] acadoWorkspace.H / g not refreshed: %s\n", alore_nmpc_last_error(g_h));
+        return false;
+    }
+    bool copied = hipMemcpyAsync(acadoWorkspace.H, g_H, sizeof(float) * ACADO_QP_NV * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr) == hipSuccess;
+    if (with_g) copied = copied && hipMemcpyAsync(acadoWorkspace.g, g_g, sizeof(float) * ACADO_QP_NV, hipMemcpyDeviceToHost, nullptr) == hipSuccess;
+    return copied;
 }
 } // namespace
 
@@ -126,9 +131,9 @@ int acado_preparationStep(void)
     (void)hipMemcpyAsync(acadoWorkspace.d, g_d, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, nullptr);
     (void)hipMemcpyAsync(acadoWorkspace.evGx, g_gx, sizeof(float) * 9 * N, hipMemcpyDeviceToHost, nullptr);
     (void)hipMemcpyAsync(acadoWorkspace.evGu, g_gu, sizeof(float) * 6 * N, hipMemcpyDeviceToHost, nullptr);
-    condense_to_workspace(false); // acado_condensePrep: the Hessian of the condensed QP belongs to the preparation
+    const bool dense_ok = condense_to_workspace(false); // acado_condensePrep: the Hessian of the condensed QP belongs to the preparation
     (void)hipStreamSynchronize(nullptr);
-    return 0;
+    return dense_ok ? 0 : 29;
 }
 
 int acado_feedbackStep(void)
@@ -151,7 +156,7 @@ int acado_feedbackStep(void)
         acadoWorkspace.lb[i] = acadoVariables.lbValues[i] - acadoVariables.u[i];
         acadoWorkspace.ub[i] = acadoVariables.ubValues[i] - acadoVariables.u[i];
     }
-    condense_to_workspace(true); // acado_condenseFdb: gradient of the condensed QP for the measured state (H again: same linearisation)
+    const bool dense_ok = condense_to_workspace(true); // acado_condenseFdb: gradient of the condensed QP for the measured state (H again: same linearisation)
     const int rc = alore_nmpc_rti(g_h, &g_dev, 1, 1, nullptr);
     alore_nmpc_set_linearization_point(g_h, nullptr, nullptr);
     int status = 0;
@@ -162,7 +167,7 @@ int acado_feedbackStep(void)
     (void)hipStreamSynchronize(nullptr);
     for (int i = 0; i < ACADO_QP_NV; ++i) acadoWorkspace.x[i] = acadoVariables.u[i] - u_old[i];
     g_have_prep = false;
-    return ok(rc) ? status : 29;
+    return (ok(rc) && dense_ok) ? status : 29;
 }
 
 void acado_shiftStates(int strategy, real_t* const xEnd, real_t* const uEnd)

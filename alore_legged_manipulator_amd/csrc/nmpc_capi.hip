@@ -845,7 +845,8 @@ int alore_nmpc_condense(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B,
     if (!h || !dev || !out || B <= 0 || !out->H || !out->g || !out->lb || !out->ub || !dev->x || !dev->u || !dev->od || !dev->y || !dev->yN ||
         !dev->W || !dev->WN || !dev->x0 || !dev->lbValues || !dev->ubValues)
         return fail(h, ALORE_NMPC_E_INVALID, "condense: bad argument");
-    if (h->cfg.N > 64) return fail(h, ALORE_NMPC_E_UNSUPPORTED, "condense: horizons up to 64 (the E blocks of a problem live in LDS)");
+    if (h->cfg.N > 64 || (long)nmpc::condense_lds_bytes(h->cfg.N) > (long)h->lds_limit)
+        return fail(h, ALORE_NMPC_E_UNSUPPORTED, "condense: horizons up to 64 (the E blocks of a problem live in LDS) and within this device's LDS per workgroup");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, nmpc::launch_condense(*dev, h->lin_x, h->lin_u, B, h->cfg.N, h->cfg.dt, h->shared, out->H, out->g, out->lb, out->ub, (hipStream_t)stream));
     return ALORE_NMPC_OK;
@@ -856,6 +857,8 @@ int alore_nmpc_dense_qp(alore_nmpc_handle h, int B, int n, const alore_nmpc_dens
 {
     if (!h || !qp || B <= 0 || n < 1 || n > 128 || !qp->H || !qp->g || !qp->lb || !qp->ub || !x || !y || !status || !n_iter)
         return fail(h, ALORE_NMPC_E_INVALID, "dense_qp: bad argument (n <= 128)");
+    if ((long)nmpc::dense_qp_lds_bytes(n) > (long)h->lds_limit)
+        return fail(h, ALORE_NMPC_E_UNSUPPORTED, "dense_qp: the factor of an n x n Hessian does not fit this device's LDS per workgroup (n = 128 needs 68 KB)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, nmpc::launch_dense_qp(B, n, qp->H, qp->g, qp->lb, qp->ub, x, y, status, n_iter, h->cfg.max_as_iter, (hipStream_t)stream));
     return ALORE_NMPC_OK;

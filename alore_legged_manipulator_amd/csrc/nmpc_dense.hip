@@ -281,11 +281,13 @@ hipError_t launch_condense(const alore_nmpc_batch& b, const float* lin_x, const 
                            float* g, float* lb, float* ub, hipStream_t s)
 {
     const size_t lds = condense_lds_bytes(N);
-    static size_t raised = 0;
-    if (lds > 48 * 1024 && lds > raised) {
+    int dev = 0;
+    if (const hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    static size_t raised[16] = {0}; // per device: the attribute belongs to the function on ONE device
+    if (lds > 48 * 1024 && lds > raised[dev & 15]) {
         const hipError_t e = hipFuncSetAttribute((const void*)condense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised = lds;
+        raised[dev & 15] = lds;
     }
     hipLaunchKernelGGL(condense_kernel, dim3(B), dim3(DT), lds, s, b, lin_x, lin_u, B, N, make_irk(dt), shared, H, g, lb, ub);
     return hipGetLastError();
@@ -295,11 +297,13 @@ hipError_t launch_dense_qp(int B, int n, const float* H, const float* g, const f
                            int* n_iter, int max_iter, hipStream_t s)
 {
     const size_t lds = dense_qp_lds_bytes(n);
-    static size_t raised = 0;
-    if (lds > 48 * 1024 && lds > raised) {
+    int dev = 0;
+    if (const hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    static size_t raised[16] = {0}; // per device: the attribute belongs to the function on ONE device
+    if (lds > 48 * 1024 && lds > raised[dev & 15]) {
         const hipError_t e = hipFuncSetAttribute((const void*)dense_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised = lds;
+        raised[dev & 15] = lds;
     }
     hipLaunchKernelGGL(dense_qp_kernel, dim3(B), dim3(DT), lds, s, n, H, g, lb, ub, x, y, status, n_iter, max_iter);
     return hipGetLastError();

@@ -68,6 +68,8 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
 // nmpc_dense.hip: the condensed QP of the reference's dense interface (acadoWorkspace.H / g / lb / ub, acado_solve)
 hipError_t launch_condense(const alore_nmpc_batch& b, const float* lin_x, const float* lin_u, int B, int N, float dt, unsigned shared, float* H,
                            float* g, float* lb, float* ub, hipStream_t s);
+size_t condense_lds_bytes(int N);  // dynamic LDS of one workgroup of the two kernels above / below
+size_t dense_qp_lds_bytes(int n);
 hipError_t launch_dense_qp(int B, int n, const float* H, const float* g, const float* lb, const float* ub, float* x, float* y, int* status,
                            int* n_iter, int max_iter, hipStream_t s);
 

@@ -25,6 +25,23 @@ def partition(total: int, world: int, rank: int) -> Tuple[int, int]:
     return offset, count
 
 
+def pad_rows(t, rows: int):
+    """`t` with its leading dimension padded with zeros to `rows`: ranks of an uneven partition (partition(): the first
+    total % world ranks own one problem more) bring equal shapes to the all-gather"""
+    import torch
+    if t.shape[0] == rows:
+        return t
+    pad = torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    return torch.cat([t, pad], dim=0)
+
+
+def concat_gathered(out, counts: List[int], dim: int = 0):
+    """the padded slabs of an all-gather ([world, rows_max, ...]) cut back to the ranks' real counts and joined in rank order:
+    the global batch in its global problem order"""
+    import torch
+    return torch.cat([out[r].narrow(dim, 0, c) for r, c in enumerate(counts)], dim=dim)
+
+
 class ResultGatherer:
     """All-gather of result tensors with equal per-rank shapes.
 

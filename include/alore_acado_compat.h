@@ -12,8 +12,15 @@
  * Served from the GPU: acado_initializeSolver, acado_initializeNodesByForwardSimulation,
  * acado_preparationStep, acado_feedbackStep, acado_shiftStates, acado_shiftControls, acado_getKKT,
  * acado_getObjective, acado_getNWSR, acado_integrate, acado_rhs, acado_diffs, acado_getErrorString.
- * Workspace members kept up to date: d, evGx, evGu (preparation), Dx0, lb, ub, x (= delta u), y (= dual).
- * The dense condensed QP (H, g, E, ...) is never formed, so acado_solve() reports RET_INIT_FAILED.
+ * acadoWorkspace members kept up to date (what Tracked_nmpc::MpcWrapper and acado_solve() read):
+ *   acado_preparationStep: d, evGx, evGu (acado_modelSimulation, CG/acado_solver.c:35-78), H and the state-independent part of g of
+ *     the condensed QP (formed on the GPU by alore_nmpc_condense: what acado_condensePrep leaves, :365-891);
+ *   acado_feedbackStep: Dx0, lb, ub, g (with the Dx0 terms: acado_condenseFdb, :893-960), x (= delta u), y (= dual);
+ *   acado_solve(): solves the dense QP that is in H, g, lb, ub (alore_nmpc_dense_qp), primal into x, dual into y.
+ * NOT refreshed -- the intermediates of the reference's O(N^2) condensing, which the stage-wise solver never forms and the
+ * reference's wrapper never reads: E (d x_k / d u_j blocks), Q1, Q2, R1, R2, QN1, QN2 (weight slices, :171-211), Dy, DyN, QDy
+ * (stacked residuals, :327-363), sbar, w1, w2, QGx, QGu and the state pieces of the integrator (rk_*).  They keep whatever the
+ * caller put there.  ALORE_ACADO_DENSE_WORKSPACE=0 switches the H / g refresh off (then acado_solve() has nothing to solve).
  */
 #ifndef ALORE_ACADO_COMPAT_H
 #define ALORE_ACADO_COMPAT_H

@@ -1,4 +1,4 @@
-"""Worker of tests/test_shard_gloo.py: one rank of a world_size-2 gloo job on CPU.
+"""Worker of tests/test_shard_gloo.py: one rank of a world_size-2 (or -3: uneven partition) gloo job on CPU.
 
 Exercises the multi-GPU data path of bench.py with the CPU stand-ins that exist
 on a machine without GPUs: each rank owns a contiguous block of the global batch
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from alore_legged_manipulator_amd.scenarios import make_batch, problem  # noqa: E402
-from alore_legged_manipulator_amd.shard import ResultGatherer, partition  # noqa: E402
+from alore_legged_manipulator_amd.shard import ResultGatherer, concat_gathered, pad_rows, partition  # noqa: E402
 from oracle.drivers import Oracle  # noqa: E402
 
 
@@ -89,9 +89,10 @@ def bench_pass_bookkeeping(rank, world):
     last = g.wait()
     checks["gather shape"] = tuple(last["x"].shape) == (world, 1, B, N + 1, 3)
     checks["own slab"] = torch.equal(last["x"][rank][0], eng.ts["x"][W + K - 1]) and bool((last["status"] == 0).all())
-    other = make_batch(B, N, seed=77, offset=(1 - rank) * B)             # what the other rank must have sent
+    peer = (rank + 1) % world
+    other = make_batch(B, N, seed=77, offset=peer * B)                    # what the next rank must have sent
     e2 = OracleEngine(B, N, 1); e2.load(other); e2.rti(1, 0)
-    checks["peer slab"] = torch.equal(last["u"][1 - rank][0], e2.ts["u"][0])
+    checks["peer slab"] = torch.equal(last["u"][peer][0], e2.ts["u"][0])
     # last-batch-only gather
     submits.clear(); eng.launches.clear()
     el2, dms2, _ = timed_pass(eng, batch, "last", K, W, ge, g, hooks, world)
@@ -109,7 +110,7 @@ def bench_pass_bookkeeping(rank, world):
     checks["converged: one gather per step"] = len(seen) == W + K and eng.launches == list(range(W + K)) and not graph3
     checks["converged: own slab"] = torch.equal(lastc["x"][rank], eng.ts["x"][W + K - 1]) and torch.equal(lastc["kkt"][rank], eng.ts["kkt"][W + K - 1])
     e3 = OracleEngine(B, N, 1); e3.load(other); e3.rti(2, 0)
-    checks["converged: peer slab"] = torch.equal(lastc["x"][1 - rank], e3.ts["x"][0]) and torch.equal(lastc["u"][1 - rank], e3.ts["u"][0])
+    checks["converged: peer slab"] = torch.equal(lastc["x"][peer], e3.ts["x"][0]) and torch.equal(lastc["u"][peer], e3.ts["u"][0])
     checks["converged: every problem of every rank"] = tuple(lastc["status"].shape) == (world, B) and int(lastc["status"].sum()) == 0
     e1 = OracleEngine(B, N, 1); e1.load(batch); e1.rti(1, 0)
     checks["converged: two iterations differ from one"] = not torch.equal(e1.ts["u"][0], eng.ts["u"][W + K - 1])
@@ -135,15 +136,17 @@ def bench_pass_bookkeeping(rank, world):
 def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    N, total, steps = 20, 22, 3  # 22 problems over 2 ranks: 11 + 11; steps = buckets of different sizes
+    N, total, steps = 20, 22, 3  # 22 problems: 11 + 11 over 2 ranks, 8 + 7 + 7 over 3; steps = buckets of different sizes
     off, cnt = partition(total, world, rank)
-    assert cnt == 11 and off == rank * 11
+    counts = [partition(total, world, r)[1] for r in range(world)]
+    assert counts == ([11, 11] if world == 2 else [8, 7, 7] if world == 3 else counts) and off == sum(counts[:rank]) and cnt == counts[rank]
+    rows = max(counts)  # ranks with one problem fewer pad their slab: the collective wants equal shapes
     g = ResultGatherer(dist, world)
     xs, us, sts = [], [], []
     for s in range(steps):
         batch = make_batch(cnt, N, seed=1000 + s, offset=off)
         x, u, st = solve(batch, N)
-        xs.append(torch.from_numpy(x)); us.append(torch.from_numpy(u)); sts.append(torch.from_numpy(st))
+        xs.append(pad_rows(torch.from_numpy(x), rows)); us.append(pad_rows(torch.from_numpy(u), rows)); sts.append(pad_rows(torch.from_numpy(st), rows))
     # bucket 1: steps 0..1 in one collective per tensor, bucket 2: step 2
     g.submit({"x": torch.stack(xs[:2]), "u": torch.stack(us[:2]), "status": torch.stack(sts[:2])})
     first = {k: v.clone() for k, v in g.wait().items()}
@@ -156,10 +159,10 @@ def main():
             x, u, st = solve(full, N)
             src = first if s < 2 else second
             i = s if s < 2 else 0
-            gx = torch.cat([src["x"][r][i] for r in range(world)]).numpy()
-            gu = torch.cat([src["u"][r][i] for r in range(world)]).numpy()
-            gs = torch.cat([src["status"][r][i] for r in range(world)]).numpy()
-            ok = ok and np.array_equal(gx, x) and np.array_equal(gu, u) and np.array_equal(gs, st)
+            gx = concat_gathered(src["x"][:, i], counts).numpy()   # [world, rows, ...] -> the global batch in problem order
+            gu = concat_gathered(src["u"][:, i], counts).numpy()
+            gs = concat_gathered(src["status"][:, i], counts).numpy()
+            ok = ok and gx.shape[0] == total and np.array_equal(gx, x) and np.array_equal(gu, u) and np.array_equal(gs, st)
         print("GATHER_OK" if ok else "GATHER_MISMATCH", flush=True)
     ok = bench_pass_bookkeeping(rank, world) and ok
     dist.barrier()

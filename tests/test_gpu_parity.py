@@ -362,6 +362,7 @@ def test_wide_problems_three_ticks_against_oracle(nmpc_mod):
     print(f"wide: {len(err_k)} QPs; vs float64 truth: kernel max {err_k.max():.2e} median {np.median(err_k):.2e}; "
           f"reference max {err_r.max():.2e} median {np.median(err_r):.2e}; beyond 1e-4 of the reference: {loose}")
     assert err_k.max() < 1e-4 and err_k.max() <= err_r.max()
+    assert loose <= len(err_k) // 200, (loose, len(err_k))   # measured: 2 of 1398 (0.14 %); bound 0.5 %
     assert long_runs >= 3        # the safeguard ran
 
 
@@ -507,29 +508,43 @@ def test_every_lane_mapping_against_the_oracle(nmpc_mod, N, lanes):
             assert abs(out["kkt"][p] - orc.get_kkt()) <= 2e-3 * max(1.0, orc.get_kkt())
 
 
-def check_against_oracle_and_float64(batch, out, u_in, picks, N, tag):
-    """The rule of test_wide_problems_three_ticks_against_oracle for one cold tick: never more than 1e-3 from the oracle;
-    wherever the kernel is more than 1e-4 (BASELINE.json) from the oracle it must be closer than the oracle to the float64
-    minimiser of the oracle's own condensed QP and within 1e-4 of it."""
+def check_against_oracle_and_float64(batch, out, u_in, picks, N, tag, max_loose_share=0.01):
+    """The rule of test_wide_problems_three_ticks_against_oracle for one cold tick (distances are element-wise relative errors
+    with an absolute floor of 1, `relerr`):
+      * never more than 5e-4 from the oracle -- except where the ORACLE misses the float64 minimiser of its own condensed QP by more
+        than 1e-4 (the reference's float32 homotopy does, on ill-conditioned problems): there 1e-3, and at most one such problem in 400;
+      * wherever the kernel is more than 1e-4 (BASELINE.json) from the oracle it must be closer than the oracle to that float64
+        minimiser and within 1e-4 of it ("loose" problems), and their share is bounded: <= max_loose_share of the picks.
+    Measured in round 5 (MI355X): stress batch, every mapping: 2 of 457 picks loose (0.44 %; the picks are every 9th problem plus
+    every one with >= 10 working-set iterations, i.e. the hard ones), one of them 6.1e-4 from the oracle (oracle 1.7e-4 from the
+    float64 minimiser, kernel 5.6e-5); slots of the timed configuration: 0 of 180 loose, worst 6.1e-5; wide batch, 3 ticks: 2 of 1398."""
     orc = Oracle(N)
-    err_k, err_r, loose = [], [], 0
+    err_k, err_r, loose, worst, oracle_off = [], [], 0, 0.0, 0
     for b in picks:
         orc.reset(); orc.initialize_solver(); orc.load(problem(batch, b)); orc.preparation_step()
         assert orc.feedback_step() == 0 and out["status"][b] == 0, (tag, b)
         eu, ex = relerr(out["u"][b].reshape(-1), orc.v["u"]), relerr(out["x"][b].reshape(-1), orc.v["x"])
+        worst = max(worst, eu, ex)
         n = 2 * N
         du_true = exact_box_qp(orc.v["H"].reshape(n, n), orc.v["g"], orc.v["lb"], orc.v["ub"])
         scale = max(1.0, float(np.max(np.abs(orc.v["u"]))))
         ek = float(np.max(np.abs((out["u"][b].reshape(-1).astype(np.float64) - u_in[b].reshape(-1)) - du_true))) / scale
         er = float(np.max(np.abs(orc.v["dx"].astype(np.float64) - du_true))) / scale
         err_k.append(ek); err_r.append(er)
-        assert eu < 1e-3 and ex < 1e-3, (tag, b, eu, ex, ek, er)   # hard cap; the criterion follows
+        if max(eu, ex) >= 5e-4:   # hard cap, lifted only where the oracle is demonstrably the one that is off
+            oracle_off += 1
+            assert er > 1e-4 and max(eu, ex) < 1e-3, (tag, b, eu, ex, ek, er)
         if max(eu, ex) >= 1e-4:
             loose += 1
+            print(f"  {tag}: problem {b} beyond 1e-4 of the oracle: u {eu:.2e} x {ex:.2e}; from the float64 minimiser: kernel {ek:.2e}, oracle {er:.2e}")
             assert ek < er and ek < 1e-4, (tag, b, eu, ex, ek, er)
     err_k, err_r = np.array(err_k), np.array(err_r)
-    print(f"{tag}: {len(err_k)} QPs; vs float64 truth: kernel max {err_k.max():.2e}, oracle max {err_r.max():.2e}; beyond 1e-4 of the oracle: {loose}")
+    print(f"{tag}: {len(err_k)} QPs; vs float64 truth: kernel max {err_k.max():.2e}, oracle max {err_r.max():.2e}; beyond 1e-4 of the oracle: {loose} "
+          f"({100.0 * loose / len(err_k):.2f} %), beyond 5e-4 (oracle off): {oracle_off}, worst distance from the oracle {worst:.2e}")
     assert err_k.max() < 1e-4
+    assert loose <= max(1, int(max_loose_share * len(err_k))), (tag, loose, len(err_k))
+    assert oracle_off <= max(1, len(err_k) // 400), (tag, oracle_off, len(err_k))
+    return loose, len(err_k), worst
 
 
 @pytest.mark.gpu

@@ -28,3 +28,16 @@ def test_two_rank_gather_matches_single_process():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_OK" in r.stdout
     assert "BENCH_PASS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]   # bench.py's timed passes under gloo
+
+
+def test_three_ranks_uneven_partition():
+    """world_size 3, 22 problems -> 8 / 7 / 7: the ranks with one problem fewer pad their slabs for the all-gather, rank 0 cuts the
+    gathered slabs back to the real counts and finds the single-process solve of the whole batch; bench.py's timed passes
+    (every-batch buckets, last batch, converged solve + gather) run with three ranks too."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GATHER_OK" in r.stdout
+    assert "BENCH_PASS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -11,7 +11,7 @@ restore of the sweep (bracketed by s_setprio 3 / s_setprio 0).  The Makefile run
 the object on failure, so a compiler that allocates differently cannot ship the masked form unnoticed;
 tests/test_masked_regions.py runs it again on the same file.
 
-usage: check_masked_regions.py <nmpc_block_kernel gfx950 .s file>"""
+usage: check_masked_regions.py [--strict] <nmpc_block_kernel gfx950 .s file>"""
 import re
 import sys
 
@@ -32,8 +32,8 @@ def check(path):
             if "s_endpgm" in ln:
                 name = None
     masked = {k: v for k, v in kernels.items() if "ILi16ELi2E" in k or "ILi32ELi1E" in k}
-    if len(masked) != 10:  # diag / no-diag, each also as the single-iteration build, and the stamped one, of (16, 2) and (32, 1)
-        return [f"expected 10 instantiations of (16, 2) and (32, 1), found {len(masked)}: {sorted(kernels)}"]
+    if not masked:  # whatever set of (16, 2) / (32, 1) instantiations the file holds is checked; none at all means the scan found nothing
+        return [f"no instantiation of (16, 2) or (32, 1) found among {sorted(kernels)}"]
     findings = []
     for k, lines in masked.items():
         windows, cur = [], None
@@ -78,10 +78,21 @@ def check(path):
     return findings
 
 
+def is_hazard(finding):
+    """the finding the scan exists for (spill / reload traffic under a partial EXEC mask: wrong results); the others say that the
+    scan did not recognise the shape of the code -- another compiler version lays the sweep out differently -- and nothing about
+    the code itself"""
+    return "register-file traffic" in finding
+
+
 if __name__ == "__main__":
-    if len(sys.argv) != 2:
+    # exit status 1 (the Makefile then deletes the object): on a hazard always; on a shape the scan does not recognise only with
+    # --strict (csrc/Makefile: STRICT_MASK_CHECK=1, what tests/test_masked_regions.py asserts), otherwise that is a warning
+    args = [a for a in sys.argv[1:] if a != "--strict"]
+    strict = "--strict" in sys.argv[1:]
+    if len(args) != 1:
         sys.exit(__doc__)
-    f = check(sys.argv[1])
+    f = check(args[0])
     for line in f:
-        print("check_masked_regions:", line, file=sys.stderr)
-    sys.exit(1 if f else 0)
+        print("check_masked_regions:", ("" if (strict or is_hazard(line)) else "warning: ") + line, file=sys.stderr)
+    sys.exit(1 if any(strict or is_hazard(line) for line in f) else 0)
