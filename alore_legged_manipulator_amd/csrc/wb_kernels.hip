@@ -410,6 +410,11 @@ struct RicArgs {
     // they are (no weights applied, no penalty gradient added), resN the terminal gradient, the initial state step is zero
     int refine = 0;
     const float* resN = nullptr;           // [B][48]
+    // exact working-set mode (alore_wb_set_constraint_mode): the sweep solves the REDUCED problem of the current working set --
+    // B, vec, next are the reduced copies, the input weights differ per stage (a force component tied to a face of the friction
+    // pyramid adds mu^2 R to the normal force it follows) and the input gradients arrive as they are
+    const float* wrs = nullptr;            // [B][N][32] diagonal of R per stage, null = the shared weights w
+    int gu_direct = 0;                     // 1: vec[128..159] is the input gradient itself, not (u - uref)
 };
 
 // 44.2 KB: three workgroups per CU (the register budget of the kernel asks for no more).  P A, Qxx, the gains K0 / R / K
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
     const int ia0 = tid, ia1 = tid + RIC_THREADS, ia2 = (tid + 2 * RIC_THREADS) < 48 * 12 ? tid + 2 * RIC_THREADS : 48 * 12 - 1;
     const int ib0 = tid, ib1 = (tid + RIC_THREADS) < 48 * 8 ? tid + RIC_THREADS : 48 * 8 - 1;
     float4 pa0, pa1, pa2, pb0, pb1;
-    float pvec, ppen = 0.f;
+    float pvec, ppen = 0.f, pwr = 1.f;
 #define RIC_REQUEST_A(kk)                                                                                    \
     {                                                                                                        \
         const float4* Ag_ = reinterpret_cast<const float4*>(g.A32 + ((size_t)b * N + (kk)) * NX * NX);       \
@@ -579,6 +584,7 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         pb0 = Bg_[ib0]; pb1 = Bg_[ib1];                                                                      \
         pvec = g.vec[((size_t)b * N + (kk)) * VEC + vi];                                                     \
         if (PENALTY && !g.refine && tid >= 72 && tid < 96) ppen = g.pen[((size_t)b * N + (kk)) * PEN + 288 + tid - 72]; \
+        if (g.wrs && tid >= 128 && tid < 160) pwr = g.wrs[((size_t)b * N + (kk)) * 32 + tid - 128];           \
     }
 #define RIC_PUT4(base, ld, per_row, idx, v)                                                                  \
     { float* dst_ = (base) + ((idx) / (per_row)) * (ld) + 4 * ((idx) % (per_row)); dst_[0] = (v).x; dst_[1] = (v).y; dst_[2] = (v).z; dst_[3] = (v).w; }
@@ -595,7 +601,10 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
         if (tid < 48) S.d[tid] = pvec;                                                                       \
         else if (tid < 96) S.gx[tid - 48] = g.refine ? pvec : S.wq[tid - 48] * pvec + ppen; /* + rho J_c' (J_c v) on the velocities */ \
         else if (tid < 128) S.dxn[tid - 96] = pvec;                                                          \
-        else if (tid < 160) S.gu[tid - 128] = g.refine ? pvec : S.wr[tid - 128] * pvec;                      \
+        else if (tid < 160) {                                                                                \
+            if (g.wrs) S.wr[tid - 128] = pwr; /* read by the inverting wavefront after the next barrier */       \
+            S.gu[tid - 128] = (g.refine || g.gu_direct) ? pvec : S.wr[tid - 128] * pvec;                       \
+        }                                                                                                    \
     }
     RIC_REQUEST_A(N - 1)
     RIC_REQUEST_B(N - 1)
@@ -1209,6 +1218,416 @@ __global__ __launch_bounds__(256) void refine_apply_kernel(double* dx, double* d
     }
 }
 
+// ---- exact working-set mode (alore_wb_set_constraint_mode(h, 1)) --------------------------------------------------------
+// The inequality constraints of the LQ problem of a real-time iteration -- torque boxes, no force on a foot in the air, the
+// friction pyramid |fx|, |fy| <= mu fz (which contains fz >= 0) of a stance foot -- solved EXACTLY by a working-set iteration
+// around the unconstrained MFMA sweep, the scheme of the planar kernel (nmpc_block_kernel.hip) carried over:
+//   reduce   the active rows of the current working set are ELIMINATED from the stage data: an input held at a bound is a
+//            constant (its column of B moves into the defect), a tangential force tied to a face of the pyramid follows the
+//            normal force (fx = +-mu fz: its column is added to the column of fz, its weight mu^2 R to the weight of fz);
+//   sweep    riccati_kernel on the reduced data, nothing clamped inside;
+//   expand + multipliers + update (ws_step_kernel, float64, one workgroup per problem): the eliminated inputs follow from the
+//            solution; the gradient of the Lagrangian with respect to every ORIGINAL input, g_u = R (u + du - uref) + B' lambda
+//            with the costates lambda_k = Q (x_k + dx_k - xref_k) + A_k' lambda_{k+1}, is the multiplier of a held input
+//            (sign-checked: released when it pulls inward) and ~0 on the free ones; free inputs that left their bounds
+//            are held.  All changes of a sweep at once, until the set repeats (or ws_max sweeps).
+// Working-set codes per input:
+enum : unsigned char { WS_FREE = 0, WS_LOWER = 1, WS_UPPER = 2, WS_TIE_POS = 3, WS_TIE_NEG = 4, WS_ZERO = 5 };
+
+__global__ __launch_bounds__(64) void ws_reduce_kernel(const float* B32, const float* vec, const double* next, const unsigned char* ws, const double* u,
+                                                        const double* uref, const double* w, float mu, float* Bw, float* vecw, double* nextw, float* wrs)
+{
+    __shared__ float val[32];   // constant part of an eliminated input: du_i = val_i (+ tie_i * du_fz)
+    __shared__ float tie[32];   // +-mu for a tied tangential component, else 0
+    __shared__ int code[32];
+    const int item = blockIdx.x, t = threadIdx.x;
+    const double* uk = u + (size_t)item * NU;
+    const double* Rd = w + NX;
+    if (t < 32) {
+        const int c = t < NU ? ws[(size_t)item * 32 + t] : WS_FREE;
+        float v = 0.f, ti = 0.f;
+        if (t < b2z1::NJ) {
+            const float eff = (float)b2z1::EFFORT[t];
+            if (c == WS_LOWER) v = -eff - (float)uk[t];
+            else if (c == WS_UPPER) v = eff - (float)uk[t];
+        } else if (t < NU) {
+            const int foot = (t - b2z1::NJ) / 3, iz = b2z1::NJ + 3 * foot + 2;
+            if (c == WS_ZERO) v = -(float)uk[t];
+            else if (c == WS_TIE_POS) { ti = mu; v = mu * (float)uk[iz] - (float)uk[t]; }
+            else if (c == WS_TIE_NEG) { ti = -mu; v = -mu * (float)uk[iz] - (float)uk[t]; }
+        }
+        code[t] = c; val[t] = v; tie[t] = ti;
+    }
+    __syncthreads();
+    if (t < NX) { // row t of B: held inputs into the defect, tied ones onto their normal force
+        const float* br = B32 + ((size_t)item * NX + t) * NUP;
+        float* bo = Bw + ((size_t)item * NX + t) * NUP;
+        float row[NUP];
+#pragma unroll
+        for (int i = 0; i < NUP; ++i) row[i] = br[i];
+        double dadd = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            if (code[i] != WS_FREE) dadd += (double)row[i] * (double)val[i];
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int ix = b2z1::NJ + 3 * f;
+            row[ix + 2] += tie[ix] * row[ix] + tie[ix + 1] * row[ix + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) bo[i] = code[i] != WS_FREE ? 0.f : row[i];
+        bo[30] = 0.f; bo[31] = 0.f;
+        vecw[(size_t)item * VEC + t] = (float)((double)vec[(size_t)item * VEC + t] + dadd);
+        nextw[(size_t)item * NX + t] = next[(size_t)item * NX + t] + dadd;
+    }
+    // input gradients and weights of the reduced problem; the other pieces of vec travel as they are
+    if (t < 32) {
+        float gu = 0.f, wr = t < NU ? (float)Rd[t] : 1.f;
+        if (t < NU && code[t] == WS_FREE) {
+            gu = wr * vec[(size_t)item * VEC + 128 + t];
+            if (t >= b2z1::NJ && (t - b2z1::NJ) % 3 == 2) { // a normal force: what follows it
+                for (int a = 1; a <= 2; ++a) {
+                    const int ia = t - a; // fy, fx of the same foot
+                    if (tie[ia] != 0.f) {
+                        const float ra = (float)Rd[ia];
+                        wr += tie[ia] * tie[ia] * ra;
+                        gu += tie[ia] * ra * ((float)(uk[ia] - uref[(size_t)item * NU + ia]) + val[ia]);
+                    }
+                }
+            }
+        }
+        vecw[(size_t)item * VEC + 128 + t] = gu;
+        wrs[(size_t)item * 32 + t] = wr;
+        vecw[(size_t)item * VEC + 96 + t] = vec[(size_t)item * VEC + 96 + t];
+    }
+    if (t < NX) vecw[(size_t)item * VEC + 48 + t] = vec[(size_t)item * VEC + 48 + t];
+}
+
+// The point the iteration stands at: z, a FEASIBLE input step of the problem (z = 0 at the start: the iterate itself is feasible).
+// One workgroup per problem, float64: the state step of z by the linearised dynamics (dxz), the cost f(z), the costates and the
+// gradient g_u of the cost with respect to every input, and from (z, g_u) the BINDING set -- the rows active at z whose multiplier
+// has the right sign -- as the working set of the next sweep (projected Newton, Bertsekas 1982: the binding set comes from the
+// gradient at a feasible point, never from the multipliers of an infeasible subspace minimiser, so the iteration cannot run in circles).
+__device__ __forceinline__ double wb_stage_cost(const double* Qd, const double* Rd, const double* xk, const double* dxk, const double* xrk,
+                                                const double* uk, const double* zk, const double* urk, int t)
+{
+    double c = 0.0;
+    if (t < NX) { const double e = xk[t] + dxk[t] - xrk[t]; c += 0.5 * Qd[t] * e * e; }
+    if (t < NU) { const double e = uk[t] + zk[t] - urk[t]; c += 0.5 * Rd[t] * e * e; }
+    return c;
+}
+__device__ __forceinline__ double wb_wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void ws_point_kernel(const float* A32, const float* B32, const double* next, const double* x, const double* u, const double* x0,
+                                                       const double* xref, const double* uref, const double* w, const double* z, double* dxz, unsigned char* ws,
+                                                       const unsigned char* stance, float mu, int N, int limits, int cones, double* fval, int* set_changed,
+                                                       int* total_changed, double* gu_out)
+{
+    __shared__ double dxa[NX], dxb_[NX], lam[NX], lamn[NX], gu[32], gsc[32], zn[32];
+    __shared__ int nchg;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const double *Qd = w, *Rd = w + NX, *QNd = w + NX + NU;
+    const double* xb = x + (size_t)b * (N + 1) * NX;
+    const double* xr = xref + (size_t)b * (N + 1) * NX;
+    double* dxo = dxz + (size_t)b * (N + 1) * NX;
+    if (t == 0) nchg = 0;
+    if (t < NX) { dxa[t] = x0[(size_t)b * NX + t] - xb[t]; dxo[t] = dxa[t]; }
+    __syncthreads();
+    double cost = 0.0;
+    double *cur = dxa, *nxt = dxb_;
+    for (int k = 0; k < N; ++k) { // forward: the state step of z, the cost
+        const size_t item = (size_t)b * N + k;
+        cost += wb_stage_cost(Qd, Rd, xb + (size_t)k * NX, cur, xr + (size_t)k * NX, u + item * NU, z + item * NU, uref + item * NU, t);
+        if (t < NX) {
+            const float* Ar = A32 + (item * NX + t) * NX;
+            const float* Br = B32 + (item * NX + t) * NUP;
+            double acc = next[item * NX + t] - xb[(size_t)(k + 1) * NX + t];
+            for (int j = 0; j < NX; ++j) acc += (double)Ar[j] * cur[j];
+            for (int j = 0; j < NU; ++j) acc += (double)Br[j] * z[item * NU + j];
+            nxt[t] = acc;
+            dxo[(size_t)(k + 1) * NX + t] = acc;
+        }
+        __syncthreads();
+        double* sw = cur; cur = nxt; nxt = sw;
+    }
+    if (t < NX) {
+        const double e = xb[(size_t)N * NX + t] + cur[t] - xr[(size_t)N * NX + t];
+        cost += 0.5 * QNd[t] * e * e;
+        lamn[t] = QNd[t] * e;
+    }
+    cost = wb_wave_sum(cost);
+    if (t == 0) fval[b] = cost;
+    __syncthreads();
+    for (int k = N - 1; k >= 0; --k) { // backward: costates, input gradients, the binding set of every stage
+        const size_t item = (size_t)b * N + k;
+        const float* A = A32 + item * NX * NX;
+        const float* Bm = B32 + item * NX * NUP;
+        const double* dxk = dxo + (size_t)k * NX;
+        if (t < NU) {
+            double acc = Rd[t] * (u[item * NU + t] + z[item * NU + t] - uref[item * NU + t]);
+            double mag = fabs(acc);
+            for (int j = 0; j < NX; ++j) { const double term = (double)Bm[j * NUP + t] * lamn[j]; acc += term; mag += fabs(term); }
+            gu[t] = acc; gsc[t] = mag;
+            zn[t] = u[item * NU + t] + z[item * NU + t];
+            if (gu_out) gu_out[item * NU + t] = acc;
+        }
+        if (t < NX) {
+            double acc = Qd[t] * (xb[(size_t)k * NX + t] + dxk[t] - xr[(size_t)k * NX + t]);
+            for (int j = 0; j < NX; ++j) acc += (double)A[j * NX + t] * lamn[j];
+            lam[t] = acc;
+        }
+        __syncthreads();
+        int moved = 0;
+        if (t < b2z1::NJ && limits) {
+            const double eff = b2z1::EFFORT[t], tolv = 1e-7 * eff, tolg = 1e-9 * gsc[t];
+            const unsigned char c = ws[item * 32 + t];
+            unsigned char n = WS_FREE;
+            if (zn[t] <= -eff + tolv && gu[t] > tolg) n = WS_LOWER;       // at the lower bound and the cost rises inward
+            else if (zn[t] >= eff - tolv && gu[t] < -tolg) n = WS_UPPER;
+            if (n != c) { ws[item * 32 + t] = n; moved = 1; }
+        } else if (t >= b2z1::NJ && t < b2z1::NJ + 4 && cones) {
+            const int f = t - b2z1::NJ, ix = b2z1::NJ + 3 * f, iy = ix + 1, iz = ix + 2;
+            const bool st = stance ? stance[item * 4 + f] != 0 : true;
+            const unsigned char cx = ws[item * 32 + ix], cy = ws[item * 32 + iy], cz = ws[item * 32 + iz];
+            unsigned char nx_ = WS_FREE, ny_ = WS_FREE, nz_ = WS_FREE;
+            const double m = (double)mu, fz = zn[iz], tolv = 1e-7 * (1.0 + fabs(fz)), tolg = 1e-9 * (gsc[ix] + gsc[iy] + gsc[iz]);
+            if (!st) { nx_ = ny_ = nz_ = WS_ZERO; }
+            else if (fz <= tolv) {
+                // at the apex: binding while -g lies in the polar cone of the pyramid, g_z - mu (|g_x| + |g_y|) >= 0
+                if (gu[iz] - m * (fabs(gu[ix]) + fabs(gu[iy])) >= -tolg) { nx_ = ny_ = nz_ = WS_ZERO; }
+            } else {
+                // on a face: multiplier of  fx - mu fz <= 0  is -g_x, of  -fx - mu fz <= 0  is g_x
+                if (zn[ix] >= m * fz - tolv && gu[ix] < -tolg) nx_ = WS_TIE_POS;
+                else if (zn[ix] <= -m * fz + tolv && gu[ix] > tolg) nx_ = WS_TIE_NEG;
+                if (zn[iy] >= m * fz - tolv && gu[iy] < -tolg) ny_ = WS_TIE_POS;
+                else if (zn[iy] <= -m * fz + tolv && gu[iy] > tolg) ny_ = WS_TIE_NEG;
+            }
+            if (nx_ != cx || ny_ != cy || nz_ != cz) {
+                ws[item * 32 + ix] = nx_; ws[item * 32 + iy] = ny_; ws[item * 32 + iz] = nz_;
+                moved = (nx_ != cx) + (ny_ != cy) + (nz_ != cz);
+            }
+        }
+        if (moved) atomicAdd(&nchg, moved);
+        if (t < NX) lamn[t] = lam[t];
+        __syncthreads();
+    }
+    if (t == 0) {
+        set_changed[b] = nchg;
+        if (nchg) atomicAdd(total_changed, nchg);
+    }
+}
+
+// The step of the primal active-set method (Nocedal & Wright, Alg. 16.3), one workgroup per problem, float64.  The sweep's solution of the
+// reduced problem, expanded to all inputs (zs, with the state step dxs of the sweep's own closed-loop forward pass), is the minimiser on
+// the face of the working set; z moves towards it along the straight line -- both ends satisfy the linearised dynamics, so does every
+// point between them, and the state step is the same combination: nothing is rolled out open-loop through the (unstable) dynamics -- as
+// far as the first row outside the working set allows (ratio test); that row joins the working set.  full[b] = 1: the whole step was
+// taken, z is the face minimiser and ws_release_kernel may look at its multipliers.
+__global__ __launch_bounds__(256) void ws_ratio_kernel(const double* u, double* z, double* zs, double* dxz, const double* dxs, unsigned char* ws,
+                                                        const unsigned char* stance, float mu, int N, int limits, int cones, int* full, int* blocked_total)
+{
+    __shared__ double amin[256];
+    __shared__ int aidx[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double m = (double)mu;
+    for (int e = tid; e < N * NU; e += 256) { // expand the eliminated inputs of the sweep's solution
+        const int k = e / NU, i = e % NU;
+        const size_t item = (size_t)b * N + k;
+        const int code = ws[item * 32 + i];
+        if (code == WS_FREE) continue;
+        const double ui = u[item * NU + i];
+        double v;
+        if (i < b2z1::NJ) v = (code == WS_LOWER ? -b2z1::EFFORT[i] : b2z1::EFFORT[i]) - ui;
+        else if (code == WS_ZERO) v = -ui;
+        else {
+            const int iz = b2z1::NJ + 3 * ((i - b2z1::NJ) / 3) + 2;
+            v = (code == WS_TIE_POS ? 1.0 : -1.0) * m * (u[item * NU + iz] + zs[item * NU + iz]) - ui;
+        }
+        zs[item * NU + i] = v;
+    }
+    __syncthreads();
+    // ratio test over the rows outside the working set: candidate id = (stage * 64 + row) * 2 + side
+    double best = 1.0;
+    int bid = -1;
+    auto consider = [&](double c, double dir, int id) { // row value c <= 0 at z, changes by dir per unit step
+        if (dir > 1e-14 * (1.0 + fabs(c))) {
+            const double a = (c >= 0.0 ? 0.0 : -c / dir);
+            if (a < best || (a == best && bid >= 0 && id < bid)) { best = a; bid = id; }
+        }
+    };
+    for (int e = tid; e < N * 26; e += 256) {
+        const int k = e / 26, r = e % 26;
+        const size_t item = (size_t)b * N + k;
+        if (r < b2z1::NJ) {
+            if (!limits || ws[item * 32 + r] != WS_FREE) continue;
+            const double eff = b2z1::EFFORT[r], v = u[item * NU + r] + z[item * NU + r], pv = zs[item * NU + r] - z[item * NU + r];
+            consider(v - eff, pv, (k * 64 + r) * 2 + 1);
+            consider(-v - eff, -pv, (k * 64 + r) * 2);
+        } else if (cones) {
+            const int f = (r - b2z1::NJ) >> 1, ax = (r - b2z1::NJ) & 1, ix = b2z1::NJ + 3 * f, ia = ix + ax, iz = ix + 2;
+            const bool st = stance ? stance[item * 4 + f] != 0 : true;
+            if (!st || ws[item * 32 + iz] == WS_ZERO) continue;
+            const int ca = ws[item * 32 + ia];
+            const double fa = u[item * NU + ia] + z[item * NU + ia], fz = u[item * NU + iz] + z[item * NU + iz];
+            const double pa = zs[item * NU + ia] - z[item * NU + ia], pz = zs[item * NU + iz] - z[item * NU + iz];
+            if (ca != WS_TIE_POS) consider(fa - m * fz, pa - m * pz, (k * 64 + 32 + 2 * f + ax) * 2 + 1);
+            if (ca != WS_TIE_NEG) consider(-fa - m * fz, -pa - m * pz, (k * 64 + 32 + 2 * f + ax) * 2);
+        }
+    }
+    amin[tid] = best; aidx[tid] = bid;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double a2 = amin[tid + o]; const int i2 = aidx[tid + o];
+            if (i2 >= 0 && (aidx[tid] < 0 || a2 < amin[tid] || (a2 == amin[tid] && i2 < aidx[tid]))) { amin[tid] = a2; aidx[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    const double alpha = aidx[0] >= 0 ? fmin(amin[0], 1.0) : 1.0;
+    const int blk = (aidx[0] >= 0 && amin[0] < 1.0) ? aidx[0] : -1;
+    __syncthreads();
+    for (int e = tid; e < N * NU; e += 256) { const size_t i = (size_t)b * N * NU + e; z[i] += alpha * (zs[i] - z[i]); }
+    for (int e = tid; e < (N + 1) * NX; e += 256) { const size_t i = (size_t)b * (N + 1) * NX + e; dxz[i] += alpha * (dxs[i] - dxz[i]); }
+    if (tid == 0) {
+        full[b] = blk < 0 ? 1 : 0;
+        if (blk >= 0) {
+            atomicAdd(blocked_total, 1);
+            const int side = blk & 1, row = (blk >> 1) & 63, k = blk >> 7;
+            const size_t item = (size_t)b * N + k;
+            if (row < 32) ws[item * 32 + row] = side ? WS_UPPER : WS_LOWER;
+            else {
+                const int f = (row - 32) >> 1, ax = (row - 32) & 1, ix = b2z1::NJ + 3 * f, ia = ix + ax;
+                const int old = ws[item * 32 + ia];
+                if (old == WS_TIE_POS || old == WS_TIE_NEG) { ws[item * 32 + ix] = ws[item * 32 + ix + 1] = ws[item * 32 + ix + 2] = WS_ZERO; } // both faces of an axis: the apex
+                else ws[item * 32 + ia] = side ? WS_TIE_POS : WS_TIE_NEG;
+            }
+        }
+    }
+}
+
+// At a face minimiser (full[b] = 1): costates and the gradient of the cost with respect to every input from (dxz, z); the multiplier of
+// every held row is sign-checked and the WORST offender (largest violation relative to the size of the terms of its gradient) leaves the
+// working set; none: the problem is solved (done[b] = 1).  One workgroup per problem.
+__global__ __launch_bounds__(64) void ws_release_kernel(const float* A32, const float* B32, const double* x, const double* u, const double* xref, const double* uref,
+                                                         const double* w, const double* z, const double* dxz, unsigned char* ws, const unsigned char* stance, float mu,
+                                                         int N, const int* full, int* done, int* open_total, double* gu_out)
+{
+    __shared__ double lam[NX], lamn[NX], gu[32], gsc[32];
+    __shared__ double wv[64];
+    __shared__ int wi[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (!full[b]) { if (t == 0) { done[b] = 1; atomicAdd(open_total, 1); } return; } // done[b]: 1 while the problem is still open
+    const double *Qd = w, *Rd = w + NX, *QNd = w + NX + NU;
+    const double* xb = x + (size_t)b * (N + 1) * NX;
+    const double* xr = xref + (size_t)b * (N + 1) * NX;
+    const double* dxo = dxz + (size_t)b * (N + 1) * NX;
+    const double m = (double)mu;
+    if (t < NX) lamn[t] = QNd[t] * (xb[(size_t)N * NX + t] + dxo[(size_t)N * NX + t] - xr[(size_t)N * NX + t]);
+    double worst = 0.0; // most negative normalised multiplier seen by this thread
+    int wid = -1;       // (stage * 32 + input), for a foot at the apex its fz
+    __syncthreads();
+    for (int k = N - 1; k >= 0; --k) {
+        const size_t item = (size_t)b * N + k;
+        const float* A = A32 + item * NX * NX;
+        const float* Bm = B32 + item * NX * NUP;
+        if (t < NU) {
+            double acc = Rd[t] * (u[item * NU + t] + z[item * NU + t] - uref[item * NU + t]);
+            double mag = fabs(acc);
+            for (int j = 0; j < NX; ++j) { const double term = (double)Bm[j * NUP + t] * lamn[j]; acc += term; mag += fabs(term); }
+            gu[t] = acc; gsc[t] = mag + 1e-300;
+            if (gu_out) gu_out[item * NU + t] = acc;
+        }
+        if (t < NX) {
+            double acc = Qd[t] * (xb[(size_t)k * NX + t] + dxo[(size_t)k * NX + t] - xr[(size_t)k * NX + t]);
+            for (int j = 0; j < NX; ++j) acc += (double)A[j * NX + t] * lamn[j];
+            lam[t] = acc;
+        }
+        __syncthreads();
+        if (t < NU) {
+            const int c = ws[item * 32 + t];
+            double lm = 0.0, sc = gsc[t]; // multiplier (>= 0 wanted)
+            bool held = false;
+            if (t < b2z1::NJ) {
+                if (c == WS_LOWER) { lm = gu[t]; held = true; } else if (c == WS_UPPER) { lm = -gu[t]; held = true; }
+            } else {
+                const int f = (t - b2z1::NJ) / 3, ax = (t - b2z1::NJ) % 3, ix = b2z1::NJ + 3 * f;
+                const bool st = stance ? stance[item * 4 + f] != 0 : true;
+                if (st && ax < 2 && c == WS_TIE_POS) { lm = -gu[t]; held = true; }
+                else if (st && ax < 2 && c == WS_TIE_NEG) { lm = gu[t]; held = true; }
+                else if (st && ax == 2 && c == WS_ZERO) { // apex: stay while g_z - mu (|g_x| + |g_y|) >= 0
+                    lm = gu[t] - m * (fabs(gu[ix]) + fabs(gu[ix + 1])); sc = gsc[ix] + gsc[ix + 1] + gsc[t]; held = true;
+                }
+            }
+            if (held) {
+                const double rel = lm / sc;
+                if (rel < -3e-4 && rel < worst) { worst = rel; wid = k * 32 + t; } // the sweep is float32: a multiplier that misses zero by less is zero
+            }
+        }
+        if (t < NX) lamn[t] = lam[t];
+        __syncthreads();
+    }
+    wv[t] = worst; wi[t] = wid;
+    __syncthreads();
+    if (t == 0) {
+        double bw = 0.0; int bi = -1;
+        for (int i = 0; i < 64; ++i)
+            if (wi[i] >= 0 && (bi < 0 || wv[i] < bw || (wv[i] == bw && wi[i] < bi))) { bw = wv[i]; bi = wi[i]; }
+        if (bi < 0) done[b] = 0;
+        else {
+            done[b] = 1;
+            atomicAdd(open_total, 1);
+            const int k = bi / 32, i = bi % 32;
+            const size_t item = (size_t)b * N + k;
+            if (ws[item * 32 + i] == WS_ZERO) { const int ix = i - 2; ws[item * 32 + ix] = ws[item * 32 + ix + 1] = ws[item * 32 + i] = WS_FREE; } // off the apex
+            else ws[item * 32 + i] = WS_FREE;
+        }
+    }
+}
+
+// the finished step of the exact mode: refuse a step that is not finite, add it to the iterate; the applied inputs satisfy the
+// constraints to the last bit (torques clipped, forces projected: what float32 rounding of the sweep may have left outside)
+__global__ __launch_bounds__(256) void ws_apply_kernel(const double* dx, const double* du, double* x, double* u, int N, int* status, const unsigned char* stance, float mu)
+{
+    __shared__ int bad_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* dxb = dx + (size_t)b * (N + 1) * NX;
+    const double* dub = du + (size_t)b * N * NU;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int i = tid; i < (N + 1) * NX; i += 256) bad |= !isfinite(dxb[i]);
+    for (int i = tid; i < N * NU; i += 256) bad |= !isfinite(dub[i]);
+    if (bad) bad_s = 1;
+    __syncthreads();
+    const bool failed = bad_s != 0 || (status && status[b] != 0);
+    __syncthreads();
+    if (tid == 0 && status) status[b] = failed ? 1 : 0;
+    if (failed) return;
+    double* xw = x + (size_t)b * (N + 1) * NX;
+    double* uw = u + (size_t)b * N * NU;
+    for (int i = tid; i < (N + 1) * NX; i += 256) xw[i] += dxb[i];
+    for (int i = tid; i < N * b2z1::NJ; i += 256) {
+        const int k = i / b2z1::NJ, j = i % b2z1::NJ;
+        const double lim = b2z1::EFFORT[j];
+        double val = uw[(size_t)k * NU + j] + dub[(size_t)k * NU + j];
+        uw[(size_t)k * NU + j] = val > lim ? lim : (val < -lim ? -lim : val);
+    }
+    for (int it = tid; it < N * 4; it += 256) {
+        const int kk = it >> 2, foot = it & 3, i0 = kk * NU + b2z1::NJ + 3 * foot;
+        const bool st = stance ? stance[((size_t)b * N + kk) * 4 + foot] != 0 : true;
+        const double fzr = uw[i0 + 2] + dub[i0 + 2], fz = st ? (fzr > 0.0 ? fzr : 0.0) : 0.0, lim = (double)mu * fz;
+        double fx = uw[i0] + dub[i0], fy = uw[i0 + 1] + dub[i0 + 1];
+        fx = fx > lim ? lim : (fx < -lim ? -lim : fx);
+        fy = fy > lim ? lim : (fy < -lim ? -lim : fy);
+        uw[i0] = fx; uw[i0 + 1] = fy; uw[i0 + 2] = fz;
+    }
+}
+
 // one lane per evaluation point (alore_wb_aba): the articulated-body algorithm of wb_aba.h
 __global__ __launch_bounds__(64) void aba_kernel(int n, const double* q, const double* v, const double* u, double grav, double* acc)
 {
@@ -1258,6 +1677,13 @@ struct alore_wb_solver {
     int refine = 0;                    // alore_wb_set_refinement
     float *d_res = nullptr, *d_resN = nullptr; // [B][N][VEC], [B][48] residuals of the refinement pass
     double *d_ex = nullptr, *d_eu = nullptr;   // its correction
+    // exact working-set mode (alore_wb_set_constraint_mode)
+    int exact = 0, ws_max = 8, ws_sweeps = 0;
+    unsigned char* d_ws = nullptr;             // [B][N][32] working-set codes, kept from one real-time iteration to the next
+    float *d_Bw = nullptr, *d_vecw = nullptr, *d_wrs = nullptr; // the reduced stage data
+    double *d_nextw = nullptr, *d_gu = nullptr;                 // ... and the input gradients (multipliers) at the point the iteration stands at
+    double *d_z = nullptr, *d_dxz = nullptr, *d_fval = nullptr; // that point (a feasible input step), its state step, its cost
+    int *d_changed = nullptr, *d_total = nullptr, *d_nonfull = nullptr, *d_moved = nullptr; // d_total: [0] set changes, [1] non-full steps, [2] problems that moved
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     float ms_lin = -1.f, ms_ric = -1.f;
     bool timed = false;
@@ -1365,7 +1791,8 @@ int alore_wb_destroy(alore_wb_handle h)
             std::fprintf(stderr, "\n");
         }
     }
-    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance, h->d_pen, h->d_res, h->d_resN, h->d_ex, h->d_eu, h->d_F};
+    void* ptrs[] = {h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_A, h->d_B, h->d_next, h->d_dx, h->d_du, h->d_K, h->d_kff, h->d_stamps, h->d_status, h->d_vec, h->d_stance, h->d_pen, h->d_res, h->d_resN, h->d_ex, h->d_eu, h->d_F,
+                    h->d_ws, h->d_Bw, h->d_vecw, h->d_wrs, h->d_nextw, h->d_gu, h->d_changed, h->d_total, h->d_nonfull, h->d_moved, h->d_z, h->d_dxz, h->d_fval};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -1496,6 +1923,40 @@ int alore_wb_set_refinement(alore_wb_handle h, int enable)
     return ALORE_WB_OK;
 }
 
+int alore_wb_set_constraint_mode(alore_wb_handle h, int mode, int max_sweeps)
+{
+    if (!h || mode < 0 || mode > 1 || (mode == 1 && (max_sweeps < 1 || max_sweeps > 4096)))
+        return fail(h, ALORE_WB_E_INVALID, "set_constraint_mode: mode 0 / 1, 1 .. 4096 sweeps");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    WB_TRY(h, hipDeviceSynchronize());
+    if (mode == 1 && !h->d_ws) {
+        const size_t B = h->cfg.max_problems, n = B * h->cfg.horizon;
+        if (zalloc(&h->d_ws, n * 32) != hipSuccess || zalloc(&h->d_Bw, n * wb::NX * wb::NUP) != hipSuccess || zalloc(&h->d_vecw, n * wb::VEC) != hipSuccess ||
+            zalloc(&h->d_wrs, n * 32) != hipSuccess || zalloc(&h->d_nextw, n * wb::NX) != hipSuccess || zalloc(&h->d_gu, n * wb::NU) != hipSuccess ||
+            zalloc(&h->d_changed, B) != hipSuccess || zalloc(&h->d_total, (size_t)4) != hipSuccess || zalloc(&h->d_nonfull, B) != hipSuccess ||
+            zalloc(&h->d_moved, B) != hipSuccess || zalloc(&h->d_z, n * wb::NU) != hipSuccess || zalloc(&h->d_dxz, B * (h->cfg.horizon + 1) * wb::NX) != hipSuccess ||
+            zalloc(&h->d_fval, B) != hipSuccess)
+            return fail(h, ALORE_WB_E_NOMEM, "set_constraint_mode: device memory");
+    }
+    if (mode == 1) WB_TRY(h, hipMemset(h->d_ws, 0, (size_t)h->cfg.max_problems * h->cfg.horizon * 32)); // every input free
+    h->exact = mode;
+    if (mode == 1) h->ws_max = max_sweeps;
+    return ALORE_WB_OK;
+}
+
+int alore_wb_working_set_info(alore_wb_handle h, int B, int* sweeps, int* changed, unsigned char* ws, double* input_gradients)
+{
+    if (!h || B <= 0 || B > h->cfg.max_problems || !h->d_ws) return fail(h, ALORE_WB_E_INVALID, "working_set_info: the exact mode has not been enabled");
+    WB_TRY(h, hipSetDevice(h->cfg.device));
+    WB_TRY(h, hipDeviceSynchronize());
+    const size_t n = (size_t)B * h->cfg.horizon;
+    if (sweeps) *sweeps = h->ws_sweeps;
+    if (changed) WB_TRY(h, hipMemcpy(changed, h->d_moved, sizeof(int) * B, hipMemcpyDeviceToHost)); // 1: still open when the sweeps ran out
+    if (ws) WB_TRY(h, hipMemcpy(ws, h->d_ws, n * 32, hipMemcpyDeviceToHost));
+    if (input_gradients) WB_TRY(h, hipMemcpy(input_gradients, h->d_gu, sizeof(double) * n * wb::NU, hipMemcpyDeviceToHost));
+    return ALORE_WB_OK;
+}
+
 int alore_wb_set_contact_schedule(alore_wb_handle h, int B, const unsigned char* stance)
 {
     if (!h || B <= 0 || B > h->cfg.max_problems) return fail(h, ALORE_WB_E_INVALID, "set_contact_schedule: bad argument");
@@ -1540,6 +2001,7 @@ int alore_wb_shift_iterate(alore_wb_handle h, int B, void* stream)
     if (!h || B <= 0 || B > h->cfg.max_problems) return fail(h, ALORE_WB_E_INVALID, "shift_iterate: bad argument");
     WB_TRY(h, hipSetDevice(h->cfg.device));
     wb::shift_kernel<<<B, 64, 0, (hipStream_t)stream>>>(B, h->cfg.horizon, h->d_x, h->d_u);
+    if (h->d_ws) WB_TRY(h, hipMemsetAsync(h->d_ws, 0, (size_t)h->cfg.max_problems * h->cfg.horizon * 32, (hipStream_t)stream));
     WB_TRY(h, hipGetLastError());
     return ALORE_WB_OK;
 }
@@ -1562,6 +2024,7 @@ int alore_wb_set_iterate(alore_wb_handle h, int B, const double* x, const double
     WB_TRY(h, hipDeviceSynchronize()); // work enqueued on the caller's (possibly non-blocking) stream must be done
     WB_TRY(h, hipMemcpy(h->d_x, x, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyHostToDevice));
     WB_TRY(h, hipMemcpy(h->d_u, u, sizeof(double) * B * N * wb::NU, hipMemcpyHostToDevice));
+    if (h->d_ws) WB_TRY(h, hipMemset(h->d_ws, 0, (size_t)h->cfg.max_problems * N * 32)); // a new iterate: the working set starts free
     return ALORE_WB_OK;
 }
 
@@ -1609,6 +2072,8 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
         WB_TRY(h, hipFuncSetAttribute((const void*)wb::riccati_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(wb::RicLds)));
         lds_set[h->cfg.device & 15] = true;
     }
+    if (h->exact && (h->rows || h->rho > 0.0 || h->refine))
+        return fail(h, ALORE_WB_E_INVALID, "rti: the exact working-set mode runs without contact rows, contact penalty and refinement");
     for (int it = 0; it < n_iter; ++it) {
         const bool last = it == n_iter - 1;
         if (last) WB_TRY(h, hipEventRecord(h->ev[0], s));
@@ -1627,6 +2092,38 @@ int alore_wb_rti(alore_wb_handle h, int B, int n_iter, void* stream)
         wb::RicArgs r{h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_K, h->d_kff, h->d_dx, h->d_du, N, (refine || rows) ? 0 : 1, h->d_status, h->limits, h->d_stamps ? h->d_stamps + 32 : nullptr, h->d_vec,
                        rows ? 0 : h->cones, h->mu, h->d_stance};
         if (pen) r.pen = h->d_pen;
+        if (h->exact) {
+            // exact working-set iteration around the unconstrained sweep (see ws_reduce_kernel); the host reads one counter per sweep
+            wb::RicArgs q = r;
+            q.B32 = h->d_Bw; q.vec = h->d_vecw; q.next = h->d_nextw; q.wrs = h->d_wrs; q.gu_direct = 1; q.limits = 0; q.cones = 0; q.apply = 0;
+            const float mu_c = h->cones ? h->mu : 0.f;
+            WB_TRY(h, hipMemsetAsync(h->d_z, 0, sizeof(double) * n * wb::NU, s)); // the iterate is feasible: the iteration starts at the zero step
+            WB_TRY(h, hipMemsetAsync(h->d_total, 0, 4 * sizeof(int), s));
+            // starting working set: the rows active at the iterate whose multiplier there has the right sign (and the zero-force rows)
+            wb::ws_point_kernel<<<B, 64, 0, s>>>(h->d_A, h->d_B, h->d_next, h->d_x, h->d_u, h->d_x0, h->d_xref, h->d_uref, h->d_w, h->d_z, h->d_dxz, h->d_ws, h->d_stance,
+                                                 mu_c, N, h->limits, h->cones, h->d_fval, h->d_changed, h->d_total, h->d_gu);
+            int sweeps = 0, open = 0;
+            for (;;) {
+                WB_TRY(h, hipMemsetAsync(h->d_total, 0, 4 * sizeof(int), s));
+                wb::ws_reduce_kernel<<<(unsigned)n, 64, 0, s>>>(h->d_B, h->d_vec, h->d_next, h->d_ws, h->d_u, h->d_uref, h->d_w, mu_c, h->d_Bw, h->d_vecw, h->d_nextw, h->d_wrs);
+                wb::riccati_kernel<false><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(q);
+                wb::ws_ratio_kernel<<<B, 256, 0, s>>>(h->d_u, h->d_z, h->d_du, h->d_dxz, h->d_dx, h->d_ws, h->d_stance, mu_c, N, h->limits, h->cones, h->d_nonfull, h->d_total + 1);
+                wb::ws_release_kernel<<<B, 64, 0, s>>>(h->d_A, h->d_B, h->d_x, h->d_u, h->d_xref, h->d_uref, h->d_w, h->d_z, h->d_dxz, h->d_ws, h->d_stance, mu_c, N,
+                                                       h->d_nonfull, h->d_moved, h->d_total + 2, h->d_gu);
+                ++sweeps;
+                WB_TRY(h, hipMemcpyAsync(&open, h->d_total + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+                WB_TRY(h, hipStreamSynchronize(s));
+                if (open == 0 || sweeps >= h->ws_max) break;
+            }
+            h->ws_sweeps = sweeps;
+            // the step of the iteration: (dxz, z) of the last point
+            WB_TRY(h, hipMemcpyAsync(h->d_dx, h->d_dxz, sizeof(double) * B * (N + 1) * wb::NX, hipMemcpyDeviceToDevice, s));
+            WB_TRY(h, hipMemcpyAsync(h->d_du, h->d_z, sizeof(double) * n * wb::NU, hipMemcpyDeviceToDevice, s));
+            WB_TRY(h, hipMemsetAsync(h->d_status, 0, sizeof(int) * B, s));
+            wb::ws_apply_kernel<<<B, 256, 0, s>>>(h->d_dx, h->d_du, h->d_x, h->d_u, N, h->d_status, h->d_stance, h->cones ? h->mu : 3.0e38f);
+            if (last) WB_TRY(h, hipEventRecord(h->ev[2], s));
+            continue;
+        }
         if (pen) wb::riccati_kernel<true><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         else wb::riccati_kernel<false><<<B, wb::RIC_THREADS, sizeof(wb::RicLds), s>>>(r);
         if (rows) wb::contact_rows_apply_kernel<<<B, 256, 0, s>>>(h->d_F, h->d_dx, h->d_du, h->d_x, h->d_u, N, 1, h->d_status, h->d_stance);

@@ -38,6 +38,8 @@ def _bind(L):
         "alore_wb_set_torque_limits": (C.c_int, [H, C.c_int]),
         "alore_wb_set_contact_constraints": (C.c_int, [H, C.c_int, C.c_double]),
         "alore_wb_set_contact_schedule": (C.c_int, [H, C.c_int, C.c_void_p]),
+        "alore_wb_set_constraint_mode": (C.c_int, [H, C.c_int, C.c_int]),
+        "alore_wb_working_set_info": (C.c_int, [H, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, DP]),
         "alore_wb_set_contact_penalty": (C.c_int, [H, C.c_double]),
         "alore_wb_set_refinement": (C.c_int, [H, C.c_int]),
         "alore_wb_set_contact_rows": (C.c_int, [H, C.c_int]),
@@ -136,6 +138,21 @@ class BatchedWholeBody:
     def set_contact_constraints(self, enable: bool, mu: float = 0.7):
         """friction pyramid + unilateral normal force of the stance feet, zero force of the swing feet, inside the sweep"""
         self._check(self.L.alore_wb_set_contact_constraints(self.h, 1 if enable else 0, float(mu)))
+
+    def set_constraint_mode(self, exact: bool, max_sweeps: int = 8):
+        """inequality constraints by one projection per stage inside the sweep (False, the default) or EXACTLY, by a working-set
+        iteration around the unconstrained sweep (alore_wb_set_constraint_mode)"""
+        self._check(self.L.alore_wb_set_constraint_mode(self.h, 1 if exact else 0, int(max_sweeps)))
+
+    def working_set_info(self, B: int):
+        """(sweeps of the last real-time iteration, changes per problem in its last sweep [B], codes [B][N][32], input gradients [B][N][30])"""
+        N = self.N
+        sweeps = C.c_int(0)
+        changed = np.zeros(B, np.int32)
+        ws = np.zeros((B, N, 32), np.uint8)
+        gu = np.zeros((B, N, NU), np.float64)
+        self._check(self.L.alore_wb_working_set_info(self.h, B, C.byref(sweeps), changed.ctypes.data_as(C.POINTER(C.c_int)), ws.ctypes.data_as(C.c_void_p), _dp(gu)))
+        return int(sweeps.value), changed, ws, gu
 
     def set_contact_rows(self, enable: bool = True):
         """hard contact rows J_c(q_k) v_{k+1} = 0 of the stance feet, solved for the foot forces (alore_wb_set_contact_rows)"""

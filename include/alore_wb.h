@@ -106,6 +106,30 @@ int alore_wb_linearize(alore_wb_handle h, int B, double *A, double *Bm, double *
  * feet do not move -- is alore_wb_set_contact_penalty below (velocity level, as a penalty on J_c v) or, as hard equality
  * rows, alore_wb_set_contact_rows. */
 int alore_wb_set_contact_constraints(alore_wb_handle h, int enable, double mu);
+/* How the inequality constraints -- torque boxes (alore_wb_set_torque_limits), and with alore_wb_set_contact_constraints the friction
+ * pyramid of the stance feet (|fx|, |fy| <= mu fz, hence fz >= 0) and f = 0 of the feet in the air -- are handled:
+ *   mode 0 (default)  one projection per stage inside the Riccati sweep, as described above: one sweep, an approximation of the
+ *                     constrained LQ solution (exact when nothing is clamped);
+ *   mode 1            EXACT: a primal active-set iteration (Nocedal & Wright, Alg. 16.3) around the unconstrained sweep.  The rows of the
+ *                     working set are eliminated from the stage data (an input at a bound is a constant, a tangential force on a face
+ *                     of the pyramid follows the normal force: its column of B joins the column of fz, its weight mu^2 R the weight of
+ *                     fz), the sweep solves the reduced problem -- the minimiser on the face of the working set --, the current feasible
+ *                     step moves towards it along the straight line as far as the first row outside the working set allows (ratio test,
+ *                     float64; the state step is the same combination of the two closed-loop state steps, nothing is rolled out
+ *                     open-loop), that row joins the working set; at a face minimiser the gradient of the cost with respect to every
+ *                     input (float64, from the costates) gives the multipliers of the held rows and the worst wrong-signed one leaves.
+ *                     One row in or out per sweep and problem, until every problem has a face minimiser with correct signs or
+ *                     `max_sweeps` (1 .. 4096) sweeps have run: as many sweeps as the working set of the slowest problem of the batch
+ *                     differs from its starting guess (the rows active at the iterate).  This is the reference mode -- the minimiser of
+ *                     the inequality-constrained LQ problem (tests/test_wb_gpu.py: against a float64 active-set solve of the condensed QP
+ *                     built from the oracle's own linearisation) --, not the control-rate one.  The working set is kept from one real-time
+ *                     iteration to the next and reset by alore_wb_set_iterate / alore_wb_shift_iterate.  alore_wb_rti is then synchronous
+ *                     (the host reads one counter per sweep) and runs without contact rows, contact penalty and refinement.
+ * alore_wb_working_set_info: sweeps of the last real-time iteration; per problem 1 if it was still open when the sweeps ran out
+ * (0 = solved); the working set itself, codes [B][N][32] (0 free, 1 lower, 2 upper bound, 3 / 4 on the + / - face of the pyramid, 5 zero
+ * force); the input gradients [B][N][30] at the last face minimiser (the multipliers).  Any pointer may be NULL. */
+int alore_wb_set_constraint_mode(alore_wb_handle h, int mode, int max_sweeps);
+int alore_wb_working_set_info(alore_wb_handle h, int B, int *sweeps, int *changed, unsigned char *ws, double *input_gradients);
 int alore_wb_set_contact_schedule(alore_wb_handle h, int B, const unsigned char *stance);
 /* Contact consistency of the stance feet through the contact Jacobian J_c(q) (12 x 24: world-frame velocity of the four foot
  * points per unit generalized velocity -- the transpose of the map that takes the foot forces into the dynamics): the stage

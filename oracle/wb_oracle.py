@@ -456,3 +456,116 @@ def solve_lq_clamped(A, B, d, Q, R, QN, gx, gu, gN, dx0, u_cur, effort, tol=1e-4
         du[k] = Ks[k] @ dx[k] + ks[k]
         dx[k + 1] = A[k] @ dx[k] + B[k] @ du[k] + d[k]
     return dx, du, nclamp
+
+
+def solve_lq_inequality(A, B, d, Q, R, QN, gx, gu, gN, dx0, u_cur, effort=None, mu=None, stance=None, max_iter=20000):
+    """The INEQUALITY-constrained LQ problem of one real-time iteration, solved exactly (float64): the problem of solve_lq plus
+         |u_k,i + du_k,i| <= effort_i                       (i < 18, if `effort` is given)
+         f_k,j + df_k,j = 0                                 (foot j in the air at stage k, if `mu` is given; stance [N][4])
+         |fx|, |fy| <= mu fz  of the updated force          (foot j in contact: the friction pyramid, which contains fz >= 0)
+       The states are eliminated (dx = x_free + Gamma du), the dense QP in the N nu inputs is solved by a primal active-set method
+       (Nocedal & Wright, Numerical Optimization, Alg. 16.3) from a feasible point; every equality-constrained subproblem is
+       solved through the inverse of the (positive definite) condensed Hessian and the Schur complement of the working rows.
+       Test infrastructure for the exact mode of the kernels (include/alore_wb.h: alore_wb_set_constraint_mode); PARITY UNPINNED
+       like the rest of this file: checked by its own KKT residuals (returned) and against solve_lq when nothing is active.
+       Returns dx (N+1, nx), du (N, nu), info = {active rows, iterations, kkt (stationarity / feasibility / dual feasibility)}."""
+    N = len(A); nx, nu = B[0].shape
+    n = N * nu
+    # dx_k = xf_k + sum_j G[k][j] du_j
+    xf = np.zeros((N + 1, nx)); xf[0] = dx0
+    Gam = np.zeros(((N + 1) * nx, n))
+    for k in range(N):
+        xf[k + 1] = A[k] @ xf[k] + d[k]
+        Gam[(k + 1) * nx:(k + 2) * nx] = A[k] @ Gam[k * nx:(k + 1) * nx]
+        Gam[(k + 1) * nx:(k + 2) * nx, k * nu:(k + 1) * nu] += B[k]
+    Qbar = np.zeros(((N + 1) * nx, (N + 1) * nx)); gxb = np.zeros((N + 1) * nx)
+    for k in range(N):
+        Qbar[k * nx:(k + 1) * nx, k * nx:(k + 1) * nx] = _stage_Q(Q, k); gxb[k * nx:(k + 1) * nx] = gx[k]
+    Qbar[N * nx:, N * nx:] = QN; gxb[N * nx:] = gN
+    Rbar = np.kron(np.eye(N), R); gub = np.concatenate([np.asarray(g_, float) for g_ in gu])
+    H = Gam.T @ Qbar @ Gam + Rbar
+    H = 0.5 * (H + H.T)
+    g = Gam.T @ (Qbar @ xf.reshape(-1) + gxb) + gub
+    # rows: a' du <= b (inequalities), e' du = f (equalities)
+    rows, rhs, eq = [], [], []
+    u_cur = np.asarray(u_cur, float).reshape(N, nu)
+    z = np.zeros(n)
+    for k in range(N):
+        if effort is not None:
+            for i in range(18):
+                a = np.zeros(n); a[k * nu + i] = 1.0
+                rows.append(a.copy()); rhs.append(effort[i] - u_cur[k, i]); eq.append(False)
+                rows.append(-a); rhs.append(effort[i] + u_cur[k, i]); eq.append(False)
+                z[k * nu + i] = np.clip(u_cur[k, i], -effort[i], effort[i]) - u_cur[k, i]
+        if mu is not None:
+            stk = stance[k] if stance is not None else (1, 1, 1, 1)
+            for j in range(4):
+                ix = k * nu + 18 + 3 * j
+                f = u_cur[k, 18 + 3 * j:21 + 3 * j]
+                if not stk[j]:
+                    for c in range(3):
+                        a = np.zeros(n); a[ix + c] = 1.0
+                        rows.append(a); rhs.append(-f[c]); eq.append(True)
+                        z[ix + c] = -f[c]
+                else:
+                    for c in range(2):
+                        for sgn in (1.0, -1.0):   # sgn f_c - mu fz <= 0 of the updated force
+                            a = np.zeros(n); a[ix + c] = sgn; a[ix + 2] = -mu
+                            rows.append(a); rhs.append(-(sgn * f[c] - mu * f[2])); eq.append(False)
+                    fz = max(f[2], 0.0)
+                    z[ix + 2] = fz - f[2]
+                    for c in range(2):
+                        z[ix + c] = np.clip(f[c], -mu * fz, mu * fz) - f[c]
+    Cm = np.array(rows) if rows else np.zeros((0, n)); bv = np.array(rhs) if rows else np.zeros(0); eq = np.array(eq, bool)
+    from scipy.linalg import cho_factor, cho_solve
+    Hc = cho_factor(H)
+    W = list(np.nonzero(eq)[0])
+    it = 0
+    lam = np.zeros(len(bv))
+    while True:
+        it += 1
+        if it > max_iter:
+            raise RuntimeError("solve_lq_inequality: iteration limit")
+        grad = H @ z + g
+        Hig = cho_solve(Hc, grad)
+        if W:
+            Aw = Cm[W]
+            HiAt = cho_solve(Hc, Aw.T)
+            S = Aw @ HiAt
+            lw = np.linalg.solve(S, -(Aw @ Hig))
+            p = -Hig - HiAt @ lw
+            p -= HiAt @ np.linalg.solve(S, Aw @ p)   # back onto the null space of the working rows (rounding of the two solves)
+        else:
+            lw = np.zeros(0)
+            p = -Hig
+        # the subspace minimiser is reached when the step no longer lowers the objective beyond rounding
+        if np.max(np.abs(p)) < 1e-9 * (1.0 + np.max(np.abs(z))) or abs(grad @ p) < 1e-15 * (1.0 + abs(g @ z)):
+            ineq = [(l, w) for l, w in zip(lw, W) if not eq[w]]
+            if not ineq or min(l for l, _ in ineq) >= -1e-10:
+                lam[:] = 0.0
+                for l, w in zip(lw, W):
+                    lam[w] = l
+                break
+            worst = min(ineq)[1]
+            W.remove(worst)
+            continue
+        Ap = Cm @ p
+        slack = bv - Cm @ z
+        alpha, block = 1.0, -1
+        inW = np.zeros(len(bv), bool); inW[W] = True
+        cand = np.nonzero((~inW) & (Ap > 1e-12 * (1.0 + np.max(np.abs(p)))))[0]
+        if cand.size:
+            ratios = np.maximum(slack[cand], 0.0) / Ap[cand]
+            j = int(np.argmin(ratios))
+            if ratios[j] < 1.0:
+                alpha, block = float(ratios[j]), int(cand[j])
+        z = z + alpha * p
+        if block >= 0:
+            W.append(block)
+    du = z.reshape(N, nu)
+    dx = (xf.reshape(-1) + Gam @ z).reshape(N + 1, nx)
+    stat = float(np.max(np.abs(H @ z + g + Cm.T @ lam))) if len(bv) else float(np.max(np.abs(H @ z + g)))
+    feas = float(max(np.max(Cm[~eq] @ z - bv[~eq], initial=0.0), np.max(np.abs(Cm[eq] @ z - bv[eq]), initial=0.0))) if len(bv) else 0.0
+    dual = float(-min(np.min(lam[~eq], initial=0.0), 0.0)) if len(bv) else 0.0
+    return dx, du, {"active": int(len(W)), "active_inequalities": int(sum(1 for w in W if not eq[w])), "iterations": it,
+                    "kkt": {"stationarity": stat, "feasibility": feas, "dual": dual, "scale": float(np.max(np.abs(g)))}}

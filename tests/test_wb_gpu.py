@@ -566,3 +566,97 @@ def test_contact_penalty_keeps_the_stance_feet_still(model):
     # the swing foot is not held: its point still moves in the penalised solution
     J = model.contact_jacobian(res[5000.0][2][0, 3, :24])
     assert np.linalg.norm((J @ res[5000.0][2][0, 3, 24:])[9:12]) > 5 * held[0]
+
+
+def _oracle_lq_inputs(model, xi, ui, x0, xref, uref, Q, R, QN, b, N, dt):
+    """The LQ problem of one real-time iteration from the ORACLE's own float64 dynamics and linearisation (oracle/wb_oracle.py:
+    step, linearize) -- nothing of the kernels in it."""
+    from oracle.wb_oracle import linearize, step
+    A, Bm, d = [], [], []
+    for k in range(N):
+        a_, b_ = linearize(model, xi[b, k], ui[b, k], dt)
+        A.append(a_); Bm.append(b_)
+        d.append(step(model, xi[b, k], ui[b, k], dt) - xi[b, k + 1])
+    gx = [Q * (xi[b, k] - xref[b, k]) for k in range(N)]
+    gu = [R * (ui[b, k] - uref[b, k]) for k in range(N)]
+    gN = QN * (xi[b, N] - xref[b, N])
+    return A, Bm, d, np.diag(Q), np.diag(R), np.diag(QN), gx, gu, gN, x0[b] - xi[b, 0]
+
+
+@pytest.mark.parametrize("case", ["torque_limits", "friction_pyramid", "swing_foot"])
+def test_exact_working_set_mode_finds_the_minimiser_of_the_inequality_constrained_lq_problem(model, case):
+    """alore_wb_set_constraint_mode(exact): the working-set iteration around the unconstrained MFMA sweep against the float64
+    active-set solve of the inequality-constrained QP (oracle/wb_oracle.py: solve_lq_inequality, KKT residuals checked) built from
+    the ORACLE's linearisation -- on the three scenarios of the projection tests above: joint torques at their limits, tangential
+    forces on the faces of a slippery friction pyramid, a foot leaving the ground.  The step must match to 1e-4 (relative to the
+    largest component), the working set must have settled, the applied inputs satisfy the constraints exactly.  Printed beside it:
+    how far the default mode (one projection per stage inside the sweep) is from that minimiser on the same problem."""
+    from alore_legged_manipulator_amd.whole_body import BatchedWholeBody
+    from oracle.wb_oracle import solve_lq_inequality
+    B, N, dt = 2, 20, 0.01
+    Q, R, QN = weights()
+    Q = Q.copy()
+    mu, stance, effort = None, None, None
+    if case == "torque_limits":
+        x0, xref, uref, xi, ui = make_problems(model, B, N, seed=31, spread=0.3)
+        xref = xref.copy(); xref[:, :, 18:24] += np.array([0.9, -0.8, 0.9, -0.7, 0.8, -0.9])
+        Q[18:24] = 4000.0; effort = model.effort
+    elif case == "friction_pyramid":
+        x0, xref, uref, xi, ui = make_problems(model, B, N, seed=5, spread=0.2)
+        xref = xref.copy(); xref[:, :, 1] += 0.25
+        Q[:3] = 5000.0; mu = 0.15
+    else:
+        x0, xref, uref, xi, ui = make_problems(model, B, N, seed=9, spread=0.2)
+        mu = 0.7
+        stance = np.ones((B, N, 4), np.uint8); stance[:, 6:, 1] = 0
+    QN = 10 * Q if case != "swing_foot" else QN
+    if mu is not None:   # a feasible start for the force constraints: the library projects the applied forces, so does the test's iterate
+        f = ui[:, :, 18:30].reshape(B, N, 4, 3).copy()
+        if stance is not None:
+            f[~stance.astype(bool)] = 0.0
+        f[..., 2] = np.maximum(f[..., 2], 0.0)
+        m32 = float(np.float32(mu))
+        f[..., 0] = np.clip(f[..., 0], -m32 * f[..., 2], m32 * f[..., 2]); f[..., 1] = np.clip(f[..., 1], -m32 * f[..., 2], m32 * f[..., 2])
+        ui = ui.copy(); ui[:, :, 18:30] = f.reshape(B, N, 12)
+
+    def run(exact):
+        eng = BatchedWholeBody(B, N, dt)
+        eng.set_weights(Q, R, QN)
+        eng.set_torque_limits(effort is not None)
+        if mu is not None:
+            eng.set_contact_constraints(True, mu)
+        if stance is not None:
+            eng.set_contact_schedule(stance)
+        eng.set_constraint_mode(exact, 1000)
+        eng.set_problem(x0, xref, uref)
+        eng.set_iterate(xi, ui)
+        eng.rti(1)
+        dx, du = eng.last_step()
+        _, u1 = eng.get_iterate()
+        info = eng.working_set_info(B) if exact else None
+        assert (eng.status()[:B] == 0).all()
+        return dx, du, u1, info
+
+    dx_e, du_e, u_e, (sweeps, changed, ws, gu) = run(True)
+    dx_p, du_p, u_p, _ = run(False)
+    worst_e, worst_p, active = 0.0, 0.0, 0
+    mu_lib = None if mu is None else float(np.float32(mu))
+    for b in range(B):
+        rx, ru, info = solve_lq_inequality(*_oracle_lq_inputs(model, xi, ui, x0, xref, uref, Q, R, QN, b, N, dt), ui[b], effort, mu_lib,
+                                           None if stance is None else stance[b])
+        k = info["kkt"]
+        assert k["stationarity"] < 1e-8 * max(1.0, k["scale"]) and k["feasibility"] < 1e-9 and k["dual"] < 1e-9, info
+        active += info["active"]
+        sx, su = np.max(np.abs(rx)), np.max(np.abs(ru))
+        worst_e = max(worst_e, np.max(np.abs(dx_e[b] - rx)) / sx, np.max(np.abs(du_e[b] - ru)) / su)
+        worst_p = max(worst_p, np.max(np.abs(dx_p[b] - rx)) / sx, np.max(np.abs(du_p[b] - ru)) / su)
+    held = int((ws[:, :, :30] != 0).sum())
+    print(f"{case}: {active} active rows (inequalities at their bound, zero-force equalities) in the float64 optimum, {held} inputs held by the kernel's working set after {sweeps} sweeps "
+          f"(changes in the last: {changed.tolist()}); rel dev from the optimum: exact mode {worst_e:.2e}, one projection per stage {worst_p:.2e}")
+    assert active > 0
+    assert (changed == 0).all(), (sweeps, changed)
+    assert worst_e < 1e-4, worst_e
+    if effort is not None:
+        assert np.all(np.abs(u_e[:, :, :18]) <= model.effort + 1e-9)
+    if mu is not None:
+        assert _inside_contact_constraints(u_e, mu, stance)

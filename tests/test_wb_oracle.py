@@ -288,3 +288,32 @@ def test_contact_rows_restatement_is_the_limit_of_the_penalty_and_holds_the_rows
         px, pu = penalised(rho)
         e.append(max(np.max(np.abs(px - dx)), np.max(np.abs(pu - du))))
     assert e[1] < 0.02 * e[0] and e[1] < 1e-3 * max(np.max(np.abs(dx)), np.max(np.abs(du)))
+
+
+def test_inequality_constrained_lq_solver_satisfies_its_kkt_conditions():
+    """oracle/wb_oracle.py: solve_lq_inequality (the checker of the kernels' exact working-set mode) on a random LQ problem with
+    torque boxes, a friction pyramid per stance foot and a foot in the air: stationarity, feasibility and the signs of the
+    multipliers to rounding; with nothing active it is solve_lq."""
+    from oracle.wb_oracle import solve_lq, solve_lq_inequality
+    rng = np.random.default_rng(0)
+    N, nx, nu = 4, 48, 30
+    A = [np.eye(nx) + 0.05 * rng.standard_normal((nx, nx)) for _ in range(N)]
+    B = [0.3 * rng.standard_normal((nx, nu)) for _ in range(N)]
+    d = [0.1 * rng.standard_normal(nx) for _ in range(N)]
+    Q = np.diag(rng.uniform(1, 5, nx)); R = np.diag(rng.uniform(0.1, 1, nu)); QN = 3 * Q
+    gx = [rng.standard_normal(nx) for _ in range(N)]; gu = [rng.standard_normal(nu) for _ in range(N)]; gN = rng.standard_normal(nx)
+    dx0 = rng.standard_normal(nx)
+    u = np.zeros((N, nu)); u[:, 18:30].reshape(N, 4, 3)[:, :, 2] = 5.0
+    stance = np.ones((N, 4), int); stance[2:, 1] = 0
+    dx, du, info = solve_lq_inequality(A, B, d, Q, R, QN, gx, gu, gN, dx0, u, np.full(18, 0.5), 0.5, stance)
+    k = info["kkt"]
+    assert info["active_inequalities"] > 10
+    assert k["stationarity"] < 1e-10 * k["scale"] and k["feasibility"] < 1e-12 and k["dual"] < 1e-12
+    un = u + du
+    f = un[:, 18:30].reshape(N, 4, 3)
+    assert np.all(np.abs(un[:, :18]) <= 0.5 + 1e-12) and np.all(np.abs(f[..., :2]) <= 0.5 * f[..., 2:3] + 1e-12) and np.all(np.abs(f[~stance.astype(bool)]) < 1e-12)
+    for k_ in range(N):   # the dynamics rows hold
+        assert np.max(np.abs(dx[k_ + 1] - (A[k_] @ dx[k_] + B[k_] @ du[k_] + d[k_]))) < 1e-10
+    dx2, du2, info2 = solve_lq_inequality(A, B, d, Q, R, QN, gx, gu, gN, dx0, u, np.full(18, 1e9))
+    dx3, du3 = solve_lq(A, B, d, Q, R, QN, gx, gu, gN, dx0)
+    assert info2["active"] == 0 and np.max(np.abs(du2 - du3)) < 1e-10 and np.max(np.abs(dx2 - dx3)) < 1e-10
