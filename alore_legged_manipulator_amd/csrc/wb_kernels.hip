@@ -1024,68 +1024,152 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 // follow from the solved dx, dtau afterwards.  A foot in the air (contact schedule) has the row f = 0 instead.
 // One wavefront per (problem, stage), float64; G^-1 by Gauss-Jordan on the 12 x 79 augmented block in LDS.
 constexpr int FCOL = 68; // floats per force row of the stored map: F_x (48) | F_tau (18) | f0 | pad
+__device__ long long g_rows_stamps[8]; // diagnostic: cycles per phase of workgroup 0 of the last launch (tools/wb_rows_time.py reads it)
+#define ROWS_STAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_rows_stamps[i] = (long long)__builtin_readcyclecounter();
 __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32, double* next, float* vec, const float* pen, const unsigned char* stance,
-                                                          const double* u, int N, float* Fg)
+                                                             const double* u, int N, float* Fg)
 {
     constexpr int MC = 80; // G (12) | J A_v (48) | J B_v,tau (18) | J next_v (1) | pad
     __shared__ double Mx[12 * MC];
     __shared__ double Jl[12 * NV];
     __shared__ double Bf[NX * 12];
-    __shared__ double colp[12];
+    __shared__ double Src[NV * MC]; // the velocity rows of [B_f | A | B_tau | next]: what J_c multiplies, column-aligned with Mx
+    __shared__ double colp[24];
     const int item = blockIdx.x, lane = threadIdx.x;
     float* A = A32 + (size_t)item * NX * NX;
     float* Bm = B32 + (size_t)item * NX * NUP;
     double* nx = next + (size_t)item * NX;
     const float* J = pen + (size_t)item * PEN; // written with rho = 1: J_c itself, rows of swing feet zero
     const unsigned char* st = stance ? stance + (size_t)item * 4 : nullptr;
-    for (int e = lane; e < 12 * NV; e += 64) Jl[e] = (double)J[e];
-    for (int e = lane; e < NX * 12; e += 64) Bf[e] = (double)Bm[(e / 12) * NUP + b2z1::NJ + e % 12];
+    ROWS_STAMP(0)
+    // every global read of the set-up is issued before the first LDS store (a rolled loop waits for one load per trip: 30 round trips)
+    {
+        float jv[5], bv[9], av[18], tv[7];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int e = lane + 64 * q; jv[q] = e < 12 * NV ? J[e] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; bv[q] = Bm[(e / 12) * NUP + b2z1::NJ + e % 12]; } // 576 = 9 x 64
+#pragma unroll
+        for (int q = 0; q < 18; ++q) { const int e = lane + 64 * q; av[q] = A[(NQ + e / NX) * NX + e % NX]; }           // 1152 = 18 x 64
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { const int e = lane + 64 * q; tv[q] = e < NV * b2z1::NJ ? Bm[(NQ + e / b2z1::NJ) * NUP + e % b2z1::NJ] : 0.f; }
+        const double nv = lane < NV ? nx[NQ + lane] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int e = lane + 64 * q; if (e < 12 * NV) Jl[e] = (double)jv[q]; }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; Bf[e] = (double)bv[q]; if (e / 12 >= NQ) Src[(e / 12 - NQ) * MC + e % 12] = (double)bv[q]; }
+#pragma unroll
+        for (int q = 0; q < 18; ++q) { const int e = lane + 64 * q; Src[(e / NX) * MC + 12 + e % NX] = (double)av[q]; }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { const int e = lane + 64 * q; if (e < NV * b2z1::NJ) Src[(e / b2z1::NJ) * MC + 60 + e % b2z1::NJ] = (double)tv[q]; }
+        if (lane < NV) { Src[lane * MC + 78] = nv; Src[lane * MC + 79] = 0.0; }
+    }
     __syncthreads();
-    for (int col = lane; col < 79; col += 64) {
+    // [G | J A_v | J B_v,tau | J next_v] = J_c [B_f | A | B_tau | next]_v.  The right factor is staged in LDS first (coalesced global
+    // reads, no lane-dependent branches in the product); then a lane owns a column: its source value of row c is read once and meets
+    // the 12 entries of column c of J_c, which every lane reads from the same LDS address (broadcast): 12 independent accumulators
+    ROWS_STAMP(1)
+    // [G | J A_v | J B_v,tau | J next_v] = J_c [B_f | A | B_tau | next]_v on the float64 matrix cores (v_mfma_f64_16x16x4_f64: lane l supplies
+    // A[l & 15][l >> 4] and B[l >> 4][l & 15], receives C[(l >> 4) + 4 r][l & 15]): J_c padded to 16 rows, 5 column tiles x 6 k-steps
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int r16 = lane & 15, kq = lane >> 4;
+    {
+        double ja[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) ja[t] = r16 < 12 ? Jl[r16 * NV + 4 * t + kq] : 0.0;
+#pragma unroll
+        for (int tj = 0; tj < 5; ++tj) {
+            double sb[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) sb[t] = Src[(4 * t + kq) * MC + 16 * tj + r16];
+            d4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[t], sb[t], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Mx[(kq + 4 * r) * MC + 16 * tj + r16] = c[r]; // rows 0 .. 11
+        }
+    }
+    __syncthreads();
+    // a lane owns columns `lane` and (lanes 0 .. 14) `lane + 64` of the 12 x 79 block, in REGISTERS through the elimination
+    double m0[12], m1[12];
+    const int col1 = lane + 64 < 79 ? lane + 64 : 78;
+#pragma unroll
+    for (int r = 0; r < 12; ++r) { m0[r] = Mx[r * MC + lane]; m1[r] = Mx[r * MC + col1]; }
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+        if (st && !st[r / 3]) { // foot in the air: the row  df_r = -f_r
+            m0[r] = (lane < 12) ? ((lane == r) ? 1.0 : 0.0) : 0.0;
+            m1[r] = (col1 == 78) ? u[(size_t)item * NU + b2z1::NJ + r] : 0.0;
+        }
+    }
+    __syncthreads(); // Mx is written again after the elimination
+    ROWS_STAMP(2)
+    // Gauss-Jordan without pivoting (G is symmetric positive definite) on the register columns: lane p hands column p of G round
+    // through LDS (two buffers in turn: one barrier per pivot), every lane updates its own columns
+#pragma unroll
+    for (int p = 0; p < 12; ++p) {
+        double* cp = colp + 12 * (p & 1);
+        if (lane == p) {
+#pragma unroll
+            for (int r = 0; r < 12; ++r) cp[r] = m0[r];
+        }
+        __syncthreads();
+        const double inv = 1.0 / cp[p];
+        const double pv0 = m0[p] * inv, pv1 = m1[p] * inv;
+#pragma unroll
         for (int r = 0; r < 12; ++r) {
-            const bool in_contact = !st || st[r / 3];
-            double acc = 0.0;
-            if (in_contact) {
-                if (col < 12) { for (int c = 0; c < NV; ++c) acc += Jl[r * NV + c] * Bf[(NQ + c) * 12 + col]; }
-                else if (col < 60) { for (int c = 0; c < NV; ++c) acc += Jl[r * NV + c] * (double)A[(NQ + c) * NX + col - 12]; }
-                else if (col < 78) { for (int c = 0; c < NV; ++c) acc += Jl[r * NV + c] * (double)Bm[(NQ + c) * NUP + col - 60]; }
-                else { for (int c = 0; c < NV; ++c) acc += Jl[r * NV + c] * nx[NQ + c]; }
-            } else { // foot in the air: the row  df_r = -f_r  (no force)
-                if (col < 12) acc = (col == r) ? 1.0 : 0.0;
-                else if (col == 78) acc = u[(size_t)item * NU + b2z1::NJ + r];
-            }
-            Mx[r * MC + col] = acc;
+            const double cr = cp[r];
+            m0[r] = (r == p) ? pv0 : m0[r] - cr * pv0;
+            m1[r] = (r == p) ? pv1 : m1[r] - cr * pv1;
         }
     }
+#pragma unroll
+    for (int r = 0; r < 12; ++r) { Mx[r * MC + lane] = m0[r]; if (lane + 64 < 79) Mx[r * MC + lane + 64] = m1[r]; }
     __syncthreads();
-    for (int p = 0; p < 12; ++p) { // Gauss-Jordan without pivoting: G is symmetric positive definite
-        if (lane < 12) colp[lane] = Mx[lane * MC + p];
-        __syncthreads();
-        const double inv = 1.0 / colp[p];
-        for (int col = lane; col < 79; col += 64) {
-            const double pv = Mx[p * MC + col] * inv;
-            for (int r = 0; r < 12; ++r) Mx[r * MC + col] = (r == p) ? pv : Mx[r * MC + col] - colp[r] * pv;
-        }
-        __syncthreads();
-    }
+    ROWS_STAMP(3)
     // F = -G^-1 [ ... ]: columns 12 .. 78 of the reduced block
     float* F = Fg + (size_t)item * 12 * FCOL;
     for (int e = lane; e < 12 * FCOL; e += 64) {
         const int r = e / FCOL, c = e % FCOL;
         F[e] = c < 67 ? (float)(-Mx[r * MC + 12 + c]) : 0.f;
     }
-    // the forces leave the dynamics
-    for (int e = lane; e < NX * NX; e += 64) {
-        const int i = e / NX, j = e % NX;
-        double acc = 0.0;
-        for (int q = 0; q < 12; ++q) acc -= Bf[i * 12 + q] * Mx[q * MC + 12 + j];
-        A[e] = (float)((double)A[e] + acc);
-    }
-    for (int e = lane; e < NX * b2z1::NJ; e += 64) {
-        const int i = e / b2z1::NJ, t = e % b2z1::NJ;
-        double acc = 0.0;
-        for (int q = 0; q < 12; ++q) acc -= Bf[i * 12 + q] * Mx[q * MC + 60 + t];
-        Bm[i * NUP + t] = (float)((double)Bm[i * NUP + t] + acc);
+    ROWS_STAMP(4)
+    // the forces leave the dynamics: A <- A + B_f F_x, B_tau <- B_tau + B_f F_tau.  A lane owns a COLUMN (of A: lanes 0 .. 47; of B_tau:
+    // 18 lanes in a second round): its 12 entries of the reduced block stay in registers, the rows of B_f are broadcast reads, the
+    // row-wise read-modify-write of A / B is coalesced across the lanes
+    {
+        // [A | B_tau] (48 x 66) -= B_f (48 x 12) X (12 x 66) on the float64 matrix cores: 3 row tiles x 5 column tiles x 3 k-steps, the
+        // accumulators start as the current entries (float32 -> float64, fetched in the C layout: four 64-byte row pieces per load)
+        double bfa[3][3];
+#pragma unroll
+        for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bfa[ti][t] = -Bf[(16 * ti + r16) * 12 + 4 * t + kq];
+#pragma unroll 1
+        for (int tj = 0; tj < 5; ++tj) {
+            const int cfull = 16 * tj + r16;                 // column of [A | B_tau | pad]
+            const bool live = cfull < NX + b2z1::NJ;
+            float* cbase = cfull < NX ? A + cfull : Bm + (live ? cfull - NX : 0);
+            const int ld = cfull < NX ? NX : NUP;
+            double xb[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) xb[t] = live ? Mx[(4 * t + kq) * MC + 12 + cfull] : 0.0;
+            float cv[3][4];
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cv[ti][r] = live ? cbase[(16 * ti + kq + 4 * r) * ld] : 0.f;
+#pragma unroll
+            for (int ti = 0; ti < 3; ++ti) {
+                d4 c = {(double)cv[ti][0], (double)cv[ti][1], (double)cv[ti][2], (double)cv[ti][3]};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) c = __builtin_amdgcn_mfma_f64_16x16x4f64(bfa[ti][t], xb[t], c, 0, 0, 0);
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cbase[(16 * ti + kq + 4 * r) * ld] = (float)c[r];
+                }
+            }
+        }
     }
     if (lane < NX) {
         double acc = 0.0;
@@ -1094,7 +1178,9 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
         vec[(size_t)item * VEC + lane] = (float)((double)vec[(size_t)item * VEC + lane] + acc);
     }
     __syncthreads();
+    ROWS_STAMP(5)
     for (int e = lane; e < NX * 12; e += 64) Bm[(e / 12) * NUP + b2z1::NJ + e % 12] = 0.f;
+    ROWS_STAMP(6)
 }
 
 // the foot forces of the solved step, df = F_x dx + F_tau dtau + f0, then what the Riccati kernel does with a finished step
@@ -1781,6 +1867,13 @@ int alore_wb_create(const alore_wb_config* cfg, alore_wb_handle* out)
 int alore_wb_destroy(alore_wb_handle h)
 {
     if (!h) return ALORE_WB_E_INVALID;
+    if (h->d_stamps) { // diagnostic: contact rows kernel, workgroup 0 of the last launch
+        long long rs[8];
+        if (hipMemcpyFromSymbol(rs, HIP_SYMBOL(wb::g_rows_stamps), sizeof(rs)) == hipSuccess && rs[6] > rs[0]) {
+            std::fprintf(stderr, "[alore_wb stamps] contact rows kernel, workgroup 0, cycles: stage-in %lld, J x [..] %lld, elimination %lld, map out %lld, A / B update %lld, rest %lld\n",
+                         rs[1] - rs[0], rs[2] - rs[1], rs[3] - rs[2], rs[4] - rs[3], rs[5] - rs[4], rs[6] - rs[5]);
+        }
+    }
     if (h->d_stamps) { // diagnostic: cycles of workgroup 0 per phase, summed over all launches
         long long st[64];
         if (hipMemcpy(st, h->d_stamps, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {
