@@ -1220,7 +1220,7 @@ next_item:
     // The grid build stores the iterate and the dual straight from the registers of the lane that owns the stage -- 12- and 8-byte
     // pieces of a span the wavefront writes completely, like the loads of phase 0; L2 merges them into whole lines -- instead of
     // transposing them through LDS into 16-byte pieces (76 LDS writes, 26 reads and their waits per wavefront)
-    constexpr bool DIRECT = FULLN;
+    constexpr bool DIRECT = FULLN; // measured on the (16, 2) single-iteration build too (one batch at a time): 22.2 us per launch either way
     if constexpr (DIRECT) {
         if (valid && !skip) {
             typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
@@ -1231,12 +1231,14 @@ next_item:
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int k = j * S + s;
-                f3u vx; vx.x = x[s][0]; vx.y = x[s][1]; vx.z = x[s][2];
-                f2u vu; vu.x = u[s][0]; vu.y = u[s][1];
-                f2u vd; vd.x = mu0[s]; vd.y = mu1[s];
-                *reinterpret_cast<f3u*>(gx + 3 * k) = vx;
-                *reinterpret_cast<f2u*>(gu + 2 * k) = vu;
-                *reinterpret_cast<f2u*>(gdl + 2 * k) = vd;
+                if (FULLN || k < N) {
+                    f3u vx; vx.x = x[s][0]; vx.y = x[s][1]; vx.z = x[s][2];
+                    f2u vu; vu.x = u[s][0]; vu.y = u[s][1];
+                    f2u vd; vd.x = mu0[s]; vd.y = mu1[s];
+                    *reinterpret_cast<f3u*>(gx + 3 * k) = vx;
+                    *reinterpret_cast<f2u*>(gu + 2 * k) = vu;
+                    *reinterpret_cast<f2u*>(gdl + 2 * k) = vd;
+                }
             }
             if (j == top) {
                 f3u vn; vn.x = xN[0]; vn.y = xN[1]; vn.z = xN[2];

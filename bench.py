@@ -957,6 +957,52 @@ def main():
                     be["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             extras["backend_to_nmpc_pipeline"] = be
             del e10, pl
+            # the same pipeline at the size ONE GPU of BASELINE configs[4] carries: 4 object classes x 16384 poses / 8 GPUs = 8192 plans
+            # (about four residencies of the planner kernel), planned in one launch, handed over device to device, 100 closed-loop ticks
+            try:
+                B8 = 8192
+                fts8 = monte_carlo_goals(B8, seed=44)
+                pl8 = BatchedMSPlanner(B8, 16, device=local_rank)
+                pl8.set_free_map(half=20.0)
+                pl8.set_problems(fts8)
+                pl8.plan(); torch.cuda.synchronize(dev)
+                t_a = time.perf_counter()
+                pl8.plan()
+                res8 = pl8.results()
+                t_b = time.perf_counter()
+                be8 = {"problems": B8, "ms_per_launch_device": pl8.last_plan_ms(), "ms_wall_incl_results": (t_b - t_a) * 1e3,
+                       "plans_per_s": B8 / (pl8.last_plan_ms() * 1e-3), "ok": int(res8["ok"].sum()),
+                       "cost_evaluations_mean": float(res8["evals"].mean()), "cost_evaluations_max": int(res8["evals"].max())}
+                e11 = BatchedNmpc(B8, N, device=local_rank, diagnostics=False)
+                W8 = np.tile(np.diag([10, 10, 0.5, 0.1, 0.1]).astype(np.float32), (B8, N, 1, 1))
+                WN8 = np.tile(np.diag([10, 10, 0.5]).astype(np.float32), (B8, 1, 1))
+                e11.load({"W": W8, "WN": WN8})
+                e11.refs_init(max_pieces=16, max_checkpoints=128)
+                t_a = time.perf_counter()
+                e11.refs_set_from_backend(pl8)
+                torch.cuda.synchronize(dev)
+                be8["handover_to_nmpc_store_ms"] = (time.perf_counter() - t_a) * 1e3
+                icr8 = np.array([[(0.0, -0.3, 0.3), (0.2, -0.3, 0.3), (0.1, -0.25, 0.25), (0.3, -0.35, 0.35)][b % 4] for b in range(B8)])
+                e11.plant_init()
+                e11.plant_set_state(np.array([ft.start_xytheta for ft in fts8]), icr8)
+                e11.closed_loop_reset()
+                e11.closed_loop_tick(0.05)
+                torch.cuda.synchronize(dev)
+                t_a = time.perf_counter()
+                e11.closed_loop_run(0.06, 0.01, 100)
+                torch.cuda.synchronize(dev)
+                be8["closed_loop_100_ticks_ms"] = (time.perf_counter() - t_a) * 1e3
+                be8["unsolved_last_tick"] = int((e11.t["status"] != 0).sum().item())
+                try:
+                    rec = json.load(open(os.path.join(ROOT, "profiles", "backend_valu.json")))
+                    ach = B8 * float(rec["valu_instructions_per_wavefront"]) / (pl8.last_plan_ms() * 1e-3) / 1e9
+                    be8["valu_f64_issue_frac"] = ach / (1024 * 2.4e9 / 4 / 1e9)
+                except Exception:
+                    pass
+                extras["backend_to_nmpc_pipeline_8192"] = be8
+                del e11, pl8
+            except Exception as e:  # pragma: no cover
+                extras["backend_to_nmpc_pipeline_8192"] = {"error": f"{type(e).__name__}: {e}"}
         except Exception as e:  # pragma: no cover
             extras["backend_to_nmpc_pipeline"] = {"error": f"{type(e).__name__}: {e}"}
         # whole-body class (BASELINE configs[2]): B = 4096 B2 + Z1 problems, N = 20, one real-time iteration =
