@@ -36,6 +36,13 @@
 
 #include "nmpc_core.h"
 
+// -DALORE_PHASE_MARKERS (tools/asm_phases.py, never the shipped build): every phase boundary leaves `; @phase <name>` in the assembly
+#ifdef ALORE_PHASE_MARKERS
+#define PHASE(name) asm volatile("; @phase " name)
+#else
+#define PHASE(name)
+#endif
+
 namespace nmpc {
 namespace {
 
@@ -417,6 +424,7 @@ next_item:
     const int WA = (G * 25 * N + 255) & ~255, oW = 0, oY = WA;
     const int oX = 0, oU = G * nx, oDL = oU + G * nu;
 
+    PHASE("load");
     // ---- phase 0.  W and y (read again for the objective) go HBM -> LDS by DMA, no registers: the wavefront's
     //      problems are contiguous, one instruction moves 1 KB.  The iterate, od, the bounds and the dual are read by
     //      the lane that owns the stage straight into its registers (12- and 8-byte pieces of one contiguous span).
@@ -563,6 +571,7 @@ next_item:
     // (od, the raw bounds) are dead after phase A instead of live across the whole body
     const int n_sqp = ONCE ? 1 : p.n_sqp;
     for (int sqp = 0; sqp < n_sqp; ++sqp) {
+    PHASE("linearise+cost");
         // ---- phase A: linearise, Gauss-Newton cost, bounds on the step, working-set guess from the dual
         int infeasible = 0;
 #pragma unroll
@@ -635,6 +644,7 @@ next_item:
         const float Dx0 = x00 - gfirst<L>(x[0][0], lane), Dx1 = x01 - gfirst<L>(x[0][1], lane),
                     Dx2 = x02 - gfirst<L>(x[0][2], lane);
 
+    PHASE("prediction");
         // ---- working-set prediction for cold starts (see nmpc_kernels.hip): projected Barzilai-Borwein steps on
         //      the condensed QP, its Hessian applied stage-wise by prefix / suffix sums (serial inside the lane's
         //      block, DPP scan across the group).  Only a guess: the sweeps below iterate to a fixed point.
@@ -794,6 +804,7 @@ next_item:
             if (STAMP) t_pg = __builtin_amdgcn_s_memtime() - tp0;
         }
 
+    PHASE("sweep_setup");
         // ---- phase B: working-set iterations; the sweeps go lane by lane through the group
         float V[9];    // cost-to-go travelling down the lanes: P00 P01 P02 P11 P12 P22 p0 p1 p2
         float Vin[9];  // cost-to-go at the upper end of this lane's block (kept for restarts)
@@ -965,10 +976,12 @@ next_item:
         for (;;) {
             long long tb0 = 0;
             if (STAMP) tb0 = __builtin_amdgcn_s_memtime();
+    PHASE("backward");
             backward_sweep(changed, khi / S);
             long long tf0 = 0;
             if (STAMP) { tf0 = __builtin_amdgcn_s_memtime(); t_b += tf0 - tb0; }
 
+    PHASE("forward");
             // ---- forward sweep: every lane condenses its block into one affine map under the current working set,
             //      a DPP scan over the lanes gives the state step entering each block, then the lanes walk their own
             //      stages in parallel (nmpc_core.h: forward_step)
@@ -1010,6 +1023,7 @@ next_item:
         }
         n_iter = (n_iter == 0) ? 1 : (changed ? n_iter : n_iter + 1); // + the confirming sweep
 
+    PHASE("safeguard");
         // ---- safeguard (nmpc_core.h: AS_SWITCH): primal active-set iteration for the rare problem whose
         //      primal-dual update has not settled; one change of the working set per sweep.  Cold path.
         {
@@ -1104,6 +1118,7 @@ next_item:
                             : (pd_fail ? RET_INIT_FAILED_CHOLESKY : (changed ? RET_MAX_NWSR_REACHED : RET_OK));
         if (STAMP && sqp == 0) t4 = __builtin_amdgcn_s_memtime();
 
+    PHASE("kkt+expand");
         // ---- phase C: KKT value (acado_getKKT), expand (acado_expand), carry the dual
         if (DIAG) { // free response (du = 0) entering every stage, for acado_getKKT: A is a shear, so prefix sums do it
                     // (here and not before the sweeps: nine registers per lane less across them)
@@ -1179,6 +1194,7 @@ next_item:
     }
     if (STAMP) t5 = __builtin_amdgcn_s_memtime();
 
+    PHASE("objective+store");
     // ---- objective at the returned iterate (acado_getObjective), then the iterate back through LDS
     float obj = 0.0f;
     if (DIAG) {
@@ -1317,8 +1333,12 @@ next_item:
     }
     };
     if constexpr (FULLN && !STAMP) {
+#ifdef ALORE_ONLY_DIAGW // analysis builds (tools/asm_phases.py): one path in the assembly
+        body(std::true_type{});
+#else
         if (__builtin_expect(wdiag, 1)) body(std::true_type{}); // block frequencies steer the register allocator: the copies go to the rare path
         else body(std::false_type{});
+#endif
     } else {
         body(std::false_type{});
     }

@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
+    ap.add_argument("--no-stress-check", action="store_true",
+                    help="skip the parity check on the stress distribution (counter passes: its grids run the general-weights path and would be averaged in)")
     ap.add_argument("--headline", choices=("rti", "converged_all_gather"), default="rti",
                     help="which pass the line's `value` is: rti = sharded real-time iterations (default, BASELINE's metric on configs[1]); "
                          "converged_all_gather = the north star's unit -- every step solves its batch to convergence (15 real-time iterations in one "
@@ -621,7 +623,7 @@ def main():
 
     # ... and the same timed configuration on the stress distribution (outside every timed region; the slots are reloaded after)
     stress = None
-    if rank == 0 and a.steps > 0 and world == 1:
+    if rank == 0 and a.steps > 0 and world == 1 and not a.no_stress_check:
         try:
             stress = parity_stress_check(eng, N, a.warmup, a.steps, hooks)
         except Exception as e:  # pragma: no cover

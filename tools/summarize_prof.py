@@ -31,6 +31,11 @@ def from_rocpd(db, lines):
             "select name, grid_x, count(*), avg(end-start), min(end-start), max(end-start) from kernels where name like '%nmpc::rti_%' "
             "group by name, grid_x order by name, grid_x"):
         lines.append(f"{name},{gx},{n},{avg:.1f},{mn},{mx}")
+    # every launch of the grid build in launch order (a bench.py run: 5-batch warm-up grids, the 200-batch steady-state grid, then the
+    # TIMED K-batch grid, the same grid again for the parity spot check and once more on the stress distribution)
+    lines.append("# nmpc::rti_block_kernel<4, 5, ...> launches in order: grid_x,duration_ns")
+    for gx, dur in c.execute("select grid_x, end-start from kernels where name like '%nmpc::rti_block_kernel<4, 5%' order by start"):
+        lines.append(f"{gx},{dur}")
     lines.append("# launch geometry / resources per nmpc kernel")
     for r in c.execute("select distinct name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size "
                        "from kernels"):

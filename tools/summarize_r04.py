@@ -82,7 +82,7 @@ if main_k:
         "bytes_per_launch": e["bytes_per_launch"], "raw": e["raw"], "algorithmic_bytes_per_launch": 4192 * B,
         "kernel": "nmpc::rti_block_kernel", "instantiation": main_k[0],
         "one_batch_at_a_time": {k: v for k, v in rec.items() if k not in main_k},
-        "source": f"profiles/{tag}_* (tools/profile_r04.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, eager launches)",
+        "source": f"profiles/{tag}_* (tools/profile_r05.sh / profile_r04.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, eager launches)",
         "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --no-graph --steps 200 --warmup 200: every launch of "
                "the many-batch build serves 200 batches of B problems, the per-launch mean is divided by 200 (`bytes_per_launch` = bytes of ONE B-problem "
                "batch, the unit of roofline.achieved). bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 reports half the bytes of 16-byte-per-lane "
