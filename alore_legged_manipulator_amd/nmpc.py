@@ -175,12 +175,16 @@ class BatchedNmpc:
     def rti_range(self, first: int, count: int, n_sqp: int = 1) -> None:
         """slots first .. first + count - 1 by ONE call into the library (independent slots are solved together, see
         alore_nmpc_rti_many)"""
-        if first < 0 or count < 1 or first + count > self.slots:
-            raise ValueError(f"rti_range: slots {first} .. {first + count - 1} outside 0 .. {self.slots - 1}")
-        if not hasattr(self, "_batch_array"):
-            self._batch_array = (Batch * self.slots)(*self._batches)
-        self._check(self.lib.alore_nmpc_rti_many(self.h, C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch)),
-                                                int(count), self.B, int(n_sqp), self._stream()))
+        args = getattr(self, "_range_args", {}).get((first, count))   # made by prepare_range: nothing but the call is left
+        if args is None:
+            if first < 0 or count < 1 or first + count > self.slots:
+                raise ValueError(f"rti_range: slots {first} .. {first + count - 1} outside 0 .. {self.slots - 1}")
+            if not hasattr(self, "_batch_array"):
+                self._batch_array = (Batch * self.slots)(*self._batches)
+            args = (C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch)), C.c_int(count), C.c_int(self.B))
+        rc = self.lib.alore_nmpc_rti_many(self.h, args[0], args[1], args[2], n_sqp, self._stream())
+        if rc != 0:
+            self._check(rc)
 
     def prepare_range(self, first: int, count: int) -> None:
         """the independence check of rti_range(first, count) ahead of time (alore_nmpc_rti_many_prepare): later calls on these
@@ -189,8 +193,11 @@ class BatchedNmpc:
             raise ValueError(f"prepare_range: slots {first} .. {first + count - 1} outside 0 .. {self.slots - 1}")
         if not hasattr(self, "_batch_array"):
             self._batch_array = (Batch * self.slots)(*self._batches)
-        self._check(self.lib.alore_nmpc_rti_many_prepare(self.h, C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch)),
-                                                        int(count), self.B))
+        ptr = C.cast(C.byref(self._batch_array, first * C.sizeof(Batch)), C.POINTER(Batch))
+        self._check(self.lib.alore_nmpc_rti_many_prepare(self.h, ptr, int(count), self.B))
+        if not hasattr(self, "_range_args"):
+            self._range_args = {}
+        self._range_args[(first, count)] = (ptr, C.c_int(count), C.c_int(self.B))
 
     def linearize(self) -> dict:
         torch = self.torch
