@@ -710,7 +710,8 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     if (const char* e = std::getenv("ALORE_NMPC_OVERLAP")) ways = std::atoi(e);
     ways = ways < 1 ? 1 : (ways > 32 ? 32 : ways);
     if (ways > count) ways = count;
-    if (ways > 1 && (h->timing || h->stamps)) ways = 1;
+    if (ways > 1 && h->stamps) ways = 1;
+    if (ways > 1 && h->timing && h->many_mode != 0) ways = 1; // per-launch timing of the streams mode: in order; the groups mode times its grid(s) as one
     if (ways > 1) {
         // the independence check (a sort of 15 x count address ranges) is remembered for the descriptor set it passed on: a host
         // that steps the same slots every tick pays for it once (alore_nmpc_rti_many_prepare: before the first tick)
@@ -748,7 +749,15 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
         (void)nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g1, B);
         if (constant_strides(batches, count, stride) && (long long)g1.grid * count <= 0x7fffffffLL) {
             const long inflight = (long)B * count;
-            return rti_group(h, batches, count, B, n_sqp, stream, (int)(inflight > clampB ? clampB : inflight), stride);
+            // alore_nmpc_set_timing: HIP events on the launch stream directly around the grid (alore_nmpc_get_launch_info: last_kernel_ms is
+            // then the duration of the ONE grid that served the `count` batches)
+            if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, main_s));
+            const int rc = rti_group(h, batches, count, B, n_sqp, stream, (int)(inflight > clampB ? clampB : inflight), stride);
+            if (h->timing && rc == ALORE_NMPC_OK) {
+                HIP_TRY(h, hipEventRecord(h->ev1, main_s));
+                h->timed_pending = true;
+            }
+            return rc;
         }
         static const bool alternate = getenv("ALORE_NMPC_GROUP_STREAMS") && atoi(getenv("ALORE_NMPC_GROUP_STREAMS")) == 2;
         const int n_groups = (count + nmpc::GROUP_MAX - 1) / nmpc::GROUP_MAX;

@@ -1025,7 +1025,8 @@ __global__ __launch_bounds__(RIC_THREADS, 3) void riccati_kernel(RicArgs g)
 // One wavefront per (problem, stage), float64; G^-1 by Gauss-Jordan on the 12 x 79 augmented block in LDS.
 constexpr int FCOL = 68; // floats per force row of the stored map: F_x (48) | F_tau (18) | f0 | pad
 __device__ long long g_rows_stamps[8]; // diagnostic: cycles per phase of workgroup 0 of the last launch (tools/wb_rows_time.py reads it)
-#define ROWS_STAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_rows_stamps[i] = (long long)__builtin_readcyclecounter();
+// ... and a scheduling fence: without it the loads of a later phase are hoisted over the earlier ones (338 registers, one wavefront per SIMD)
+#define ROWS_STAMP(i) __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) g_rows_stamps[i] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32, double* next, float* vec, const float* pen, const unsigned char* stance,
                                                              const double* u, int N, float* Fg)
 {
@@ -1033,8 +1034,7 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
     __shared__ double Mx[12 * MC];
     __shared__ double Jl[12 * NV];
     __shared__ double Bf[NX * 12];
-    __shared__ double Src[NV * MC]; // the velocity rows of [B_f | A | B_tau | next]: what J_c multiplies, column-aligned with Mx
-    __shared__ double colp[24];
+    __shared__ double colp[144]; // the twelve pivot columns of the elimination
     const int item = blockIdx.x, lane = threadIdx.x;
     float* A = A32 + (size_t)item * NX * NX;
     float* Bm = B32 + (size_t)item * NX * NUP;
@@ -1042,32 +1042,19 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
     const float* J = pen + (size_t)item * PEN; // written with rho = 1: J_c itself, rows of swing feet zero
     const unsigned char* st = stance ? stance + (size_t)item * 4 : nullptr;
     ROWS_STAMP(0)
-    // every global read of the set-up is issued before the first LDS store (a rolled loop waits for one load per trip: 30 round trips)
+    // every global read of the set-up is issued before the first LDS store (a rolled loop waits for one load per trip)
     {
-        float jv[5], bv[9], av[18], tv[7];
+        float jv[5], bv[9];
 #pragma unroll
         for (int q = 0; q < 5; ++q) { const int e = lane + 64 * q; jv[q] = e < 12 * NV ? J[e] : 0.f; }
 #pragma unroll
         for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; bv[q] = Bm[(e / 12) * NUP + b2z1::NJ + e % 12]; } // 576 = 9 x 64
 #pragma unroll
-        for (int q = 0; q < 18; ++q) { const int e = lane + 64 * q; av[q] = A[(NQ + e / NX) * NX + e % NX]; }           // 1152 = 18 x 64
-#pragma unroll
-        for (int q = 0; q < 7; ++q) { const int e = lane + 64 * q; tv[q] = e < NV * b2z1::NJ ? Bm[(NQ + e / b2z1::NJ) * NUP + e % b2z1::NJ] : 0.f; }
-        const double nv = lane < NV ? nx[NQ + lane] : 0.0;
-#pragma unroll
         for (int q = 0; q < 5; ++q) { const int e = lane + 64 * q; if (e < 12 * NV) Jl[e] = (double)jv[q]; }
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; Bf[e] = (double)bv[q]; if (e / 12 >= NQ) Src[(e / 12 - NQ) * MC + e % 12] = (double)bv[q]; }
-#pragma unroll
-        for (int q = 0; q < 18; ++q) { const int e = lane + 64 * q; Src[(e / NX) * MC + 12 + e % NX] = (double)av[q]; }
-#pragma unroll
-        for (int q = 0; q < 7; ++q) { const int e = lane + 64 * q; if (e < NV * b2z1::NJ) Src[(e / b2z1::NJ) * MC + 60 + e % b2z1::NJ] = (double)tv[q]; }
-        if (lane < NV) { Src[lane * MC + 78] = nv; Src[lane * MC + 79] = 0.0; }
+        for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; Bf[e] = (double)bv[q]; }
     }
     __syncthreads();
-    // [G | J A_v | J B_v,tau | J next_v] = J_c [B_f | A | B_tau | next]_v.  The right factor is staged in LDS first (coalesced global
-    // reads, no lane-dependent branches in the product); then a lane owns a column: its source value of row c is read once and meets
-    // the 12 entries of column c of J_c, which every lane reads from the same LDS address (broadcast): 12 independent accumulators
     ROWS_STAMP(1)
     // [G | J A_v | J B_v,tau | J next_v] = J_c [B_f | A | B_tau | next]_v on the float64 matrix cores (v_mfma_f64_16x16x4_f64: lane l supplies
     // A[l & 15][l >> 4] and B[l >> 4][l & 15], receives C[(l >> 4) + 4 r][l & 15]): J_c padded to 16 rows, 5 column tiles x 6 k-steps
@@ -1079,9 +1066,18 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
         for (int t = 0; t < 6; ++t) ja[t] = r16 < 12 ? Jl[r16 * NV + 4 * t + kq] : 0.0;
 #pragma unroll
         for (int tj = 0; tj < 5; ++tj) {
+            // the B operand -- the velocity rows of [B_f | A | B_tau | next | 0], column 16 tj + r16 -- straight from where it lives: B_f from
+            // LDS, A and B_tau from global memory (16 consecutive floats per row piece), next from its float64 array
+            const int col = 16 * tj + r16;
+            const float* fsrc = col < 60 ? A + NQ * NX + (col >= 12 ? col - 12 : 0) : Bm + NQ * NUP + (col < 78 ? col - 60 : 0);
+            const int fld = col < 60 ? NX : NUP;
             double sb[6];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) sb[t] = Src[(4 * t + kq) * MC + 16 * tj + r16];
+            for (int t = 0; t < 6; ++t) {
+                const int row = 4 * t + kq;
+                const float fv = fsrc[row * fld];
+                sb[t] = col < 12 ? Bf[(NQ + row) * 12 + col] : (col < 78 ? (double)fv : (col == 78 ? nx[NQ + row] : 0.0));
+            }
             d4 c = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int t = 0; t < 6; ++t) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ja[t], sb[t], c, 0, 0, 0);
@@ -1105,22 +1101,35 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
     __syncthreads(); // Mx is written again after the elimination
     ROWS_STAMP(2)
     // Gauss-Jordan without pivoting (G is symmetric positive definite) on the register columns: lane p hands column p of G round
-    // through LDS (two buffers in turn: one barrier per pivot), every lane updates its own columns
+    // through LDS and every lane updates its first column; the twelve pivot columns stay in LDS and the second column (lanes 0 .. 14)
+    // goes through the same twelve steps afterwards, without barriers (both columns in one unrolled loop cost 338 registers: one
+    // wavefront per SIMD)
 #pragma unroll
     for (int p = 0; p < 12; ++p) {
-        double* cp = colp + 12 * (p & 1);
+        double* cp = colp + 12 * p;
         if (lane == p) {
 #pragma unroll
             for (int r = 0; r < 12; ++r) cp[r] = m0[r];
         }
         __syncthreads();
-        const double inv = 1.0 / cp[p];
-        const double pv0 = m0[p] * inv, pv1 = m1[p] * inv;
+        const double cpp = cp[p];
+        double inv = __builtin_amdgcn_rcp(cpp); // hardware reciprocal + two Newton steps: full float64 accuracy at a fifth of the division's instructions
+        inv = inv * (2.0 - cpp * inv); inv = inv * (2.0 - cpp * inv);
+        const double pv0 = m0[p] * inv;
 #pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            const double cr = cp[r];
-            m0[r] = (r == p) ? pv0 : m0[r] - cr * pv0;
-            m1[r] = (r == p) ? pv1 : m1[r] - cr * pv1;
+        for (int r = 0; r < 12; ++r) m0[r] = (r == p) ? pv0 : m0[r] - cp[r] * pv0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane + 64 < 79) {
+#pragma unroll
+        for (int p = 0; p < 12; ++p) {
+            const double* cp = colp + 12 * p;
+            const double cpp = cp[p];
+            double inv = __builtin_amdgcn_rcp(cpp);
+            inv = inv * (2.0 - cpp * inv); inv = inv * (2.0 - cpp * inv);
+            const double pv1 = m1[p] * inv;
+#pragma unroll
+            for (int r = 0; r < 12; ++r) m1[r] = (r == p) ? pv1 : m1[r] - cp[r] * pv1;
         }
     }
 #pragma unroll
@@ -1145,7 +1154,7 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
         for (int ti = 0; ti < 3; ++ti)
 #pragma unroll
             for (int t = 0; t < 3; ++t) bfa[ti][t] = -Bf[(16 * ti + r16) * 12 + 4 * t + kq];
-#pragma unroll 1
+#pragma unroll
         for (int tj = 0; tj < 5; ++tj) {
             const int cfull = 16 * tj + r16;                 // column of [A | B_tau | pad]
             const bool live = cfull < NX + b2z1::NJ;

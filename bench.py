@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
     ap.add_argument("--no-stress-check", action="store_true",
                     help="skip the parity check on the stress distribution (counter passes: its grids run the general-weights path and would be averaged in)")
+    ap.add_argument("--bench-events", action="store_true",
+                    help="time the single-grid passes with events recorded by bench.py around the Python call (the placement of round 4) instead of "
+                         "the library's own events around the hipLaunchKernel")
     ap.add_argument("--headline", choices=("rti", "converged_all_gather"), default="rti",
                     help="which pass the line's `value` is: rti = sharded real-time iterations (default, BASELINE's metric on configs[1]); "
                          "converged_all_gather = the north star's unit -- every step solves its batch to convergence (15 real-time iterations in one "
@@ -500,7 +503,16 @@ def main():
                 torch.cuda.synchronize(dev)
                 return None
 
+        lib_events = False   # the next timed region is timed by the library's own HIP events around its one launch (set by main)
+
         def device_timer(self):
+            if self.lib_events:
+                class N:  # nothing to record here: two more event records would only stand between the barrier and the launch
+                    def start(self_inner): pass
+                    def stop(self_inner): pass
+                    def elapsed_ms(self_inner): return 0.0
+                return N()
+
             class T:  # HIP events on the launch stream; read after the barrier that follows the timed region
                 def __init__(self_inner):
                     # torch creates the HIP event at its first record(): done here, before the barrier that opens the timed region
@@ -540,13 +552,33 @@ def main():
     hooks.single_grid = one_grid
     # a short run's LONG_STEPS pass goes first: the contract pass (W warm-up steps, barrier, K timed steps, barrier) then starts on a
     # GPU that has been busy for a millisecond instead of one that idled through the set-up of this process
+    # Passes that are ONE grid are timed by the library itself (alore_nmpc_set_timing): HIP events on the launch stream recorded by the
+    # same C call directly before and after the hipLaunchKernel of the grid.  Events recorded by the bench around the Python call would
+    # also contain the host's time inside the call -- 8 .. 10 us of an idle GPU waiting for its dispatch, which is not the kernel -- and
+    # cost the region's host clock two more event records.  `--bench-events` keeps the round-4 placement.
+    lib_events = one_grid and world == 1 and a.graph == "auto" and not a.bench_events   # eager launches only: events inside a stream capture cannot be read
+
+    def grid_event_ms(region_ms):
+        if not lib_events:
+            return region_ms, None
+        kms = float(eng.launch_info()["last_kernel_ms"])
+        if not kms > 0.0:
+            raise RuntimeError("the library's launch events returned no duration")
+        return kms, None
+    if lib_events:
+        eng.set_timing(True)
+        hooks.lib_events = True
     steady = None
     if long_steps:
         el_l, dms_l, g_l = timed_pass("none", long_steps)
+        dms_l, reg_l = grid_event_ms(dms_l)
         steady = {"steps": long_steps, "value": float(B) * long_steps / el_l, "ms_per_step": el_l / long_steps * 1e3,
                   "kernel_ms_avg": dms_l / long_steps, "hip_graph": g_l,
                   "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_l / long_steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
     elapsed, dev_ms, used_graph = timed_pass(primary, a.steps)
+    dev_ms, region_events_ms = grid_event_ms(dev_ms)
+    eng.set_timing(False)
+    hooks.lib_events = False
     host_breakdown = dict(getattr(hooks, "last_host_breakdown_us", {}))
     info = eng.launch_info()
     # the same K steps strictly one after the other (one launch in flight): what a single launch costs, and the figure the
@@ -689,6 +721,9 @@ def main():
                          "launches_in_flight": a.overlap,
                          "batches_per_launch": per_launch, "kernel_launches": n_launches,
                          "kernel_ms_per_launch": dev_ms / n_launches,
+                         "events": ("HIP events on the launch stream, recorded by the library directly before and after the hipLaunchKernel of the grid "
+                                    "(alore_nmpc_set_timing; --bench-events: recorded by bench.py around the Python call instead)" if lib_events
+                                    else "HIP events on the launch stream, recorded by bench.py around the timed region"),
                          "note": ("achieved = algorithmic bytes of one B-problem batch / kernel_ms_avg, kernel_ms_avg = HIP-event time of "
                                   "the timed region / K batches.  many_mode groups: ONE grid of nmpc::rti_block_kernel serves the K "
                                   "batches of the timed region (alore_nmpc_rti_many; the slots sit at constant strides), so a profiler's "
