@@ -83,6 +83,7 @@ SYMBOLS = (
     ("alore_nmpc_rti_many", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("alore_nmpc_set_launch_overlap", C.c_int, [C.c_void_p, C.c_int]),
     ("alore_nmpc_rti_many_prepare", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int]),
+    ("alore_nmpc_synchronize", C.c_int, [C.c_void_p, C.c_void_p]),
     ("alore_nmpc_set_many_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("alore_nmpc_set_problem_mask", C.c_int, [C.c_void_p, C.c_void_p]),
     ("alore_nmpc_condense", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

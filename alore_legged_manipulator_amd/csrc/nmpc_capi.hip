@@ -806,6 +806,13 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     return rc;
 }
 
+int alore_nmpc_synchronize(alore_nmpc_handle h, void* stream)
+{
+    if (!h) return ALORE_NMPC_E_INVALID;
+    HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));
+    return ALORE_NMPC_OK;
+}
+
 int alore_nmpc_rti_many_prepare(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B)
 {
     if (!h || !batches || count < 1 || B <= 0) return fail(h, ALORE_NMPC_E_INVALID, "rti_many_prepare: bad argument");

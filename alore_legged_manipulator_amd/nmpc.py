@@ -117,6 +117,15 @@ class BatchedNmpc:
         """n_sqp x (acado_preparationStep + acado_feedbackStep) for the whole batch, one launch."""
         self._check(self.lib.alore_nmpc_rti(self.h, C.byref(self._batches[slot]), self.B, int(n_sqp), self._stream()))
 
+    def rti_sync(self, n_sqp: int = 1, slot: int = 0) -> None:
+        """rti() and wait for it (alore_nmpc_rti + alore_nmpc_synchronize on the current stream): the synchronous control tick"""
+        st = self._stream()
+        rc = self.lib.alore_nmpc_rti(self.h, C.byref(self._batches[slot]), self.B, n_sqp, st)
+        if rc == 0:
+            rc = self.lib.alore_nmpc_synchronize(self.h, st)
+        if rc != 0:
+            self._check(rc)
+
     def input_column(self, node: int, slot: int = 0):
         """inputs of one node of every problem and the status (alore_nmpc_input_column): (cmd [B][2] float32, status [B])"""
         import numpy as np

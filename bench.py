@@ -31,6 +31,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -791,13 +792,27 @@ def main():
                 e2.ts["x"][0].copy_(xs0); e2.ts["u"][0].copy_(us0); e2.ts["dual"][0].copy_(ds0)
                 torch.cuda.synchronize(dev)
                 t_a = time.perf_counter()
-                e2.rti(1, slot=0)
-                torch.cuda.synchronize(dev)
+                e2.rti_sync(1, slot=0)   # alore_nmpc_rti + alore_nmpc_synchronize (the launch stream; torch.cuda.synchronize waits for the whole device)
                 ts.append(time.perf_counter() - t_a)
             ts = np.array(ts[50:]) * 1e3
             lat[f"B{b_lat}"] = {"launches": int(ts.size), "p50_ms": float(np.percentile(ts, 50)), "p99_ms": float(np.percentile(ts, 99)),
                                 "max_ms": float(ts.max())}
-        result["latency"] = {"what": "one synchronous alore_nmpc_rti launch (enqueue + kernel + stream sync), host clock", **lat}
+        result["latency"] = {"what": "one synchronous real-time iteration from the MpcWrapper::solve cold start (alore_nmpc_rti + alore_nmpc_synchronize: enqueue + kernel + "
+                                     "stream synchronisation), host clock of this Python process through ctypes", **lat}
+        # the same pair from a C++ host (the reference's controller is C++): tools/micro/rti_latency, built by csrc/Makefile
+        try:
+            import subprocess
+            exe = os.path.join(ROOT, "tools", "micro", "rti_latency")
+            cpp = {}
+            for b_lat in (1, 64, B):
+                out = subprocess.run([exe, str(b_lat)], capture_output=True, text=True, timeout=120).stdout
+                m = re.search(r"enqueue p50 ([0-9.]+) us; .* p50 ([0-9.]+)  p99 ([0-9.]+) us; status (\d+)", out)
+                cpp[f"B{b_lat}"] = {"enqueue_p50_ms": float(m.group(1)) * 1e-3, "p50_ms": float(m.group(2)) * 1e-3, "p99_ms": float(m.group(3)) * 1e-3,
+                                    "status": int(m.group(4))}
+            result["latency"]["cpp_host"] = {"what": "the same pair called from C++ through the C ABI (tools/micro/rti_latency.cpp), 2000 cold-start solves of a "
+                                                     "bound-hitting problem", **cpp}
+        except Exception as e:  # pragma: no cover
+            result["latency"]["cpp_host"] = {"error": f"{type(e).__name__}: {e}"}
         # converged solve: K = 15 real-time iterations inside one launch (MpcWrapper::solve + 14 update() calls of the
         # reference collapsed into one kernel: the I/O contract is read and written once, the arithmetic 15 times)
         e3 = BatchedNmpc(B, N, device=local_rank, slots=52)

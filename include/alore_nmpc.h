@@ -168,6 +168,10 @@ int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int 
  * of B): results of different mappings agree to float32 rounding; pin lanes_per_problem where the bits of a single
  * alore_nmpc_rti launch are wanted. */
 int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch *batches, int count, int B, int n_sqp, void *stream);
+/* Wait for the work enqueued on `stream` (hipStreamSynchronize on the solver's device): what a synchronous control tick does after
+ * alore_nmpc_rti, for callers that do not link the HIP runtime themselves.  One robot, cold start, through this pair from a C++
+ * host: 22 us p50 (tools/micro/rti_latency.cpp), of which 2.4 us is the enqueue. */
+int alore_nmpc_synchronize(alore_nmpc_handle h, void *stream);
 /* The independence check of alore_nmpc_rti_many (one sort of 15 x count address ranges) ahead of time: validates the set and
  * remembers it -- the descriptors themselves, with B and the shared-member mask -- so that alore_nmpc_rti_many calls on it, or
  * on any contiguous run of it, go straight to the launch.  A host that steps the same slots every tick calls it once (a stream
