@@ -349,6 +349,22 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p_arg, co
     constexpr bool MASKED = (L == 16 && S == 2) || (L == 32 && S == 1); // see backward_sweep
     const int N = FULLN ? L * S : p_arg.N;
     int item = (int)blockIdx.x; // block of G problems this workgroup works on
+    // XCD shares (grid builds, RtiGroup::xcd_on).  The hardware deals the workgroups of a grid to the eight XCDs round-robin -- workgroup w
+    // runs on XCD w mod 8, each XCD gets the same number -- and the XCDs of a part differ by several per cent in speed under this load,
+    // so a grid lasts as long as its slowest XCD.  With shares, XCD x works on xcd_share[x] consecutive blocks from xcd_base[x]: the grid
+    // is launched with 8 x max(share) workgroups, those beyond their XCD's share leave at once, and the shares follow the finishing times
+    // the last workgroups of every XCD left in host memory at the previous launches (nmpc_capi.hip: rti_group).  Results do not depend
+    // on which workgroup solves a block.
+    if constexpr (FULLN && !PERSIST) {
+        const auto& g0 = *reinterpret_cast<const __attribute__((address_space(4))) RtiGroup*>(
+            (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(RtiParams) + 7) & ~(size_t)7));
+        if (g0.xcd_on) {
+            const int x = (int)blockIdx.x & 7, xcd_k = (int)blockIdx.x >> 3;
+            if (blockIdx.x == 0 && threadIdx.x == 0 && g0.xcd_end != nullptr) g0.xcd_end[32] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); // the grid's start
+            if (xcd_k >= g0.xcd_share[x]) return;
+            item = g0.xcd_base[x] + xcd_k;
+        }
+    }
 next_item:
     int lane = threadIdx.x;
     // the kernel arguments, read through the kernel-argument segment pointer (what `p_arg`, `grp_arg` are)
@@ -405,9 +421,9 @@ next_item:
             o[5] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); // HW_ID, XCC_ID
         }
     }
-    if (grp.stagger_x1024 > 0 && item == (int)blockIdx.x && item < grp.stagger_blocks) {
+    if (grp.stagger_x1024 > 0 && (PERSIST ? item == (int)blockIdx.x : true) && (int)blockIdx.x < grp.stagger_blocks) {
         const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long wait = ((unsigned long long)item * (unsigned)grp.stagger_x1024) >> 10;
+        const unsigned long long wait = ((unsigned long long)blockIdx.x * (unsigned)grp.stagger_x1024) >> 10;
         while (__builtin_amdgcn_s_memrealtime() - ts < wait) __builtin_amdgcn_s_sleep(2);
     }
     long long t0 = 0, t1 = 0, t4 = 0, t5 = 0, t_b = 0, t_f = 0, t_pg = 0;
@@ -1316,6 +1332,15 @@ next_item:
         if (DIAG && pb.kkt) pb.kkt[prob] = kkt;
         if (DIAG && pb.obj) pb.obj[prob] = obj;
     }
+    if constexpr (FULLN && !PERSIST) {
+        if (grp.xcd_on && grp.xcd_end != nullptr) { // the last four workgroups of an XCD leave the time they finished at (host memory: read without a copy)
+            const int x = (int)blockIdx.x & 7, left = grp.xcd_share[x] - 1 - ((int)blockIdx.x >> 3); // recomputed: nothing is kept live across the body for it
+            if (left < 4 && lane == 0) {
+                __builtin_amdgcn_s_waitcnt(0x0F70); // the results are on their way out: the stamp follows them
+                grp.xcd_end[x * 4 + left] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+            }
+        }
+    }
     if constexpr (TRACE) {
         if (grp.trace) {
             int worst = 0; // sweeps of the slowest problem of the wavefront
@@ -1420,6 +1445,8 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
     grp.trace = nullptr;
     grp.counter = nullptr;
     grp.persist_blocks = 0;
+    grp.xcd_on = 0;
+    grp.xcd_end = nullptr;
     grp.b[0] = p.b;
     return launch_rti_block_group(p, grp, g, s);
 }
@@ -1479,6 +1506,11 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
     void* args[] = {const_cast<RtiParams*>(&p), const_cast<RtiGroup*>(&grp)};
     unsigned blocks = (unsigned)g.grid * (unsigned)grp.count;
     if (persist && blocks > (unsigned)grp.persist_blocks) blocks = (unsigned)grp.persist_blocks;
+    if (!persist && grp.xcd_on) {
+        int mx = 0;
+        for (int x = 0; x < 8; ++x) mx = grp.xcd_share[x] > mx ? grp.xcd_share[x] : mx;
+        blocks = 8u * (unsigned)mx;
+    }
     e = hipLaunchKernel(fn, dim3(blocks), dim3(64), args, g.lds_bytes, s);
     if (e != hipSuccess) return e;
     return hipGetLastError();

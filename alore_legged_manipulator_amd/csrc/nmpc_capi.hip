@@ -2,6 +2,7 @@
 // Thin host layer: argument checks, launch geometry, HIP stream/event plumbing.
 // There is no CPU path behind this ABI: without a GPU alore_nmpc_create fails.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,13 @@ struct alore_nmpc_solver {
     long long* d_stamps = nullptr;
     // ticket counters of the persistent grids (nmpc_block_kernel.hip: PERSIST): a ring of pairs, one pair per launch in turn, so
     // that grids of this handle that overlap on different streams never share one; every pair is back at 0 when its grid ends
+    // XCD shares of the grid builds (nmpc_block_kernel.hip: RtiGroup::xcd_on): relative speed of the eight XCDs as the finishing times of
+    // their last workgroups showed it at the previous launches, the host-memory record the running launch writes, its event
+    double xcd_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    unsigned long long* xcd_rec = nullptr;  // pinned host memory [8][4] end stamps + [32] start stamp
+    hipEvent_t xcd_ev = nullptr;
+    bool xcd_pending = false;
+    int xcd_updates = 0;
     static constexpr int kTicketRing = 16;
     int* d_tickets = nullptr;
     unsigned ticket_turn = 0;
@@ -213,6 +221,17 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
         (void)alore_nmpc_destroy(h);
         return ALORE_NMPC_E_HIP;
     }
+    if (hipHostMalloc((void**)&h->xcd_rec, sizeof(unsigned long long) * 40, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->xcd_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)alore_nmpc_destroy(h);
+        return ALORE_NMPC_E_HIP;
+    }
+    std::memset(h->xcd_rec, 0, sizeof(unsigned long long) * 40);
+    if (const char* sp = std::getenv("ALORE_NMPC_XCD_SPEEDS")) { // diagnostic / tests: preset relative speeds "a,b,c,d,e,f,g,h"
+        double v[8];
+        if (std::sscanf(sp, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7) == 8)
+            for (int x = 0; x < 8; ++x) h->xcd_speed[x] = v[x] > 0.05 ? v[x] : 0.05;
+    }
     const char* st = std::getenv("ALORE_NMPC_STAMPS");
     h->stamps = st && st[0] == '1';
     *out = h;
@@ -237,6 +256,11 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     }
     if (h->d_stamps) (void)hipFree(h->d_stamps);
     if (h->d_tickets) (void)hipFree(h->d_tickets);
+    if (std::getenv("ALORE_NMPC_XCD_DEBUG") && h->xcd_updates > 0)
+        std::fprintf(stderr, "[alore_nmpc xcd shares] %d updates; relative speeds %.3f %.3f %.3f %.3f %.3f %.3f %.3f %.3f\n", h->xcd_updates, h->xcd_speed[0],
+                     h->xcd_speed[1], h->xcd_speed[2], h->xcd_speed[3], h->xcd_speed[4], h->xcd_speed[5], h->xcd_speed[6], h->xcd_speed[7]);
+    if (h->xcd_ev) { (void)hipEventSynchronize(h->xcd_ev); (void)hipEventDestroy(h->xcd_ev); }
+    if (h->xcd_rec) (void)hipHostFree(h->xcd_rec);
     for (int w = 0; w < 31; ++w) {
         if (h->side[w]) (void)hipStreamDestroy(h->side[w]);
         if (h->join_ev[w]) (void)hipEventDestroy(h->join_ev[w]);
@@ -630,6 +654,69 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
         grp.counter = h->d_tickets + 2 * (h->ticket_turn++ % alore_nmpc_solver::kTicketRing);
         grp.persist_blocks = 4 * h->n_cu;
     }
+    // XCD shares (see the kernel): grids of at least two residencies of the (4, 5) grid build.  The record of the previous such launch, if it
+    // has finished, moves the speed estimates (damped); this launch leaves its own record unless the previous one is still in flight.
+    // ALORE_NMPC_XCD_SHARES=0 (diagnostic): equal shares, as the hardware deals them.
+    grp.xcd_on = 0;
+    grp.xcd_end = nullptr;
+    static const bool xcd_shares_on = !(getenv("ALORE_NMPC_XCD_SHARES") && atoi(getenv("ALORE_NMPC_XCD_SHARES")) == 0);
+    const long total_items = (long)g.grid * count;
+    if (xcd_shares_on && !grp.counter && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && total_items >= 2L * 4 * h->n_cu && total_items < (1L << 28)) {
+        bool record = true;
+        if (h->xcd_pending) {
+            if (hipEventQuery(h->xcd_ev) == hipSuccess) {
+                const unsigned long long t0 = h->xcd_rec[32];
+                double dur[8], mean = 0.0;
+                bool ok = t0 != 0;
+                for (int x = 0; x < 8 && ok; ++x) {
+                    unsigned long long e = 0;
+                    for (int i = 0; i < 4; ++i) e = h->xcd_rec[x * 4 + i] > e ? h->xcd_rec[x * 4 + i] : e;
+                    ok = e > t0;
+                    dur[x] = (double)(e - t0);
+                    mean += dur[x] / 8.0;
+                }
+                if (ok && mean > 1000.0) { // 10 us of the 100 MHz counter: anything shorter says nothing
+                    double norm = 0.0;
+                    for (int x = 0; x < 8; ++x) { // an XCD that finished late is slower than its share assumed
+                        double v = h->xcd_speed[x] * std::pow(mean / dur[x], 0.7);
+                        h->xcd_speed[x] = v;
+                        norm += v / 8.0;
+                    }
+                    for (int x = 0; x < 8; ++x) {
+                        double v = h->xcd_speed[x] / norm;
+                        h->xcd_speed[x] = v < 0.85 ? 0.85 : (v > 1.15 ? 1.15 : v);
+                    }
+                    ++h->xcd_updates;
+                }
+                h->xcd_pending = false;
+            } else {
+                record = false; // the record is still being written: equal-or-last shares, no new record
+            }
+        }
+        double sum = 0.0;
+        for (int x = 0; x < 8; ++x) sum += h->xcd_speed[x];
+        long given = 0;
+        double frac[8];
+        for (int x = 0; x < 8; ++x) {
+            const double want = (double)total_items * h->xcd_speed[x] / sum;
+            grp.xcd_share[x] = (int)want;
+            frac[x] = want - (double)grp.xcd_share[x];
+            given += grp.xcd_share[x];
+        }
+        while (given < total_items) { // the remainder to the largest fractions
+            int bx = 0;
+            for (int x = 1; x < 8; ++x) bx = frac[x] > frac[bx] ? x : bx;
+            ++grp.xcd_share[bx]; frac[bx] = -1.0; ++given;
+        }
+        int base = 0;
+        for (int x = 0; x < 8; ++x) { grp.xcd_base[x] = base; base += grp.xcd_share[x]; }
+        grp.xcd_on = 1;
+        if (record) {
+            std::memset(h->xcd_rec, 0, sizeof(unsigned long long) * 40);
+            void* alias = nullptr;
+            if (hipHostGetDevicePointer(&alias, h->xcd_rec, 0) == hipSuccess) grp.xcd_end = (unsigned long long*)alias;
+        }
+    }
     static const char* trace_path = getenv("ALORE_NMPC_TRACE");
     grp.trace = nullptr;
     if (trace_path && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && batches[0].kkt && batches[0].obj) {
@@ -658,6 +745,11 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
         return ALORE_NMPC_OK;
     }
     HIP_TRY(h, nmpc::launch_rti_block_group(p, grp, g, (hipStream_t)stream));
+    if (grp.xcd_end) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+        if (cap == hipStreamCaptureStatusNone && hipEventRecord(h->xcd_ev, (hipStream_t)stream) == hipSuccess) h->xcd_pending = true;
+    }
     h->last_geom = g;
     h->last_geom.grid = g.grid * count;
     h->have_geom = true;

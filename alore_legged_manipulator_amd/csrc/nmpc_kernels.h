@@ -37,6 +37,9 @@ struct RtiGroup {
     long long* trace;     // diagnostic (ALORE_NMPC_TRACE): 8 words per workgroup, see the kernel; else null
     int* counter;         // persistent grid: [0] tickets handed out, [1] workgroups that have left (both 0 between launches); else null
     int persist_blocks;   // persistent grid: workgroups launched (one per SIMD slot); items beyond them are taken by ticket
+    int xcd_on;           // 1: XCD x (workgroups w = x mod 8) works on xcd_share[x] consecutive blocks from xcd_base[x] (see the kernel)
+    int xcd_share[8], xcd_base[8];
+    unsigned long long* xcd_end; // [8][4] host memory: finishing times (100 MHz counter) of the last four workgroups of every XCD, or null
     long long stride[15]; // bytes, in the member order of alore_nmpc_batch
     alore_nmpc_batch b[GROUP_MAX];
 };

@@ -1036,11 +1036,13 @@ def test_prepared_descriptor_sets_and_overlapping_batches(nmpc_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["ALORE_NMPC_PERSIST=1", "ALORE_NMPC_TRACE=%TRACE%"])
+@pytest.mark.parametrize("env", ["ALORE_NMPC_PERSIST=1", "ALORE_NMPC_TRACE=%TRACE%", "ALORE_NMPC_XCD_SPEEDS=1.3,0.7,1.0,1.15,0.85,1.0,0.5,1.5",
+                                 "ALORE_NMPC_XCD_SHARES=0"])
 def test_the_persistent_grid_and_the_traced_twin_return_the_bits_of_the_plain_grid(nmpc_mod, env, tmp_path):
-    """The opt-in persistent grid (blocks of problems by ticket) and the instrumented twin of the grid build (per-SIMD trace) run the
-    same arithmetic as the plain grid: a 24-batch rti_range in a child process with the switch on returns the bits of this process's
-    plain grid; the trace file parses (tools/trace_timeline.py) and accounts for every workgroup."""
+    """The opt-in persistent grid (blocks of problems by ticket), the instrumented twin of the grid build (per-SIMD trace), strongly
+    uneven XCD shares (preset speeds: every XCD works on a different number of blocks, surplus workgroups leave at once) and equal
+    shares run the same arithmetic as the default grid: a 24-batch rti_range in a child process with the switch on returns the bits of
+    the default; the trace file parses (tools/trace_timeline.py) and accounts for every workgroup."""
     import subprocess
     import sys
     B, N, slots = 4096, 20, 24

@@ -28,7 +28,7 @@ for r in range(reps):
     torch.cuda.synchronize()
     eng.rti_range(W, K)
     torch.cuda.synchronize()
-files = sorted(glob.glob(prefix + ".*"), key=lambda f: int(f.rsplit(".", 1)[1]))
+files = sorted((f for f in glob.glob(prefix + ".*") if f.rsplit(".", 1)[1].isdigit()), key=lambda f: int(f.rsplit(".", 1)[1]))
 for f in files[1::2]:  # the K-batch grids
     print(f"==== {os.path.basename(f)}")
     sys.stdout.flush()
