@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <vector>
 #include <new>
@@ -38,6 +39,14 @@ struct alore_nmpc_solver {
     unsigned char* d_mask = nullptr; // [B] alore_nmpc_closed_loop_reset
     nmpc::PlantParams plant{};
     bool has_plant = false;
+    // alore_nmpc_closed_loop_run: the sampler of tick t + 1 runs on cl_side beside the solve of tick t, into the second of two
+    // reference buffers (the caller's y / yN and these), its float64 headings into cl_psi for the plant step to complete
+    hipStream_t cl_side = nullptr;
+    hipEvent_t cl_rti_done[2] = {}, cl_samp_done[2] = {}, cl_fork = nullptr;
+    float* cl_y = nullptr;   // [B][N][5]
+    float* cl_yN = nullptr;  // [B][3]
+    double* cl_psi[2] = {};  // [B][N + 1]
+    int cl_B = 0;
     // Polynome -> store on the device: staging + workspace for chunks of kPolyChunk messages
     static constexpr int kPolyChunk = 2048;
     char* d_poly = nullptr;       // packed message arrays (layout: poly_layout)
@@ -270,6 +279,15 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->refs.coef) (void)hipFree(h->refs.coef);
     if (h->refs.ckpt) (void)hipFree(h->refs.ckpt);
     if (h->refs.meta) (void)hipFree(h->refs.meta);
+    if (h->cl_side) (void)hipStreamDestroy(h->cl_side);
+    for (int i = 0; i < 2; ++i) {
+        if (h->cl_rti_done[i]) (void)hipEventDestroy(h->cl_rti_done[i]);
+        if (h->cl_samp_done[i]) (void)hipEventDestroy(h->cl_samp_done[i]);
+        if (h->cl_psi[i]) (void)hipFree(h->cl_psi[i]);
+    }
+    if (h->cl_fork) (void)hipEventDestroy(h->cl_fork);
+    if (h->cl_y) (void)hipFree(h->cl_y);
+    if (h->cl_yN) (void)hipFree(h->cl_yN);
     if (h->d_est) (void)hipFree(h->d_est);
     if (h->d_icr) (void)hipFree(h->d_icr);
     if (h->d_psi) (void)hipFree(h->d_psi);
@@ -1354,9 +1372,77 @@ int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch* dev,
                                int delay_num, void* stream)
 {
     if (n_ticks < 0 || !(dt_tick > 0.0)) return fail(h, ALORE_NMPC_E_INVALID, "closed_loop_run: bad argument");
+    static const bool serial = [] { const char* e = getenv("ALORE_NMPC_CLOSED_LOOP_SERIAL"); return e && atoi(e) != 0; }();
+    const bool ahead = !serial && n_ticks >= 3 && h && h->has_plant && dev && dev->y && dev->yN && dev->x0 && B > 0 && B <= h->refs_B &&
+                       delay_num >= 0 && nmpc::ref_sample_ahead_supported(h->cfg.N);
+    if (!ahead) {
+        for (int t = 0; t < n_ticks; ++t) {
+            const int rc = alore_nmpc_closed_loop_tick(h, dev, B, t0 + dt_tick * t, delay_num, stream);
+            if (rc != ALORE_NMPC_OK) return rc;
+        }
+        return ALORE_NMPC_OK;
+    }
+    // The chain of a tick is sampler -> solve -> plant, and the sampler needs the pose only for x0 and for the turns that the heading
+    // walk starts from (smooth_yaw's first step): everything else of tick t + 1 is sampled on a second stream BESIDE the solve of
+    // tick t, into the other of two reference buffers; the plant step of tick t then writes x0 and shifts the headings.  The
+    // critical path of a tick is solve + plant.
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    const int N = h->cfg.N, node = delay_num < N ? delay_num : N - 1;
+    if (!h->cl_side) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->cl_side, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(h, hipEventCreateWithFlags(&h->cl_rti_done[i], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->cl_samp_done[i], hipEventDisableTiming));
+        }
+        HIP_TRY(h, hipEventCreateWithFlags(&h->cl_fork, hipEventDisableTiming));
+    }
+    if (h->cl_B < B) {
+        if (h->cl_y) (void)hipFree(h->cl_y);
+        if (h->cl_yN) (void)hipFree(h->cl_yN);
+        h->cl_y = nullptr; h->cl_yN = nullptr; h->cl_B = 0;
+        for (int i = 0; i < 2; ++i) { if (h->cl_psi[i]) (void)hipFree(h->cl_psi[i]); h->cl_psi[i] = nullptr; }
+        HIP_TRY(h, hipMalloc(&h->cl_y, sizeof(float) * (size_t)B * N * 5));
+        HIP_TRY(h, hipMalloc(&h->cl_yN, sizeof(float) * (size_t)B * 3));
+        for (int i = 0; i < 2; ++i) HIP_TRY(h, hipMalloc(&h->cl_psi[i], sizeof(double) * (size_t)B * (N + 1)));
+        h->cl_B = B;
+    }
+    alore_nmpc_batch buf[2] = {*dev, *dev};
+    buf[1].y = h->cl_y;
+    buf[1].yN = h->cl_yN;
+    // both buffers start as the caller's references: a robot without a trajectory keeps them, whichever buffer its tick reads
+    HIP_TRY(h, hipMemcpyAsync(h->cl_y, dev->y, sizeof(float) * (size_t)B * N * 5, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->cl_yN, dev->yN, sizeof(float) * (size_t)B * 3, hipMemcpyDeviceToDevice, s));
+    // tick 0 is sampled whole (od, x0 from the current pose)
+    HIP_TRY(h, nmpc::launch_ref_sample(h->refs, *dev, B, N, (double)h->cfg.dt, t0, h->d_est, h->d_icr, h->d_goal, h->d_psi, 1, s));
+    HIP_TRY(h, hipEventRecord(h->cl_fork, s));
+    HIP_TRY(h, hipStreamWaitEvent(h->cl_side, h->cl_fork, 0));
+    static const bool cl_debug = getenv("ALORE_NMPC_CL_DEBUG") != nullptr;
+    const auto host_t0 = std::chrono::steady_clock::now();
     for (int t = 0; t < n_ticks; ++t) {
-        const int rc = alore_nmpc_closed_loop_tick(h, dev, B, t0 + dt_tick * t, delay_num, stream);
-        if (rc != ALORE_NMPC_OK) return rc;
+        const bool more = t + 1 < n_ticks;
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (more) { // the solve of tick t - 1 was the last reader of the buffer this sampler writes
+            if (t >= 1) HIP_TRY(h, hipStreamWaitEvent(h->cl_side, h->cl_rti_done[nxt], 0));
+            HIP_TRY(h, nmpc::launch_ref_sample_ahead(h->refs, buf[nxt], B, N, (double)h->cfg.dt, t0 + dt_tick * (t + 1), h->d_icr, h->cl_psi[nxt],
+                                                    h->cl_side));
+            HIP_TRY(h, hipEventRecord(h->cl_samp_done[nxt], h->cl_side));
+        }
+        const int rc = alore_nmpc_rti(h, &buf[cur], B, 1, stream);
+        if (rc != ALORE_NMPC_OK) { (void)hipStreamSynchronize(h->cl_side); return rc; }
+        if (more) {
+            HIP_TRY(h, hipEventRecord(h->cl_rti_done[cur], s));
+            HIP_TRY(h, hipStreamWaitEvent(s, h->cl_samp_done[nxt], 0));
+        }
+        HIP_TRY(h, nmpc::launch_plant_ahead(buf[cur], buf[nxt], h->refs, B, N, node, t0 + dt_tick * t, h->d_icr, h->d_goal, h->d_est, h->d_vw,
+                                           more ? h->cl_psi[nxt] : nullptr, h->plant, s));
+    }
+    if (cl_debug)
+        fprintf(stderr, "closed_loop_run: %d ticks enqueued in %.1f us per tick of host time\n", n_ticks,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / n_ticks);
+    if ((n_ticks - 1) & 1) { // the last tick read the internal buffer: the caller's y / yN are those of the last tick afterwards, as in a tick-by-tick run
+        HIP_TRY(h, hipMemcpyAsync(const_cast<float*>(dev->y), h->cl_y, sizeof(float) * (size_t)B * N * 5, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(const_cast<float*>(dev->yN), h->cl_yN, sizeof(float) * (size_t)B * 3, hipMemcpyDeviceToDevice, s));
     }
     return ALORE_NMPC_OK;
 }

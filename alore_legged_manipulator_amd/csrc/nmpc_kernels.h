@@ -127,6 +127,13 @@ struct PlantParams { // simulator.h: max_a_, max_domega_, Pose_pub_rate_ (a peri
 };
 hipError_t launch_plant(const alore_nmpc_batch& b, int B, int N, int node, const double* icr, const int* at_goal,
                         double* pose, double* vw, const PlantParams& p, hipStream_t st);
+// closed_loop_run: the pose-independent part of the sampling of a tick ahead of its pose, and the plant step that completes it
+bool ref_sample_ahead_supported(int N);
+hipError_t launch_ref_sample_ahead(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now, const double* icr,
+                                   double* psi_rel, hipStream_t st);
+hipError_t launch_plant_ahead(const alore_nmpc_batch& b, const alore_nmpc_batch& next, const RefStore& s, int B, int N, int node, double now,
+                              const double* icr, int* at_goal, double* pose, double* vw, const double* psi_rel, const PlantParams& p,
+                              hipStream_t st);
 hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now,
                              const double* est, const double* icr, int* at_goal, double* psi_scratch, int do_smooth,
                              hipStream_t st);

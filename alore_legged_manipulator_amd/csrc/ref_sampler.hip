@@ -22,6 +22,9 @@ using minco::eval_pv;
 
 // node j of robot r: everything of getRefPoints / setTrajectory / setICRParameters for that node; returns false when the
 // robot has no trajectory (nothing written), else the normalised heading in `psi_out` (also written to y / yN as float)
+// AHEAD: the pose-independent part only, for a tick whose pose does not exist yet (closed_loop_run samples tick t + 1 beside the
+// solve of tick t): no x0, no at-goal flag, no od (constant over a run: the first tick of the run wrote it)
+template <bool AHEAD = false>
 __device__ __forceinline__ bool ref_sample_node(const RefStore& s, const alore_nmpc_batch& b, int N, double dt, double now,
                                                 const double* est, const double* icr, int* at_goal, int r, int j, double& psi_out)
 {
@@ -77,6 +80,7 @@ __device__ __forceinline__ bool ref_sample_node(const RefStore& s, const alore_n
         float* yN = const_cast<float*>(b.yN) + (size_t)r * 3;
         yN[0] = (float)X; yN[1] = (float)Y; yN[2] = (float)psi;
     }
+    if (AHEAD) return true;
     float* od = const_cast<float*>(b.od) + ((size_t)r * (N + 1) + j) * 3; // setICRParameters
     od[0] = (float)icr[(size_t)r * 3]; od[1] = (float)yr; od[2] = (float)yl;
     if (j == 0) {
@@ -103,17 +107,20 @@ __global__ void ref_sample_kernel(RefStore s, alore_nmpc_batch b, int B, int N, 
 // >= N + 1), the sequential walk of the reference (node i is unwrapped against the already unwrapped node i - 1; node 0
 // against the measured heading) hands the value from lane to lane by shuffles, all in float64 and cast afterwards like
 // ref_unwrap_kernel below.  Replaces two launches and the round trip of the raw headings through memory.
-template <int G>
+// AHEAD (see ref_sample_node): node 0 keeps its normalised heading (the walk is the same whatever node 0 is shifted by: every
+// later node follows its predecessor), the float64 headings of the walk go to psi_rel [B][N + 1]; plant_ahead_kernel shifts the
+// 21 headings of a robot by the turns that node 0 is away from the pose it produces.
+template <int G, bool AHEAD = false>
 __global__ void ref_sample_smooth_kernel(RefStore s, alore_nmpc_batch b, int B, int N, double dt, double now, const double* est,
-                                         const double* icr, int* at_goal)
+                                         const double* icr, int* at_goal, double* psi_rel = nullptr)
 {
     const int per_block = blockDim.x / G;
     const int r0 = blockIdx.x * per_block + threadIdx.x / G, j = threadIdx.x % G;
     const bool in_range = r0 < B && j <= N;
     const int r = r0 < B ? r0 : B - 1;
     double cur = 0.0;
-    const bool have = in_range && ref_sample_node(s, b, N, dt, now, est, icr, at_goal, r, j, cur);
-    const double th = est[(size_t)r * 3 + 2];
+    const bool have = in_range && ref_sample_node<AHEAD>(s, b, N, dt, now, est, icr, at_goal, r, j, cur);
+    const double th = AHEAD ? cur : est[(size_t)r * 3 + 2];
     double prev = th;                          // what this node is unwrapped against (lane 0: the measured heading)
     for (int i = 0; i <= N; ++i) {             // wavefront-uniform
         if (j == i) {
@@ -130,6 +137,7 @@ __global__ void ref_sample_smooth_kernel(RefStore s, alore_nmpc_batch b, int B, 
     if (have) {
         if (j < N) const_cast<float*>(b.y)[((size_t)r * N + j) * 5 + 2] = (float)cur;
         else const_cast<float*>(b.yN)[(size_t)r * 3 + 2] = (float)cur;
+        if (AHEAD) psi_rel[(size_t)r * (N + 1) + j] = cur;
     }
 }
 
@@ -378,6 +386,64 @@ __global__ void plant_kernel(alore_nmpc_batch b, int B, int N, int node, const d
     vw[(size_t)r * 2] = v; vw[(size_t)r * 2 + 1] = w;
 }
 
+// The plant step of tick t and what the sampler of tick t + 1 could not do without the pose it produces (closed_loop_run): the
+// at-goal flag of tick t (getRefPoints' test, from `now` of tick t), the plant as above, then x0 <- pose and smooth_yaw's first
+// step -- node 0 against the measured heading, mpc.cpp:248-277 -- as a shift of all N + 1 headings of the walk by the same turns.
+// `nb` is the batch of tick t + 1 (its y / yN hold the references sampled ahead), psi_rel their float64 headings.
+__global__ void plant_ahead_kernel(alore_nmpc_batch b, alore_nmpc_batch nb, RefStore s, int B, int N, int node, double now, const double* icr,
+                                   int* at_goal, double* pose, double* vw, const double* psi_rel /* null: the run ends with tick t */, PlantParams p)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    const double* m = s.meta + (size_t)r * 8;
+    const bool valid = m[6] != 0.0;
+    const int goal = (valid && (now - m[0]) > m[1] + 1.0) ? 1 : 0;
+    double right = (double)b.u[((size_t)r * N + node) * 2], left = (double)b.u[((size_t)r * N + node) * 2 + 1];
+    const double c0 = (valid && psi_rel) ? psi_rel[(size_t)r * (N + 1)] : 0.0;
+    if (goal) { right = 0.0; left = 0.0; }
+    const double xv = icr[(size_t)r * 3], yr = icr[(size_t)r * 3 + 1], yl = icr[(size_t)r * 3 + 2];
+    const double desired_v = (left + right) / 2.0 - (right - left) / (yl - yr) * (yl + yr) / 2.0;
+    const double vy = -(right - left) / (yl - yr) * xv;
+    const double desired_w = (right - left) / (yl - yr);
+    double x = pose[(size_t)r * 3], y = pose[(size_t)r * 3 + 1], th = pose[(size_t)r * 3 + 2];
+    double v = vw[(size_t)r * 2], w = vw[(size_t)r * 2 + 1];
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    for (int k = 0; k < p.substeps; ++k) {
+        if (fabs(v - desired_v) >= p.pose_pub_period * p.max_a) v += p.pose_pub_period * p.max_a * (desired_v - v) / fabs(desired_v - v);
+        else v = desired_v;
+        if (fabs(w - desired_w) >= p.pose_pub_period * p.max_domega) w += p.pose_pub_period * p.max_domega * (desired_w - w) / fabs(desired_w - w);
+        else w = desired_w;
+        x += v * p.propa_period * cs;
+        y += v * p.propa_period * sn;
+        th += w * p.propa_period;
+        sincos(th, &sn, &cs);
+        x -= vy * p.propa_period * sn;
+        y += vy * p.propa_period * cs;
+    }
+    pose[(size_t)r * 3] = x; pose[(size_t)r * 3 + 1] = y; pose[(size_t)r * 3 + 2] = th;
+    vw[(size_t)r * 2] = v; vw[(size_t)r * 2 + 1] = w;
+    at_goal[r] = goal;
+    if (!valid || !psi_rel) return; // no trajectory: the references and x0 stay as they are, like in the sampler
+    float* x0 = const_cast<float*>(nb.x0) + (size_t)r * 3;
+    x0[0] = (float)x; x0[1] = (float)y; x0[2] = (float)th;
+    int turns = 0; // net steps of 2 pi that smooth_yaw's two loops move node 0 by
+    {
+        double cur = c0, dyaw = cur - th;
+        while (dyaw >= M_PI / 2) { cur -= M_PI * 2; dyaw = cur - th; --turns; }
+        while (dyaw <= -M_PI / 2) { cur += M_PI * 2; dyaw = cur - th; ++turns; }
+    }
+    if (turns == 0) return;
+    const double* pr = psi_rel + (size_t)r * (N + 1);
+    float* yy = const_cast<float*>(nb.y) + (size_t)r * N * 5;
+    for (int j = 0; j <= N; ++j) {
+        double cur = pr[j];
+        for (int k = 0; k < (turns > 0 ? turns : -turns); ++k) cur += turns > 0 ? M_PI * 2 : -M_PI * 2;
+        if (j < N) yy[(size_t)j * 5 + 2] = (float)cur;
+        else const_cast<float*>(nb.yN)[(size_t)r * 3 + 2] = (float)cur;
+    }
+}
+
 // MpcWrapper::solve's reset (mpc_wrapper.cpp:267-275) from the plant's pose: one thread per (robot, node)
 __global__ void iterate_reset_kernel(alore_nmpc_batch b, int B, int N, const double* pose, const unsigned char* mask)
 {
@@ -400,6 +466,25 @@ hipError_t launch_plant(const alore_nmpc_batch& b, int B, int N, int node, const
                         double* pose, double* vw, const PlantParams& p, hipStream_t st)
 {
     hipLaunchKernelGGL(plant_kernel, dim3((B + 127) / 128), dim3(128), 0, st, b, B, N, node, icr, at_goal, pose, vw, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_plant_ahead(const alore_nmpc_batch& b, const alore_nmpc_batch& next, const RefStore& s, int B, int N, int node, double now,
+                              const double* icr, int* at_goal, double* pose, double* vw, const double* psi_rel, const PlantParams& p,
+                              hipStream_t st)
+{
+    hipLaunchKernelGGL(plant_ahead_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b, next, s, B, N, node, now, icr, at_goal, pose, vw, psi_rel, p);
+    return hipGetLastError();
+}
+
+bool ref_sample_ahead_supported(int N) { return N + 1 <= 64; }
+hipError_t launch_ref_sample_ahead(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now, const double* icr,
+                                   double* psi_rel, hipStream_t st)
+{
+    if (N + 1 <= 32)
+        hipLaunchKernelGGL((ref_sample_smooth_kernel<32, true>), dim3((B + 3) / 4), dim3(128), 0, st, s, b, B, N, dt, now, nullptr, icr, nullptr, psi_rel);
+    else
+        hipLaunchKernelGGL((ref_sample_smooth_kernel<64, true>), dim3((B + 1) / 2), dim3(128), 0, st, s, b, B, N, dt, now, nullptr, icr, nullptr, psi_rel);
     return hipGetLastError();
 }
 

@@ -157,3 +157,70 @@ def test_device_closed_loop_matches_host_driven_loop():
         v, w = m.init_pva[3], m.init_pva[2]
         ref = arc_pose(v, w, 0.1, 0.01 * T)
         assert _m.hypot(pose_d[b, 0] - ref[0], pose_d[b, 1] - ref[1]) < 0.15 and abs(pose_d[b, 2] - ref[2]) < 0.3, (b, pose_d[b], ref)
+
+
+def test_closed_loop_run_samples_ahead_and_returns_what_tick_by_tick_returns():
+    """alore_nmpc_closed_loop_run samples tick t + 1 on a second stream beside the solve of tick t (two reference buffers; the
+    plant step writes x0 and shifts the headings by the turns smooth_yaw's first step finds, mpc.cpp:248-277): the plant
+    states, the iterate and the references after the run must be those of the same ticks issued one by one.  The robots
+    cover a heading that crosses pi (the walk starts one turn away from the normalised references), a trajectory that
+    ends inside the run (at-goal flag, zero command), a robot without a trajectory (its references stay the caller's) and
+    both parities of the tick count (the last tick reads the caller's buffer or the internal one)."""
+    from alore_legged_manipulator_amd.nmpc import BatchedNmpc
+    from alore_legged_manipulator_amd.host import Polynome
+    B, N, dt = 16, 20, 0.01
+    rng = np.random.default_rng(11)
+    msgs, robots = [], []
+    pose0 = np.zeros((B, 3))
+    for b in range(B):
+        if b == 5:
+            continue  # no trajectory
+        v, w = rng.uniform(0.4, 1.2), rng.uniform(-0.8, 0.8)
+        th0 = 0.0
+        Tp = np.array([0.5, 0.5, 0.5])
+        if b in (1, 2):   # starts near pi and turns through it (b = 1 upwards, b = 2 downwards from -pi)
+            th0, w = (3.0, 0.9) if b == 1 else (-3.05, -0.9)
+        if b == 3:        # over after 0.3 s: at the goal 1 s later
+            Tp = np.array([0.1, 0.1, 0.1])
+        Tc = np.cumsum(Tp)
+        msgs.append(Polynome(np.stack([th0 + w * Tc[:-1], v * Tc[:-1]], 1), Tp, [th0, 0, w, v, 0, 0], [th0 + w * Tc[-1], v * Tc[-1], w, v, 0, 0],
+                             [0, 0, 0], [-0.3, 0.3, 0.1], 0.0))
+        robots.append(b)
+        pose0[b] = [rng.uniform(-0.03, 0.03), rng.uniform(-0.03, 0.03), th0 + rng.uniform(-0.05, 0.05)]
+    icr = np.tile([0.1, -0.3, 0.3], (B, 1))
+    W = np.tile(np.diag([10, 10, 0.5, 0.1, 0.1]).astype(np.float32), (B, N, 1, 1))
+    WN = np.tile(np.diag([10, 10, 0.5]).astype(np.float32), (B, 1, 1))
+    y_user = rng.normal(0, 0.1, (B, N, 5)).astype(np.float32)
+    yN_user = rng.normal(0, 0.1, (B, 3)).astype(np.float32)
+
+    def fresh():
+        e = BatchedNmpc(B, N, dt)
+        e.load({"W": W, "WN": WN, "x": np.tile(pose0[:, None, :], (1, N + 1, 1)), "u": np.zeros((B, N, 2)), "y": y_user, "yN": yN_user,
+                "x0": pose0.astype(np.float32), "od": np.tile(np.float32([0.1, -0.3, 0.3]), (B, N + 1, 1))})
+        e.refs_init(max_pieces=4, max_checkpoints=32)
+        e.refs_set_polynomes(np.array(robots), msgs)
+        e.plant_init()
+        e.plant_set_state(pose0, icr)
+        return e
+
+    names = ("x", "u", "y", "yN", "x0", "od", "status")
+    for ticks in (150, 37):
+        one, run = fresh(), fresh()
+        for t in range(ticks):
+            one.closed_loop_tick(0.01 * (t + 1), delay_num=1)
+        run.closed_loop_run(0.01, 0.01, ticks, delay_num=1)
+        p1, v1, g1 = one.plant_get_state()
+        p2, v2, g2 = run.plant_get_state()
+        assert np.isfinite(p2).all()
+        assert np.array_equal(g1, g2), (g1, g2)
+        if ticks == 150:
+            assert g1[3] == 1 and g1.sum() == 1
+            assert abs(p1[1, 2]) > math.pi and abs(p1[2, 2]) > math.pi        # the two headings did cross pi
+        assert np.max(np.abs(p1 - p2)) < 1e-6 and np.max(np.abs(v1 - v2)) < 1e-6, (np.max(np.abs(p1 - p2)), np.max(np.abs(v1 - v2)))
+        f1, f2 = one.fetch(names=names), run.fetch(names=names)
+        for k in names:
+            a, c = f1[k].astype(np.float64), f2[k].astype(np.float64)
+            assert np.max(np.abs(a - c)) < 2e-6 * max(1.0, np.max(np.abs(a))), (ticks, k, np.max(np.abs(a - c)))
+        assert np.array_equal(f2["y"][5], y_user[5]) and np.array_equal(f2["yN"][5], yN_user[5])    # no trajectory: untouched
+        # the references of the robots that turned through pi follow the heading (not the normalised angle)
+        assert np.max(np.abs(f2["y"][1, :, 2] - p2[1, 2])) < 1.0 and np.max(np.abs(f2["y"][2, :, 2] - p2[2, 2])) < 1.0
