@@ -39,10 +39,8 @@ struct alore_nmpc_solver {
     unsigned char* d_mask = nullptr; // [B] alore_nmpc_closed_loop_reset
     nmpc::PlantParams plant{};
     bool has_plant = false;
-    // alore_nmpc_closed_loop_run: the sampler of tick t + 1 runs on cl_side beside the solve of tick t, into the second of two
+    // alore_nmpc_closed_loop_run: the sampler of tick t + 1 runs in the grid of the solve of tick t, into the second of two
     // reference buffers (the caller's y / yN and these), its float64 headings into cl_psi for the plant step to complete
-    hipStream_t cl_side = nullptr;
-    hipEvent_t cl_rti_done[2] = {}, cl_samp_done[2] = {}, cl_fork = nullptr;
     float* cl_y = nullptr;   // [B][N][5]
     float* cl_yN = nullptr;  // [B][3]
     double* cl_psi[2] = {};  // [B][N + 1]
@@ -279,13 +277,8 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->refs.coef) (void)hipFree(h->refs.coef);
     if (h->refs.ckpt) (void)hipFree(h->refs.ckpt);
     if (h->refs.meta) (void)hipFree(h->refs.meta);
-    if (h->cl_side) (void)hipStreamDestroy(h->cl_side);
-    for (int i = 0; i < 2; ++i) {
-        if (h->cl_rti_done[i]) (void)hipEventDestroy(h->cl_rti_done[i]);
-        if (h->cl_samp_done[i]) (void)hipEventDestroy(h->cl_samp_done[i]);
+    for (int i = 0; i < 2; ++i)
         if (h->cl_psi[i]) (void)hipFree(h->cl_psi[i]);
-    }
-    if (h->cl_fork) (void)hipEventDestroy(h->cl_fork);
     if (h->cl_y) (void)hipFree(h->cl_y);
     if (h->cl_yN) (void)hipFree(h->cl_yN);
     if (h->d_est) (void)hipFree(h->d_est);
@@ -501,8 +494,12 @@ void fill_params(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_
 }
 
 // one launch for one batch; B_in_flight = problems of all launches that run concurrently with it (0: only this one)
-int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream, int B_in_flight)
+// `co` (alore_nmpc_closed_loop_run): the sampler of the next tick, to run in the same grid when the mapping has such a build;
+// *co_done says whether it did
+int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream, int B_in_flight, const nmpc::AheadSampler* co = nullptr,
+            bool* co_done = nullptr)
 {
+    if (co_done) *co_done = false;
     if (!batch_complete(dev)) return fail(h, ALORE_NMPC_E_INVALID, "rti: batch has NULL members");
     nmpc::LaunchGeom g;
     static const int forced_wpb = getenv("ALORE_NMPC_WPB") ? atoi(getenv("ALORE_NMPC_WPB")) : 0; // diagnostic: 1 or 4
@@ -527,7 +524,12 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
         p.stamps = h->d_stamps;
     }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-    HIP_TRY(h, g.block ? nmpc::launch_rti_block(p, g, s) : nmpc::launch_rti(p, g, s));
+    if (co && !h->timing && nmpc::rti_block_sampler_supported(p, g)) {
+        HIP_TRY(h, nmpc::launch_rti_block_sampler(p, g, *co, s));
+        *co_done = true;
+    } else {
+        HIP_TRY(h, g.block ? nmpc::launch_rti_block(p, g, s) : nmpc::launch_rti(p, g, s));
+    }
     if (h->timing) {
         HIP_TRY(h, hipEventRecord(h->ev1, s));
         h->timed_pending = true;
@@ -1383,20 +1385,13 @@ int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch* dev,
         return ALORE_NMPC_OK;
     }
     // The chain of a tick is sampler -> solve -> plant, and the sampler needs the pose only for x0 and for the turns that the heading
-    // walk starts from (smooth_yaw's first step): everything else of tick t + 1 is sampled on a second stream BESIDE the solve of
-    // tick t, into the other of two reference buffers; the plant step of tick t then writes x0 and shifts the headings.  The
-    // critical path of a tick is solve + plant.
+    // walk starts from (smooth_yaw's first step): everything else of tick t + 1 is sampled by extra workgroups of the grid that
+    // solves tick t (rti_block_sampler_kernel), into the other of two reference buffers; the plant step of tick t then writes x0
+    // and shifts the headings.  The chain of a tick is solve + plant, two launches on the caller's stream.  (A second stream for
+    // the sampler was built first: its two cross-stream events per tick cost what the overlap saved.)
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     const int N = h->cfg.N, node = delay_num < N ? delay_num : N - 1;
-    if (!h->cl_side) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->cl_side, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(h, hipEventCreateWithFlags(&h->cl_rti_done[i], hipEventDisableTiming));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->cl_samp_done[i], hipEventDisableTiming));
-        }
-        HIP_TRY(h, hipEventCreateWithFlags(&h->cl_fork, hipEventDisableTiming));
-    }
     if (h->cl_B < B) {
         if (h->cl_y) (void)hipFree(h->cl_y);
         if (h->cl_yN) (void)hipFree(h->cl_yN);
@@ -1415,31 +1410,28 @@ int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch* dev,
     HIP_TRY(h, hipMemcpyAsync(h->cl_yN, dev->yN, sizeof(float) * (size_t)B * 3, hipMemcpyDeviceToDevice, s));
     // tick 0 is sampled whole (od, x0 from the current pose)
     HIP_TRY(h, nmpc::launch_ref_sample(h->refs, *dev, B, N, (double)h->cfg.dt, t0, h->d_est, h->d_icr, h->d_goal, h->d_psi, 1, s));
-    HIP_TRY(h, hipEventRecord(h->cl_fork, s));
-    HIP_TRY(h, hipStreamWaitEvent(h->cl_side, h->cl_fork, 0));
-    static const bool cl_debug = getenv("ALORE_NMPC_CL_DEBUG") != nullptr;
-    const auto host_t0 = std::chrono::steady_clock::now();
     for (int t = 0; t < n_ticks; ++t) {
         const bool more = t + 1 < n_ticks;
         const int cur = t & 1, nxt = cur ^ 1;
-        if (more) { // the solve of tick t - 1 was the last reader of the buffer this sampler writes
-            if (t >= 1) HIP_TRY(h, hipStreamWaitEvent(h->cl_side, h->cl_rti_done[nxt], 0));
-            HIP_TRY(h, nmpc::launch_ref_sample_ahead(h->refs, buf[nxt], B, N, (double)h->cfg.dt, t0 + dt_tick * (t + 1), h->d_icr, h->cl_psi[nxt],
-                                                    h->cl_side));
-            HIP_TRY(h, hipEventRecord(h->cl_samp_done[nxt], h->cl_side));
-        }
-        const int rc = alore_nmpc_rti(h, &buf[cur], B, 1, stream);
-        if (rc != ALORE_NMPC_OK) { (void)hipStreamSynchronize(h->cl_side); return rc; }
-        if (more) {
-            HIP_TRY(h, hipEventRecord(h->cl_rti_done[cur], s));
-            HIP_TRY(h, hipStreamWaitEvent(s, h->cl_samp_done[nxt], 0));
-        }
+        nmpc::AheadSampler sa{};
+        sa.store = h->refs;
+        sa.y = const_cast<float*>(buf[nxt].y);
+        sa.yN = const_cast<float*>(buf[nxt].yN);
+        sa.icr = h->d_icr;
+        sa.psi_rel = h->cl_psi[nxt];
+        sa.dt = (double)h->cfg.dt;
+        sa.now = t0 + dt_tick * (t + 1);
+        sa.B = B;
+        sa.N = N;
+        bool sampled = false;
+        if (!batch_complete(&buf[cur])) return fail(h, ALORE_NMPC_E_INVALID, "closed_loop_run: batch has NULL members");
+        const int rc = rti_one(h, &buf[cur], B, 1, stream, 0, more ? &sa : nullptr, &sampled);
+        if (rc != ALORE_NMPC_OK) return rc;
+        if (more && !sampled) // no build of this mapping carries the sampler: its own launch, in the chain
+            HIP_TRY(h, nmpc::launch_ref_sample_ahead(h->refs, buf[nxt], B, N, sa.dt, sa.now, h->d_icr, h->cl_psi[nxt], s));
         HIP_TRY(h, nmpc::launch_plant_ahead(buf[cur], buf[nxt], h->refs, B, N, node, t0 + dt_tick * t, h->d_icr, h->d_goal, h->d_est, h->d_vw,
                                            more ? h->cl_psi[nxt] : nullptr, h->plant, s));
     }
-    if (cl_debug)
-        fprintf(stderr, "closed_loop_run: %d ticks enqueued in %.1f us per tick of host time\n", n_ticks,
-                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / n_ticks);
     if ((n_ticks - 1) & 1) { // the last tick read the internal buffer: the caller's y / yN are those of the last tick afterwards, as in a tick-by-tick run
         HIP_TRY(h, hipMemcpyAsync(const_cast<float*>(dev->y), h->cl_y, sizeof(float) * (size_t)B * N * 5, hipMemcpyDeviceToDevice, s));
         HIP_TRY(h, hipMemcpyAsync(const_cast<float*>(dev->yN), h->cl_yN, sizeof(float) * (size_t)B * 3, hipMemcpyDeviceToDevice, s));

@@ -127,6 +127,19 @@ struct PlantParams { // simulator.h: max_a_, max_domega_, Pose_pub_rate_ (a peri
 };
 hipError_t launch_plant(const alore_nmpc_batch& b, int B, int N, int node, const double* icr, const int* at_goal,
                         double* pose, double* vw, const PlantParams& p, hipStream_t st);
+// the reference sampler's part of a grid that also solves (rti_block_sampler_kernel): pose-independent sampling of the NEXT tick
+struct AheadSampler {
+    RefStore store;
+    float* y;            // [B][N][5] references of the next tick
+    float* yN;           // [B][3]
+    const double* icr;   // [B][3]
+    double* psi_rel;     // [B][N + 1] float64 headings of the walk
+    double dt, now;
+    int B, N;
+    int first_block;     // set by the launcher: workgroups from here on are the sampler's
+};
+bool rti_block_sampler_supported(const RtiParams& p, const LaunchGeom& g);
+hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, const AheadSampler& sa, hipStream_t s);
 // closed_loop_run: the pose-independent part of the sampling of a tick ahead of its pose, and the plant step that completes it
 bool ref_sample_ahead_supported(int N);
 hipError_t launch_ref_sample_ahead(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now, const double* icr,

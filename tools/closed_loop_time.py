@@ -23,6 +23,10 @@ def main():
     e7.refs_init(max_pieces=4, max_checkpoints=40)
     e7.refs_set_polynomes(np.arange(B), msgs)
     e7.plant_init()
+    side = torch.cuda.Stream(device=dev) if os.environ.get("CL_STREAM") else None
+    if side is not None:
+        torch.cuda.synchronize(dev)
+        torch.cuda.set_stream(side)
     for rep in range(3):
         e7.plant_set_state(np.zeros((B, 3)), np.tile([0.1, -0.3, 0.3], (B, 1)))
         e7.closed_loop_reset()
