@@ -352,9 +352,20 @@ __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p_arg, co
 // where a kernel of its own would stand in the tick's chain (kernels of one stream run one after the other; a second stream costs
 // two cross-stream events per tick, ~5 us each on this stack: tools/micro/cross_stream.hip; hipExtAnyOrderLaunch does not overlap
 // kernels of one stream on gfx950: tools/micro/any_order.hip).
+// `pl.on`: the plant step of the PREVIOUS tick runs in front of the solve, on the first lane of each problem's group (it produces the
+// pose the solve starts from: x0, and the turns its references are shifted by) -- as a kernel of its own it cost 4.7 us of the
+// tick's chain for three memory round trips and a microsecond of arithmetic.
 template <int L, int S, bool DIAG>
-__global__ __launch_bounds__(64) void rti_block_sampler_kernel(const RtiParams p_arg, const RtiGroup grp_arg, const AheadSampler sa)
+__global__ __launch_bounds__(64) void rti_block_sampler_kernel(const RtiParams p_arg, const RtiGroup grp_arg, const AheadSampler sa, const PlantAhead pl)
 {
+    if ((int)blockIdx.x < sa.first_block && pl.on) {
+        const int r = (int)blockIdx.x * (64 / L) + (int)threadIdx.x / L;
+        if ((int)threadIdx.x % L == 0 && r < pl.B) plant_ahead_one(pl, r);
+        // the solve's loads below (vector loads and LDS-DMA, this wavefront's) read what these lanes stored
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     if ((int)blockIdx.x >= sa.first_block) {
         alore_nmpc_batch nb{};
         nb.y = sa.y;
@@ -495,7 +506,7 @@ bool rti_block_sampler_supported(const RtiParams& p, const LaunchGeom& g)
 {
     return g.block && p.n_sqp == 1 && p.stamps == nullptr && p.N + 1 <= 32 && ((g.L == 16 && g.RS == 2) || (g.L == 32 && g.RS == 1));
 }
-hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, const AheadSampler& sa_in, hipStream_t s)
+hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, const AheadSampler& sa_in, const PlantAhead* plant, hipStream_t s)
 {
     if (!rti_block_sampler_supported(p, g)) return hipErrorInvalidValue;
     RtiGroup grp;
@@ -527,7 +538,10 @@ hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, con
     }
     AheadSampler sa = sa_in;
     sa.first_block = g.grid;
-    void* args[] = {const_cast<RtiParams*>(&p), &grp, &sa};
+    PlantAhead pl{};
+    if (plant) { pl = *plant; pl.on = 1; }
+    static_assert(sizeof(RtiParams) + sizeof(RtiGroup) + sizeof(AheadSampler) + sizeof(PlantAhead) + 32 <= 4096, "kernel arguments: 4 KB");
+    void* args[] = {const_cast<RtiParams*>(&p), &grp, &sa, &pl};
     const unsigned blocks = (unsigned)g.grid + (unsigned)((sa.B + 1) / 2);
     e = hipLaunchKernel(fn, dim3(blocks), dim3(64), args, g.lds_bytes, s);
     if (e != hipSuccess) return e;

@@ -497,7 +497,7 @@ void fill_params(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_
 // `co` (alore_nmpc_closed_loop_run): the sampler of the next tick, to run in the same grid when the mapping has such a build;
 // *co_done says whether it did
 int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream, int B_in_flight, const nmpc::AheadSampler* co = nullptr,
-            bool* co_done = nullptr)
+            bool* co_done = nullptr, const nmpc::PlantAhead* plant = nullptr)
 {
     if (co_done) *co_done = false;
     if (!batch_complete(dev)) return fail(h, ALORE_NMPC_E_INVALID, "rti: batch has NULL members");
@@ -525,9 +525,10 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
     }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
     if (co && !h->timing && nmpc::rti_block_sampler_supported(p, g)) {
-        HIP_TRY(h, nmpc::launch_rti_block_sampler(p, g, *co, s));
+        HIP_TRY(h, nmpc::launch_rti_block_sampler(p, g, *co, plant, s));
         *co_done = true;
     } else {
+        if (plant) HIP_TRY(h, nmpc::launch_plant_ahead(*plant, s)); // no build of this mapping carries it: its own launch, in front of the solve
         HIP_TRY(h, g.block ? nmpc::launch_rti_block(p, g, s) : nmpc::launch_rti(p, g, s));
     }
     if (h->timing) {
@@ -1410,6 +1411,25 @@ int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch* dev,
     HIP_TRY(h, hipMemcpyAsync(h->cl_yN, dev->yN, sizeof(float) * (size_t)B * 3, hipMemcpyDeviceToDevice, s));
     // tick 0 is sampled whole (od, x0 from the current pose)
     HIP_TRY(h, nmpc::launch_ref_sample(h->refs, *dev, B, N, (double)h->cfg.dt, t0, h->d_est, h->d_icr, h->d_goal, h->d_psi, 1, s));
+    // per tick ONE launch: [plant step of tick t - 1 -> solve of tick t] beside [sampler of tick t + 1]
+    auto plant_of = [&](int t, bool more) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        nmpc::PlantAhead a{};
+        a.u = buf[cur].u;
+        a.x0 = const_cast<float*>(buf[nxt].x0);
+        a.y = const_cast<float*>(buf[nxt].y);
+        a.yN = const_cast<float*>(buf[nxt].yN);
+        a.meta = h->refs.meta;
+        a.icr = h->d_icr;
+        a.at_goal = h->d_goal;
+        a.pose = h->d_est;
+        a.vw = h->d_vw;
+        a.psi_rel = more ? h->cl_psi[nxt] : nullptr;
+        a.p = h->plant;
+        a.now = t0 + dt_tick * t;
+        a.B = B; a.N = N; a.node = node;
+        return a;
+    };
     for (int t = 0; t < n_ticks; ++t) {
         const bool more = t + 1 < n_ticks;
         const int cur = t & 1, nxt = cur ^ 1;
@@ -1421,17 +1441,17 @@ int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch* dev,
         sa.psi_rel = h->cl_psi[nxt];
         sa.dt = (double)h->cfg.dt;
         sa.now = t0 + dt_tick * (t + 1);
-        sa.B = B;
+        sa.B = more ? B : 0; // the last tick has nothing to sample for
         sa.N = N;
         bool sampled = false;
         if (!batch_complete(&buf[cur])) return fail(h, ALORE_NMPC_E_INVALID, "closed_loop_run: batch has NULL members");
-        const int rc = rti_one(h, &buf[cur], B, 1, stream, 0, more ? &sa : nullptr, &sampled);
+        const nmpc::PlantAhead prev = plant_of(t > 0 ? t - 1 : 0, true);
+        const int rc = rti_one(h, &buf[cur], B, 1, stream, 0, &sa, &sampled, t > 0 ? &prev : nullptr);
         if (rc != ALORE_NMPC_OK) return rc;
         if (more && !sampled) // no build of this mapping carries the sampler: its own launch, in the chain
             HIP_TRY(h, nmpc::launch_ref_sample_ahead(h->refs, buf[nxt], B, N, sa.dt, sa.now, h->d_icr, h->cl_psi[nxt], s));
-        HIP_TRY(h, nmpc::launch_plant_ahead(buf[cur], buf[nxt], h->refs, B, N, node, t0 + dt_tick * t, h->d_icr, h->d_goal, h->d_est, h->d_vw,
-                                           more ? h->cl_psi[nxt] : nullptr, h->plant, s));
     }
+    HIP_TRY(h, nmpc::launch_plant_ahead(plant_of(n_ticks - 1, false), s)); // the plant step of the last tick
     if ((n_ticks - 1) & 1) { // the last tick read the internal buffer: the caller's y / yN are those of the last tick afterwards, as in a tick-by-tick run
         HIP_TRY(h, hipMemcpyAsync(const_cast<float*>(dev->y), h->cl_y, sizeof(float) * (size_t)B * N * 5, hipMemcpyDeviceToDevice, s));
         HIP_TRY(h, hipMemcpyAsync(const_cast<float*>(dev->yN), h->cl_yN, sizeof(float) * (size_t)B * 3, hipMemcpyDeviceToDevice, s));

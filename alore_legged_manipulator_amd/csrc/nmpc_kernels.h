@@ -125,6 +125,23 @@ struct PlantParams { // simulator.h: max_a_, max_domega_, Pose_pub_rate_ (a peri
     double max_a, max_domega, pose_pub_period, propa_period;
     int substeps; // StatePropaCallback calls per control tick
 };
+// the plant step of tick t with the completion of tick t + 1's references (ref_sampler_device.h: plant_ahead_one)
+struct PlantAhead {
+    const float* u;        // [B][N][2] inputs the solve of tick t left
+    float* x0;             // [B][3]    of tick t + 1
+    float* y;              // [B][N][5] references of tick t + 1, sampled ahead
+    float* yN;             // [B][3]
+    const double* meta;    // RefStore::meta
+    const double* icr;     // [B][3]
+    int* at_goal;          // [B]
+    double* pose;          // [B][3]
+    double* vw;            // [B][2]
+    const double* psi_rel; // [B][N + 1] float64 headings of the walk of tick t + 1, or null: the run ends with tick t
+    PlantParams p;
+    double now;            // time of tick t
+    int B, N, node;
+    int on;                // rti_block_sampler_kernel: 1 = this step runs in front of the solve (else the field is ignored)
+};
 hipError_t launch_plant(const alore_nmpc_batch& b, int B, int N, int node, const double* icr, const int* at_goal,
                         double* pose, double* vw, const PlantParams& p, hipStream_t st);
 // the reference sampler's part of a grid that also solves (rti_block_sampler_kernel): pose-independent sampling of the NEXT tick
@@ -139,14 +156,12 @@ struct AheadSampler {
     int first_block;     // set by the launcher: workgroups from here on are the sampler's
 };
 bool rti_block_sampler_supported(const RtiParams& p, const LaunchGeom& g);
-hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, const AheadSampler& sa, hipStream_t s);
+hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, const AheadSampler& sa, const PlantAhead* plant, hipStream_t s);
 // closed_loop_run: the pose-independent part of the sampling of a tick ahead of its pose, and the plant step that completes it
 bool ref_sample_ahead_supported(int N);
 hipError_t launch_ref_sample_ahead(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now, const double* icr,
                                    double* psi_rel, hipStream_t st);
-hipError_t launch_plant_ahead(const alore_nmpc_batch& b, const alore_nmpc_batch& next, const RefStore& s, int B, int N, int node, double now,
-                              const double* icr, int* at_goal, double* pose, double* vw, const double* psi_rel, const PlantParams& p,
-                              hipStream_t st);
+hipError_t launch_plant_ahead(const PlantAhead& a, hipStream_t st);
 hipError_t launch_ref_sample(const RefStore& s, const alore_nmpc_batch& b, int B, int N, double dt, double now,
                              const double* est, const double* icr, int* at_goal, double* psi_scratch, int do_smooth,
                              hipStream_t st);

@@ -266,22 +266,7 @@ __global__ void plant_kernel(alore_nmpc_batch b, int B, int N, int node, const d
     const double desired_w = (right - left) / (yl - yr);
     double x = pose[(size_t)r * 3], y = pose[(size_t)r * 3 + 1], th = pose[(size_t)r * 3 + 2];
     double v = vw[(size_t)r * 2], w = vw[(size_t)r * 2 + 1];
-    // the heading changes once per substep: its sine / cosine after the update are those the next substep starts with --
-    // one sincos per substep instead of four separate evaluations
-    double sn, cs;
-    sincos(th, &sn, &cs);
-    for (int s = 0; s < p.substeps; ++s) {
-        if (fabs(v - desired_v) >= p.pose_pub_period * p.max_a) v += p.pose_pub_period * p.max_a * (desired_v - v) / fabs(desired_v - v);
-        else v = desired_v;
-        if (fabs(w - desired_w) >= p.pose_pub_period * p.max_domega) w += p.pose_pub_period * p.max_domega * (desired_w - w) / fabs(desired_w - w);
-        else w = desired_w;
-        x += v * p.propa_period * cs;
-        y += v * p.propa_period * sn;
-        th += w * p.propa_period;
-        sincos(th, &sn, &cs);
-        x -= vy * p.propa_period * sn;
-        y += vy * p.propa_period * cs;
-    }
+    plant_substeps(p, desired_v, desired_w, vy, x, y, th, v, w);
     pose[(size_t)r * 3] = x; pose[(size_t)r * 3 + 1] = y; pose[(size_t)r * 3 + 2] = th;
     vw[(size_t)r * 2] = v; vw[(size_t)r * 2 + 1] = w;
 }
@@ -290,58 +275,10 @@ __global__ void plant_kernel(alore_nmpc_batch b, int B, int N, int node, const d
 // at-goal flag of tick t (getRefPoints' test, from `now` of tick t), the plant as above, then x0 <- pose and smooth_yaw's first
 // step -- node 0 against the measured heading, mpc.cpp:248-277 -- as a shift of all N + 1 headings of the walk by the same turns.
 // `nb` is the batch of tick t + 1 (its y / yN hold the references sampled ahead), psi_rel their float64 headings.
-__global__ void plant_ahead_kernel(alore_nmpc_batch b, alore_nmpc_batch nb, RefStore s, int B, int N, int node, double now, const double* icr,
-                                   int* at_goal, double* pose, double* vw, const double* psi_rel /* null: the run ends with tick t */, PlantParams p)
+__global__ void plant_ahead_kernel(PlantAhead a)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= B) return;
-    const double* m = s.meta + (size_t)r * 8;
-    const bool valid = m[6] != 0.0;
-    const int goal = (valid && (now - m[0]) > m[1] + 1.0) ? 1 : 0;
-    double right = (double)b.u[((size_t)r * N + node) * 2], left = (double)b.u[((size_t)r * N + node) * 2 + 1];
-    const double c0 = (valid && psi_rel) ? psi_rel[(size_t)r * (N + 1)] : 0.0;
-    if (goal) { right = 0.0; left = 0.0; }
-    const double xv = icr[(size_t)r * 3], yr = icr[(size_t)r * 3 + 1], yl = icr[(size_t)r * 3 + 2];
-    const double desired_v = (left + right) / 2.0 - (right - left) / (yl - yr) * (yl + yr) / 2.0;
-    const double vy = -(right - left) / (yl - yr) * xv;
-    const double desired_w = (right - left) / (yl - yr);
-    double x = pose[(size_t)r * 3], y = pose[(size_t)r * 3 + 1], th = pose[(size_t)r * 3 + 2];
-    double v = vw[(size_t)r * 2], w = vw[(size_t)r * 2 + 1];
-    double sn, cs;
-    sincos(th, &sn, &cs);
-    for (int k = 0; k < p.substeps; ++k) {
-        if (fabs(v - desired_v) >= p.pose_pub_period * p.max_a) v += p.pose_pub_period * p.max_a * (desired_v - v) / fabs(desired_v - v);
-        else v = desired_v;
-        if (fabs(w - desired_w) >= p.pose_pub_period * p.max_domega) w += p.pose_pub_period * p.max_domega * (desired_w - w) / fabs(desired_w - w);
-        else w = desired_w;
-        x += v * p.propa_period * cs;
-        y += v * p.propa_period * sn;
-        th += w * p.propa_period;
-        sincos(th, &sn, &cs);
-        x -= vy * p.propa_period * sn;
-        y += vy * p.propa_period * cs;
-    }
-    pose[(size_t)r * 3] = x; pose[(size_t)r * 3 + 1] = y; pose[(size_t)r * 3 + 2] = th;
-    vw[(size_t)r * 2] = v; vw[(size_t)r * 2 + 1] = w;
-    at_goal[r] = goal;
-    if (!valid || !psi_rel) return; // no trajectory: the references and x0 stay as they are, like in the sampler
-    float* x0 = const_cast<float*>(nb.x0) + (size_t)r * 3;
-    x0[0] = (float)x; x0[1] = (float)y; x0[2] = (float)th;
-    int turns = 0; // net steps of 2 pi that smooth_yaw's two loops move node 0 by
-    {
-        double cur = c0, dyaw = cur - th;
-        while (dyaw >= M_PI / 2) { cur -= M_PI * 2; dyaw = cur - th; --turns; }
-        while (dyaw <= -M_PI / 2) { cur += M_PI * 2; dyaw = cur - th; ++turns; }
-    }
-    if (turns == 0) return;
-    const double* pr = psi_rel + (size_t)r * (N + 1);
-    float* yy = const_cast<float*>(nb.y) + (size_t)r * N * 5;
-    for (int j = 0; j <= N; ++j) {
-        double cur = pr[j];
-        for (int k = 0; k < (turns > 0 ? turns : -turns); ++k) cur += turns > 0 ? M_PI * 2 : -M_PI * 2;
-        if (j < N) yy[(size_t)j * 5 + 2] = (float)cur;
-        else const_cast<float*>(nb.yN)[(size_t)r * 3 + 2] = (float)cur;
-    }
+    if (r < a.B) plant_ahead_one(a, r);
 }
 
 // MpcWrapper::solve's reset (mpc_wrapper.cpp:267-275) from the plant's pose: one thread per (robot, node)
@@ -369,11 +306,9 @@ hipError_t launch_plant(const alore_nmpc_batch& b, int B, int N, int node, const
     return hipGetLastError();
 }
 
-hipError_t launch_plant_ahead(const alore_nmpc_batch& b, const alore_nmpc_batch& next, const RefStore& s, int B, int N, int node, double now,
-                              const double* icr, int* at_goal, double* pose, double* vw, const double* psi_rel, const PlantParams& p,
-                              hipStream_t st)
+hipError_t launch_plant_ahead(const PlantAhead& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(plant_ahead_kernel, dim3((B + 63) / 64), dim3(64), 0, st, b, next, s, B, N, node, now, icr, at_goal, pose, vw, psi_rel, p);
+    hipLaunchKernelGGL(plant_ahead_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 

@@ -120,5 +120,82 @@ __device__ __forceinline__ void ref_sample_smooth_body(const RefStore& s, const 
     }
 }
 
+// The substeps of one control tick (StatePropaCallback, simulator.h:234-275).  The heading changes once per substep and its sine /
+// cosine after the update are those the next substep starts with: one evaluation per tick, then a rotation by the substep's angle
+// w * period -- a few milliradians, whose sine and cosine are short series (next terms d^9 / 9! and d^8 / 8!: below the last bit
+// for |d| < 0.03); a larger angle takes the full evaluation.  The reference calls cos and sin four times per substep; the rotation
+// differs from them by rounding (1e-16 per substep, nothing carried over to the next tick).
+__device__ __forceinline__ void plant_substeps(const PlantParams& p, double desired_v, double desired_w, double vy, double& x, double& y, double& th,
+                                               double& v, double& w)
+{
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    for (int k = 0; k < p.substeps; ++k) {
+        if (fabs(v - desired_v) >= p.pose_pub_period * p.max_a) v += p.pose_pub_period * p.max_a * (desired_v - v) / fabs(desired_v - v);
+        else v = desired_v;
+        if (fabs(w - desired_w) >= p.pose_pub_period * p.max_domega) w += p.pose_pub_period * p.max_domega * (desired_w - w) / fabs(desired_w - w);
+        else w = desired_w;
+        x += v * p.propa_period * cs;
+        y += v * p.propa_period * sn;
+        const double d = w * p.propa_period;
+        th += d;
+        if (fabs(d) < 0.03) {
+            const double d2 = d * d;
+            const double sd = d * (1.0 - d2 * (1.0 / 6.0) * (1.0 - d2 * (1.0 / 20.0) * (1.0 - d2 * (1.0 / 42.0))));
+            const double cd = 1.0 - d2 * 0.5 * (1.0 - d2 * (1.0 / 12.0) * (1.0 - d2 * (1.0 / 30.0)));
+            const double c1 = cs * cd - sn * sd, s1 = sn * cd + cs * sd;
+            cs = c1; sn = s1;
+        } else {
+            sincos(th, &sn, &cs);
+        }
+        x -= vy * p.propa_period * sn;
+        y += vy * p.propa_period * cs;
+    }
+}
+
+// The plant step of tick t for robot r and what the sampler of tick t + 1 could not do without the pose it produces: the at-goal
+// flag of tick t (getRefPoints' test, from `now` of tick t), the plant (simulator.h:234-275, see plant_kernel), then x0 <- pose
+// and smooth_yaw's first step -- node 0 against the measured heading, mpc.cpp:248-277 -- as a shift of all N + 1 headings of the
+// walk by the same turns.  y / yN are the references of tick t + 1 (sampled ahead), psi_rel their float64 headings (null: the
+// run ends with tick t).
+__device__ __forceinline__ void plant_ahead_one(const PlantAhead& a, int r)
+{
+    const int N = a.N;
+    const double* m = a.meta + (size_t)r * 8;
+    const bool valid = m[6] != 0.0;
+    const int goal = (valid && (a.now - m[0]) > m[1] + 1.0) ? 1 : 0;
+    double right = (double)a.u[((size_t)r * N + a.node) * 2], left = (double)a.u[((size_t)r * N + a.node) * 2 + 1];
+    const double c0 = (valid && a.psi_rel) ? a.psi_rel[(size_t)r * (N + 1)] : 0.0;
+    if (goal) { right = 0.0; left = 0.0; }
+    const double xv = a.icr[(size_t)r * 3], yr = a.icr[(size_t)r * 3 + 1], yl = a.icr[(size_t)r * 3 + 2];
+    const double desired_v = (left + right) / 2.0 - (right - left) / (yl - yr) * (yl + yr) / 2.0;
+    const double vy = -(right - left) / (yl - yr) * xv;
+    const double desired_w = (right - left) / (yl - yr);
+    double x = a.pose[(size_t)r * 3], y = a.pose[(size_t)r * 3 + 1], th = a.pose[(size_t)r * 3 + 2];
+    double v = a.vw[(size_t)r * 2], w = a.vw[(size_t)r * 2 + 1];
+    plant_substeps(a.p, desired_v, desired_w, vy, x, y, th, v, w);
+    a.pose[(size_t)r * 3] = x; a.pose[(size_t)r * 3 + 1] = y; a.pose[(size_t)r * 3 + 2] = th;
+    a.vw[(size_t)r * 2] = v; a.vw[(size_t)r * 2 + 1] = w;
+    a.at_goal[r] = goal;
+    if (!valid || !a.psi_rel) return; // no trajectory: the references and x0 stay as they are, like in the sampler
+    float* x0 = a.x0 + (size_t)r * 3;
+    x0[0] = (float)x; x0[1] = (float)y; x0[2] = (float)th;
+    int turns = 0; // net steps of 2 pi that smooth_yaw's two loops move node 0 by
+    {
+        double cur = c0, dyaw = cur - th;
+        while (dyaw >= M_PI / 2) { cur -= M_PI * 2; dyaw = cur - th; --turns; }
+        while (dyaw <= -M_PI / 2) { cur += M_PI * 2; dyaw = cur - th; ++turns; }
+    }
+    if (turns == 0) return;
+    const double* pr = a.psi_rel + (size_t)r * (N + 1);
+    float* yy = a.y + (size_t)r * N * 5;
+    for (int j = 0; j <= N; ++j) {
+        double cur = pr[j];
+        for (int k = 0; k < (turns > 0 ? turns : -turns); ++k) cur += turns > 0 ? M_PI * 2 : -M_PI * 2;
+        if (j < N) yy[(size_t)j * 5 + 2] = (float)cur;
+        else a.yN[(size_t)r * 3 + 2] = (float)cur;
+    }
+}
+
 } // namespace nmpc
 #endif
