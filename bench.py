@@ -1167,7 +1167,9 @@ def main():
         except Exception as e:  # pragma: no cover
             extras["ltv_mpc"] = {"error": f"{type(e).__name__}: {e}"}
         # Monte-Carlo closed-loop rollout with no host in the loop: per tick, references from the plant's pose ->
-        # one real-time iteration -> command into the simulator plant (alore_nmpc_closed_loop_tick)
+        # one real-time iteration -> command into the simulator plant (alore_nmpc_closed_loop_tick); closed_loop_run issues ONE launch
+        # per tick: [plant step of tick t - 1 -> solve of tick t] with the pose-independent sampling of tick t + 1 on extra workgroups
+        # of the same grid (results of the ticks one by one: tests/test_closed_loop.py)
         try:
             from alore_legged_manipulator_amd.host import Polynome
             rng = np.random.default_rng(7)
@@ -1192,6 +1194,7 @@ def main():
             pose, _, goal = e7.plant_get_state()
             extras["device_closed_loop"] = {"robots": B, "ticks": nt, "ms_per_tick": (t_b - t_a) / nt * 1e3,
                                             "robot_ticks_per_s": B * nt / (t_b - t_a),
+                                            "launches_per_tick": 1,
                                             "unsolved_last_tick": int((e7.t["status"] != 0).sum().item()),
                                             "finite": bool(np.isfinite(pose).all())}
             del e7
