@@ -23,13 +23,13 @@ def check(path):
     text = open(path).read().splitlines()
     kernels, name = {}, None
     for ln in text:
-        m = re.match(r"^(_ZN4nmpc16rti_block_kernel\S+):", ln)
+        m = re.match(r"^(_ZN4nmpc(?:16rti_block_kernel|24rti_block_sampler_kernel)\S+):", ln)  # the second kind includes the same body (nmpc_block_body.inc)
         if m:
             name = m.group(1)
             kernels[name] = []
         elif name is not None:
             kernels[name].append(ln)
-            if "s_endpgm" in ln:
+            if ln.startswith(".Lfunc_end"):  # not the first s_endpgm: a kernel may leave early on another path (the sampler's workgroups)
                 name = None
     masked = {k: v for k, v in kernels.items() if "ILi16ELi2E" in k or "ILi32ELi1E" in k}
     if not masked:  # whatever set of (16, 2) / (32, 1) instantiations the file holds is checked; none at all means the scan found nothing
