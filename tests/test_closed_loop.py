@@ -159,16 +159,19 @@ def test_device_closed_loop_matches_host_driven_loop():
         assert _m.hypot(pose_d[b, 0] - ref[0], pose_d[b, 1] - ref[1]) < 0.15 and abs(pose_d[b, 2] - ref[2]) < 0.3, (b, pose_d[b], ref)
 
 
-def test_closed_loop_run_samples_ahead_and_returns_what_tick_by_tick_returns():
-    """alore_nmpc_closed_loop_run samples tick t + 1 on a second stream beside the solve of tick t (two reference buffers; the
-    plant step writes x0 and shifts the headings by the turns smooth_yaw's first step finds, mpc.cpp:248-277): the plant
-    states, the iterate and the references after the run must be those of the same ticks issued one by one.  The robots
-    cover a heading that crosses pi (the walk starts one turn away from the normalised references), a trajectory that
-    ends inside the run (at-goal flag, zero command), a robot without a trajectory (its references stay the caller's) and
-    both parities of the tick count (the last tick reads the caller's buffer or the internal one)."""
+@pytest.mark.parametrize("B,tick_counts", [(16, (150, 37)), (600, (24,)), (4104, (13,))])
+def test_closed_loop_run_samples_ahead_and_returns_what_tick_by_tick_returns(B, tick_counts):
+    """alore_nmpc_closed_loop_run issues one launch per tick: the pose-independent sampling of tick t + 1 on extra workgroups of
+    the grid that solves tick t (two reference buffers), the plant step of tick t - 1 -- which writes x0 and shifts the headings
+    by the turns smooth_yaw's first step finds, mpc.cpp:248-277 -- in front of the solve.  The plant states, the iterate and the
+    references after the run must be those of the same ticks issued one by one.  The robots cover a heading that crosses pi (the
+    walk starts one turn away from the normalised references), a trajectory that ends inside the run (at-goal flag, zero
+    command), a robot without a trajectory (its references stay the caller's) and both parities of the tick count (the last tick
+    reads the caller's buffer or the internal one).  B = 16 runs the (32, 1) mapping, 600 the (16, 2) mapping, 4104 a mapping
+    without such a build ((8, 3): plant step, solve and sampler are launches in a row)."""
     from alore_legged_manipulator_amd.nmpc import BatchedNmpc
     from alore_legged_manipulator_amd.host import Polynome
-    B, N, dt = 16, 20, 0.01
+    N, dt = 20, 0.01
     rng = np.random.default_rng(11)
     msgs, robots = [], []
     pose0 = np.zeros((B, 3))
@@ -179,7 +182,7 @@ def test_closed_loop_run_samples_ahead_and_returns_what_tick_by_tick_returns():
         th0 = 0.0
         Tp = np.array([0.5, 0.5, 0.5])
         if b in (1, 2):   # starts near pi and turns through it (b = 1 upwards, b = 2 downwards from -pi)
-            th0, w = (3.0, 0.9) if b == 1 else (-3.05, -0.9)
+            th0, w = (3.1, 0.9) if b == 1 else (-3.12, -0.9)   # the reference passes pi within the first ten ticks
         if b == 3:        # over after 0.3 s: at the goal 1 s later
             Tp = np.array([0.1, 0.1, 0.1])
         Tc = np.cumsum(Tp)
@@ -204,7 +207,10 @@ def test_closed_loop_run_samples_ahead_and_returns_what_tick_by_tick_returns():
         return e
 
     names = ("x", "u", "y", "yN", "x0", "od", "status")
-    for ticks in (150, 37):
+
+    def f_refs(e):
+        return e.fetch(names=("y",))["y"][:, :, 2]
+    for ticks in tick_counts:
         one, run = fresh(), fresh()
         for t in range(ticks):
             one.closed_loop_tick(0.01 * (t + 1), delay_num=1)
@@ -216,11 +222,13 @@ def test_closed_loop_run_samples_ahead_and_returns_what_tick_by_tick_returns():
         if ticks == 150:
             assert g1[3] == 1 and g1.sum() == 1
             assert abs(p1[1, 2]) > math.pi and abs(p1[2, 2]) > math.pi        # the two headings did cross pi
+        assert np.all(np.abs(f_refs(run)[[1, 2], 0]) > math.pi - 0.2)          # ... and so did their references: the walks start a turn away
         assert np.max(np.abs(p1 - p2)) < 1e-6 and np.max(np.abs(v1 - v2)) < 1e-6, (np.max(np.abs(p1 - p2)), np.max(np.abs(v1 - v2)))
         f1, f2 = one.fetch(names=names), run.fetch(names=names)
         for k in names:
             a, c = f1[k].astype(np.float64), f2[k].astype(np.float64)
             assert np.max(np.abs(a - c)) < 2e-6 * max(1.0, np.max(np.abs(a))), (ticks, k, np.max(np.abs(a - c)))
         assert np.array_equal(f2["y"][5], y_user[5]) and np.array_equal(f2["yN"][5], yN_user[5])    # no trajectory: untouched
-        # the references of the robots that turned through pi follow the heading (not the normalised angle)
+        # the references of the robots that turn through pi follow the heading (not the normalised angle)
         assert np.max(np.abs(f2["y"][1, :, 2] - p2[1, 2])) < 1.0 and np.max(np.abs(f2["y"][2, :, 2] - p2[2, 2])) < 1.0
+        one.close(); run.close()
