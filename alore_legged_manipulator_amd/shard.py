@@ -143,15 +143,34 @@ def timed_pass(eng, batch, mode: str, K: int, warmup: int, gather_every: int, ga
               one launch, the cold start of MpcWrapper::solve + its update() calls) and the converged trajectories (x, u,
               status, kkt) are all-gathered to every rank, one collective per tensor per step, issued asynchronously right
               behind the solve so that it runs under the next step's solve, all completed inside the timed region.
+      converged_in_flight -- the same unit with the steps of a bucket (`gather_every` independent batches) solved by ONE grid
+              (alore_nmpc_rti_many with `conv_iters` iterations: the packed lane mapping fills the chip, as the headline's pass does
+              for single iterations) and ONE all-gather per tensor and bucket behind it, running under the next bucket's grid.
     Returns (elapsed seconds, device milliseconds, graph used): both times are the MAXIMUM over the ranks, measured
     between two barriers.  bench.py calls this with the GPU hooks; tests/dist_worker.py with HostHooks under gloo."""
     import time
     do_gather = world > 1 and mode == "full"
     gather_last = world > 1 and mode == "last"
     converged = mode == "converged"
+    converged_many = mode == "converged_in_flight"
     ge = max(1, gather_every)
 
     def run_steps(first, count):
+        if converged_many:
+            lo = first
+            while lo < first + count:
+                n = min(ge, first + count - lo)
+                if hasattr(eng, "rti_range"):
+                    eng.rti_range(lo, n, conv_iters)
+                else:
+                    for i in range(lo, lo + n):
+                        eng.rti(conv_iters, slot=i)
+                if gatherer is not None:
+                    gatherer.submit({k: eng.ts[k][lo:lo + n] for k in ("x", "u", "status", "kkt")})
+                lo += n
+            if gatherer is not None:
+                gatherer.wait()
+            return
         if converged:
             for i in range(first, first + count):
                 eng.rti(conv_iters, slot=i)
@@ -176,7 +195,7 @@ def timed_pass(eng, batch, mode: str, K: int, warmup: int, gather_every: int, ga
     run_steps(0, warmup)
     hooks.barrier()
     replay = None
-    if not do_gather and not converged and K > 0:  # never with collectives between the solves
+    if not do_gather and not converged and not converged_many and K > 0:  # never with collectives between the solves
         if hasattr(eng, "prepare_range"):
             # the independence check of the K timed slots before the timed region, for eager launches as a stream capture
             # has it (alore_nmpc_rti_many_prepare: a host that steps the same slots every tick pays for it once)

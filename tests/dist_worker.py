@@ -114,6 +114,19 @@ def bench_pass_bookkeeping(rank, world):
     checks["converged: every problem of every rank"] = tuple(lastc["status"].shape) == (world, B) and int(lastc["status"].sum()) == 0
     e1 = OracleEngine(B, N, 1); e1.load(batch); e1.rti(1, 0)
     checks["converged: two iterations differ from one"] = not torch.equal(e1.ts["u"][0], eng.ts["u"][W + K - 1])
+    # ... and with the steps of a bucket in one grid / one gather per bucket (the engine here has no rti_range: one launch per step)
+    submits.clear(); eng.launches.clear()
+    g3 = ResultGatherer(dist, world, depth=2)
+    seen3 = []
+    orig3 = g3.submit
+    g3.submit = lambda t: (seen3.append({k: tuple(v.shape) for k, v in t.items()}), orig3(t))[1]
+    el4, dms4, graph4 = timed_pass(eng, batch, "converged_in_flight", K, W, ge, g3, hooks, world, conv_iters=2)
+    lastf = g3.wait()
+    n_buckets = -(-W // ge) + -(-K // ge)
+    checks["in flight: one gather per bucket"] = len(seen3) == n_buckets and eng.launches == list(range(W + K)) and not graph4
+    checks["in flight: own slab"] = torch.equal(lastf["x"][rank][-1], eng.ts["x"][W + K - 1]) and torch.equal(lastf["kkt"][rank][-1], eng.ts["kkt"][W + K - 1])
+    checks["in flight: peer slab"] = torch.equal(lastf["x"][peer][-1], e3.ts["x"][0]) and torch.equal(lastf["u"][peer][-1], e3.ts["u"][0])
+    checks["in flight: the same trajectories as one step at a time"] = torch.equal(lastf["x"][:, -1], lastc["x"]) and torch.equal(lastf["status"][:, -1], lastc["status"])
     # secondary pass that fails on every rank before any collective: caught, the primary figure stands
     class Boom(OracleEngine):
         def load(self, batch, slot=None):

@@ -763,11 +763,13 @@ def test_overlapped_launches_of_independent_slots_give_the_in_order_bits(nmpc_mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_sqp", [2, 15])
 @pytest.mark.parametrize("mode", ["groups", "streams"])
 @pytest.mark.parametrize("lanes", [BLOCK | 4, BLOCK | 16])
-def test_launches_in_flight_with_two_iterations_and_shared_members(nmpc_mod, lanes, mode):
-    """alore_nmpc_rti_many on the builds that keep the iteration loop (n_sqp = 2), with W / bounds / od read from one shared
-    copy, five slots in flight: the bits of slot-by-slot launches."""
+def test_launches_in_flight_with_two_iterations_and_shared_members(nmpc_mod, lanes, mode, n_sqp):
+    """alore_nmpc_rti_many on the builds that keep the iteration loop (n_sqp = 2; 15 = the converged solves that bench.py's
+    converged_all_gather.in_flight keeps in one grid), with W / bounds / od read from one shared copy, five slots in flight: the
+    bits of slot-by-slot launches."""
     import torch
     B, N, slots = 300, 20, 5
     batch = make_batch(B, N, seed=8, fast_tail=0.3)
@@ -776,14 +778,14 @@ def test_launches_in_flight_with_two_iterations_and_shared_members(nmpc_mod, lan
     ref.load(batch, slot=None)
     ref.set_shared_members(W=True, bounds=True, od=True)
     for s in range(slots):
-        ref.rti(2, slot=s)
+        ref.rti(n_sqp, slot=s)
     torch.cuda.synchronize()
     eng = nmpc_mod.BatchedNmpc(B, N, slots=slots, lanes_per_problem=lanes)
     eng.load(batch, slot=None)
     eng.set_shared_members(W=True, bounds=True, od=True)
     eng.set_launch_overlap(5)
     eng.set_many_mode(mode)
-    eng.rti_range(0, slots, n_sqp=2)
+    eng.rti_range(0, slots, n_sqp=n_sqp)
     torch.cuda.synchronize()
     assert (eng.ts["status"] == 0).all()
     for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj"):
