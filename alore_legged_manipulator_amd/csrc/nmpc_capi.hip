@@ -1260,6 +1260,18 @@ int alore_nmpc_plant_init(alore_nmpc_handle h, const alore_plant_params* p)
     h->plant.max_a = p->max_acc; h->plant.max_domega = p->max_domega;
     h->plant.pose_pub_period = p->pose_pub_period; h->plant.propa_period = p->state_propa_period;
     h->plant.substeps = p->substeps;
+    // closed_loop_run's second reference buffer and the float64 headings of the walk sampled ahead (nothing is allocated inside a run)
+    if (h->cl_B < h->refs_B) {
+        const int Bc = h->refs_B, N = h->cfg.N;
+        if (h->cl_y) (void)hipFree(h->cl_y);
+        if (h->cl_yN) (void)hipFree(h->cl_yN);
+        h->cl_y = nullptr; h->cl_yN = nullptr; h->cl_B = 0;
+        for (int i = 0; i < 2; ++i) { if (h->cl_psi[i]) (void)hipFree(h->cl_psi[i]); h->cl_psi[i] = nullptr; }
+        HIP_TRY(h, hipMalloc(&h->cl_y, sizeof(float) * (size_t)Bc * N * 5));
+        HIP_TRY(h, hipMalloc(&h->cl_yN, sizeof(float) * (size_t)Bc * 3));
+        for (int i = 0; i < 2; ++i) HIP_TRY(h, hipMalloc(&h->cl_psi[i], sizeof(double) * (size_t)Bc * (N + 1)));
+        h->cl_B = Bc;
+    }
     h->has_plant = true;
     return ALORE_NMPC_OK;
 }
@@ -1393,16 +1405,7 @@ int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch* dev,
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     const int N = h->cfg.N, node = delay_num < N ? delay_num : N - 1;
-    if (h->cl_B < B) {
-        if (h->cl_y) (void)hipFree(h->cl_y);
-        if (h->cl_yN) (void)hipFree(h->cl_yN);
-        h->cl_y = nullptr; h->cl_yN = nullptr; h->cl_B = 0;
-        for (int i = 0; i < 2; ++i) { if (h->cl_psi[i]) (void)hipFree(h->cl_psi[i]); h->cl_psi[i] = nullptr; }
-        HIP_TRY(h, hipMalloc(&h->cl_y, sizeof(float) * (size_t)B * N * 5));
-        HIP_TRY(h, hipMalloc(&h->cl_yN, sizeof(float) * (size_t)B * 3));
-        for (int i = 0; i < 2; ++i) HIP_TRY(h, hipMalloc(&h->cl_psi[i], sizeof(double) * (size_t)B * (N + 1)));
-        h->cl_B = B;
-    }
+    if (h->cl_B < B) return fail(h, ALORE_NMPC_E_INVALID, "closed_loop_run: more robots than plant_init allocated for");
     alore_nmpc_batch buf[2] = {*dev, *dev};
     buf[1].y = h->cl_y;
     buf[1].yN = h->cl_yN;
