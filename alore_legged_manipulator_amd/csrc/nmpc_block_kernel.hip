@@ -502,13 +502,20 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
 
 // The solve of one batch with the sampler's workgroups behind it in the same grid; false when this (mapping, mode) has no such build
 // (the caller then launches the two kernels one after the other)
-bool rti_block_sampler_supported(const RtiParams& p, const LaunchGeom& g)
+// 2: the sampler's workgroups run beside the solver's (builds of at most 256 registers: a SIMD holds one wavefront of each); 1: the
+// grid carries the plant step only (the (8, 3) build takes 303 registers: the sampler's wavefronts would queue behind the solver's
+// with one slot per SIMD -- as a kernel of its own the sampler has eight); 0: neither
+int rti_block_sampler_supported(const RtiParams& p, const LaunchGeom& g)
 {
-    return g.block && p.n_sqp == 1 && p.stamps == nullptr && p.N + 1 <= 32 && ((g.L == 16 && g.RS == 2) || (g.L == 32 && g.RS == 1));
+    if (!(g.block && p.n_sqp == 1 && p.stamps == nullptr && p.N + 1 <= 32)) return 0;
+    if ((g.L == 16 && g.RS == 2) || (g.L == 32 && g.RS == 1)) return 2;
+    if (g.L == 8 && g.RS == 3) return 1;
+    return 0;
 }
 hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, const AheadSampler& sa_in, const PlantAhead* plant, hipStream_t s)
 {
-    if (!rti_block_sampler_supported(p, g)) return hipErrorInvalidValue;
+    const int kind = rti_block_sampler_supported(p, g);
+    if (kind == 0 || (kind == 1 && sa_in.B > 0)) return hipErrorInvalidValue;
     RtiGroup grp;
     grp.count = 1;
     grp.blocks_per_batch = g.grid;
@@ -523,14 +530,15 @@ hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, con
     for (int m = 0; m < 15; ++m) grp.stride[m] = 0;
     grp.b[0] = p.b;
     const bool diag = p.b.kkt != nullptr || p.b.obj != nullptr;
-    const int v = (g.L == 16 ? 0 : 2) + (diag ? 0 : 1);
+    const int v = (g.L == 16 ? 0 : (g.L == 32 ? 2 : 4)) + (diag ? 0 : 1);
     const void* fn = g.L == 16 ? (diag ? (const void*)rti_block_sampler_kernel<16, 2, true> : (const void*)rti_block_sampler_kernel<16, 2, false>)
-                               : (diag ? (const void*)rti_block_sampler_kernel<32, 1, true> : (const void*)rti_block_sampler_kernel<32, 1, false>);
+                   : g.L == 32 ? (diag ? (const void*)rti_block_sampler_kernel<32, 1, true> : (const void*)rti_block_sampler_kernel<32, 1, false>)
+                               : (diag ? (const void*)rti_block_sampler_kernel<8, 3, true> : (const void*)rti_block_sampler_kernel<8, 3, false>);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     dev &= 15;
-    static size_t configured[16][4] = {{0}};
+    static size_t configured[16][6] = {{0}};
     if (g.lds_bytes > configured[dev][v]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
         if (e != hipSuccess) return e;

@@ -524,9 +524,12 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
         p.stamps = h->d_stamps;
     }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-    if (co && !h->timing && nmpc::rti_block_sampler_supported(p, g)) {
-        HIP_TRY(h, nmpc::launch_rti_block_sampler(p, g, *co, plant, s));
-        *co_done = true;
+    const int fused = (co && !h->timing) ? nmpc::rti_block_sampler_supported(p, g) : 0;
+    if (fused == 2 || (fused == 1 && plant)) {
+        nmpc::AheadSampler sa = *co;
+        if (fused == 1) sa.B = 0; // this build has no room for the sampler's wavefronts: the caller launches it behind the solve
+        HIP_TRY(h, nmpc::launch_rti_block_sampler(p, g, sa, plant, s));
+        *co_done = fused == 2 || co->B == 0;
     } else {
         if (plant) HIP_TRY(h, nmpc::launch_plant_ahead(*plant, s)); // no build of this mapping carries it: its own launch, in front of the solve
         HIP_TRY(h, g.block ? nmpc::launch_rti_block(p, g, s) : nmpc::launch_rti(p, g, s));

@@ -155,7 +155,7 @@ struct AheadSampler {
     int B, N;
     int first_block;     // set by the launcher: workgroups from here on are the sampler's
 };
-bool rti_block_sampler_supported(const RtiParams& p, const LaunchGeom& g);
+int rti_block_sampler_supported(const RtiParams& p, const LaunchGeom& g); // 2: sampler + plant step in the solver's grid, 1: plant step only, 0: neither
 hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, const AheadSampler& sa, const PlantAhead* plant, hipStream_t s);
 // closed_loop_run: the pose-independent part of the sampling of a tick ahead of its pose, and the plant step that completes it
 bool ref_sample_ahead_supported(int N);

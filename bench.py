@@ -1219,6 +1219,26 @@ def main():
                                             "unsolved_last_tick": int((e7.t["status"] != 0).sum().item()),
                                             "finite": bool(np.isfinite(pose).all())}
             del e7
+            # other fleet sizes: 64 and 512 robots (the (32, 1) / (16, 2) mappings: one launch per tick), 8192 (one GPU's share of
+            # configs[4]; the (8, 3) mapping has no room for the sampler's wavefronts: plant step + solve in one launch, the sampler behind)
+            sizes = {}
+            for Bf in (64, 512, 8192):
+                ef = BatchedNmpc(Bf, N, device=local_rank, diagnostics=False)
+                bf = make_batch(Bf, N)
+                ef.load({k: bf[k] for k in ("W", "WN", "lbValues", "ubValues")})
+                ef.refs_init(max_pieces=4, max_checkpoints=40)
+                mf = [msgs[i % B] for i in range(Bf)]
+                ef.refs_set_polynomes(np.arange(Bf), mf)
+                ef.plant_init()
+                ef.plant_set_state(np.zeros((Bf, 3)), np.tile([0.1, -0.3, 0.3], (Bf, 1)))
+                ef.closed_loop_run(0.01, 0.01, 20)
+                torch.cuda.synchronize(dev)
+                t_a = time.perf_counter()
+                ef.closed_loop_run(0.01 * 21, 0.01, nt)
+                torch.cuda.synchronize(dev)
+                sizes[str(Bf)] = (time.perf_counter() - t_a) / nt * 1e3
+                del ef
+            extras["device_closed_loop"]["ms_per_tick_other_fleet_sizes"] = sizes
         except Exception as e:  # pragma: no cover
             extras["device_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
         # compact I/O (secondary figure): weights, bounds and ICR parameters shared by the batch
