@@ -49,9 +49,9 @@ def test_newest_committed_bench_json_is_clean():
         pytest.skip("no bench record of this round committed yet")
     line = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     check_line(line)
-    if "extras" not in line:
-        # since round 4 the profile script records the default-length line without the extras (`--no-extras`) and the full
-        # line under the driver's flags beside it: the full one carries the contract's blocks
+    if "extras" not in line or "cpu_baseline" not in line:
+        # since round 4 the default-length line is recorded without the extras and / or the CPU baseline (`--no-extras`,
+        # `--no-cpu-baseline`) and the full line under the driver's flags beside it: the full one carries the contract's blocks
         full = files[-1].replace("_bench.json", "_bench_driver_flags.json")
         assert os.path.exists(full), full
         line = json.loads(open(full).read().strip().splitlines()[-1])
