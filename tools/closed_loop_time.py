@@ -18,7 +18,7 @@ def main():
     T = np.array([1.0, 1.0, 1.0]); Tc = np.cumsum(T)
     msgs = [Polynome(np.stack([w * Tc[:-1], v * Tc[:-1]], 1), T, [0, 0, w, v, 0, 0], [w * Tc[-1], v * Tc[-1], w, v, 0, 0],
                      [0, 0, 0], [-0.3, 0.3, 0.1], 0.0) for v, w in vw]
-    e7 = BatchedNmpc(B, N, device=0, diagnostics=False, lanes_per_problem=int(os.environ.get('CL_LANES', '0')))
+    e7 = BatchedNmpc(B, N, device=0, diagnostics=False, lanes_per_problem=int(os.environ.get('CL_LANES', '0')), warm_start_steps=int(os.environ.get('CL_PG', '-1')))
     e7.load({k: batch[k] for k in ("W", "WN", "lbValues", "ubValues")})
     e7.refs_init(max_pieces=4, max_checkpoints=40)
     e7.refs_set_polynomes(np.arange(B), msgs)
