@@ -494,6 +494,9 @@ void fill_params(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_
 }
 
 // one launch for one batch; B_in_flight = problems of all launches that run concurrently with it (0: only this one)
+int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B, int n_sqp, void* stream, int B_in_flight,
+              const long long* stride);
+
 // `co` (alore_nmpc_closed_loop_run): the sampler of the next tick, to run in the same grid when the mapping has such a build;
 // *co_done says whether it did
 int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, void* stream, int B_in_flight, const nmpc::AheadSampler* co = nullptr,
@@ -524,6 +527,20 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
         p.stamps = h->d_stamps;
     }
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
+    // one batch that is a grid of several residencies by itself (B >= 32768 on the packed mapping): what alore_nmpc_rti_many gives the
+    // batches of a call -- staggered first residency, XCD shares, the prediction length of a full chip -- applies to it as it stands
+    static const bool big_as_group = !(getenv("ALORE_NMPC_BIG_AS_GROUP") && atoi(getenv("ALORE_NMPC_BIG_AS_GROUP")) == 0);
+    if (big_as_group && use_block && g.L == 4 && g.RS == 5 && !h->stamps && !co && !plant && (long)g.grid >= 2L * 4 * h->n_cu) {
+        const int rc = rti_group(h, dev, 1, B, n_sqp, stream, B, nullptr);
+        if (rc != ALORE_NMPC_OK) return rc;
+        if (h->timing) {
+            HIP_TRY(h, hipEventRecord(h->ev1, s));
+            h->timed_pending = true;
+        }
+        h->last_geom = g;
+        h->have_geom = true;
+        return ALORE_NMPC_OK;
+    }
     const int fused = (co && !h->timing) ? nmpc::rti_block_sampler_supported(p, g) : 0;
     if (fused == 2 || (fused == 1 && plant)) {
         nmpc::AheadSampler sa = *co;

@@ -20,6 +20,8 @@ def main():
                      [0, 0, 0], [-0.3, 0.3, 0.1], 0.0) for v, w in vw]
     e7 = BatchedNmpc(B, N, device=0, diagnostics=False, lanes_per_problem=int(os.environ.get('CL_LANES', '0')), warm_start_steps=int(os.environ.get('CL_PG', '-1')))
     e7.load({k: batch[k] for k in ("W", "WN", "lbValues", "ubValues")})
+    if os.environ.get("CL_SHARED"):   # one robot class: W / WN, the bounds and od are one copy (alore_nmpc_set_shared_members)
+        e7.set_shared_members(W=True, bounds=True, od=True)
     e7.refs_init(max_pieces=4, max_checkpoints=40)
     e7.refs_set_polynomes(np.arange(B), msgs)
     e7.plant_init()
