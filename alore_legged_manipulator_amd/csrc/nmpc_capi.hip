@@ -5,7 +5,6 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <chrono>
 #include <cstring>
 #include <vector>
 #include <new>
@@ -1419,9 +1418,9 @@ int alore_nmpc_closed_loop_run(alore_nmpc_handle h, const alore_nmpc_batch* dev,
     }
     // The chain of a tick is sampler -> solve -> plant, and the sampler needs the pose only for x0 and for the turns that the heading
     // walk starts from (smooth_yaw's first step): everything else of tick t + 1 is sampled by extra workgroups of the grid that
-    // solves tick t (rti_block_sampler_kernel), into the other of two reference buffers; the plant step of tick t then writes x0
-    // and shifts the headings.  The chain of a tick is solve + plant, two launches on the caller's stream.  (A second stream for
-    // the sampler was built first: its two cross-stream events per tick cost what the overlap saved.)
+    // solves tick t (rti_block_sampler_kernel), into the other of two reference buffers; the plant step of tick t writes x0 and
+    // shifts the headings, and runs in front of the solve of tick t + 1 in that solve's grid.  One launch per tick on the caller's
+    // stream.  (A second stream for the sampler was built first: its two cross-stream events per tick cost what the overlap saved.)
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     const int N = h->cfg.N, node = delay_num < N ? delay_num : N - 1;
