@@ -61,6 +61,10 @@ struct alore_nmpc_solver {
     // pinned staging for alore_nmpc_batch_upload / _download from pageable host memory
     char* stage_up = nullptr;
     char* stage_down = nullptr;
+    char* pose_stage[2] = {};      // alore_nmpc_refs_sample: pose + ICR of a tick
+    size_t pose_cap[2] = {};
+    hipEvent_t pose_ev[2] = {};
+    unsigned pose_turn = 0;
     size_t stage_up_cap = 0, stage_down_cap = 0;
     // alore_nmpc_rti_many: launches of independent batches in flight at once (side streams forked from the caller's)
     int overlap = 16;
@@ -278,6 +282,10 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     if (h->refs.meta) (void)hipFree(h->refs.meta);
     for (int i = 0; i < 2; ++i)
         if (h->cl_psi[i]) (void)hipFree(h->cl_psi[i]);
+    for (int i = 0; i < 2; ++i) {
+        if (h->pose_ev[i]) { (void)hipEventSynchronize(h->pose_ev[i]); (void)hipEventDestroy(h->pose_ev[i]); }
+        if (h->pose_stage[i]) (void)hipHostFree(h->pose_stage[i]);
+    }
     if (h->cl_y) (void)hipFree(h->cl_y);
     if (h->cl_yN) (void)hipFree(h->cl_yN);
     if (h->d_est) (void)hipFree(h->d_est);
@@ -1246,8 +1254,26 @@ int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch* dev, int
         return fail(h, ALORE_NMPC_E_INVALID, "refs_sample: bad argument");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(h, hipMemcpyAsync(h->d_est, est, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemcpyAsync(h->d_icr, icr, sizeof(double) * B * 3, hipMemcpyHostToDevice, s));
+    // pose and ICR from pageable memory go through pinned staging (two buffers in turn, so that the call never waits for its
+    // predecessor's copies): a hipMemcpyAsync out of pageable memory blocks the host for the whole transfer, twice per tick
+    const size_t bytes = sizeof(double) * (size_t)B * 3;
+    const double *se = est, *si = icr;
+    int turn = -1;
+    if (!host_is_pinned(est) || !host_is_pinned(icr)) {
+        turn = h->pose_turn++ & 1;
+        if (h->pose_ev[turn]) HIP_TRY(h, hipEventSynchronize(h->pose_ev[turn]));
+        if (int rc = grow_stage(h, h->pose_stage[turn], h->pose_cap[turn], 2 * bytes)) return rc;
+        std::memcpy(h->pose_stage[turn], est, bytes);
+        std::memcpy(h->pose_stage[turn] + bytes, icr, bytes);
+        se = reinterpret_cast<const double*>(h->pose_stage[turn]);
+        si = reinterpret_cast<const double*>(h->pose_stage[turn] + bytes);
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_est, se, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_icr, si, bytes, hipMemcpyHostToDevice, s));
+    if (turn >= 0) {
+        if (!h->pose_ev[turn]) HIP_TRY(h, hipEventCreateWithFlags(&h->pose_ev[turn], hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->pose_ev[turn], s));
+    }
     HIP_TRY(h, nmpc::launch_ref_sample(h->refs, *dev, B, h->cfg.N, (double)h->cfg.dt, now, h->d_est, h->d_icr, h->d_goal,
                                        h->d_psi, do_smooth, s));
     if (at_goal) {

@@ -87,6 +87,7 @@ public:
     {
         if (h_) {
             if (d_mask_) (void)hipFree(d_mask_);
+            if (goal_pinned_) (void)alore_nmpc_host_free(goal_pinned_);
             alore_nmpc_batch_free(h_, &dev_);
             alore_nmpc_destroy(h_);
         }
@@ -221,7 +222,14 @@ public:
         run.kkt = nullptr; run.obj = nullptr;
         check(alore_nmpc_rti(h_, &run, B, 1, nullptr));
         x_stale_ = true;
-        if (pending_goal_) { check(alore_nmpc_refs_at_goal(h_, B, pending_goal_, nullptr)); pending_goal_ = nullptr; }
+        // the at-goal flags come back through pinned memory (a copy into pageable memory blocks the host until the stream has drained to it)
+        // and are handed over behind the tick's one synchronisation below
+        int* goal_out = pending_goal_;
+        pending_goal_ = nullptr;
+        if (goal_out) {
+            if (!goal_pinned_ && alore_nmpc_host_alloc(sizeof(int) * (size_t)B, (void**)&goal_pinned_) != ALORE_NMPC_OK) throw std::runtime_error("alore_nmpc_host_alloc (at-goal flags)");
+            check(alore_nmpc_refs_at_goal(h_, B, goal_pinned_, nullptr));
+        }
         if (cmd_node >= 0 && cmd_node < kSamples) {
             cmd_.resize((size_t)B * 2);
             check(alore_nmpc_input_column(h_, &dev_, B, cmd_node, cmd_.data(), status_.data(), nullptr)); // waits for the stream
@@ -235,6 +243,7 @@ public:
             u_stale_ = false;
         }
         if (hipStreamSynchronize(nullptr) != hipSuccess) throw std::runtime_error("hipStreamSynchronize");
+        if (goal_out) std::memcpy(goal_out, goal_pinned_, sizeof(int) * (size_t)B);
         acado_is_prepared_ = false;
         if (do_preparation) acado_is_prepared_ = true; // the preparation is fused into the next launch
         return true;
@@ -314,6 +323,7 @@ private:
     bool acado_is_prepared_ = false, dirty_costs_ = true, dirty_iterate_ = true, device_refs_ = false;
     mutable bool x_stale_ = false; // x_ lags the device copy (downloaded on demand)
     int* pending_goal_ = nullptr;
+    int* goal_pinned_ = nullptr; // pinned landing area of the at-goal flags
     unsigned char* d_mask_ = nullptr; // device copy of the solve mask of the tick (setSolveMask)
     const double dt_;
 };
