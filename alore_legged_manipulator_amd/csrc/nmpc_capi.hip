@@ -288,8 +288,7 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
     }
     if (h->cl_y) (void)hipFree(h->cl_y);
     if (h->cl_yN) (void)hipFree(h->cl_yN);
-    if (h->d_est) (void)hipFree(h->d_est);
-    if (h->d_icr) (void)hipFree(h->d_icr);
+    if (h->d_est) (void)hipFree(h->d_est); // d_icr is its second half
     if (h->d_psi) (void)hipFree(h->d_psi);
     if (h->d_goal) (void)hipFree(h->d_goal);
     if (h->d_vw) (void)hipFree(h->d_vw);
@@ -1053,8 +1052,7 @@ int alore_nmpc_refs_init(alore_nmpc_handle h, int B, int max_pieces, int max_che
         {(void**)&h->refs.coef, sizeof(double) * B * max_pieces * 12},
         {(void**)&h->refs.ckpt, sizeof(double) * B * max_checkpoints * 2},
         {(void**)&h->refs.meta, sizeof(double) * B * 8},
-        {(void**)&h->d_est, sizeof(double) * B * 3},
-        {(void**)&h->d_icr, sizeof(double) * B * 3},
+        {(void**)&h->d_est, sizeof(double) * B * 6}, // pose [B][3], then ICR [B][3]: one block, one copy per tick
         {(void**)&h->d_psi, sizeof(double) * B * (h->cfg.N + 1)},
         {(void**)&h->d_goal, sizeof(int) * B},
     };
@@ -1072,6 +1070,7 @@ int alore_nmpc_refs_init(alore_nmpc_handle h, int B, int max_pieces, int max_che
         h->refs_B = 0;
         return fail(h, ALORE_NMPC_E_NOMEM, "refs_init: hipMalloc", e);
     }
+    h->d_icr = h->d_est + (size_t)B * 3;
     return ALORE_NMPC_OK;
 }
 
@@ -1268,8 +1267,12 @@ int alore_nmpc_refs_sample(alore_nmpc_handle h, const alore_nmpc_batch* dev, int
         se = reinterpret_cast<const double*>(h->pose_stage[turn]);
         si = reinterpret_cast<const double*>(h->pose_stage[turn] + bytes);
     }
-    HIP_TRY(h, hipMemcpyAsync(h->d_est, se, bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(h, hipMemcpyAsync(h->d_icr, si, bytes, hipMemcpyHostToDevice, s));
+    if (turn >= 0 && B == h->refs_B) { // staged back to back, stored back to back: one copy
+        HIP_TRY(h, hipMemcpyAsync(h->d_est, se, 2 * bytes, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->d_est, se, bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(h->d_icr, si, bytes, hipMemcpyHostToDevice, s));
+    }
     if (turn >= 0) {
         if (!h->pose_ev[turn]) HIP_TRY(h, hipEventCreateWithFlags(&h->pose_ev[turn], hipEventDisableTiming));
         HIP_TRY(h, hipEventRecord(h->pose_ev[turn], s));

@@ -390,15 +390,23 @@ public:
         robots.at((size_t)b).emergencyStop();
         if (out) { *out = RobotCommand{}; out->state_published = true; }
     }
+    std::vector<double> tick_est_, tick_icr_;
+    std::vector<int> tick_goal_, tick_fresh_robots_;
+    std::vector<const Polynome*> tick_fresh_msgs_;
+    std::vector<char> tick_solving_;
     // One CmdCallback for every robot.  cmd: B entries.  A robot without odometry or trajectory publishes nothing.
     void tick(double now, RobotCommand* cmd)
     {
         const int B = mpc_wrapper_.B, N = mpc_wrapper_.kSamples;
         const int node = params_.delay_num < N ? params_.delay_num : N - 1;
-        std::vector<double> est((size_t)B * 3, 0.0), icr((size_t)B * 3, 0.0);
-        std::vector<int> goal(B, 0), fresh_robots;
-        std::vector<const Polynome*> fresh_msgs;
-        std::vector<char> solving(B, 0);
+        // the tick's work arrays are members: nothing is allocated per tick
+        std::vector<double>&est = tick_est_, &icr = tick_icr_;
+        std::vector<int>&goal = tick_goal_, &fresh_robots = tick_fresh_robots_;
+        std::vector<const Polynome*>& fresh_msgs = tick_fresh_msgs_;
+        std::vector<char>& solving = tick_solving_;
+        est.assign((size_t)B * 3, 0.0); icr.assign((size_t)B * 3, 0.0);
+        goal.assign(B, 0); solving.assign(B, 0);
+        fresh_robots.clear(); fresh_msgs.clear();
         for (int b = 0; b < B; ++b) {
             RobotNode& r = robots[b];
             cmd[b] = RobotCommand{};
