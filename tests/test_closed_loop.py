@@ -159,19 +159,20 @@ def test_device_closed_loop_matches_host_driven_loop():
         assert _m.hypot(pose_d[b, 0] - ref[0], pose_d[b, 1] - ref[1]) < 0.15 and abs(pose_d[b, 2] - ref[2]) < 0.3, (b, pose_d[b], ref)
 
 
-@pytest.mark.parametrize("B,tick_counts", [(16, (150, 37)), (600, (24,)), (4104, (13,))])
-def test_closed_loop_run_samples_ahead_and_returns_what_tick_by_tick_returns(B, tick_counts):
+@pytest.mark.parametrize("B,N,tick_counts", [(16, 20, (150, 37)), (600, 20, (24,)), (4104, 20, (13,)), (16, 12, (24,)), (16, 40, (24,))])
+def test_closed_loop_run_samples_ahead_and_returns_what_tick_by_tick_returns(B, N, tick_counts):
     """alore_nmpc_closed_loop_run issues one launch per tick: the pose-independent sampling of tick t + 1 on extra workgroups of
     the grid that solves tick t (two reference buffers), the plant step of tick t - 1 -- which writes x0 and shifts the headings
     by the turns smooth_yaw's first step finds, mpc.cpp:248-277 -- in front of the solve.  The plant states, the iterate and the
     references after the run must be those of the same ticks issued one by one.  The robots cover a heading that crosses pi (the
     walk starts one turn away from the normalised references), a trajectory that ends inside the run (at-goal flag, zero
     command), a robot without a trajectory (its references stay the caller's) and both parities of the tick count (the last tick
-    reads the caller's buffer or the internal one).  B = 16 runs the (32, 1) mapping, 600 the (16, 2) mapping, 4104 a mapping
-    without such a build ((8, 3): plant step, solve and sampler are launches in a row)."""
+    reads the caller's buffer or the internal one).  B = 16 runs the (32, 1) mapping, 600 the (16, 2) mapping, 4104 the (8, 3)
+    mapping (plant step in the solver's grid, the sampler a launch of its own); N = 12 a shorter horizon on the same builds, N = 40
+    a horizon whose mapping has no such build (plant step, solve and sampler are launches in a row)."""
     from alore_legged_manipulator_amd.nmpc import BatchedNmpc
     from alore_legged_manipulator_amd.host import Polynome
-    N, dt = 20, 0.01
+    dt = 0.01
     rng = np.random.default_rng(11)
     msgs, robots = [], []
     pose0 = np.zeros((B, 3))
