@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Time per tick of the device-resident closed loop (bench.py's device_closed_loop leg alone): B robots, 200 ticks."""
+"""Time per tick of the device-resident closed loop (bench.py's device_closed_loop leg alone): B robots, 200 ticks.
+
+    python3 tools/closed_loop_time.py [robots]
+Environment (experiments): ALORE_NMPC_CLOSED_LOOP_SERIAL=1 (library: the three kernels of a tick in a row), CL_LANES (lanes_per_problem of
+the engine, e.g. 272 = the (16, 2) stage-block mapping), CL_PG (warm_start_steps), CL_SHARED=1 (W / bounds / od as one copy), CL_STREAM=1
+(a torch stream of its own instead of the default stream)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
