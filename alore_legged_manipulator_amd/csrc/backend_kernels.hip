@@ -232,14 +232,17 @@ struct Lds {
     double gdT[P];
     double gk[2][P + 1][3];                           // gradient w.r.t. the knot states
     double cy[P * NS], sy[P * NS], fx[P * NS], fy[P * NS]; // fx / fy become the chain coefficients
-    double E[P * NS * 6];                             // node terms of the coefficient gradient [node][E0 E1 E2][d]
+    // node terms of the coefficient gradient, [order 0 1 2][dimension theta s] per node -- stored without the entries that are zero
+    // by construction (no penalty acts on s itself: order 0 of s is never written; the order-2 terms come from the penalties of
+    // pass A, which sit on the even nodes only): Ea = [node][order 0 of theta, order 1 of theta, order 1 of s], Eb = [even node]
+    // [order 2 of theta, order 2 of s].  8.8 KB instead of 13 (with the knot factors gone: five workgroups per CU instead of four)
+    double Ea[P * NS * 3];
+    double Eb[P * (RES + 1) * 2];
     double nodeT[P * NS];
     double posx[RES * P + 1], posy[RES * P + 1];      // pose at the Simpson panel ends
     double x[3 * P], g[3 * P], d[3 * P], xp[3 * P], gp[3 * P];
     double alpha[MEM_MAX];
     double pf[16];
-    // elimination factors of the knot system of this evaluation (knot_pcr): per step and knot alpha, gamma (2 x 2 each), then D^-1
-    double pcr_f[P <= 16 ? 4 : 5][P <= 16 ? 16 : 32][8], pcr_d[P <= 16 ? 16 : 32][4];
 };
 
 extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -287,7 +290,7 @@ template <int S, bool DPP> __device__ __forceinline__ B2 lane_down(const B2& m) 
 struct PcrState { B2 Lk, Dk, Uk; double r0, r1, r2, r3; };
 
 template <int S, bool DPP>
-__device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk, LDSQ double* fac)
+__device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk, double (&fac)[8])
 {
     const B2 Lm = lane_up<S, DPP>(q.Lk), Dm = lane_up<S, DPP>(q.Dk), Um = lane_up<S, DPP>(q.Uk);
     const double m0 = lane_up<S, DPP>(q.r0), m1 = lane_up<S, DPP>(q.r1), m2 = lane_up<S, DPP>(q.r2), m3 = lane_up<S, DPP>(q.r3);
@@ -314,11 +317,11 @@ __device__ __forceinline__ void pcr_step(PcrState& q, bool act, int e, int nk, L
     } else q.Uk = {0, 0, 0, 0};
 }
 
-// the same elimination on right-hand sides only, with the factors a factorising call left in LDS (the knot matrix of an
+// the same elimination on right-hand sides only, with the factors a factorising call left in the lane's registers (the knot matrix of an
 // evaluation serves twice: spline, then its adjoint): a step is 16 shifted values + 16 multiply-adds instead of two 2 x 2
 // inverses and four block products
 template <int S, bool DPP>
-__device__ __forceinline__ void pcr_replay(double (&r)[4], const LDSQ double* fac)
+__device__ __forceinline__ void pcr_replay(double (&r)[4], const double (&fac)[8])
 {
     const double m0 = lane_up<S, DPP>(r[0]), m1 = lane_up<S, DPP>(r[1]), m2 = lane_up<S, DPP>(r[2]), m3 = lane_up<S, DPP>(r[3]);
     const double p0 = lane_down<S, DPP>(r[0]), p1 = lane_down<S, DPP>(r[1]), p2 = lane_down<S, DPP>(r[2]), p3 = lane_down<S, DPP>(r[3]);
@@ -330,25 +333,27 @@ __device__ __forceinline__ void pcr_replay(double (&r)[4], const LDSQ double* fa
 }
 
 // rhs / solution: y[d][lane][0..1] in LDS for d = 0, 1 (the caller's layout); all 64 lanes must call.  REPLAY = false
-// factorises (and leaves the factors in L.pcr_f / L.pcr_d), REPLAY = true solves with the factors of the last factorising call.
+// factorises (and leaves the factors of the lane's knot in F / D: registers of the caller -- 4.6 KB of LDS until round 5, which
+// cost a workgroup per CU), REPLAY = true solves with the factors of the last factorising call.
+struct PcrFactors { double F[5][8], D[4]; };
 template <int P, bool REPLAY>
-__device__ __forceinline__ void knot_pcr(LDSQ Lds<P>& L, int M, const LDSQ double* T, LDSQ double (*y0)[2], LDSQ double (*y1)[2])
+__device__ __forceinline__ void knot_pcr(LDSQ Lds<P>& L, int M, const LDSQ double* T, LDSQ double (*y0)[2], LDSQ double (*y1)[2], PcrFactors& pf)
 {
     constexpr bool DPP = P <= 16; // all knots (<= 15) in one DPP row
     constexpr int PL = P <= 16 ? 16 : 32;
     const int e = threadIdx.x, nk = M - 1;
     const bool act = e < nk;
-    const int el = act ? e : PL - 1; // slot PL - 1 is never a knot: the idle lanes keep zero factors there (finite operands for them)
+    (void)PL; // idle lanes (e >= nk) compute zero factors of their own (no neighbour on either side) and never use D
     if constexpr (REPLAY) {
         double r[4] = {0.0, 0.0, 0.0, 0.0};
         if (act) { r[0] = y0[e][0]; r[1] = y0[e][1]; r[2] = y1[e][0]; r[3] = y1[e][1]; }
-        if (1 < nk) pcr_replay<1, DPP>(r, L.pcr_f[0][el]);
-        if (2 < nk) pcr_replay<2, DPP>(r, L.pcr_f[1][el]);
-        if (4 < nk) pcr_replay<4, DPP>(r, L.pcr_f[2][el]);
-        if (8 < nk) pcr_replay<8, DPP>(r, L.pcr_f[3][el]);
-        if constexpr (P > 16) { if (16 < nk) pcr_replay<16, false>(r, L.pcr_f[4][el]); }
+        if (1 < nk) pcr_replay<1, DPP>(r, pf.F[0]);
+        if (2 < nk) pcr_replay<2, DPP>(r, pf.F[1]);
+        if (4 < nk) pcr_replay<4, DPP>(r, pf.F[2]);
+        if (8 < nk) pcr_replay<8, DPP>(r, pf.F[3]);
+        if constexpr (P > 16) { if (16 < nk) pcr_replay<16, false>(r, pf.F[4]); }
         if (act) {
-            const B2 di{L.pcr_d[el][0], L.pcr_d[el][1], L.pcr_d[el][2], L.pcr_d[el][3]};
+            const B2 di{pf.D[0], pf.D[1], pf.D[2], pf.D[3]};
             y0[e][0] = di.a * r[0] + di.b * r[1]; y0[e][1] = di.c * r[0] + di.d * r[1];
             y1[e][0] = di.a * r[2] + di.b * r[3]; y1[e][1] = di.c * r[2] + di.d * r[3];
         }
@@ -364,16 +369,14 @@ __device__ __forceinline__ void knot_pcr(LDSQ Lds<P>& L, int M, const LDSQ doubl
         if (k < M - 1) { const minco::Mat2 u = minco::knot_upper(r); q.Uk = {u.a, u.b, u.c, u.d}; }
         q.r0 = y0[e][0]; q.r1 = y0[e][1]; q.r2 = y1[e][0]; q.r3 = y1[e][1];
     }
-    LDSQ double* f0 = L.pcr_f[0][el];
-    const int fstep = PL * 8;
-    if (1 < nk) pcr_step<1, DPP>(q, act, e, nk, f0);
-    if (2 < nk) pcr_step<2, DPP>(q, act, e, nk, f0 + fstep);
-    if (4 < nk) pcr_step<4, DPP>(q, act, e, nk, f0 + 2 * fstep);
-    if (8 < nk) pcr_step<8, DPP>(q, act, e, nk, f0 + 3 * fstep);
-    if constexpr (P > 16) { if (16 < nk) pcr_step<16, false>(q, act, e, nk, f0 + 4 * fstep); }
+    if (1 < nk) pcr_step<1, DPP>(q, act, e, nk, pf.F[0]);
+    if (2 < nk) pcr_step<2, DPP>(q, act, e, nk, pf.F[1]);
+    if (4 < nk) pcr_step<4, DPP>(q, act, e, nk, pf.F[2]);
+    if (8 < nk) pcr_step<8, DPP>(q, act, e, nk, pf.F[3]);
+    if constexpr (P > 16) { if (16 < nk) pcr_step<16, false>(q, act, e, nk, pf.F[4]); }
     if (act) {
         const B2 di = inv2(q.Dk);
-        L.pcr_d[el][0] = di.a; L.pcr_d[el][1] = di.b; L.pcr_d[el][2] = di.c; L.pcr_d[el][3] = di.d;
+        pf.D[0] = di.a; pf.D[1] = di.b; pf.D[2] = di.c; pf.D[3] = di.d;
         y0[e][0] = di.a * q.r0 + di.b * q.r1; y0[e][1] = di.c * q.r0 + di.d * q.r1;
         y1[e][0] = di.a * q.r2 + di.b * q.r3; y1[e][1] = di.c * q.r2 + di.d * q.r3;
     }
@@ -443,7 +446,10 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     }
     __syncthreads();
     BE_STAMP(2)
-    knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1]);
+    {
+        PcrFactors pcr; // not kept: the adjoint solve below eliminates again (see there)
+        knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1], pcr);
+    }
     __syncthreads();
     for (int t = lane; t < 2 * (M - 1); t += 64) { // lane = (knot, dim): one round (was a walk over the knots on two lanes)
         const int k = 1 + (t >> 1), d = t & 1;
@@ -532,8 +538,12 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
                          (gb[1][0] += ws * c.w_cen_acc * df * (2 * d1[0] * d1[1] * d1[1]),
                           gb[1][1] += ws * c.w_cen_acc * df * (2 * d1[0] * d1[0] * d1[1])));
         }
-        LDSQ double* E = L.E + node * 6;
-        E[0] = gb[0][0]; E[1] = gb[0][1]; E[2] = gb[1][0]; E[3] = gb[1][1]; E[4] = gb[2][0]; E[5] = gb[2][1];
+        LDSQ double* E = L.Ea + node * 3;
+        E[0] = gb[0][0]; E[1] = gb[1][0]; E[2] = gb[1][1]; // gb[0][1] stays zero: nothing penalises s itself
+        if ((j & 1) == 0) {
+            LDSQ double* E2 = L.Eb + (i * (RES + 1) + (j >> 1)) * 2;
+            E2[0] = gb[2][0]; E2[1] = gb[2][1];
+        }
         L.nodeT[node] = gT;
     }
     __syncthreads();
@@ -609,7 +619,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
             }
             L.fx[node] = gpx;
             L.fy[node] = gpy;
-            L.E[node * 6 + 0] += gb0;
+            L.Ea[node * 3 + 0] += gb0;
             L.nodeT[node] += gT;
         }
     } else { // way-point attraction at the end of every piece
@@ -664,10 +674,10 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         const double fxv = d1[1] * cy + d1[0] * xvI * sy, fyv = d1[1] * sy - d1[0] * xvI * cy;
         // d(dx)/d(theta coefficients) = b0 (-s' sin + th' xv cos) + b1 xv sin ; d(dy)/.. = b0 (s' cos - th' xv sin) - b1 xv cos
         // (the reference's sign of the th' xv sin term, optimizer.cpp:822; exact would be +)
-        LDSQ double* E = L.E + node * 6;
+        LDSQ double* E = L.Ea + node * 3;
         E[0] += cint * ((-d1[1] * sy + d1[0] * xvI * cy) * cx + (d1[1] * cy - d1[0] * xvI * sy) * cyy);
-        E[2] += cint * xvI * (sy * cx - cy * cyy);
-        E[3] += cint * (cy * cx + sy * cyy);
+        E[1] += cint * xvI * (sy * cx - cy * cyy);
+        E[2] += cint * (cy * cx + sy * cyy);
         const double XT = (d2[1] * cy - d1[1] * d1[0] * sy + d2[0] * xvI * sy + d1[0] * d1[0] * xvI * cy) * ialpha * cint + div_res6(fxv);
         const double YT = (d2[1] * sy + d1[1] * d1[0] * cy - d2[0] * xvI * cy + d1[0] * d1[0] * xvI * sy) * ialpha * cint + div_res6(fyv);
         L.nodeT[node] += XT * cx + YT * cyy;
@@ -683,8 +693,9 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         const double half = L.T[i] / (2 * RES);
         double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int j = 0; j < NS; ++j) {
-            const LDSQ double* E = L.E + (i * NS + j) * 6;
-            const double tt = j * half, E0 = E[d], E1 = E[2 + d], E2 = E[4 + d];
+            const LDSQ double* E = L.Ea + (i * NS + j) * 3;
+            const double tt = j * half, E0 = (d == 0) ? E[0] : 0.0, E1 = E[1 + d],
+                         E2 = ((j & 1) == 0) ? L.Eb[(i * (RES + 1) + (j >> 1)) * 2 + d] : 0.0;
             double pw[6];
             pw[0] = 1.0;
 #pragma unroll
@@ -707,21 +718,21 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     BE_STAMP(12)
     // ---- adjoint of the spline: coefficient gradient -> knot-state gradient -> knot system -> variables
     // phase 1: every (piece, dim) lane turns its coefficient gradient into the gradients of its two knot states;
-    // the start knot is written directly, the end knot goes through a staging slot (E is free by now)
+    // the start knot is written directly, the end knot goes through a staging slot (Ea is free by now)
     for (int t = lane; t < 2 * M; t += 64) {
         const int i = t >> 1, d = t & 1;
         const minco::InvT q(L.T[i], L.iT[i]);
         double G[6], g0[3], g1[3];
         for (int k = 0; k < 6; ++k) G[k] = L.gdC[(6 * i + k) * 2 + d];
         minco::hermite_adjoint(q, G, g0, g1);
-        for (int k = 0; k < 3; ++k) { L.gk[d][i][k] = g0[k]; L.E[t * 3 + k] = g1[k]; }
+        for (int k = 0; k < 3; ++k) { L.gk[d][i][k] = g0[k]; L.Ea[t * 3 + k] = g1[k]; }
         if (i == M - 1) for (int k = 0; k < 3; ++k) L.gk[d][M][k] = 0.0;
     }
     __syncthreads();
     BE_STAMP(13)
     for (int t = lane; t < 2 * M; t += 64) {
         const int i = t >> 1, d = t & 1;
-        for (int k = 0; k < 3; ++k) L.gk[d][i + 1][k] += L.E[t * 3 + k];
+        for (int k = 0; k < 3; ++k) L.gk[d][i + 1][k] += L.Ea[t * 3 + k];
     }
     __syncthreads();
     BE_STAMP(14)
@@ -732,7 +743,13 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     }
     __syncthreads();
     BE_STAMP(15)
-    knot_pcr<P, true>(L, M, L.T, L.y[0], L.y[1]); // K is symmetric: the same system, its factors are in LDS
+    // K is symmetric: the same system.  Its elimination is done again rather than replayed from stored factors: kept in LDS they were
+    // 4.6 KB -- a workgroup per CU --, kept in registers across the passes between the two solves they pushed the kernel past 256
+    // registers (one wavefront per SIMD); the second elimination costs 3 % of an evaluation
+    {
+        PcrFactors pcr;
+        knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1], pcr);
+    }
     __syncthreads();
     BE_STAMP(16)
     // way-point and tail gradients: lane = (knot 1..M, dim)
@@ -1318,9 +1335,12 @@ __device__ void load_problem(const Params& prm, unsigned lbase, int b)
 
 } // namespace
 
-// LDS admits four workgroups per CU (one wavefront per SIMD): the register file of a SIMD belongs to one wavefront
+// Round 5: LDS admits FIVE workgroups per CU (31.6 KB each) and the kernel keeps to 256 registers (waves_per_eu(2, 2): 251 with the
+// same 300 B of scratch as the 254 it took with a SIMD to itself), so one SIMD of a CU holds a second wavefront: 8192 plans
+// 49.0 -> 46.2 ms.  (Measured the other way first: a padded block that admits three workgroups per CU takes 63.5 ms -- the launch is
+// total work / slots.)
 template <int P>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void backend_kernel(const Params* __restrict__ gp)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void backend_kernel(const Params* __restrict__ gp)
 {
     if (gp->stamps && blockIdx.x == 0 && threadIdx.x == 0) gp->stamps[63] = (long long)__builtin_readcyclecounter();
     const Params& prm = *gp;
@@ -1471,8 +1491,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
-// four workgroups of the 16-piece build share a CU's 160 KB (one wavefront per SIMD): 40400 B today
-static_assert(sizeof(Lds<16>) <= 160 * 1024 / 4, "Lds<16> must leave room for four workgroups per CU");
+// five workgroups of the 16-piece build share a CU's 160 KB: 31568 B today (round 4: 40400 B, four workgroups)
+static_assert(sizeof(Lds<16>) <= 160 * 1024 / 5, "Lds<16> must leave room for five workgroups per CU");
 
 size_t lds_bytes(int P)
 {
