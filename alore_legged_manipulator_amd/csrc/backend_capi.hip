@@ -24,7 +24,7 @@ struct alore_backend_planner {
     int* r_ok = nullptr;
     backend::Status* r_status = nullptr;
     // workspace
-    double *d_hist = nullptr, *d_gram = nullptr, *d_x = nullptr, *d_g = nullptr, *d_lam = nullptr, *d_rho = nullptr, *d_cost = nullptr, *d_err = nullptr;
+    double *d_hist = nullptr, *d_gram = nullptr, *d_pcr = nullptr, *d_x = nullptr, *d_g = nullptr, *d_lam = nullptr, *d_rho = nullptr, *d_cost = nullptr, *d_err = nullptr;
     int* d_ret = nullptr;
     long long* d_stamps = nullptr; // ALORE_BE_STAMPS=1: diagnostic phase cycles of workgroup 0
     backend::Params* d_params = nullptr; // the kernel reads its parameter block from here
@@ -72,7 +72,7 @@ void free_all(alore_backend_handle h)
         (void)hipFree(h->d_stamps);
     }
     void* ptrs[] = {h->d_map, h->d_M, h->d_cut, h->d_inner, h->d_initT, h->d_pos, h->d_head, h->d_tail, h->d_sxy, h->d_fxy, h->d_sxyt,
-                    h->r_inner, h->r_T, h->r_coef, h->r_tail, h->r_ok, h->r_status, h->d_hist, h->d_gram, h->d_x, h->d_g, h->d_lam, h->d_rho,
+                    h->r_inner, h->r_T, h->r_coef, h->r_tail, h->r_ok, h->r_status, h->d_hist, h->d_gram, h->d_pcr, h->d_x, h->d_g, h->d_lam, h->d_rho,
                     h->d_cost, h->d_err, h->d_ret, h->d_params, h->d_order};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -90,6 +90,7 @@ backend::Params base_params(alore_backend_handle h, int count, int mode)
     p.res = backend::ResultStore{h->r_inner, h->r_T, h->r_coef, h->r_tail, h->r_ok, h->r_status};
     p.hist = h->d_hist;
     p.gram = h->d_gram;
+    p.pcr = h->d_pcr;
     p.count = count;
     p.mode = mode;
     p.x_io = h->d_x;
@@ -162,6 +163,7 @@ int alore_backend_create(const alore_backend_config* cfg, int device, int max_pi
     A(dalloc(&h->r_ok, B)); A(dalloc(&h->r_status, B));
     A(dalloc(&h->d_hist, B * backend::MEM_MAX * 2 * ns));
     A(dalloc(&h->d_gram, B * (size_t)backend::GRAM_DOUBLES));
+    A(dalloc(&h->d_pcr, B * (size_t)backend::PCR_DOUBLES));
     if (std::getenv("ALORE_BE_STAMPS")) A(dalloc(&h->d_stamps, (size_t)64));
     A(dalloc(&h->d_x, B * ns)); A(dalloc(&h->d_g, B * ns)); A(dalloc(&h->d_lam, B * 2)); A(dalloc(&h->d_rho, B * 2));
     A(dalloc(&h->d_cost, B)); A(dalloc(&h->d_err, B * 2)); A(dalloc(&h->d_ret, B * 3)); A(dalloc(&h->d_params, 1)); A(dalloc(&h->d_order, B));

@@ -446,9 +446,22 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     }
     __syncthreads();
     BE_STAMP(2)
+    // the lane's elimination factors leave through global memory (4.6 KB per problem, read back once for the adjoint solve below:
+    // kept in LDS they cost a workgroup per CU, kept in registers across the passes in between a wavefront per SIMD, and
+    // eliminating twice costs 9 % more instructions per plan)
+    constexpr int PCR_PL = P <= 16 ? 16 : 32, PCR_ST = P <= 16 ? 4 : 5;
+    GLBQ double* pcr_ws = (GLBQ double*)uni_ptr(prm.pcr) + (size_t)uni(e.prob) * PCR_DOUBLES;
     {
-        PcrFactors pcr; // not kept: the adjoint solve below eliminates again (see there)
+        PcrFactors pcr;
         knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1], pcr);
+        if (lane < PCR_PL) {
+#pragma unroll
+            for (int st = 0; st < PCR_ST; ++st)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pcr_ws[(st * PCR_PL + lane) * 8 + k] = pcr.F[st][k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pcr_ws[PCR_ST * PCR_PL * 8 + lane * 4 + k] = pcr.D[k];
+        }
     }
     __syncthreads();
     for (int t = lane; t < 2 * (M - 1); t += 64) { // lane = (knot, dim): one round (was a walk over the knots on two lanes)
@@ -743,12 +756,23 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     }
     __syncthreads();
     BE_STAMP(15)
-    // K is symmetric: the same system.  Its elimination is done again rather than replayed from stored factors: kept in LDS they were
-    // 4.6 KB -- a workgroup per CU --, kept in registers across the passes between the two solves they pushed the kernel past 256
-    // registers (one wavefront per SIMD); the second elimination costs 3 % of an evaluation
-    {
+    { // K is symmetric: the same system, replayed with the factors of the spline solve (read back from the problem's workspace)
         PcrFactors pcr;
-        knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1], pcr);
+#pragma unroll
+        for (int st = 0; st < 5; ++st)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pcr.F[st][k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pcr.D[k] = 0.0;
+        if (lane < PCR_PL) {
+#pragma unroll
+            for (int st = 0; st < PCR_ST; ++st)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pcr.F[st][k] = pcr_ws[(st * PCR_PL + lane) * 8 + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pcr.D[k] = pcr_ws[PCR_ST * PCR_PL * 8 + lane * 4 + k];
+        }
+        knot_pcr<P, true>(L, M, L.T, L.y[0], L.y[1], pcr);
     }
     __syncthreads();
     BE_STAMP(16)
@@ -1335,10 +1359,11 @@ __device__ void load_problem(const Params& prm, unsigned lbase, int b)
 
 } // namespace
 
-// Round 5: LDS admits FIVE workgroups per CU (31.6 KB each) and the kernel keeps to 256 registers (waves_per_eu(2, 2): 251 with the
-// same 300 B of scratch as the 254 it took with a SIMD to itself), so one SIMD of a CU holds a second wavefront: 8192 plans
-// 49.0 -> 46.2 ms.  (Measured the other way first: a padded block that admits three workgroups per CU takes 63.5 ms -- the launch is
-// total work / slots.)
+// Round 5: LDS admits FIVE workgroups per CU (31.6 KB each: the knot factors travel through global memory, the node terms are
+// stored without their structural zeros) and the kernel keeps to 256 registers (waves_per_eu(2, 2): 256 and 340 B of scratch
+// against 254 and 300 B with a SIMD to itself), so one SIMD of a CU holds a second wavefront: 8192 plans 49.0 -> 44.1 ms, the
+// same evaluations plan by plan.  (Measured the other way first: a padded block that admits three workgroups per CU takes
+// 63.5 ms -- the launch is total work / slots.  With the adjoint solve eliminating again instead of replaying: 46.2 ms.)
 template <int P>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void backend_kernel(const Params* __restrict__ gp)
 {
