@@ -163,7 +163,7 @@ int alore_backend_create(const alore_backend_config* cfg, int device, int max_pi
     A(dalloc(&h->r_ok, B)); A(dalloc(&h->r_status, B));
     A(dalloc(&h->d_hist, B * backend::MEM_MAX * 2 * ns));
     A(dalloc(&h->d_gram, B * (size_t)backend::GRAM_DOUBLES));
-    A(dalloc(&h->d_pcr, B * (size_t)backend::PCR_DOUBLES));
+    A(dalloc(&h->d_pcr, B * (size_t)backend::WS_DOUBLES));
     if (std::getenv("ALORE_BE_STAMPS")) A(dalloc(&h->d_stamps, (size_t)64));
     A(dalloc(&h->d_x, B * ns)); A(dalloc(&h->d_g, B * ns)); A(dalloc(&h->d_lam, B * 2)); A(dalloc(&h->d_rho, B * 2));
     A(dalloc(&h->d_cost, B)); A(dalloc(&h->d_err, B * 2)); A(dalloc(&h->d_ret, B * 3)); A(dalloc(&h->d_params, 1)); A(dalloc(&h->d_order, B));

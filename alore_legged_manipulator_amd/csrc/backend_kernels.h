@@ -15,6 +15,9 @@ constexpr int MEM_MAX = 256; // L-BFGS history slots per problem (global_plannin
 // per problem, next to the history: for every aligned chunk of 8 slots the 8 x 8 block G[k][l] = s_k . y_l (k < l; the rest stays
 // zero) row by row, its transpose, then y's and 1 / y's per slot (backend_kernels.hip: two_loop_gram)
 constexpr int PCR_DOUBLES = 5 * 32 * 8 + 32 * 4; // per problem: [step][knot][alpha, gamma (2 x 2 each)], then [knot][D^-1]
+// ... followed in the same per-problem workspace by two node arrays of an evaluation that are written and read once or twice and so need
+// no LDS: the order-2 node terms of the even nodes [32 * 9][2] and the duration-gradient terms per node [32 * 17]
+constexpr int WS_EB = PCR_DOUBLES, WS_NODET = WS_EB + 32 * 9 * 2, WS_DOUBLES = WS_NODET + 32 * 17;
 constexpr int GRAM_G = 0, GRAM_GT = (MEM_MAX / 8) * 64, GRAM_YS = 2 * GRAM_GT, GRAM_RYS = GRAM_YS + MEM_MAX, GRAM_DOUBLES = GRAM_RYS + MEM_MAX;
 
 enum Mode { MODE_PLAN = 0, MODE_EVAL = 1, MODE_LBFGS = 2 };
@@ -55,7 +58,7 @@ struct Params {
     ResultStore res;
     double* hist; // [B][MEM_MAX][2][3P]
     double* gram; // [B][GRAM_DOUBLES], zero-initialised once (the lower triangles are never written)
-    double* pcr;  // [B][PCR_DOUBLES] elimination factors of the knot system of the current evaluation (spline solve -> adjoint solve)
+    double* pcr;  // [B][WS_DOUBLES] per-problem workspace of an evaluation: elimination factors of the knot system of the current evaluation (spline solve -> adjoint solve)
     int count, mode;
     // MODE_EVAL / MODE_LBFGS
     int stage, max_iter;

@@ -230,16 +230,18 @@ struct Lds {
     double coef[P * 12];                              // (6 i + q) * 2 + d
     double gdC[P * 12];
     double gdT[P];
-    double gk[2][P + 1][3];                           // gradient w.r.t. the knot states
     double cy[P * NS], sy[P * NS], fx[P * NS], fy[P * NS]; // fx / fy become the chain coefficients
     // node terms of the coefficient gradient, [order 0 1 2][dimension theta s] per node -- stored without the entries that are zero
     // by construction (no penalty acts on s itself: order 0 of s is never written; the order-2 terms come from the penalties of
-    // pass A, which sit on the even nodes only): Ea = [node][order 0 of theta, order 1 of theta, order 1 of s], Eb = [even node]
-    // [order 2 of theta, order 2 of s].  8.8 KB instead of 13 (with the knot factors gone: five workgroups per CU instead of four)
+    // pass A, which sit on the even nodes only): Ea = [node][order 0 of theta, order 1 of theta, order 1 of s] here, [even node][order 2 of theta,
+    // order 2 of s] and the duration-gradient term per node in the problem's global workspace (Params::pcr: written once or twice,
+    // read once per evaluation).  6.5 KB of LDS instead of 15: six workgroups per CU
     double Ea[P * NS * 3];
-    double Eb[P * (RES + 1) * 2];
-    double nodeT[P * NS];
-    double posx[RES * P + 1], posy[RES * P + 1];      // pose at the Simpson panel ends
+    union { // the pose at the Simpson panel ends is dead (after the pose-dependent terms) before the adjoint of the spline begins
+        double posx[RES * P + 1];
+        double gk[2][P + 1][3];                       // gradient w.r.t. the knot states
+    };
+    double posy[RES * P + 1];
     double x[3 * P], g[3 * P], d[3 * P], xp[3 * P], gp[3 * P];
     double alpha[MEM_MAX];
     double pf[16];
@@ -450,7 +452,9 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     // kept in LDS they cost a workgroup per CU, kept in registers across the passes in between a wavefront per SIMD, and
     // eliminating twice costs 9 % more instructions per plan)
     constexpr int PCR_PL = P <= 16 ? 16 : 32, PCR_ST = P <= 16 ? 4 : 5;
-    GLBQ double* pcr_ws = (GLBQ double*)uni_ptr(prm.pcr) + (size_t)uni(e.prob) * PCR_DOUBLES;
+    GLBQ double* pcr_ws = (GLBQ double*)uni_ptr(prm.pcr) + (size_t)uni(e.prob) * WS_DOUBLES;
+    GLBQ double* eb_ws = pcr_ws + WS_EB;       // [even node][2]
+    GLBQ double* nt_ws = pcr_ws + WS_NODET;    // [node]
     {
         PcrFactors pcr;
         knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1], pcr);
@@ -554,10 +558,10 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         LDSQ double* E = L.Ea + node * 3;
         E[0] = gb[0][0]; E[1] = gb[1][0]; E[2] = gb[1][1]; // gb[0][1] stays zero: nothing penalises s itself
         if ((j & 1) == 0) {
-            LDSQ double* E2 = L.Eb + (i * (RES + 1) + (j >> 1)) * 2;
+            GLBQ double* E2 = eb_ws + (i * (RES + 1) + (j >> 1)) * 2;
             E2[0] = gb[2][0]; E2[1] = gb[2][1];
         }
-        L.nodeT[node] = gT;
+        nt_ws[node] = gT;
     }
     __syncthreads();
     BE_STAMP(6)
@@ -633,7 +637,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
             L.fx[node] = gpx;
             L.fy[node] = gpy;
             L.Ea[node * 3 + 0] += gb0;
-            L.nodeT[node] += gT;
+            nt_ws[node] += gT;
         }
     } else { // way-point attraction at the end of every piece
         const GLBQ double* way = (const GLBQ double*)e.positions;
@@ -693,7 +697,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         E[2] += cint * (cy * cx + sy * cyy);
         const double XT = (d2[1] * cy - d1[1] * d1[0] * sy + d2[0] * xvI * sy + d1[0] * d1[0] * xvI * cy) * ialpha * cint + div_res6(fxv);
         const double YT = (d2[1] * sy + d1[1] * d1[0] * cy - d2[0] * xvI * cy + d1[0] * d1[0] * xvI * sy) * ialpha * cint + div_res6(fyv);
-        L.nodeT[node] += XT * cx + YT * cyy;
+        nt_ws[node] += XT * cx + YT * cyy;
     }
     __syncthreads();
     BE_STAMP(11)
@@ -708,7 +712,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         for (int j = 0; j < NS; ++j) {
             const LDSQ double* E = L.Ea + (i * NS + j) * 3;
             const double tt = j * half, E0 = (d == 0) ? E[0] : 0.0, E1 = E[1 + d],
-                         E2 = ((j & 1) == 0) ? L.Eb[(i * (RES + 1) + (j >> 1)) * 2 + d] : 0.0;
+                         E2 = ((j & 1) == 0) ? eb_ws[(i * (RES + 1) + (j >> 1)) * 2 + d] : 0.0;
             double pw[6];
             pw[0] = 1.0;
 #pragma unroll
@@ -724,7 +728,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     }
     for (int i = lane; i < M; i += 64) {
         double acc = 0.0;
-        for (int j = 0; j < NS; ++j) acc += L.nodeT[i * NS + j];
+        for (int j = 0; j < NS; ++j) acc += nt_ws[i * NS + j];
         L.gdT[i] += acc;
     }
     __syncthreads();
@@ -1315,14 +1319,14 @@ __device__ __attribute__((noinline)) bool final_collision(const Params* gp_in, u
             double gx, gy;
             const double sd = esdf(prm.map, map_inv, carry_x + ix, carry_y + iy, false, 0.0, gx, gy);
             if (sd < c.final_min_safe_dis && p < first_hit) first_hit = p;
-            L.nodeT[lane] = sd; // staging for the ordered minimum below
+            L.fx[lane] = sd; // staging for the ordered minimum below
         }
         __syncthreads();
         // the reference stops at the first hit: its reported minimum covers the panels up to and including it
         int hit = first_hit;
 #pragma unroll
         for (int mm = 32; mm >= 1; mm >>= 1) hit = min(hit, __shfl_xor(hit, mm));
-        double local = (p < NP && p <= hit) ? L.nodeT[lane] : 1.79769313486231570815e+308;
+        double local = (p < NP && p <= hit) ? L.fx[lane] : 1.79769313486231570815e+308;
 #pragma unroll
         for (int mm = 32; mm >= 1; mm >>= 1) local = fmin(local, __shfl_xor(local, mm));
         mind = fmin(mind, local);
@@ -1359,11 +1363,14 @@ __device__ void load_problem(const Params& prm, unsigned lbase, int b)
 
 } // namespace
 
-// Round 5: LDS admits FIVE workgroups per CU (31.6 KB each: the knot factors travel through global memory, the node terms are
-// stored without their structural zeros) and the kernel keeps to 256 registers (waves_per_eu(2, 2): 256 and 340 B of scratch
-// against 254 and 300 B with a SIMD to itself), so one SIMD of a CU holds a second wavefront: 8192 plans 49.0 -> 44.1 ms, the
-// same evaluations plan by plan.  (Measured the other way first: a padded block that admits three workgroups per CU takes
-// 63.5 ms -- the launch is total work / slots.  With the adjoint solve eliminating again instead of replaying: 46.2 ms.)
+// Round 5: LDS admits SIX workgroups per CU (26.4 KB each; round 4: 40.4 KB, four) and the kernel keeps to 256 registers
+// (waves_per_eu(2, 2): 256 and 340 B of scratch against 254 and 300 B with a SIMD to itself), so two SIMDs of a CU hold a second
+// wavefront: 8192 plans 49.0 -> 38.8 ms, the same evaluations plan by plan (a launch is total work / slots: a block padded to
+// three workgroups per CU takes 63.5 ms).  What left the LDS: the elimination factors of the knot system, the order-2 node terms and
+// the duration-gradient terms per node go through a per-problem global workspace (written once or twice, read once per
+// evaluation; in registers the factors cost 292 registers, eliminating twice 9 % more instructions); the node terms are stored
+// without their structural zeros; the knot-state gradient shares the bytes of the Simpson poses (dead by then).  A CU's usable
+// LDS is ~161 KB: 27.2 KB x 6 did not fit, 26.4 KB x 6 does.
 template <int P>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void backend_kernel(const Params* __restrict__ gp)
 {
@@ -1516,8 +1523,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
-// five workgroups of the 16-piece build share a CU's 160 KB: 31568 B today (round 4: 40400 B, four workgroups)
-static_assert(sizeof(Lds<16>) <= 160 * 1024 / 5, "Lds<16> must leave room for five workgroups per CU");
+// six workgroups of the 16-piece build share a CU's 160 KB: 26400 B today (round 4: 40400 B, four workgroups)
+static_assert(sizeof(Lds<16>) <= 160 * 1024 / 6, "Lds<16> must leave room for six workgroups per CU");
 
 size_t lds_bytes(int P)
 {
