@@ -17,7 +17,7 @@ constexpr int MEM_MAX = 256; // L-BFGS history slots per problem (global_plannin
 constexpr int PCR_DOUBLES = 5 * 32 * 8 + 32 * 4; // per problem: [step][knot][alpha, gamma (2 x 2 each)], then [knot][D^-1]
 // ... followed in the same per-problem workspace by two node arrays of an evaluation that are written and read once or twice and so need
 // no LDS: the order-2 node terms of the even nodes [32 * 9][2] and the duration-gradient terms per node [32 * 17]
-constexpr int WS_EB = PCR_DOUBLES, WS_NODET = WS_EB + 32 * 9 * 2, WS_DOUBLES = WS_NODET + 32 * 17;
+constexpr int WS_EB = PCR_DOUBLES, WS_NODET = WS_EB + 32 * 9 * 2, WS_CS = WS_NODET + 32 * 17, WS_DOUBLES = WS_CS + 2 * 32 * 17; // ... and cos / sin of the heading per node [node][2]
 constexpr int GRAM_G = 0, GRAM_GT = (MEM_MAX / 8) * 64, GRAM_YS = 2 * GRAM_GT, GRAM_RYS = GRAM_YS + MEM_MAX, GRAM_DOUBLES = GRAM_RYS + MEM_MAX;
 
 enum Mode { MODE_PLAN = 0, MODE_EVAL = 1, MODE_LBFGS = 2 };

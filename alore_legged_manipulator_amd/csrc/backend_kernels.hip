@@ -230,7 +230,7 @@ struct Lds {
     double coef[P * 12];                              // (6 i + q) * 2 + d
     double gdC[P * 12];
     double gdT[P];
-    double cy[P * NS], sy[P * NS], fx[P * NS], fy[P * NS]; // fx / fy become the chain coefficients
+    double fx[P * NS], fy[P * NS]; // the Simpson integrands, then the chain coefficients (cos / sin of the heading per node: global workspace)
     // node terms of the coefficient gradient, [order 0 1 2][dimension theta s] per node -- stored without the entries that are zero
     // by construction (no penalty acts on s itself: order 0 of s is never written; the order-2 terms come from the penalties of
     // pass A, which sit on the even nodes only): Ea = [node][order 0 of theta, order 1 of theta, order 1 of s] here, [even node][order 2 of theta,
@@ -455,6 +455,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
     GLBQ double* pcr_ws = (GLBQ double*)uni_ptr(prm.pcr) + (size_t)uni(e.prob) * WS_DOUBLES;
     GLBQ double* eb_ws = pcr_ws + WS_EB;       // [even node][2]
     GLBQ double* nt_ws = pcr_ws + WS_NODET;    // [node]
+    GLBQ double* cs_ws = pcr_ws + WS_CS;       // [node][cos, sin]
     {
         PcrFactors pcr;
         knot_pcr<P, false>(L, M, L.T, L.y[0], L.y[1], pcr);
@@ -517,8 +518,8 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         }
         double sy, cy;
         sincos(sg[0], &sy, &cy);
-        L.cy[node] = cy;
-        L.sy[node] = sy;
+        cs_ws[2 * node] = cy;
+        cs_ws[2 * node + 1] = sy;
         L.fx[node] = d1[1] * cy + d1[0] * xvI * sy;
         L.fy[node] = d1[1] * sy - d1[0] * xvI * cy;
         double gb[3][2] = {{0, 0}, {0, 0}, {0, 0}}, gT = 0.0;
@@ -603,7 +604,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         for (int en = lane; en < (RES + 1) * M; en += 64) {
             const int i = en / (RES + 1), je = en - i * (RES + 1), j = 2 * je, node = i * NS + j;
             const double T = L.T[i], step = T / RES, alpha = (double)je / RES, omg = (j == 0 || j == NS - 1) ? 0.5 : 1.0, ws = omg * step;
-            const double px = L.posx[RES * i + je], py = L.posy[RES * i + je], cy = L.cy[node], sy = L.sy[node];
+            const double px = L.posx[RES * i + je], py = L.posy[RES * i + je], cy = cs_ws[2 * node], sy = cs_ws[2 * node + 1];
             const LDSQ double* ci = L.coef + 12 * i;
             const double t = j * (step / 2.0);
             const double d1th = (((5.0 * ci[10] * t + 4.0 * ci[8]) * t + 3.0 * ci[6]) * t + 2.0 * ci[4]) * t + ci[2];
@@ -680,7 +681,7 @@ __device__ __attribute__((noinline)) double eval_cost(const Params* gp_in, unsig
         const int i = node / NS, j = node - i * NS;
         const double T = L.T[i], step = T / RES, t = j * (step / 2.0), cint = div_res6(T), ialpha = (double)j / (2 * RES);
         const double sw = (j == 0 || j == NS - 1) ? 1.0 : ((j & 1) ? 4.0 : 2.0);
-        const double cx = L.fx[node] * sw, cyy = L.fy[node] * sw, cy = L.cy[node], sy = L.sy[node];
+        const double cx = L.fx[node] * sw, cyy = L.fy[node] * sw, cy = cs_ws[2 * node], sy = cs_ws[2 * node + 1];
         const LDSQ double* ci = L.coef + 12 * i;
         double d1[2], d2[2];
         for (int d = 0; d < 2; ++d) {
@@ -1524,7 +1525,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // six workgroups of the 16-piece build share a CU's 160 KB: 26400 B today (round 4: 40400 B, four workgroups)
-static_assert(sizeof(Lds<16>) <= 160 * 1024 / 6, "Lds<16> must leave room for six workgroups per CU");
+static_assert(sizeof(Lds<16>) <= 160000 / 7, "Lds<16> must leave room for seven workgroups per CU");
 
 size_t lds_bytes(int P)
 {
