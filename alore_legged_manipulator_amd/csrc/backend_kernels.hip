@@ -1364,14 +1364,16 @@ __device__ void load_problem(const Params& prm, unsigned lbase, int b)
 
 } // namespace
 
-// Round 5: LDS admits SIX workgroups per CU (26.4 KB each; round 4: 40.4 KB, four) and the kernel keeps to 256 registers
-// (waves_per_eu(2, 2): 256 and 340 B of scratch against 254 and 300 B with a SIMD to itself), so two SIMDs of a CU hold a second
-// wavefront: 8192 plans 49.0 -> 38.8 ms, the same evaluations plan by plan (a launch is total work / slots: a block padded to
-// three workgroups per CU takes 63.5 ms).  What left the LDS: the elimination factors of the knot system, the order-2 node terms and
-// the duration-gradient terms per node go through a per-problem global workspace (written once or twice, read once per
-// evaluation; in registers the factors cost 292 registers, eliminating twice 9 % more instructions); the node terms are stored
-// without their structural zeros; the knot-state gradient shares the bytes of the Simpson poses (dead by then).  A CU's usable
-// LDS is ~161 KB: 27.2 KB x 6 did not fit, 26.4 KB x 6 does.
+// Round 5: LDS admits SEVEN workgroups per CU (22.0 KB each; round 4: 40.4 KB, four) and the kernel keeps to 256 registers
+// (waves_per_eu(2, 2): 256 and 340 B of scratch against 254 and 300 B with a SIMD to itself), so three SIMDs of a CU hold a second
+// wavefront: 8192 plans 49.0 -> 37.2 ms, the same evaluations plan by plan (a launch is total work / slots: a block padded to
+// three workgroups per CU takes 63.5 ms; four 49.0, five 44.1, six 38.8, seven 37.2 -- one residency of 2048 plans pays 5 % for the
+// longer evaluation: 18.5 -> 19.5 ms).  What left the LDS: the elimination factors of the knot system, the order-2 node terms, the
+// duration-gradient terms and cos / sin of the heading per node go through a per-problem global workspace (written once or twice,
+// read once or twice per evaluation, L2; in registers the factors cost 292 registers, eliminating twice 9 % more instructions); the
+// node terms are stored without their structural zeros; the knot-state gradient shares the bytes of the Simpson poses (dead by
+// then).  A CU's usable LDS is ~161 KB: 27.2 KB x 6 did not fit, 26.4 KB x 6 does.  Two wavefronts on EVERY SIMD need 20.0 KB: the
+// 2 KB of the two-loop recursion's alpha[] are what is missing.
 template <int P>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void backend_kernel(const Params* __restrict__ gp)
 {
@@ -1524,7 +1526,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
-// six workgroups of the 16-piece build share a CU's 160 KB: 26400 B today (round 4: 40400 B, four workgroups)
+// seven workgroups of the 16-piece build share a CU's 160 KB: 22048 B today (round 4: 40400 B, four workgroups)
 static_assert(sizeof(Lds<16>) <= 160000 / 7, "Lds<16> must leave room for seven workgroups per CU");
 
 size_t lds_bytes(int P)
