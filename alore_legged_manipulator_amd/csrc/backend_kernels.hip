@@ -230,7 +230,11 @@ struct Lds {
     double coef[P * 12];                              // (6 i + q) * 2 + d
     double gdC[P * 12];
     double gdT[P];
-    double fx[P * NS], fy[P * NS]; // the Simpson integrands, then the chain coefficients (cos / sin of the heading per node: global workspace)
+    union { // the two-loop recursion of L-BFGS runs between two cost evaluations: its alpha[] takes the bytes of a node array of the evaluation
+        double fx[P * NS]; // the Simpson integrands, then the chain coefficients (cos / sin of the heading per node: global workspace)
+        double alpha[MEM_MAX];
+    };
+    double fy[P * NS];
     // node terms of the coefficient gradient, [order 0 1 2][dimension theta s] per node -- stored without the entries that are zero
     // by construction (no penalty acts on s itself: order 0 of s is never written; the order-2 terms come from the penalties of
     // pass A, which sit on the even nodes only): Ea = [node][order 0 of theta, order 1 of theta, order 1 of s] here, [even node][order 2 of theta,
@@ -243,7 +247,6 @@ struct Lds {
     };
     double posy[RES * P + 1];
     double x[3 * P], g[3 * P], d[3 * P], xp[3 * P], gp[3 * P];
-    double alpha[MEM_MAX];
     double pf[16];
 };
 
@@ -1364,16 +1367,17 @@ __device__ void load_problem(const Params& prm, unsigned lbase, int b)
 
 } // namespace
 
-// Round 5: LDS admits SEVEN workgroups per CU (22.0 KB each; round 4: 40.4 KB, four) and the kernel keeps to 256 registers
-// (waves_per_eu(2, 2): 256 and 340 B of scratch against 254 and 300 B with a SIMD to itself), so three SIMDs of a CU hold a second
-// wavefront: 8192 plans 49.0 -> 37.2 ms, the same evaluations plan by plan (a launch is total work / slots: a block padded to
-// three workgroups per CU takes 63.5 ms; four 49.0, five 44.1, six 38.8, seven 37.2 -- one residency of 2048 plans pays 5 % for the
-// longer evaluation: 18.5 -> 19.5 ms).  What left the LDS: the elimination factors of the knot system, the order-2 node terms, the
-// duration-gradient terms and cos / sin of the heading per node go through a per-problem global workspace (written once or twice,
-// read once or twice per evaluation, L2; in registers the factors cost 292 registers, eliminating twice 9 % more instructions); the
-// node terms are stored without their structural zeros; the knot-state gradient shares the bytes of the Simpson poses (dead by
-// then).  A CU's usable LDS is ~161 KB: 27.2 KB x 6 did not fit, 26.4 KB x 6 does.  Two wavefronts on EVERY SIMD need 20.0 KB: the
-// 2 KB of the two-loop recursion's alpha[] are what is missing.
+// Round 5: LDS admits EIGHT workgroups per CU (20.0 KB each; round 4: 40.4 KB, four) and the kernel keeps to 256 registers
+// (waves_per_eu(2, 2): 256 and 340 B of scratch against 254 and 300 B with a SIMD to itself): two wavefronts on every SIMD.
+// 8192 plans 49.0 -> 34.7 ms, the same evaluations plan by plan (a launch is total work / slots: a block padded to three
+// workgroups per CU takes 63.5 ms; four 49.0, five 44.1, six 38.8, seven 37.2, eight 34.7 -- one residency of 2048 plans pays 5 %
+// for the longer evaluation: 18.5 -> 19.5 ms).  What left the LDS: the elimination factors of the knot system, the order-2 node
+// terms, the duration-gradient terms and cos / sin of the heading per node go through a per-problem global workspace (written once or
+// twice, read once or twice per evaluation, L2; in registers the factors cost 292 registers, eliminating twice 9 % more
+// instructions); the node terms are stored without their structural zeros; the knot-state gradient shares the bytes of the Simpson
+// poses (dead by then), the two-loop recursion's alpha[] those of a node array (it runs between two evaluations).  What fits a CU
+// was measured (tools/micro/lds_fit.hip): 8 workgroups up to 20480 B each, 7 up to 23040, 6 up to 26880, 5 up to 31744 -- not
+// 160 KB / n: the runtime's occupancy query is one too optimistic just below those sizes.
 template <int P>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void backend_kernel(const Params* __restrict__ gp)
 {
@@ -1526,8 +1530,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
-// seven workgroups of the 16-piece build share a CU's 160 KB: 22048 B today (round 4: 40400 B, four workgroups)
-static_assert(sizeof(Lds<16>) <= 160000 / 7, "Lds<16> must leave room for seven workgroups per CU");
+// eight workgroups of the 16-piece build share a CU's 160 KB: 20000 B today (round 4: 40400 B, four workgroups)
+static_assert(16 * NS >= MEM_MAX, "alpha[] shares the bytes of fx[]");
+static_assert(sizeof(Lds<16>) <= 20480, "Lds<16> must leave room for eight workgroups per CU (tools/micro/lds_fit.hip: 8 x 20480 B fit, 7 up to 23040, 6 up to 26880, 5 up to 31744)");
 
 size_t lds_bytes(int P)
 {
