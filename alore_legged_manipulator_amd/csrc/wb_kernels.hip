@@ -1032,7 +1032,6 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
 {
     constexpr int MC = 80; // G (12) | J A_v (48) | J B_v,tau (18) | J next_v (1) | pad
     __shared__ double Mx[12 * MC];
-    __shared__ double Jl[12 * NV];
     __shared__ double Bf[NX * 12];
     __shared__ double colp[144]; // the twelve pivot columns of the elimination
     const int item = blockIdx.x, lane = threadIdx.x;
@@ -1043,14 +1042,13 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
     const unsigned char* st = stance ? stance + (size_t)item * 4 : nullptr;
     ROWS_STAMP(0)
     // every global read of the set-up is issued before the first LDS store (a rolled loop waits for one load per trip)
+    float jav[6];
     {
-        float jv[5], bv[9];
+        float bv[9];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { const int e = lane + 64 * q; jv[q] = e < 12 * NV ? J[e] : 0.f; }
+        for (int t = 0; t < 6; ++t) jav[t] = (lane & 15) < 12 ? J[(lane & 15) * NV + 4 * t + (lane >> 4)] : 0.f; // J_c as the matrix cores' A operand, straight from global memory (2.3 KB of LDS less: twelve workgroups per CU)
 #pragma unroll
         for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; bv[q] = Bm[(e / 12) * NUP + b2z1::NJ + e % 12]; } // 576 = 9 x 64
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { const int e = lane + 64 * q; if (e < 12 * NV) Jl[e] = (double)jv[q]; }
 #pragma unroll
         for (int q = 0; q < 9; ++q) { const int e = lane + 64 * q; Bf[e] = (double)bv[q]; }
     }
@@ -1063,7 +1061,7 @@ __global__ __launch_bounds__(64) void contact_rows_kernel(float* A32, float* B32
     {
         double ja[6];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) ja[t] = r16 < 12 ? Jl[r16 * NV + 4 * t + kq] : 0.0;
+        for (int t = 0; t < 6; ++t) ja[t] = (double)jav[t];
 #pragma unroll
         for (int tj = 0; tj < 5; ++tj) {
             // the B operand -- the velocity rows of [B_f | A | B_tau | next | 0], column 16 tj + r16 -- straight from where it lives: B_f from
