@@ -61,6 +61,12 @@ class LaunchInfo(C.Structure):
                 ("grid", C.c_int), ("lds_bytes_per_block", C.c_int), ("last_kernel_ms", C.c_float)]
 
 
+class TwoPhaseInfo(C.Structure):
+    """alore_nmpc_two_phase_info (include/alore_nmpc.h)"""
+    _fields_ = [("last_grid_two_phase", C.c_int), ("two_phase_batches", C.c_int), ("tail_workgroups_per_batch", C.c_int),
+                ("lag_units", C.c_int), ("tail_share", C.c_float)]
+
+
 # every symbol include/alore_nmpc.h declares: (name, restype, argtypes)
 SYMBOLS = (
     ("alore_nmpc_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
@@ -85,6 +91,8 @@ SYMBOLS = (
     ("alore_nmpc_rti_many_prepare", C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_int, C.c_int]),
     ("alore_nmpc_synchronize", C.c_int, [C.c_void_p, C.c_void_p]),
     ("alore_nmpc_set_many_mode", C.c_int, [C.c_void_p, C.c_int]),
+    ("alore_nmpc_set_two_phase", C.c_int, [C.c_void_p, C.c_int]),
+    ("alore_nmpc_get_two_phase_info", C.c_int, [C.c_void_p, C.POINTER(TwoPhaseInfo)]),
     ("alore_nmpc_set_problem_mask", C.c_int, [C.c_void_p, C.c_void_p]),
     ("alore_nmpc_condense", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("alore_nmpc_dense_qp", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -31,6 +31,7 @@
 #include "nmpc_kernels.h"
 #include "ref_sampler_device.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 #include <type_traits>
@@ -340,7 +341,8 @@ int block_lds_floats(int N, int L)
 // their shader engines in fixed shares, so the grid lasts as long as its slowest XCD (they differ by ~5 % in clock under this
 // load: profiles/r05_a_timeline_*.txt); with tickets a faster XCD takes more items.  The ticket of the next item is requested
 // when the current one starts, so its latency is never waited for.
-template <int L, int S, bool DIAG, bool STAMP, bool ONCE, bool FULLN = false, bool TRACE = false, bool PERSIST = false>
+// TWOPH (grid builds): the batches of the grid are solved in two passes -- see the top of nmpc_block_body.inc.
+template <int L, int S, bool DIAG, bool STAMP, bool ONCE, bool FULLN = false, bool TRACE = false, bool PERSIST = false, bool TWOPH = false>
 __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p_arg, const RtiGroup grp_arg)
 {
 #include "nmpc_block_body.inc"
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(64) void rti_block_sampler_kernel(const RtiParams p
                                          (int)threadIdx.x, 64);
         return;
     }
-    constexpr bool STAMP = false, ONCE = true, FULLN = false, TRACE = false, PERSIST = false;
+    constexpr bool STAMP = false, ONCE = true, FULLN = false, TRACE = false, PERSIST = false, TWOPH = false;
 #include "nmpc_block_body.inc"
 }
 
@@ -431,6 +433,7 @@ hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t
     grp.persist_blocks = 0;
     grp.xcd_on = 0;
     grp.xcd_end = nullptr;
+    grp.tp_count2 = 0; grp.tp_tail = 0; grp.tp_lag = 0; grp.tp_timeout = 0; grp.tp_exits = nullptr; grp.tp_cnt = nullptr; grp.tp_entries = nullptr; grp.tp_trace = nullptr; grp.tp_rec = nullptr;
     grp.b[0] = p.b;
     return launch_rti_block_group(p, grp, g, s);
 }
@@ -471,6 +474,12 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
         v = 28 + (diag ? 0 : 1);
         fn = diag ? (const void*)rti_block_kernel<4, 5, true, false, true, true, false, true> : (const void*)rti_block_kernel<4, 5, false, false, true, true, false, true>;
     }
+    const bool twoph = grp.tp_count2 > 0;
+    if (twoph) {
+        if (!(g.L == 4 && g.RS == 5 && p.N == 20 && once && !stamp) || persist || grp.trace || grp.xcd_on) return hipErrorInvalidValue;
+        v = 31 + (diag ? 0 : 1);
+        fn = diag ? (const void*)rti_block_kernel<4, 5, true, false, true, true, false, false, true> : (const void*)rti_block_kernel<4, 5, false, false, true, true, false, false, true>;
+    }
     if (grp.trace) { // diagnostic: only the grid builds have an instrumented twin
         if (!(g.L == 4 && g.RS == 5 && p.N == 20 && once && !stamp && diag)) return hipErrorInvalidValue;
         v = persist ? 30 : 27;
@@ -481,7 +490,7 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     dev &= 15;
-    static size_t configured[16][31] = {{0}};
+    static size_t configured[16][33] = {{0}};
     if (g.lds_bytes > configured[dev][v]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
         if (e != hipSuccess) return e;
@@ -495,9 +504,20 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
         for (int x = 0; x < 8; ++x) mx = grp.xcd_share[x] > mx ? grp.xcd_share[x] : mx;
         blocks = 8u * (unsigned)mx;
     }
+    if (twoph) { // units of (blocks of a batch, tail of the batch tp_lag units before): see nmpc_block_body.inc
+        const long long units = std::max((long long)grp.count, (long long)grp.tp_count2 + grp.tp_lag);
+        const long long nb = units * ((long long)g.grid + grp.tp_tail);
+        if (nb > 0x7fffffffLL) return hipErrorInvalidValue;
+        blocks = (unsigned)nb;
+    }
     e = hipLaunchKernel(fn, dim3(blocks), dim3(64), args, g.lds_bytes, s);
     if (e != hipSuccess) return e;
     return hipGetLastError();
+}
+
+bool rti_block_two_phase_supported(const RtiParams& p, const LaunchGeom& g)
+{
+    return g.block && g.L == 4 && g.RS == 5 && p.N == 20 && p.n_sqp == 1 && p.stamps == nullptr && g.grid <= 64 * TP_KMAX;
 }
 
 // The solve of one batch with the sampler's workgroups behind it in the same grid; false when this (mapping, mode) has no such build
@@ -527,6 +547,7 @@ hipError_t launch_rti_block_sampler(const RtiParams& p, const LaunchGeom& g, con
     grp.persist_blocks = 0;
     grp.xcd_on = 0;
     grp.xcd_end = nullptr;
+    grp.tp_count2 = 0; grp.tp_tail = 0; grp.tp_lag = 0; grp.tp_timeout = 0; grp.tp_exits = nullptr; grp.tp_cnt = nullptr; grp.tp_entries = nullptr; grp.tp_trace = nullptr; grp.tp_rec = nullptr;
     for (int m = 0; m < 15; ++m) grp.stride[m] = 0;
     grp.b[0] = p.b;
     const bool diag = p.b.kkt != nullptr || p.b.obj != nullptr;

@@ -91,6 +91,24 @@ struct alore_nmpc_solver {
     bool xcd_pending = false;
     int xcd_updates = 0;
     static constexpr int kTicketRing = 16;
+    // two-phase grids (nmpc_block_kernel.hip: TWOPH): queue regions (header + entries per batch, all 0 between launches), one per launch
+    // in turn with the stream and an event of its last user; the host-memory record of the last launch (deferred problems per batch,
+    // error word) that sizes the next launch's tail
+    static constexpr int kTpRing = 4;
+    char* d_tp[kTpRing] = {};
+    size_t tp_cap[kTpRing] = {};
+    hipStream_t tp_stream[kTpRing] = {};
+    hipEvent_t tp_ev[kTpRing] = {};
+    bool tp_used[kTpRing] = {};
+    unsigned tp_turn = 0;
+    int* tp_rec = nullptr;      // pinned host memory [40]
+    hipEvent_t tp_rec_ev = nullptr;
+    bool tp_rec_pending = false;
+    double tp_share = 0.30;     // share of a batch's problems the tail is sized for
+    int two_phase = -1;         // alore_nmpc_set_two_phase: -1 automatic, 0 never, 1 wherever the build exists
+    int tp_last = 0;            // the last grid ran in two phases (launch info)
+    int tp_slot_of_launch = -1;
+    int tp_info[3] = {0, 0, 0}; // two-phase batches, tail workgroups per batch, lag of the last two-phase grid
     int* d_tickets = nullptr;
     unsigned ticket_turn = 0;
     size_t stamps_cap = 0;
@@ -237,6 +255,17 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
         return ALORE_NMPC_E_HIP;
     }
     std::memset(h->xcd_rec, 0, sizeof(unsigned long long) * 40);
+    if (hipHostMalloc((void**)&h->tp_rec, sizeof(int) * 40, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->tp_rec_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)alore_nmpc_destroy(h);
+        return ALORE_NMPC_E_HIP;
+    }
+    std::memset(h->tp_rec, 0, sizeof(int) * 40);
+    for (int i = 0; i < alore_nmpc_solver::kTpRing; ++i)
+        if (hipEventCreateWithFlags(&h->tp_ev[i], hipEventDisableTiming) != hipSuccess) {
+            (void)alore_nmpc_destroy(h);
+            return ALORE_NMPC_E_HIP;
+        }
     if (const char* sp = std::getenv("ALORE_NMPC_XCD_SPEEDS")) { // diagnostic / tests: preset relative speeds "a,b,c,d,e,f,g,h"
         double v[8];
         if (std::sscanf(sp, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7) == 8)
@@ -271,6 +300,12 @@ int alore_nmpc_destroy(alore_nmpc_handle h)
                      h->xcd_speed[1], h->xcd_speed[2], h->xcd_speed[3], h->xcd_speed[4], h->xcd_speed[5], h->xcd_speed[6], h->xcd_speed[7]);
     if (h->xcd_ev) { (void)hipEventSynchronize(h->xcd_ev); (void)hipEventDestroy(h->xcd_ev); }
     if (h->xcd_rec) (void)hipHostFree(h->xcd_rec);
+    if (h->tp_rec_ev) { (void)hipEventSynchronize(h->tp_rec_ev); (void)hipEventDestroy(h->tp_rec_ev); }
+    if (h->tp_rec) (void)hipHostFree(h->tp_rec);
+    for (int i = 0; i < alore_nmpc_solver::kTpRing; ++i) {
+        if (h->tp_ev[i]) { (void)hipEventSynchronize(h->tp_ev[i]); (void)hipEventDestroy(h->tp_ev[i]); }
+        if (h->d_tp[i]) (void)hipFree(h->d_tp[i]);
+    }
     for (int w = 0; w < 31; ++w) {
         if (h->side[w]) (void)hipStreamDestroy(h->side[w]);
         if (h->join_ev[w]) (void)hipEventDestroy(h->join_ev[w]);
@@ -701,6 +736,96 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
         grp.counter = h->d_tickets + 2 * (h->ticket_turn++ % alore_nmpc_solver::kTicketRing);
         grp.persist_blocks = 4 * h->n_cu;
     }
+    // Two-phase grid (see the kernel): grids of several residencies of the (4, 5) grid build whose batches are many enough that the tail
+    // of a batch can follow its first pass at a distance of more than a residency and the last batches can run in one pass.
+    // alore_nmpc_set_two_phase / ALORE_NMPC_TWO_PHASE (diagnostic): 0 never, 1 wherever the build exists.
+    grp.tp_count2 = 0; grp.tp_tail = 0; grp.tp_lag = 0; grp.tp_timeout = 0; grp.tp_exits = nullptr; grp.tp_cnt = nullptr; grp.tp_entries = nullptr; grp.tp_trace = nullptr; grp.tp_rec = nullptr;
+    h->tp_last = 0;
+    {
+        static const char* env_tp = getenv("ALORE_NMPC_TWO_PHASE");
+        static const char* env_lag = getenv("ALORE_NMPC_TP_LAG");       // diagnostic: units between a first pass and its tail
+        static const char* env_single = getenv("ALORE_NMPC_TP_SINGLE"); // diagnostic: batches at the end of the grid that run in one pass
+        static const char* env_tail = getenv("ALORE_NMPC_TP_TAIL");     // diagnostic: tail workgroups per batch
+        // automatic = off: measured on the bench distribution (a fifth of the problems queued) the mode loses 8 % -- the queued problems pay
+        // the 5 - 9 us between a workgroup's start and its inputs a second time (profiles/r06_two_phase.txt); it gains below ~a tenth queued
+        const int want = env_tp ? atoi(env_tp) : (h->two_phase < 0 ? 0 : h->two_phase);
+        const long resident = 4L * h->n_cu;
+        // an error the last two-phase grid left: the queue is put back in order, the call fails loudly
+        if (h->tp_rec_pending && hipEventQuery(h->tp_rec_ev) == hipSuccess) {
+            h->tp_rec_pending = false;
+            if (h->tp_rec[32] != 0) {
+                const int code = h->tp_rec[32];
+                h->tp_rec[32] = 0;
+                (void)hipDeviceSynchronize();
+                for (int i = 0; i < alore_nmpc_solver::kTpRing; ++i)
+                    if (h->d_tp[i]) (void)hipMemset(h->d_tp[i], 0, h->tp_cap[i]);
+                char msg[256];
+                std::snprintf(msg, sizeof msg, "rti_many: a tail workgroup of the previous two-phase grid gave up waiting for its queue (code %d); "
+                                               "that grid left problems unsolved (alore_nmpc_set_two_phase(h, 0) turns the mode off)", code);
+                return fail(h, ALORE_NMPC_E_HIP, msg);
+            }
+            int mx = 0;
+            for (int i = 0; i < 32; ++i) mx = h->tp_rec[i] > mx ? h->tp_rec[i] : mx;
+            if (mx > 0) h->tp_share = (double)mx / (double)B; // the fullest queue of the last grid
+        }
+        bool on = want != 0 && !grp.counter && nmpc::rti_block_two_phase_supported(p, g) && (long)g.grid * count >= 2 * resident;
+        int tail = 0, lag = 0, count2 = 0;
+        if (on) {
+            tail = (int)std::ceil(h->tp_share * 1.08 * g.grid) + 3;
+            if (env_tail) tail = atoi(env_tail);
+            tail = tail < 1 ? 1 : (tail > g.grid ? g.grid : tail);
+            const long unit = (long)g.grid + tail;
+            lag = (int)((resident + resident / 8 + unit - 1) / unit);
+            if (env_lag) lag = atoi(env_lag);
+            lag = lag < 1 ? 1 : lag;
+            int single = lag;
+            if (env_single) single = atoi(env_single);
+            single = single < 0 ? 0 : single;
+            count2 = count - single;
+            on = count2 >= 1;
+        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (on) (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+        int slot = -1;
+        if (on) { // a queue region: the next of the ring whose last user is this stream or has finished
+            const size_t need = (size_t)count2 * sizeof(int) * (16 + (size_t)g.grid * (1 + g.G)); // exits (a line each), reports, entries
+            for (int tries = 0; tries < alore_nmpc_solver::kTpRing && slot < 0; ++tries) {
+                const int i = (int)(h->tp_turn++ % alore_nmpc_solver::kTpRing);
+                if (h->tp_used[i] && h->tp_stream[i] != (hipStream_t)stream && hipEventQuery(h->tp_ev[i]) != hipSuccess) continue;
+                if (h->tp_cap[i] < need) {
+                    if (cap != hipStreamCaptureStatusNone) continue; // no allocation inside a capture
+                    if (h->tp_used[i]) (void)hipEventSynchronize(h->tp_ev[i]);
+                    if (h->d_tp[i]) (void)hipFree(h->d_tp[i]);
+                    h->d_tp[i] = nullptr; h->tp_cap[i] = 0; h->tp_used[i] = false;
+                    const size_t want_bytes = need + need / 4;
+                    if (hipMalloc((void**)&h->d_tp[i], want_bytes) != hipSuccess) { (void)hipGetLastError(); continue; }
+                    if (hipMemset(h->d_tp[i], 0, want_bytes) != hipSuccess) { (void)hipFree(h->d_tp[i]); h->d_tp[i] = nullptr; continue; }
+                    h->tp_cap[i] = want_bytes;
+                }
+                slot = i;
+            }
+            on = slot >= 0;
+        }
+        if (on) {
+            grp.tp_count2 = count2;
+            grp.tp_tail = tail;
+            grp.tp_lag = lag;
+            grp.tp_timeout = 20 * 1000 * 100; // 20 ms of the 100 MHz counter
+            grp.tp_exits = reinterpret_cast<int*>(h->d_tp[slot]);
+            grp.tp_cnt = grp.tp_exits + (size_t)count2 * 16;
+            grp.tp_entries = grp.tp_cnt + (size_t)count2 * g.grid;
+            if (cap == hipStreamCaptureStatusNone && !h->tp_rec_pending) { // the record: eager launches only, one in flight at a time
+                std::memset(h->tp_rec, 0, sizeof(int) * 40);
+                void* alias = nullptr;
+                if (hipHostGetDevicePointer(&alias, h->tp_rec, 0) == hipSuccess) grp.tp_rec = (int*)alias;
+            }
+            h->tp_used[slot] = true;
+            h->tp_stream[slot] = (hipStream_t)stream;
+            h->tp_last = 1;
+            h->tp_info[0] = count2; h->tp_info[1] = tail; h->tp_info[2] = lag;
+        }
+        h->tp_slot_of_launch = on ? slot : -1;
+    }
     // XCD shares (see the kernel): grids of at least two residencies of the (4, 5) grid build.  The record of the previous such launch, if it
     // has finished, moves the speed estimates (damped); this launch leaves its own record unless the previous one is still in flight.
     // ALORE_NMPC_XCD_SHARES=0 (diagnostic): equal shares, as the hardware deals them.
@@ -708,7 +833,7 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
     grp.xcd_end = nullptr;
     static const bool xcd_shares_on = !(getenv("ALORE_NMPC_XCD_SHARES") && atoi(getenv("ALORE_NMPC_XCD_SHARES")) == 0);
     const long total_items = (long)g.grid * count;
-    if (xcd_shares_on && !grp.counter && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && total_items >= 2L * 4 * h->n_cu && total_items < (1L << 28)) {
+    if (xcd_shares_on && !grp.counter && grp.tp_count2 == 0 && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && total_items >= 2L * 4 * h->n_cu && total_items < (1L << 28)) {
         bool record = true;
         if (h->xcd_pending) {
             if (hipEventQuery(h->xcd_ev) == hipSuccess) {
@@ -766,7 +891,7 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
     }
     static const char* trace_path = getenv("ALORE_NMPC_TRACE");
     grp.trace = nullptr;
-    if (trace_path && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && batches[0].kkt && batches[0].obj) {
+    if (trace_path && grp.tp_count2 == 0 && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && batches[0].kkt && batches[0].obj) {
         const size_t words = (size_t)g.grid * count * 8;
         long long* d_trace = nullptr;
         HIP_TRY(h, hipMalloc((void**)&d_trace, words * sizeof(long long)));
@@ -791,7 +916,45 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
         h->have_geom = true;
         return ALORE_NMPC_OK;
     }
+    // diagnostic (ALORE_NMPC_TP_TRACE=<file>, never under a stream capture): every workgroup of a two-phase grid leaves the real-time counter at
+    // its start / inputs landed / end and its role; synchronous, one file <file>.<n> per grid (tools/tp_trace.py)
+    static const char* tp_trace_path = getenv("ALORE_NMPC_TP_TRACE");
+    if (tp_trace_path && grp.tp_count2 > 0) {
+        const long long units = std::max((long long)count, (long long)grp.tp_count2 + grp.tp_lag);
+        const size_t words = (size_t)(units * ((long long)g.grid + grp.tp_tail)) * 4;
+        long long* d_trace = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&d_trace, words * sizeof(long long)));
+        grp.tp_trace = d_trace;
+        hipError_t e = hipMemsetAsync(d_trace, 0, words * sizeof(long long), (hipStream_t)stream);
+        if (e == hipSuccess) e = nmpc::launch_rti_block_group(p, grp, g, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        std::vector<long long> host(words);
+        if (e == hipSuccess) e = hipMemcpy(host.data(), d_trace, words * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(d_trace);
+        if (e != hipSuccess) return fail(h, ALORE_NMPC_E_HIP, "rti_many: traced two-phase launch", e);
+        static int tp_trace_seq = 0;
+        const std::string fname = std::string(tp_trace_path) + "." + std::to_string(tp_trace_seq++);
+        if (FILE* f = std::fopen(fname.c_str(), "wb")) {
+            const long long hdr[8] = {0x5054LL, (long long)(words / 4), count, g.grid, grp.tp_count2, grp.tp_tail, grp.tp_lag, 0};
+            std::fwrite(hdr, sizeof(long long), 8, f);
+            std::fwrite(host.data(), sizeof(long long), host.size(), f);
+            std::fclose(f);
+        }
+        if (grp.tp_rec && hipEventRecord(h->tp_rec_ev, (hipStream_t)stream) == hipSuccess) h->tp_rec_pending = true;
+        h->last_geom = g;
+        h->last_geom.grid = g.grid * count;
+        h->have_geom = true;
+        return ALORE_NMPC_OK;
+    }
     HIP_TRY(h, nmpc::launch_rti_block_group(p, grp, g, (hipStream_t)stream));
+    if (h->tp_slot_of_launch >= 0) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+        if (cap == hipStreamCaptureStatusNone) {
+            (void)hipEventRecord(h->tp_ev[h->tp_slot_of_launch], (hipStream_t)stream);
+            if (grp.tp_rec && hipEventRecord(h->tp_rec_ev, (hipStream_t)stream) == hipSuccess) h->tp_rec_pending = true;
+        }
+    }
     if (grp.xcd_end) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
@@ -975,6 +1138,24 @@ int alore_nmpc_set_many_mode(alore_nmpc_handle h, int mode)
 {
     if (!h || mode < 0 || mode > 1) return fail(h, ALORE_NMPC_E_INVALID, "set_many_mode: 0 (groups) or 1 (streams)");
     h->many_mode = mode;
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_set_two_phase(alore_nmpc_handle h, int mode)
+{
+    if (!h || mode < -1 || mode > 1) return fail(h, ALORE_NMPC_E_INVALID, "set_two_phase: -1 (automatic), 0 (never) or 1 (wherever the build exists)");
+    h->two_phase = mode;
+    return ALORE_NMPC_OK;
+}
+
+int alore_nmpc_get_two_phase_info(alore_nmpc_handle h, alore_nmpc_two_phase_info* out)
+{
+    if (!h || !out) return ALORE_NMPC_E_INVALID;
+    out->last_grid_two_phase = h->tp_last;
+    out->two_phase_batches = h->tp_info[0];
+    out->tail_workgroups_per_batch = h->tp_info[1];
+    out->lag_units = h->tp_info[2];
+    out->tail_share = (float)h->tp_share;
     return ALORE_NMPC_OK;
 }
 

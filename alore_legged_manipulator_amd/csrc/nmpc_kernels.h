@@ -27,6 +27,12 @@ struct RtiParams {
 
 // up to GROUP_MAX independent batches served by one grid of the stage-block kernel (by value in the kernel arguments: 24 x 120 B of the 4 KB they hold)
 constexpr int GROUP_MAX = 24;
+constexpr int TP_KMAX = 16; // two-phase grids: a tail workgroup reads the reports of its batch's blocks, up to 64 * TP_KMAX of them
+// Queue of a two-phase grid, per batch (all words 0 between launches): `cnt[block]` = 1 + problems the first-pass workgroup of that block
+// left to the tail (0: it has not reported yet), `entries[block * G + i]` = 1 + number of its i-th such problem (0: not written yet; the
+// tail workgroup that takes an entry puts it back to 0), `exits` = tail workgroups of the batch that have left (the last one puts
+// cnt[] and itself back to 0).  The first pass only stores -- no read-modify-write on a word that the other workgroups of the batch
+// hit as well (one returning add per workgroup on a per-batch counter made the whole grid wait for that word: 170 against 130 us).
 struct RtiGroup {
     int count;            // batches in this launch
     int blocks_per_batch; // workgroups per batch: block -> batch by division
@@ -40,6 +46,17 @@ struct RtiGroup {
     int xcd_on;           // 1: XCD x (workgroups w = x mod 8) works on xcd_share[x] consecutive blocks from xcd_base[x] (see the kernel)
     int xcd_share[8], xcd_base[8];
     unsigned long long* xcd_end; // [8][4] host memory: finishing times (100 MHz counter) of the last four workgroups of every XCD, or null
+    // Two-phase grids (TWOPH builds of the kernel, see nmpc_block_kernel.hip).  The grid is dealt in UNITS of blocks_per_batch + tp_tail
+    // workgroups: unit u = the blocks of batch u, then the tail workgroups of batch u - tp_lag.  Batches below tp_count2 run in two phases
+    // (first pass: no working-set prediction, one sweep; problems whose working set moves are queued for the tail workgroups, which solve
+    // them sixteen at a time with the full body); the rest in one pass.
+    int tp_count2, tp_tail, tp_lag;
+    int tp_timeout;              // ticks of the 100 MHz counter a tail workgroup waits for its chunk before it gives up (error record)
+    int* tp_exits;               // [tp_count2]
+    int* tp_cnt;                 // [tp_count2][blocks_per_batch]
+    int* tp_entries;             // [tp_count2][blocks_per_batch * 16]
+    long long* tp_trace;         // diagnostic (ALORE_NMPC_TP_TRACE): 4 words per workgroup -- real-time counter at its start, inputs landed, end; role | batch << 8 | turns << 40 -- or null
+    int* tp_rec;                 // host memory: [0 .. 31] deferred problems of batch (b mod 32), [32] != 0: a tail workgroup timed out; or null
     long long stride[15]; // bytes, in the member order of alore_nmpc_batch
     alore_nmpc_batch b[GROUP_MAX];
 };
@@ -66,6 +83,8 @@ hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
 int block_lds_floats(int N, int L);
 bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int B_in_flight = 0);
 hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
+// may a grid of this geometry run in two phases (RtiGroup::tp_*)?
+bool rti_block_two_phase_supported(const RtiParams& p, const LaunchGeom& g);
 hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const LaunchGeom& g, hipStream_t s);
 
 // nmpc_dense.hip: the condensed QP of the reference's dense interface (acadoWorkspace.H / g / lb / ub, acado_solve)

@@ -184,6 +184,17 @@ class BatchedNmpc:
         the default -- or "streams" -- one launch per slot on forked streams"""
         self._check(self.lib.alore_nmpc_set_many_mode(self.h, {"groups": 0, "streams": 1}[mode]))
 
+    def set_two_phase(self, mode) -> None:
+        """two-phase grids of rti_range (alore_nmpc_set_two_phase): "auto" / -1, False / 0 (never), True / 1 (wherever the build exists)"""
+        m = {"auto": -1, False: 0, True: 1, -1: -1, 0: 0, 1: 1}[mode]
+        self._check(self.lib.alore_nmpc_set_two_phase(self.h, m))
+
+    def two_phase_info(self) -> dict:
+        from ._lib import TwoPhaseInfo
+        ti = TwoPhaseInfo()
+        self._check(self.lib.alore_nmpc_get_two_phase_info(self.h, C.byref(ti)))
+        return {k: getattr(ti, k) for k, _ in TwoPhaseInfo._fields_}
+
     def rti_range(self, first: int, count: int, n_sqp: int = 1) -> None:
         """slots first .. first + count - 1 by ONE call into the library (independent slots are solved together, see
         alore_nmpc_rti_many)"""

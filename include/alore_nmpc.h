@@ -179,6 +179,29 @@ int alore_nmpc_synchronize(alore_nmpc_handle h, void *stream);
 int alore_nmpc_rti_many_prepare(alore_nmpc_handle h, const alore_nmpc_batch *batches, int count, int B);
 int alore_nmpc_set_many_mode(alore_nmpc_handle h, int mode); /* 0 = groups (default), 1 = streams */
 int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
+/* Two-phase grids.  The wavefront is the unit of control flow, so one problem that needs a working set makes the fifteen problems that
+ * share its wavefront pay for the working-set prediction and for every further sweep.  A grid of alore_nmpc_rti_many (groups mode,
+ * the packed mapping, N = 20, n_sqp = 1) that fills the chip several times therefore solves its batches in two passes inside the ONE
+ * launch: every problem takes one sweep on the working set its incoming dual names (no prediction); a problem whose set that sweep
+ * confirms -- the QP of acado_feedbackStep solved: QProblemB.cpp:315-506 ends after its first step when no bound blocks it -- is
+ * stored, the others stay untouched and are queued, and workgroups later in the same grid solve the queued problems sixteen at a
+ * time with prediction, working-set iteration and safeguard.  A problem is solved by exactly one of the two passes from its unmodified
+ * inputs with the arithmetic of the one-pass kernel: x, u, dual, kkt, obj and status do not depend on the mode (n_iter counts the sweeps
+ * the problem took and can be smaller).  mode: 1 wherever the build exists and the grid holds enough batches (the last ones of a grid
+ * always take one pass), 0 never, -1 automatic = 0 today.  MEASURED (round 6, profiles/r06_two_phase.txt): with a fifth of the problems
+ * queued -- the cold-start Monte-Carlo batch of bench.py -- the mode is 8 % SLOWER than the one-pass grid, because a queued problem
+ * pays the 5 - 9 us between a workgroup's start and the arrival of its inputs twice; it pays off when fewer than about a tenth of
+ * the problems move their working set in a tick (a fleet in steady tracking).  A tail workgroup waits for its queue at most 20 ms;
+ * if that ever runs out the NEXT call of the handle fails with ALORE_NMPC_E_HIP and a text (the grid then left problems unsolved). */
+int alore_nmpc_set_two_phase(alore_nmpc_handle h, int mode);
+typedef struct {
+    int last_grid_two_phase;       /* 1: the last grid of alore_nmpc_rti_many ran in two phases */
+    int two_phase_batches;         /* of that grid: batches solved in two passes (the last ones of a grid take one) */
+    int tail_workgroups_per_batch; /* workgroups per batch that solve queued problems (sized by the fullest queue of the last recorded grid) */
+    int lag_units;                 /* the tail of a batch follows its first pass this many batches later in the grid */
+    float tail_share;              /* share of a batch's problems the fullest queue of the last recorded grid held */
+} alore_nmpc_two_phase_info;
+int alore_nmpc_get_two_phase_info(alore_nmpc_handle h, alore_nmpc_two_phase_info *out);
 
 /* Problems that sit a tick out.  mask: DEVICE pointer [B] (kept by the handle until reset with NULL), 1 = solve, 0 = the
  * problem is left exactly as it is by the following alore_nmpc_rti calls -- x, u, dual, status, n_iter, kkt, obj unchanged,

@@ -1078,3 +1078,107 @@ np.savez(sys.argv[1], **out)
         assert files
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_timeline.py"), str(files[-1])], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and f"{slots * B // 16} workgroups" in r.stdout and "SIMDs used: 1024" in r.stdout, r.stdout[:500] + r.stderr[-500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["bench+stress", "ragged+mask", "scattered", "tail of one workgroup", "graph"])
+def test_two_phase_grids_return_the_bits_of_the_one_pass_grid(nmpc_mod, case):
+    """alore_nmpc_set_two_phase(h, 1): a grid whose batches are solved in two passes (first pass without prediction, problems whose working
+    set moves queued for tail workgroups later in the SAME grid) returns x, u, dual, status, kkt, obj of the one-pass grid bit for bit
+    -- every problem is solved by exactly one pass from its unmodified inputs -- and n_iter never larger.  Cases: cold Monte-Carlo
+    batches mixed with stress batches (general weights: workgroups that take one pass inside the first pass's range; 40 % queued);
+    B not a multiple of 16 with masked-out problems; batches as a descriptor table (scattered order); a tail of ONE workgroup per batch
+    (every tail workgroup takes turn after turn: the overflow path); the call replayed from a hipGraph."""
+    import torch
+    from alore_legged_manipulator_amd.scenarios import make_wide_batch
+    N = 20
+    B, slots = (4096, 12) if case != "ragged+mask" else (4092, 12)   # a multiple of 4 keeps every slot 16-byte aligned
+    batches = [make_batch(B, N, seed=500 + s, fast_tail=0.3) if s % 3 else make_wide_batch(B, N, 500 + s) for s in range(slots)]
+    order = list(range(slots))
+    if case == "scattered":
+        order = [7, 2, 11, 0, 5, 9, 1, 10, 3, 8, 6, 4]
+
+    def run(two_phase, env=None):
+        eng = nmpc_mod.BatchedNmpc(B, N, slots=slots)
+        eng.set_two_phase(two_phase)
+        for s in range(slots):
+            eng.load(batches[s], slot=s)
+        mask = None
+        if case == "ragged+mask":
+            mask = np.ones(B, dtype=np.uint8)
+            mask[::7] = 0
+            eng.set_problem_mask(mask)
+        torch.cuda.synchronize()
+        if case == "scattered":
+            import ctypes as C
+            from alore_legged_manipulator_amd._lib import Batch
+            arr = (Batch * slots)(*[eng._batches[s] for s in order])
+            eng._check(eng.lib.alore_nmpc_rti_many(eng.h, arr, slots, B, 1, eng._stream()))
+        elif case == "graph":
+            side = torch.cuda.Stream()
+            eng.rti_range(0, slots)   # eager once: the queue region exists before the capture
+            torch.cuda.synchronize()
+            for s in range(slots):
+                eng.load(batches[s], slot=s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    eng.rti_range(0, slots)
+            g.replay()
+        else:
+            eng.rti_range(0, slots)
+        torch.cuda.synchronize()
+        return {k: eng.ts[k].clone() for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj")}, eng.two_phase_info(), eng
+
+    if case == "tail of one workgroup":
+        os.environ["ALORE_NMPC_TP_TAIL"] = "1"   # read once per process by the library: this case runs in a child below
+    try:
+        if case == "tail of one workgroup":
+            import subprocess
+            import sys
+            code = f"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, {ROOT!r})
+from alore_legged_manipulator_amd.nmpc import BatchedNmpc
+from alore_legged_manipulator_amd.scenarios import make_batch, make_wide_batch
+B, N, slots = {B}, {N}, {slots}
+res = {{}}
+for tp in (0, 1):
+    eng = BatchedNmpc(B, N, slots=slots)
+    eng.set_two_phase(tp)
+    for s in range(slots):
+        eng.load(make_batch(B, N, seed=500 + s, fast_tail=0.3) if s % 3 else make_wide_batch(B, N, 500 + s), slot=s)
+    eng.rti_range(0, slots)
+    torch.cuda.synchronize()
+    res[tp] = {{k: eng.ts[k].cpu().numpy() for k in ("x", "u", "dual", "status", "n_iter", "kkt", "obj")}}
+    info = eng.two_phase_info()
+assert info["last_grid_two_phase"] == 1 and info["tail_workgroups_per_batch"] == 1, info
+for k in ("x", "u", "dual", "status", "kkt", "obj"):
+    assert np.array_equal(res[0][k], res[1][k]), k
+assert (res[1]["n_iter"] <= res[0]["n_iter"]).all()
+print("ok")
+"""
+            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+            return
+    finally:
+        os.environ.pop("ALORE_NMPC_TP_TAIL", None)
+    one, info1, _ = run(0)
+    two, info2, eng2 = run(1)
+    assert info1["last_grid_two_phase"] == 0 and info2["last_grid_two_phase"] == 1 and info2["two_phase_batches"] >= 6, (info1, info2)
+    assert 0.05 < info2["tail_share"] < 0.6 or case == "graph", info2
+    for k in ("x", "u", "dual", "status", "kkt", "obj"):
+        assert torch.equal(one[k], two[k]), (case, k)
+    assert (two["n_iter"] <= one["n_iter"]).all()
+    if case != "ragged+mask":
+        assert (two["status"] == 0).all()
+    # the queue is back in order: a second two-phase grid on the same handle gives the same bits
+    for s in range(slots):
+        eng2.load(batches[s], slot=s)
+    torch.cuda.synchronize()
+    eng2.rti_range(0, slots)
+    torch.cuda.synchronize()
+    if case != "scattered":
+        for k in ("x", "u", "dual", "status", "kkt", "obj"):
+            assert torch.equal(eng2.ts[k], one[k]), (case, "second grid", k)
