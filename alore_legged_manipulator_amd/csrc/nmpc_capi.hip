@@ -880,9 +880,19 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
             for (int x = 1; x < 8; ++x) bx = frac[x] > frac[bx] ? x : bx;
             ++grp.xcd_share[bx]; frac[bx] = -1.0; ++given;
         }
+        while (given > total_items) { // rounding can only ever give too few; if it ever gave too many, the largest share gives them back
+            int bx = 0;
+            for (int x = 1; x < 8; ++x) bx = grp.xcd_share[x] > grp.xcd_share[bx] ? x : bx;
+            --grp.xcd_share[bx]; --given;
+        }
         int base = 0;
         for (int x = 0; x < 8; ++x) { grp.xcd_base[x] = base; base += grp.xcd_share[x]; }
-        grp.xcd_on = 1;
+        grp.xcd_on = base == total_items ? 1 : 0;
+        if (record) { // never inside a stream capture: every replay would write the host record with no event to tell when
+            hipStreamCaptureStatus capx = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing((hipStream_t)stream, &capx);
+            record = capx == hipStreamCaptureStatusNone;
+        }
         if (record) {
             std::memset(h->xcd_rec, 0, sizeof(unsigned long long) * 40);
             void* alias = nullptr;
@@ -1067,6 +1077,8 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
         const bool two = alternate && n_groups > 1;
         const long inflight = (long)B * per * (two ? 2 : 1);
         const int Bf = (int)(inflight > clampB ? clampB : inflight);
+        // alore_nmpc_set_timing: the events go on the caller's stream around ALL grids of the call (in front of the fork, behind the join)
+        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, main_s));
         if (two) {
             HIP_TRY(h, hipEventRecord(h->fork_ev, main_s));
             HIP_TRY(h, hipStreamWaitEvent(h->side[0], h->fork_ev, 0));
@@ -1082,9 +1094,21 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
             if (rc == ALORE_NMPC_OK && e1 != hipSuccess) return fail(h, ALORE_NMPC_E_HIP, "rti_many: join", e1);
             if (rc == ALORE_NMPC_OK && e2 != hipSuccess) return fail(h, ALORE_NMPC_E_HIP, "rti_many: join", e2);
         }
+        if (h->timing && rc == ALORE_NMPC_OK) {
+            HIP_TRY(h, hipEventRecord(h->ev1, main_s));
+            h->timed_pending = true;
+        }
         return rc;
     }
-    // STREAMS
+    // STREAMS.  With timing on the launches of this path never fork (rti_one records the handle's ONE pair of events: two of them on
+    // different streams would pair events of different launches): in order on the caller's stream.
+    if (h->timing) {
+        for (int i = 0; i < count; ++i) {
+            const int rc1 = rti_one(h, batches + i, B, n_sqp, stream, 0);
+            if (rc1 != ALORE_NMPC_OK) return rc1;
+        }
+        return ALORE_NMPC_OK;
+    }
     HIP_TRY(h, hipEventRecord(h->fork_ev, main_s));
     int forked = 0;
     int rc = ALORE_NMPC_OK;

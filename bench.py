@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
+    ap.add_argument("--contract-repeats", type=int, default=5, help="further timed regions that bracket the contract figure (0 = none)")
     ap.add_argument("--no-stress-check", action="store_true",
                     help="skip the parity check on the stress distribution (counter passes: its grids run the general-weights path and would be averaged in)")
     ap.add_argument("--bench-events", action="store_true",
@@ -123,14 +124,18 @@ def parity_spot_check(eng, batch, N, warmup, K, hooks, per_slot=32, tol=1e-4):
             "against": "oracle/nmpc_oracle.c (float32 restatement, bit-exact with the compiled reference at N = 50)"}
 
 
-def parity_stress_check(eng, N, warmup, K, hooks, per_slot=32):
+def parity_stress_check(eng, N, warmup, K, hooks, per_slot=32, random_per_slot=700):
     """The same check on the STRESS distribution (scenarios.make_wide_batch: far-off poses, references beyond the bounds, full and
     log-uniform weights, random bounds -- long working-set iterations, the general-weights path of the kernel): the slots are
-    loaded with it and solved by the same one-call pass the timed region uses (timed here too, reported, never the headline);
-    `per_slot` problems of three slots -- half drawn at random, half those with the most working-set iterations -- against the
-    oracle AND the float64 minimiser of the oracle's own condensed QP, by the rule of tests/test_gpu_parity.py: within 1e-4 of the
-    oracle, or else closer than the oracle to the float64 minimiser and within 1e-4 of it; never beyond 5e-4 of the oracle unless
-    the oracle itself misses that minimiser by more than 1e-4 (then 1e-3)."""
+    loaded with it and solved by the same one-call pass the timed region uses (timed here too, reported, never the headline).
+    The rule of tests/test_gpu_parity.py::check_against_oracle_and_float64, shares included:
+      * per problem: within 1e-4 of the oracle, or else ("loose") closer than the oracle to the float64 minimiser of the oracle's own
+        condensed QP and within 1e-4 of it; never beyond 5e-4 of the oracle unless the oracle itself misses that minimiser by more
+        than 1e-4 (then 1e-3: "oracle off");
+      * shares: loose <= 1 % and oracle off <= 1 in 400, both over picks DRAWN AT RANDOM (`random_per_slot` problems of each of three
+        slots: an unbiased sample, large enough that a true share of 0.5 % does not trip the 1 % bound by chance);
+      * on top, the `per_slot // 2` problems with the most working-set iterations of each slot (hard-picked, so not part of a share)
+        under the per-problem rule, and `per_slot // 2` of the random ones against the float64 minimiser whatever their distance."""
     import time
     from scipy.optimize import lsq_linear
     from alore_legged_manipulator_amd.scenarios import make_wide_batch, problem
@@ -147,14 +152,27 @@ def parity_stress_check(eng, N, warmup, K, hooks, per_slot=32):
     el = time.perf_counter() - t0
     orc = Oracle(N)
     slots = sorted({warmup, warmup + K // 2, warmup + K - 1})
-    worst_o, worst_t, loose, n, ok, unsolved = 0.0, 0.0, 0, 0, True, 0
     n_var = 2 * N
+    worst_o, worst_t, ok, unsolved = 0.0, 0.0, True, 0
+    n_rnd = loose_rnd = off_rnd = n_hard = loose_hard = off_hard = n_f64 = 0
+
+    def float64_errors(b, out):
+        H = orc.v["H"].reshape(n_var, n_var).astype(np.float64); H = 0.5 * (H + H.T)
+        Lc = np.linalg.cholesky(H)
+        r = lsq_linear(Lc.T, -np.linalg.solve(Lc, orc.v["g"].astype(np.float64)),
+                       bounds=(orc.v["lb"].astype(np.float64), orc.v["ub"].astype(np.float64)), method="bvls", tol=1e-15, max_iter=2000)
+        scale = max(1.0, float(np.max(np.abs(orc.v["u"]))))
+        ek = float(np.max(np.abs((out["u"][b].reshape(-1).astype(np.float64) - wide["u"][b].reshape(-1)) - r.x))) / scale
+        er = float(np.max(np.abs(orc.v["dx"].astype(np.float64) - r.x))) / scale
+        return ek, er
+
     for si, s in enumerate(slots):
         out = eng.fetch(names=("x", "u", "status", "n_iter"), slot=s)
         unsolved += int((out["status"] != 0).sum())
-        rnd = np.random.default_rng([20261004, si]).choice(B, size=per_slot // 2, replace=False).tolist()
-        hard = np.argsort(-out["n_iter"], kind="stable")[:per_slot - per_slot // 2].tolist()
-        for b in sorted(set(rnd) | set(hard)):
+        rnd = np.random.default_rng([20261004, si]).choice(B, size=min(random_per_slot, B), replace=False).tolist()
+        always64 = set(rnd[:per_slot // 2])
+        hard = [int(b) for b in np.argsort(-out["n_iter"], kind="stable")[:per_slot - per_slot // 2] if int(b) not in set(rnd)]
+        for b, is_hard in [(b, False) for b in rnd] + [(b, True) for b in hard]:
             orc.reset(); orc.initialize_solver(); orc.load(problem(wide, int(b))); orc.preparation_step()
             if orc.feedback_step() != 0 or int(out["status"][b]) != 0:
                 ok = False
@@ -163,26 +181,30 @@ def parity_stress_check(eng, N, warmup, K, hooks, per_slot=32):
             for k in ("x", "u"):
                 ref = orc.v[k].astype(np.float64)
                 e = max(e, float(np.max(np.abs(out[k][b].reshape(-1) - ref) / np.maximum(1.0, np.abs(ref)))))
-            H = orc.v["H"].reshape(n_var, n_var).astype(np.float64); H = 0.5 * (H + H.T)
-            Lc = np.linalg.cholesky(H)
-            r = lsq_linear(Lc.T, -np.linalg.solve(Lc, orc.v["g"].astype(np.float64)),
-                           bounds=(orc.v["lb"].astype(np.float64), orc.v["ub"].astype(np.float64)), method="bvls", tol=1e-15, max_iter=2000)
-            scale = max(1.0, float(np.max(np.abs(orc.v["u"]))))
-            ek = float(np.max(np.abs((out["u"][b].reshape(-1).astype(np.float64) - wide["u"][b].reshape(-1)) - r.x))) / scale
-            er = float(np.max(np.abs(orc.v["dx"].astype(np.float64) - r.x))) / scale
-            worst_o, worst_t = max(worst_o, e), max(worst_t, ek)
-            if e >= 1e-4:
-                loose += 1
-                ok = ok and (ek < er and ek < 1e-4)
-            if e >= 5e-4:
-                ok = ok and (er > 1e-4 and e < 1e-3)
-            n += 1
-    ok = ok and worst_t < 1e-4 and unsolved == 0
-    return {"ok": bool(ok), "problems": n, "slots": slots, "worst_rel_vs_oracle": worst_o, "beyond_1e-4_of_the_oracle": loose,
+            worst_o = max(worst_o, e)
+            n_rnd, n_hard = n_rnd + (0 if is_hard else 1), n_hard + (1 if is_hard else 0)
+            if e >= 1e-4 or is_hard or b in always64:
+                ek, er = float64_errors(b, out)
+                worst_t = max(worst_t, ek)
+                n_f64 += 1
+                if e >= 1e-4:
+                    loose_rnd, loose_hard = loose_rnd + (0 if is_hard else 1), loose_hard + (1 if is_hard else 0)
+                    ok = ok and (ek < er and ek < 1e-4)
+                if e >= 5e-4:
+                    off_rnd, off_hard = off_rnd + (0 if is_hard else 1), off_hard + (1 if is_hard else 0)
+                    ok = ok and (er > 1e-4 and e < 1e-3)
+    loose_bound, off_bound = max(1, int(0.01 * n_rnd)), max(1, n_rnd // 400)
+    ok = ok and worst_t < 1e-4 and unsolved == 0 and loose_rnd <= loose_bound and off_rnd <= off_bound and off_hard <= 1
+    return {"ok": bool(ok), "problems": n_rnd + n_hard, "slots": slots, "worst_rel_vs_oracle": worst_o,
+            "random_picks": n_rnd, "beyond_1e-4_of_the_oracle_in_the_random_picks": loose_rnd, "bound_1_percent": loose_bound,
+            "beyond_5e-4_oracle_off_in_the_random_picks": off_rnd, "bound_1_in_400": off_bound,
+            "hard_picks": n_hard, "beyond_1e-4_of_the_oracle_in_the_hard_picks": loose_hard, "beyond_5e-4_in_the_hard_picks": off_hard,
+            "checked_against_the_float64_minimiser": n_f64,
             "worst_rel_vs_float64_minimiser": worst_t, "unsolved_in_the_checked_slots": unsolved, "ms_per_step_on_this_distribution": el / K * 1e3,
             "distribution": "scenarios.make_wide_batch (stress: long working-set iterations, full weights)",
-            "rule": "<= 1e-4 from the oracle, else closer than the oracle to the float64 minimiser of its condensed QP and <= 1e-4 from it; "
-                    "<= 5e-4 from the oracle unless the oracle misses that minimiser by > 1e-4 (then <= 1e-3)"}
+            "rule": "per problem: <= 1e-4 from the oracle, else closer than the oracle to the float64 minimiser of its condensed QP and <= 1e-4 "
+                    "from it; <= 5e-4 from the oracle unless the oracle misses that minimiser by > 1e-4 (then <= 1e-3).  Shares over the "
+                    "random picks: beyond 1e-4 <= 1 %, beyond 5e-4 <= 1 in 400 (tests/test_gpu_parity.py::check_against_oracle_and_float64)"}
 
 
 def usable_cores() -> int:
@@ -578,6 +600,27 @@ def main():
                   "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_l / long_steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
     elapsed, dev_ms, used_graph = timed_pass(primary, a.steps)
     dev_ms, region_events_ms = grid_event_ms(dev_ms)
+    # The contract figure is ONE region of K steps measured once (one grid of ~0.13 ms).  `value` stays that first region; five further
+    # regions -- slots reloaded, the same W warm-up steps, the same barriers, the same K -- bracket it.
+    repeats = None
+    if world == 1 and a.steps > 0 and a.contract_repeats > 0:
+        r_ms, r_k = [], []
+        for _ in range(a.contract_repeats):
+            el_r, dms_r, _g = timed_pass(primary, a.steps)
+            dms_r, _ = grid_event_ms(dms_r)
+            r_ms.append(el_r / a.steps * 1e3)
+            r_k.append(dms_r)
+        med = lambda v: float(np.median(np.asarray(v)))
+        bps = algorithmic_bytes_per_solve(N) * B
+        repeats = {"regions": a.contract_repeats, "steps": a.steps, "warmup": a.warmup,
+                   "ms_per_step": {"min": min(r_ms), "median": med(r_ms), "max": max(r_ms), "first_region_the_value_is_from": elapsed / a.steps * 1e3},
+                   "kernel_ms_per_region": {"min": min(r_k), "median": med(r_k), "max": max(r_k), "first_region": dev_ms},
+                   "hbm_frac_by_kernel_events": {"best": bps * a.steps / (min(r_k) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "median": bps * a.steps / (med(r_k) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "worst": bps * a.steps / (max(r_k) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                   "what": "further timed regions after the one `value` is from: slots reloaded, W warm-up steps, barrier, K steps, barrier; "
+                           "kernel time by the library's HIP events around the grid" if lib_events else
+                           "further timed regions after the one `value` is from; device time by HIP events around the region"}
     eng.set_timing(False)
     hooks.lib_events = False
     host_breakdown = dict(getattr(hooks, "last_host_breakdown_us", {}))
@@ -754,6 +797,8 @@ def main():
             "unsolved_problems": n_bad, "working_set_iters_mean": n_iter_mean,
             "host_clock_breakdown_us": host_breakdown,
         }
+        if repeats is not None:
+            result["contract_repeats"] = repeats
         if spot is not None:
             result["parity_spot_check"] = spot
             if not spot["ok"]:  # a fast kernel whose results differ from the reference's is not measured

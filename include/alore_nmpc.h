@@ -145,7 +145,11 @@ int alore_nmpc_batch_default_bounds(alore_nmpc_handle h, const alore_nmpc_batch 
  * mpc_wrapper.cpp:279-373).  x, u, dual are updated in place; status, n_iter are
  * written.  kkt and obj (acado_getKKT / acado_getObjective, acado_solver.c:1373-1450:
  * separate calls in the reference, never made by its wrapper) are computed and written
- * when the batch has non-NULL pointers for them, and skipped otherwise. */
+ * when the batch has non-NULL pointers for them, and skipped otherwise.
+ * n_iter follows the launch size when warm_start_steps was left to the library (< 0): a batch that fills the chip more than twice on
+ * the packed mapping (B >= 32768) is launched like the batches of alore_nmpc_rti_many -- staggered first residency, XCD shares and
+ * FOUR prediction steps instead of six -- so the sweeps a problem is reported to have taken (and the float32 rounding of its results,
+ * never the solution) can differ between B below and above that size; set warm_start_steps to pin them. */
 int alore_nmpc_rti(alore_nmpc_handle h, const alore_nmpc_batch *dev, int B, int n_sqp, void *stream);
 /* the same for `count` batches of B problems each from one call (a host that steps many independent batches -- the slots
  * of a Monte-Carlo sweep, the shards of a fleet).  One batch alone is a burst of HBM reads followed by sweeps during which

@@ -123,8 +123,11 @@ int alore_wb_set_contact_constraints(alore_wb_handle h, int enable, double mu);
  *                     differs from its starting guess (the rows active at the iterate).  This is the reference mode -- the minimiser of
  *                     the inequality-constrained LQ problem (tests/test_wb_gpu.py: against a float64 active-set solve of the condensed QP
  *                     built from the oracle's own linearisation) --, not the control-rate one.  The working set is kept from one real-time
- *                     iteration to the next and reset by alore_wb_set_iterate / alore_wb_shift_iterate.  alore_wb_rti is then synchronous
- *                     (the host reads one counter per sweep) and runs without contact rows, contact penalty and refinement.
+ *                     iteration to the next and reset by alore_wb_set_iterate / alore_wb_shift_iterate (a shifted horizon starts
+ *                     from the rows active at its iterate again: the set is not shifted with it).  alore_wb_rti then BLOCKS THE HOST
+ *                     -- one device-to-host read of the open-problem counter and one stream synchronisation per sweep, up to
+ *                     `max_sweeps` of them, all inside the `riccati` span of alore_wb_last_timing -- and CANNOT be captured into a
+ *                     hipGraph; it runs without contact rows, contact penalty and refinement.
  * alore_wb_working_set_info: sweeps of the last real-time iteration; per problem 1 if it was still open when the sweeps ran out
  * (0 = solved); the working set itself, codes [B][N][32] (0 free, 1 lower, 2 upper bound, 3 / 4 on the + / - face of the pyramid, 5 zero
  * force); the input gradients [B][N][30] at the last face minimiser (the multipliers).  Any pointer may be NULL. */
