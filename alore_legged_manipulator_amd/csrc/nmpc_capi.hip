@@ -833,7 +833,12 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
     grp.xcd_end = nullptr;
     static const bool xcd_shares_on = !(getenv("ALORE_NMPC_XCD_SHARES") && atoi(getenv("ALORE_NMPC_XCD_SHARES")) == 0);
     const long total_items = (long)g.grid * count;
-    if (xcd_shares_on && !grp.counter && grp.tp_count2 == 0 && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && total_items >= 2L * 4 * h->n_cu && total_items < (1L << 28)) {
+    // Round 6: only grids of at least `min_res` residencies (default 12).  A grid of five residencies ends when its last wavefronts end
+    // wherever the shares put them, and shares fitted on a long grid cost the next short one 3 % (20 batches right after 200: 142 us
+    // against 137.5 with equal shares, four runs each; repeated 20-batch grids: 132.4 - 134.2 with shares, 131.4 - 132.8 without); the
+    // 200-batch grid keeps its 0.5 % (5.39 against 5.42 us per batch).  profiles/r06_contract_first_region.txt
+    static const long xcd_min_res = getenv("ALORE_NMPC_XCD_MIN_RES") ? atol(getenv("ALORE_NMPC_XCD_MIN_RES")) : 12;
+    if (xcd_shares_on && !grp.counter && grp.tp_count2 == 0 && g.L == 4 && g.RS == 5 && h->cfg.N == 20 && n_sqp == 1 && total_items >= xcd_min_res * 4 * h->n_cu && total_items >= 2L * 4 * h->n_cu && total_items < (1L << 28)) {
         bool record = true;
         if (h->xcd_pending) {
             if (hipEventQuery(h->xcd_ev) == hipSuccess) {

@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds every host thread works in the baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / converged-solve extras")
+    ap.add_argument("--steady-order", choices=("first", "after"), default="first",
+                    help="a short run's 200-step steady-state pass before (default) or after the contract region and its repeats")
     ap.add_argument("--contract-repeats", type=int, default=5, help="further timed regions that bracket the contract figure (0 = none)")
     ap.add_argument("--no-stress-check", action="store_true",
                     help="skip the parity check on the stress distribution (counter passes: its grids run the general-weights path and would be averaged in)")
@@ -592,12 +594,15 @@ def main():
         eng.set_timing(True)
         hooks.lib_events = True
     steady = None
-    if long_steps:
+
+    def steady_pass():
         el_l, dms_l, g_l = timed_pass("none", long_steps)
         dms_l, reg_l = grid_event_ms(dms_l)
-        steady = {"steps": long_steps, "value": float(B) * long_steps / el_l, "ms_per_step": el_l / long_steps * 1e3,
-                  "kernel_ms_avg": dms_l / long_steps, "hip_graph": g_l,
-                  "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_l / long_steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        return {"steps": long_steps, "value": float(B) * long_steps / el_l, "ms_per_step": el_l / long_steps * 1e3,
+                "kernel_ms_avg": dms_l / long_steps, "hip_graph": g_l,
+                "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_l / long_steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if long_steps and a.steady_order == "first":
+        steady = steady_pass()
     elapsed, dev_ms, used_graph = timed_pass(primary, a.steps)
     dev_ms, region_events_ms = grid_event_ms(dev_ms)
     # The contract figure is ONE region of K steps measured once (one grid of ~0.13 ms).  `value` stays that first region; five further
@@ -621,6 +626,8 @@ def main():
                    "what": "further timed regions after the one `value` is from: slots reloaded, W warm-up steps, barrier, K steps, barrier; "
                            "kernel time by the library's HIP events around the grid" if lib_events else
                            "further timed regions after the one `value` is from; device time by HIP events around the region"}
+    if long_steps and a.steady_order == "after":
+        steady = steady_pass()
     eng.set_timing(False)
     hooks.lib_events = False
     host_breakdown = dict(getattr(hooks, "last_host_breakdown_us", {}))

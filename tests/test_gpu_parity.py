@@ -1040,8 +1040,9 @@ def test_prepared_descriptor_sets_and_overlapping_batches(nmpc_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", ["ALORE_NMPC_PERSIST=1", "ALORE_NMPC_TRACE=%TRACE%", "ALORE_NMPC_XCD_SPEEDS=1.3,0.7,1.0,1.15,0.85,1.0,0.5,1.5",
-                                 "ALORE_NMPC_XCD_SHARES=0"])
+@pytest.mark.parametrize("env", ["ALORE_NMPC_PERSIST=1", "ALORE_NMPC_TRACE=%TRACE%",
+                                 "ALORE_NMPC_XCD_SPEEDS=1.3,0.7,1.0,1.15,0.85,1.0,0.5,1.5 ALORE_NMPC_XCD_MIN_RES=2",   # shares apply from 12 residencies on by default
+                                 "ALORE_NMPC_XCD_SHARES=0 ALORE_NMPC_XCD_MIN_RES=2"])
 def test_the_persistent_grid_and_the_traced_twin_return_the_bits_of_the_plain_grid(nmpc_mod, env, tmp_path):
     """The opt-in persistent grid (blocks of problems by ticket), the instrumented twin of the grid build (per-SIMD trace), strongly
     uneven XCD shares (preset speeds: every XCD works on a different number of blocks, surplus workgroups leave at once) and equal
@@ -1063,9 +1064,9 @@ out = {{k: eng.ts[k].cpu().numpy() for k in ("x", "u", "dual", "status", "n_iter
 np.savez(sys.argv[1], **out)
 """
     trace = str(tmp_path / "trace")
-    k, v = env.replace("%TRACE%", trace).split("=")
+    switched = dict(kv.split("=") for kv in env.replace("%TRACE%", trace).split())
     res = {}
-    for tag, extra in (("plain", {}), ("switched", {k: v})):
+    for tag, extra in (("plain", {"ALORE_NMPC_XCD_MIN_RES": "2"}), ("switched", switched)):
         path = str(tmp_path / f"{tag}.npz")
         r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
