@@ -525,6 +525,8 @@ void fill_params(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_
     p->max_as_iter = h->cfg.max_as_iter;
     p->pg_steps = h->cfg.warm_start_steps;
     p->shared = h->shared;
+    static const bool no_scan = getenv("ALORE_NMPC_SCAN") && atoi(getenv("ALORE_NMPC_SCAN")) == 0; // diagnostic: backward sweeps never as a scan over the lanes
+    if (no_scan) p->shared |= 0x80000000u;
     p->RS = g.RS;
     const nmpc::IrkConst K = nmpc::make_irk(h->cfg.dt);
     p->h = K.h; p->hh = K.hh; p->c1h = K.c1h; p->c2h = K.c2h;
@@ -549,7 +551,7 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
     static const int forced_wpb = getenv("ALORE_NMPC_WPB") ? atoi(getenv("ALORE_NMPC_WPB")) : 0; // diagnostic: 1 or 4
     const int lp = h->cfg.lanes_per_problem;
     const bool use_block = block_eligible(h, dev) &&
-                           nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight);
+                           nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight, n_sqp == 1 && !h->stamps);
     if (!use_block && !nmpc::rti_geometry(B, h->cfg.N, (lp & 0x100) ? 0 : lp, h->lds_limit, h->n_cu, &g, forced_wpb))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: horizon does not fit the LDS layout");
     nmpc::RtiParams p;
@@ -689,7 +691,7 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
               const long long* stride)
 {
     nmpc::LaunchGeom g;
-    if (!nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight))
+    if (!nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight, n_sqp == 1 && !h->stamps))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti_many: horizon does not fit the stage-block kernel");
     nmpc::RtiParams p;
     fill_params(h, batches, B, n_sqp, g, &p);
@@ -1049,7 +1051,7 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     bool groups = mode == 0;
     if (groups) {
         nmpc::LaunchGeom g;
-        groups = nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B);
+        groups = nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B, n_sqp == 1 && !h->stamps);
         for (int i = 0; i < count && groups; ++i)
             groups = block_eligible(h, batches + i) && (batches[i].kkt != nullptr) == (batches[0].kkt != nullptr) &&
                      (batches[i].obj != nullptr) == (batches[0].obj != nullptr);
@@ -1063,7 +1065,7 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
         // stream and one side stream so that the tail of one grid runs under the head of the next.
         long long stride[15];
         nmpc::LaunchGeom g1;
-        (void)nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g1, B);
+        (void)nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g1, B, n_sqp == 1 && !h->stamps);
         if (constant_strides(batches, count, stride) && (long long)g1.grid * count <= 0x7fffffffLL) {
             const long inflight = (long)B * count;
             // alore_nmpc_set_timing: HIP events on the launch stream directly around the grid (alore_nmpc_get_launch_info: last_kernel_ms is

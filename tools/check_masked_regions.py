@@ -15,7 +15,9 @@ usage: check_masked_regions.py [--strict] <nmpc_block_kernel gfx950 .s file>"""
 import re
 import sys
 
-BAD = re.compile(r"\b(v_accvgpr_(read|write|mov)|scratch_(load|store)|buffer_(load|store)_dword\S*\s.*\boffen\b|v_readlane_b32|v_writelane_b32)")
+# (v_readlane_b32 / v_writelane_b32 -- the spill and reload of a SCALAR register into a lane of a vector register -- ignore EXEC by
+# definition (CDNA ISA: "ignores exec mask"), so they are safe under a partial mask and are not findings)
+BAD = re.compile(r"\b(v_accvgpr_(read|write|mov)|scratch_(load|store)|buffer_(load|store)_dword\S*\s.*\boffen\b)")
 
 
 def check(path):
