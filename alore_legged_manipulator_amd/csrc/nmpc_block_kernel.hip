@@ -323,10 +323,10 @@ __device__ __forceinline__ bool riccati_step_pk(const StagePk& s, ValuePk& V, Po
 } // namespace
 
 // LDS floats of one wavefront: W and y of its 64 / L problems, each area padded to whole 256-float DMA pieces
-int block_lds_floats(int N, int L, bool wreg)
+int block_lds_floats(int N, int L)
 {
     const int G = 64 / L;
-    return (wreg ? 0 : ((G * 25 * N + 255) & ~255)) + ((G * 5 * N + 255) & ~255);
+    return ((G * 25 * N + 255) & ~255) + ((G * 5 * N + 255) & ~255);
 }
 
 // One grid serves up to GROUP_MAX independent batches (alore_nmpc_rti_many): the descriptors travel by value in the kernel
@@ -343,8 +343,7 @@ int block_lds_floats(int N, int L, bool wreg)
 // load: profiles/r05_a_timeline_*.txt); with tickets a faster XCD takes more items.  The ticket of the next item is requested
 // when the current one starts, so its latency is never waited for.
 // TWOPH (grid builds): the batches of the grid are solved in two passes -- see the top of nmpc_block_body.inc.
-// WREG (long horizons, few lanes: (8, 7)): W_k in the registers of the lane that owns the stage, never in LDS -- see the body.
-template <int L, int S, bool DIAG, bool STAMP, bool ONCE, bool FULLN = false, bool TRACE = false, bool PERSIST = false, bool TWOPH = false, bool WREG = false>
+template <int L, int S, bool DIAG, bool STAMP, bool ONCE, bool FULLN = false, bool TRACE = false, bool PERSIST = false, bool TWOPH = false>
 __global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p_arg, const RtiGroup grp_arg)
 {
     constexpr bool SCAN_BUILD = true;
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(64) void rti_block_sampler_kernel(const RtiParams p
                                          (int)threadIdx.x, 64);
         return;
     }
-    constexpr bool STAMP = false, ONCE = true, FULLN = false, TRACE = false, PERSIST = false, TWOPH = false, WREG = false;
+    constexpr bool STAMP = false, ONCE = true, FULLN = false, TRACE = false, PERSIST = false, TWOPH = false;
     // the backward sweep stays sequential here: with the scan over the lanes (nmpc_scan.h) the (16, 2) build takes 284 registers, and the
     // sampler's wavefronts run beside the solver's only while a SIMD holds one of each (256): the tick went from 19 to 27 us
     constexpr bool SCAN_BUILD = false;
@@ -387,7 +386,7 @@ __global__ __launch_bounds__(64) void rti_block_sampler_kernel(const RtiParams p
 }
 
 // (L, S) instantiated: (4, 5) (8, 3) (16, 2) (32, 1) for horizons up to 20 / 24 / 32 / 32, (16, 4) up to 64
-bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int B_in_flight, bool once)
+bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int B_in_flight)
 {
     if (B <= 0 || N <= 0) return false;
     const int cus = n_cu > 0 ? n_cu : 256;
@@ -404,25 +403,22 @@ bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, L
         while (L > 4 && (Bo + 64 / L - 1) / (64 / L) > 4L * cus) L >>= 1;
         while (L < 16 && N > L * (L == 4 ? 5 : 3)) L <<= 1;
         if (L == 16 && N <= 32 && (Bo + 1) / 2 <= (long)cus) L = 32;
-        // long horizons (the reference's N = 50) in grids that fill the chip: 8 lanes x 7 stages, W in registers (single-iteration
-        // launches only) -- the sweeps cost N stage steps per wavefront whatever L is, and a wavefront then holds eight problems, not four
-        if (L == 16 && N > 32 && N <= 56 && once && (Bo + 3) / 4 > 4L * cus) L = 8;
+        // (long horizons -- the reference's N = 50 -- stay on (16, 4): 8 lanes x 7 stages with W_k in registers instead of LDS was built in
+        // round 6 and spills 880 registers: 49.6 against 35 us per batch in flight; what took (16, 4) to 26 us is the scan of nmpc_scan.h)
     }
     int S = 0;
     if (L == 4 && N <= 20) S = 5;
     else if (L == 8 && N <= 24) S = 3;
-    else if (L == 8 && N <= 56 && once) S = 7;
     else if (L == 16 && N <= 32) S = 2;
     else if (L == 16 && N <= 64) S = 4;
     else if (L == 32 && N <= 32) S = 1;
     if (S == 0) return false;
-    const bool wreg = (L == 8 && S == 7);
-    const size_t lds = (size_t)block_lds_floats(N, L, wreg) * 4;
+    const size_t lds = (size_t)block_lds_floats(N, L) * 4;
     if ((long)lds > lds_limit_bytes) return false;
     g->L = L;
     g->G = 64 / L;
     g->wpb = 1;
-    g->wreg = wreg ? 1 : 0;
+    g->wreg = 0;
     g->threads = 64;
     g->grid = (B + g->G - 1) / g->G;
     g->RS = S; // stages per lane
@@ -473,12 +469,6 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
     PICK(8, 3, 1)
     PICK(16, 2, 2)
     PICK(16, 4, 3)
-    if (g.L == 8 && g.RS == 7) { // W in registers: single-iteration launches, no stamps
-        if (!once || stamp) return hipErrorInvalidValue;
-        v = 33 + (diag ? 0 : 1);
-        fn = diag ? (const void*)rti_block_kernel<8, 7, true, false, true, false, false, false, false, true>
-                  : (const void*)rti_block_kernel<8, 7, false, false, true, false, false, false, false, true>;
-    }
     PICK(32, 1, 4)
 #undef PICK
     if (g.L == 4 && g.RS == 5 && p.N == 20 && once && !stamp) { // the control tick at the horizon that fills the (4, 5) mapping

@@ -215,7 +215,9 @@ int alore_nmpc_create(const alore_nmpc_config* cfg, alore_nmpc_handle* out)
     h->cfg = *cfg;
     if (h->cfg.max_as_iter <= 0) h->cfg.max_as_iter = 128;
     h->auto_pg = h->cfg.warm_start_steps < 0;
-    if (h->auto_pg) h->cfg.warm_start_steps = 6; // swept on MI355X at N = 20 and 50 (tools/dbg/bb.sh, bb2.sh)
+    // swept on MI355X: N = 20 -- 4 / 6 / 8 steps: 23.8 / 21.8 / 22.6 us per in-order launch of 4096; N = 50 (round 6, with the scanned backward
+    // sweep a prediction step is cheap beside a second sweep) -- 4 / 6 / 8 / 10: 52.4 / 48.8 / 45.7 / 47.8 us (tools/horizon_in_flight.py)
+    if (h->auto_pg) h->cfg.warm_start_steps = h->cfg.N > 32 ? 8 : 6;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->lds_limit = (int)prop.sharedMemPerBlock > 0 ? (int)prop.sharedMemPerBlock : 64 * 1024;
     if (prop.maxSharedMemoryPerMultiProcessor > (size_t)h->lds_limit)
@@ -551,7 +553,7 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
     static const int forced_wpb = getenv("ALORE_NMPC_WPB") ? atoi(getenv("ALORE_NMPC_WPB")) : 0; // diagnostic: 1 or 4
     const int lp = h->cfg.lanes_per_problem;
     const bool use_block = block_eligible(h, dev) &&
-                           nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight, n_sqp == 1 && !h->stamps);
+                           nmpc::block_geometry(B, h->cfg.N, lp & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight);
     if (!use_block && !nmpc::rti_geometry(B, h->cfg.N, (lp & 0x100) ? 0 : lp, h->lds_limit, h->n_cu, &g, forced_wpb))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti: horizon does not fit the LDS layout");
     nmpc::RtiParams p;
@@ -691,7 +693,7 @@ int rti_group(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, i
               const long long* stride)
 {
     nmpc::LaunchGeom g;
-    if (!nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight, n_sqp == 1 && !h->stamps))
+    if (!nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B_in_flight))
         return fail(h, ALORE_NMPC_E_UNSUPPORTED, "rti_many: horizon does not fit the stage-block kernel");
     nmpc::RtiParams p;
     fill_params(h, batches, B, n_sqp, g, &p);
@@ -1051,7 +1053,7 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
     bool groups = mode == 0;
     if (groups) {
         nmpc::LaunchGeom g;
-        groups = nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B, n_sqp == 1 && !h->stamps);
+        groups = nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g, B);
         for (int i = 0; i < count && groups; ++i)
             groups = block_eligible(h, batches + i) && (batches[i].kkt != nullptr) == (batches[0].kkt != nullptr) &&
                      (batches[i].obj != nullptr) == (batches[0].obj != nullptr);
@@ -1065,7 +1067,7 @@ int alore_nmpc_rti_many(alore_nmpc_handle h, const alore_nmpc_batch* batches, in
         // stream and one side stream so that the tail of one grid runs under the head of the next.
         long long stride[15];
         nmpc::LaunchGeom g1;
-        (void)nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g1, B, n_sqp == 1 && !h->stamps);
+        (void)nmpc::block_geometry(B, h->cfg.N, h->cfg.lanes_per_problem & 0xff, h->lds_limit, h->n_cu, &g1, B);
         if (constant_strides(batches, count, stride) && (long long)g1.grid * count <= 0x7fffffffLL) {
             const long inflight = (long)B * count;
             // alore_nmpc_set_timing: HIP events on the launch stream directly around the grid (alore_nmpc_get_launch_info: last_kernel_ms is

@@ -80,9 +80,8 @@ int rti_row_floats(int N, bool wreg);
 bool rti_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int forced_wpb = 0);
 hipError_t launch_rti(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
 // stage-block kernel (nmpc_block_kernel.hip): L = 4, 8 or 16 lanes per problem, each lane owns ceil(N / L) stages
-int block_lds_floats(int N, int L, bool wreg = false);
-// once: the launch is a single iteration (n_sqp = 1): the (8, 7) mapping for horizons up to 56 exists for those only
-bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int B_in_flight = 0, bool once = false);
+int block_lds_floats(int N, int L);
+bool block_geometry(int B, int N, int forced_L, int lds_limit_bytes, int n_cu, LaunchGeom* g, int B_in_flight = 0);
 hipError_t launch_rti_block(const RtiParams& p, const LaunchGeom& g, hipStream_t s);
 // may a grid of this geometry run in two phases (RtiGroup::tp_*)?
 bool rti_block_two_phase_supported(const RtiParams& p, const LaunchGeom& g);
