@@ -379,9 +379,10 @@ __global__ __launch_bounds__(64) void rti_block_sampler_kernel(const RtiParams p
         return;
     }
     constexpr bool STAMP = false, ONCE = true, FULLN = false, TRACE = false, PERSIST = false, TWOPH = false;
-    // the backward sweep stays sequential here: with the scan over the lanes (nmpc_scan.h) the (16, 2) build takes 284 registers, and the
-    // sampler's wavefronts run beside the solver's only while a SIMD holds one of each (256): the tick went from 19 to 27 us
-    constexpr bool SCAN_BUILD = false;
+    // the (16, 2) build keeps the sequential backward sweep here: with the scan over the lanes (nmpc_scan.h) it takes 284 registers, and
+    // the sampler's wavefronts run beside the solver's only while a SIMD holds one of each (256): the tick of 4096 robots went from 19
+    // to 27 us; capped at 256 registers (16 - 22 spilled) 21.0 against 19.5 us.  (32, 1) has room: 256 robots 14.3 -> 11.9 us per tick.
+    constexpr bool SCAN_BUILD = (L == 32);
 #include "nmpc_block_body.inc"
 }
 

@@ -559,6 +559,9 @@ int rti_one(alore_nmpc_handle h, const alore_nmpc_batch* dev, int B, int n_sqp, 
     nmpc::RtiParams p;
     fill_params(h, dev, B, n_sqp, g, &p);
     p.mask = h->mask;
+    // one robot / a handful (a few wavefronts, each alone on its SIMD): a second, partial sweep costs less than the prediction steps that
+    // would avoid it -- B = 1, N = 20, cold start, synchronous launch p50: 3 / 4 / 6 / 8 steps 22.7 / 23.6 / 23.8 / 24.8 us (round 6)
+    if (h->auto_pg && B <= 64 && h->cfg.N <= 32) p.pg_steps = 3;
     hipStream_t s = (hipStream_t)stream;
     if (h->stamps) {
         const size_t need = (size_t)g.grid * g.wpb * 8; // one record per wavefront
