@@ -485,7 +485,7 @@ BLOCK = 0x100  # ALORE_NMPC_BLOCK_LANES(L) = 0x100 | L (include/alore_nmpc.h)
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,lanes", [(20, BLOCK | 4), (20, BLOCK | 8), (20, BLOCK | 16), (7, BLOCK | 4), (24, BLOCK | 8),
                                      (31, BLOCK | 16), (50, BLOCK | 16), (1, BLOCK | 4), (20, BLOCK | 32), (32, BLOCK | 32),
-                                     (9, BLOCK | 32), (20, 32), (50, 64)])
+                                     (9, BLOCK | 32), (20, 32), (50, 64), (32, BLOCK | 16), (64, BLOCK | 16)])
 def test_every_lane_mapping_against_the_oracle(nmpc_mod, N, lanes):
     """Both kernels, every instantiated lane mapping (stage-block L = 4 / 8 / 16 / 32 with 5 / 3 / 2 or 4 / 1 stages per lane, the
     wavefront mapping): one tick from the cold start and one warm tick (the dual seeds the working set) of seeded
