@@ -603,6 +603,8 @@ def main():
                 "hbm_frac": algorithmic_bytes_per_solve(N) * B / (dms_l / long_steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if long_steps and a.steady_order == "first":
         steady = steady_pass()
+    if os.environ.get("ALORE_BENCH_PRE_SLEEP_MS"):   # diagnostic (profiles/r06_contract_first_region.txt): idle time in front of the contract pass
+        time.sleep(float(os.environ["ALORE_BENCH_PRE_SLEEP_MS"]) * 1e-3)
     elapsed, dev_ms, used_graph = timed_pass(primary, a.steps)
     dev_ms, region_events_ms = grid_event_ms(dev_ms)
     # The contract figure is ONE region of K steps measured once (one grid of ~0.13 ms).  `value` stays that first region; five further
