@@ -343,8 +343,14 @@ int block_lds_floats(int N, int L)
 // load: profiles/r05_a_timeline_*.txt); with tickets a faster XCD takes more items.  The ticket of the next item is requested
 // when the current one starts, so its latency is never waited for.
 // TWOPH (grid builds): the batches of the grid are solved in two passes -- see the top of nmpc_block_body.inc.
+// -DALORE_EXP_WPE=n (experiments, never the shipped build): at least n wavefronts per SIMD, i.e. at most 512 / n registers
+#ifdef ALORE_EXP_WPE
+#define ALORE_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(ALORE_EXP_WPE, ALORE_EXP_WPE)))
+#else
+#define ALORE_KERNEL_ATTR
+#endif
 template <int L, int S, bool DIAG, bool STAMP, bool ONCE, bool FULLN = false, bool TRACE = false, bool PERSIST = false, bool TWOPH = false>
-__global__ __launch_bounds__(64) void rti_block_kernel(const RtiParams p_arg, const RtiGroup grp_arg)
+__global__ __launch_bounds__(64) ALORE_KERNEL_ATTR void rti_block_kernel(const RtiParams p_arg, const RtiGroup grp_arg)
 {
     constexpr bool SCAN_BUILD = true;
 #include "nmpc_block_body.inc"
