@@ -1358,6 +1358,33 @@ def main():
             del e9
         except Exception as e:  # pragma: no cover
             extras["without_diagnostics"] = {"error": f"{type(e).__name__}: {e}"}
+        # round 6: the two-phase grid the round-5 verdict asked for (homogeneous wavefronts: a first pass without the working-set
+        # prediction, problems whose working set moves queued for tail workgroups of the same grid) beside the one-pass grid that ships:
+        # same bits, and the time of both on 20 batches of the bench batch (library events around the grid, best of 4)
+        try:
+            res_tp = {}
+            for mode in (0, 1):
+                e7 = BatchedNmpc(B, N, device=local_rank, slots=20)
+                e7.set_two_phase(mode)
+                times = []
+                for rep in range(5):
+                    e7.load(batch, slot=None)
+                    torch.cuda.synchronize(dev)
+                    e7.set_timing(rep > 0)
+                    e7.rti_range(0, 20)
+                    torch.cuda.synchronize(dev)
+                    if rep > 0:
+                        times.append(float(e7.launch_info()["last_kernel_ms"]))
+                res_tp[mode] = ({k: e7.ts[k].clone() for k in ("x", "u", "dual", "status", "kkt", "obj")}, min(times), e7.two_phase_info())
+                del e7
+            same = all(bool(torch.equal(res_tp[0][0][k], res_tp[1][0][k])) for k in res_tp[0][0])
+            extras["two_phase_grid"] = {"batches": 20, "one_pass_grid_ms": res_tp[0][1], "two_phase_grid_ms": res_tp[1][1],
+                                        "bit_equal_x_u_dual_status_kkt_obj": same, "share_of_problems_queued": res_tp[1][2]["tail_share"],
+                                        "two_phase_batches": res_tp[1][2]["two_phase_batches"],
+                                        "what": "alore_nmpc_set_two_phase(h, 1) against the default: opt-in, slower on this distribution "
+                                                "(a queued problem pays the wait for its inputs twice: profiles/r06_two_phase.txt)"}
+        except Exception as e:  # pragma: no cover
+            extras["two_phase_grid"] = {"error": f"{type(e).__name__}: {e}"}
         # the reference's own generated horizon (N = 50), same batch size: next to the compiled reference's
         # single-core time in cpu_baseline.reference_n50_single_core_us_per_solve
         try:
