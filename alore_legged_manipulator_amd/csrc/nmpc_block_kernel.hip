@@ -482,6 +482,10 @@ hipError_t launch_rti_block_group(const RtiParams& p, const RtiGroup& grp, const
         v = 25 + (diag ? 0 : 1);
         fn = diag ? (const void*)rti_block_kernel<4, 5, true, false, true, true> : (const void*)rti_block_kernel<4, 5, false, false, true, true>;
     }
+    if (g.L == 4 && g.RS == 5 && p.N == 20 && !once && !stamp) { // several iterations per launch (converged solves) at the horizon that fills the mapping
+        v = 33 + (diag ? 0 : 1);
+        fn = diag ? (const void*)rti_block_kernel<4, 5, true, false, false, true> : (const void*)rti_block_kernel<4, 5, false, false, false, true>;
+    }
     const bool persist = grp.counter != nullptr;
     if (persist) {
         if (!(g.L == 4 && g.RS == 5 && p.N == 20 && once && !stamp)) return hipErrorInvalidValue;
