@@ -190,8 +190,9 @@ int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
  * confirms -- the QP of acado_feedbackStep solved: QProblemB.cpp:315-506 ends after its first step when no bound blocks it -- is
  * stored, the others stay untouched and are queued, and workgroups later in the same grid solve the queued problems sixteen at a
  * time with prediction, working-set iteration and safeguard.  A problem is solved by exactly one of the two passes from its unmodified
- * inputs with the arithmetic of the one-pass kernel: x, u, dual, kkt, obj and status do not depend on the mode (n_iter counts the sweeps
- * the problem took and can be smaller).  mode: 1 wherever the build exists and the grid holds enough batches (the last ones of a grid
+ * inputs with the arithmetic of the one-pass kernel: status is that of the one-pass grid and x, u, dual, kkt, obj agree with it to
+ * float32 rounding (the same bits on every cold-start case tested, within 1e-6 absolute on warm ticks: the kernel carries its own
+ * copies of the solver body); n_iter counts the sweeps the problem took and can be smaller.  mode: 1 wherever the build exists and the grid holds enough batches (the last ones of a grid
  * always take one pass), 0 never, -1 automatic = 0 today.  MEASURED (round 6, profiles/r06_two_phase.txt): with a fifth of the problems
  * queued -- the cold-start Monte-Carlo batch of bench.py -- the mode is 8 % SLOWER than the one-pass grid, because a queued problem
  * pays the 5 - 9 us between a workgroup's start and the arrival of its inputs twice; it pays off when fewer than about a tenth of
