@@ -71,9 +71,13 @@ struct alore_nmpc_solver {
     bool auto_pg = false; // warm_start_steps was left to the library: 6 for a launch on its own, 3 inside a grid of many batches
     // the last descriptor set that passed the independence check of alore_nmpc_rti_many, kept whole (with the B and the shared-member
     // mask it was checked for): any contiguous run of it is independent too
-    std::vector<alore_nmpc_batch> indep_set;
-    int indep_B = 0;
-    unsigned indep_shared = 0;
+    // (four sets, least recently used replaced: a host that alternates between slot ranges -- warm-up slots and timed slots, two fleets --
+    // keeps both known; with one set the second range's call overwrote the first and every call paid the check again)
+    static constexpr int kIndepSets = 4;
+    std::vector<alore_nmpc_batch> indep_set[kIndepSets];
+    int indep_B[kIndepSets] = {0, 0, 0, 0};
+    unsigned indep_shared[kIndepSets] = {0, 0, 0, 0};
+    unsigned long long indep_used[kIndepSets] = {0, 0, 0, 0}, indep_clock = 0;
     int many_mode = 0; // alore_nmpc_rti_many: 0 = groups of batches per grid, 1 = one launch per batch on forked streams
     hipStream_t side[31] = {};
     hipEvent_t fork_ev = nullptr, join_ev[31] = {};
@@ -677,17 +681,26 @@ bool batches_independent(alore_nmpc_handle h, const alore_nmpc_batch* batches, i
 // descriptors are compared, not a digest of them.
 bool known_independent(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B)
 {
-    const size_t n = h->indep_set.size();
-    if (n == 0 || (size_t)count > n || h->indep_B != B || h->indep_shared != h->shared) return false;
-    for (size_t i0 = 0; i0 + (size_t)count <= n; ++i0)
-        if (h->indep_set[i0].x == batches[0].x && std::memcmp(&h->indep_set[i0], batches, (size_t)count * sizeof(alore_nmpc_batch)) == 0) return true;
+    for (int k = 0; k < alore_nmpc_solver::kIndepSets; ++k) {
+        const size_t n = h->indep_set[k].size();
+        if (n == 0 || (size_t)count > n || h->indep_B[k] != B || h->indep_shared[k] != h->shared) continue;
+        for (size_t i0 = 0; i0 + (size_t)count <= n; ++i0)
+            if (h->indep_set[k][i0].x == batches[0].x && std::memcmp(&h->indep_set[k][i0], batches, (size_t)count * sizeof(alore_nmpc_batch)) == 0) {
+                h->indep_used[k] = ++h->indep_clock;
+                return true;
+            }
+    }
     return false;
 }
 void remember_independent(alore_nmpc_handle h, const alore_nmpc_batch* batches, int count, int B)
 {
-    h->indep_set.assign(batches, batches + count);
-    h->indep_B = B;
-    h->indep_shared = h->shared;
+    int k = 0;
+    for (int i = 1; i < alore_nmpc_solver::kIndepSets; ++i)
+        if (h->indep_used[i] < h->indep_used[k]) k = i;
+    h->indep_set[k].assign(batches, batches + count);
+    h->indep_B[k] = B;
+    h->indep_shared[k] = h->shared;
+    h->indep_used[k] = ++h->indep_clock;
 }
 
 // `count` independent batches on the stage-block kernel as ONE grid (nmpc_block_kernel.hip: RtiGroup): by table
