@@ -195,8 +195,9 @@ int alore_nmpc_set_launch_overlap(alore_nmpc_handle h, int ways); /* 1 .. 32 */
  * copies of the solver body); n_iter counts the sweeps the problem took and can be smaller.  mode: 1 wherever the build exists and the grid holds enough batches (the last ones of a grid
  * always take one pass), 0 never, -1 automatic = 0 today.  MEASURED (round 6, profiles/r06_two_phase.txt): with a fifth of the problems
  * queued -- the cold-start Monte-Carlo batch of bench.py -- the mode is 8 % SLOWER than the one-pass grid, because a queued problem
- * pays the 5 - 9 us between a workgroup's start and the arrival of its inputs twice; it pays off when fewer than about a tenth of
- * the problems move their working set in a tick (a fleet in steady tracking).  A tail workgroup waits for its queue at most 20 ms;
+ * pays the 5 - 9 us between a workgroup's start and the arrival of its inputs twice (7 - 12 % slower on warm ticks of the same batches,
+ * which queue a fifth as well); by the slot-time model it would pay off when fewer than about a tenth of the problems move their
+ * working set in a tick.  A tail workgroup waits for its queue at most 20 ms;
  * if that ever runs out the NEXT call of the handle fails with ALORE_NMPC_E_HIP and a text (the grid then left problems unsolved). */
 int alore_nmpc_set_two_phase(alore_nmpc_handle h, int mode);
 typedef struct {
